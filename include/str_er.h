@@ -1,0 +1,235 @@
+/*
+ * str_er.h -- C ABI of libstr_er_hip.so: the MI355X (gfx950) implementation of the
+ * extremal-region scene-text detection hot path of HsiehYiChia/Scene-text-recognition.
+ *
+ * The boundary is the public surface of the reference's `class ERFilter`
+ * (inc/ER.h:110-136) for the per-plane hot loop of ERFilter::text_detect
+ * (src/ER.cpp:42-60):
+ *
+ *     compute_channels -> er_tree_extract -> non_maximum_supression -> classify
+ *
+ * Plain pointers and sizes only; no C++/torch types cross this header.  Every entry
+ * point returns 0 (STR_ER_OK) or a negative STR_ER_E* code and never throws.  All
+ * per-pixel work runs in hand-written HIP kernels; there is no CPU fallback -- if no
+ * gfx950 device is usable, str_er_create fails with STR_ER_EHIP.
+ *
+ * Paths below are relative to the reference checkout (/root/reference).
+ */
+#ifndef STR_ER_H
+#define STR_ER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STR_ER_ABI_VERSION 1
+
+/* ---- error codes (reference: loaders print+return false, src/adaboost.cpp:877-881;
+ *      CV_Assert throws on non-8UC1, src/ER.cpp:242) ------------------------------ */
+#define STR_ER_OK          0
+#define STR_ER_EINVAL     (-1)  /* bad argument (NULL, non-positive size, bad mask ...)    */
+#define STR_ER_ENOMEM     (-2)  /* host or device allocation failed                         */
+#define STR_ER_EHIP       (-3)  /* HIP runtime error / no usable device / kernel failure    */
+#define STR_ER_EIO        (-4)  /* classifier file could not be opened                      */
+#define STR_ER_EFORMAT    (-5)  /* classifier text could not be parsed                      */
+#define STR_ER_ESTATE     (-6)  /* call needs cascades that are not loaded                  */
+#define STR_ER_ECAPACITY  (-7)  /* input exceeds the capacity the context was created with  */
+
+/* which cascade: ERFilter::stc / ERFilter::wtc (inc/ER.h:117-118) */
+#define STR_ER_CASCADE_STRONG 0
+#define STR_ER_CASCADE_WEAK   1
+
+/* where an input buffer lives */
+#define STR_ER_MEM_HOST   0
+#define STR_ER_MEM_DEVICE 1     /* pointer is HIP device memory on params.device */
+
+/* stage mask for str_er_detect_* (each stage needs the previous ones) */
+#define STR_ER_STAGE_EXTRACT  1u   /* er_tree_extract          src/ER.cpp:240-374 */
+#define STR_ER_STAGE_NMS      2u   /* non_maximum_supression   src/ER.cpp:416-505 */
+#define STR_ER_STAGE_CLASSIFY 4u   /* classify                 src/ER.cpp:507-528 */
+#define STR_ER_STAGE_ALL      7u
+/* output options */
+#define STR_ER_WANT_NODES     16u  /* also return the kept-node table of every plane */
+
+/* candidate class: which list of text_detect() the ER landed in (src/ER.cpp:516-526) */
+#define STR_ER_CLS_POOL   0   /* pooled by NMS, rejected by both cascades */
+#define STR_ER_CLS_STRONG 1
+#define STR_ER_CLS_WEAK   2
+
+typedef struct str_er_ctx    str_er_ctx;
+typedef struct str_er_result str_er_result;
+
+/* Constructor arguments of ERFilter (inc/ER.h:113, src/main.cpp:22, macros
+ * inc/utils.h:6-11) plus the build's own batching/pyramid/capacity knobs.          */
+typedef struct str_er_params {
+    int32_t  thresh_step;     /* THRESH_STEP   default 8                              */
+    int32_t  min_area;        /* MIN_AREA      default 120                            */
+    int32_t  max_area;        /* MAX_AREA      default 900000                         */
+    int32_t  stability_t;     /* STABILITY_T   default 2                              */
+    double   overlap_coef;    /* OVERLAP_COEF  default 0.7                            */
+    int32_t  n_pyr_levels;    /* 1 = native resolution only (the reference);
+                                 level k>=1 is resize_linear(level k-1) to
+                                 (lround(w*2^(-k/2)), lround(h*2^(-k/2)))             */
+    uint32_t channel_mask;    /* bit i = plane i of [Y,Cr,Cb,255-Y,255-Cr,255-Cb]
+                                 (src/ER.cpp:122-127); 0x3F = the reference           */
+    int32_t  device;          /* HIP device ordinal                                   */
+    int32_t  max_width;       /* capacity: largest frame / plane width                */
+    int32_t  max_height;      /* capacity: largest frame / plane height               */
+    int32_t  max_frames;      /* capacity: frames per str_er_detect_bgr call; the
+                                 per-plane entry points accept up to
+                                 max_frames * popcount(channel_mask) * n_pyr_levels   */
+    int32_t  kept_cap;        /* per-plane capacity of the kept-node table,
+                                 0 = default max(4096, w*h/64)                        */
+    int32_t  pool_cap;        /* per-plane capacity of the NMS pool, 0 = kept_cap/4   */
+    int32_t  sibling_order;   /* tie rule where NMS depends on the flood's sibling
+                                 order: 0 = child with the largest
+                                 key claims the parent, 1 = smallest key              */
+    void    *stream;          /* hipStream_t to enqueue on; NULL = private stream     */
+} str_er_params;
+
+/* One kept node of a plane's component tree: flat form of struct ER (inc/ER.h:42-80). */
+typedef struct str_er_node {
+    uint32_t key;        /* canonical id: min linear pixel index (y*w+x) over the pixels
+                            of level == `level` inside the component                   */
+    int32_t  parent;     /* index in this plane's node table; the root points to itself
+                            (non_maximum_supression sets root->parent=root, :424)      */
+    int32_t  area;       /* ER::area as the reference computes it: pixel count +
+                            number of tree nodes in the subtree (ctor starts at 1)     */
+    uint16_t x, y, w, h; /* ER::bound                                                  */
+    uint8_t  level;      /* ER::level (quantised grey level)                           */
+    uint8_t  flags;      /* bit0: root                                                 */
+    uint16_t reserved;
+} str_er_node;           /* 24 bytes */
+
+/* One NMS survivor (member of `pool`, and of `strong`/`weak` if cls says so). */
+typedef struct str_er_cand {
+    uint32_t frame;      /* frame index inside the call (0 for the per-plane calls)    */
+    uint8_t  ch;         /* plane index 0..5 as in src/ER.cpp:122-127 (ER::ch)         */
+    uint8_t  pyr;        /* pyramid level                                              */
+    uint8_t  level;      /* ER::level                                                  */
+    uint8_t  cls;        /* STR_ER_CLS_*                                               */
+    uint16_t x, y, w, h; /* ER::bound in the plane's own coordinates                   */
+    uint32_t area;       /* ER::area (reference semantics)                             */
+    uint32_t key;        /* canonical id, see str_er_node                              */
+    int32_t  node;       /* index in the plane's kept-node table                       */
+    uint32_t plane;      /* plane index inside the result                              */
+    double   score_strong; /* stc->predict(fv): last stage score or -DBL_MAX           */
+    double   score_weak;   /* wtc->predict(fv) if the strong cascade rejected, else 0  */
+} str_er_cand;           /* 48 bytes */
+
+typedef struct str_er_plane_info {
+    uint32_t frame;
+    uint8_t  ch, pyr, reserved0, reserved1;
+    int32_t  width, height;
+    int32_t  n_created;   /* tree nodes before pruning (all (t,C) pairs)              */
+    int32_t  n_kept;      /* nodes with area > MIN_AREA, plus the root                */
+    int32_t  n_pool, n_strong, n_weak;
+    int32_t  ambiguous;   /* #nodes where >=2 child chains competed in NMS: the
+                             reference's answer depends on its flood's sibling order
+                             there; 0 = result is order-independent   */
+    int32_t  root;        /* index of the root in the kept-node table                 */
+} str_er_plane_info;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+/* Fills the reference's own defaults (src/main.cpp:22): 8,120,900000,2,0.7; six
+ * planes, one level; capacity 1920x1080x8 frames.                                     */
+void str_er_default_params(str_er_params *p);
+int  str_er_create(const str_er_params *p, str_er_ctx **out);
+void str_er_destroy(str_er_ctx *ctx);
+/* Text of the last error on this context ("" if none). ctx may be NULL for create errors. */
+const char *str_er_last_error(const str_er_ctx *ctx);
+const char *str_er_strerror(int code);
+int  str_er_abi_version(void);
+
+/* ERFilter::set_thresh_step / set_min_area (src/ER.cpp:21-30) */
+int str_er_set_thresh_step(str_er_ctx *ctx, int32_t t);
+int str_er_set_min_area(str_er_ctx *ctx, int32_t m);
+
+/* ---- models: CascadeBoost::load_classifier (src/adaboost.cpp:873-951) --------------- */
+int str_er_load_cascade(str_er_ctx *ctx, int which, const char *path);
+int str_er_load_cascade_mem(str_er_ctx *ctx, int which, const char *text, size_t len);
+/* n_stages / n_stumps of a loaded cascade (0 if not loaded) */
+int str_er_cascade_info(const str_er_ctx *ctx, int which, int32_t *n_stages, int32_t *n_stumps);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* Whole loop of ERFilter::text_detect up to and including classify
+ * (src/ER.cpp:39-60) for n_frames interleaved-BGR 8UC3 frames of w*h pixels
+ * (stride = bytes per row, frame_pitch = bytes between frames): compute_channels,
+ * optional pyramid, then per plane extract -> NMS -> classify.                        */
+int str_er_detect_bgr(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h,
+                      int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                      int mem_kind, uint32_t stages, str_er_result **out);
+
+/* The loop body (src/ER.cpp:52-59) for n_planes independent 8UC1 planes of w*h
+ * pixels (plane_pitch = bytes between planes).  This is what the reference's direct
+ * callers use (src/utils.cpp:680-684, 716-720, 763-769, 940-947, 1386-1388).        */
+int str_er_detect_planes(str_er_ctx *ctx, const uint8_t *planes, int32_t w, int32_t h,
+                         int64_t stride, int64_t plane_pitch, int32_t n_planes,
+                         int mem_kind, uint32_t stages, str_er_result **out);
+
+/* ---- single stages, one per remaining ERFilter method ------------------------------ */
+/* ERFilter::compute_channels (src/ER.cpp:114-128): planes6 receives the six w*h
+ * planes [Y,Cr,Cb,255-Y,255-Cr,255-Cb], each tightly packed (host memory).           */
+int str_er_compute_channels(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h,
+                            int64_t stride, uint8_t *planes6);
+
+/* ERFilter::classify (src/ER.cpp:507-528) on caller-supplied boxes of one host plane:
+ * boxes_xywh[4*i..4*i+3] = ER::bound.  cls/score arrays receive n entries.           */
+int str_er_classify_boxes(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h,
+                          int64_t stride, const int32_t *boxes_xywh, int32_t n,
+                          uint8_t *cls, double *score_strong, double *score_weak);
+
+/* ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816) for n boxes of one host
+ * plane: hist receives n*1024 doubles; tiles26 (optional, may be NULL) receives the
+ * n ARAN(26) tiles (src/OCR.cpp:394-430), 676 bytes each.                            */
+int str_er_lbp_hist(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h,
+                    int64_t stride, const int32_t *boxes_xywh, int32_t n,
+                    double *hist, uint8_t *tiles26);
+
+/* ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a caller-supplied kept tree
+ * (parent indices; root points to itself or -1).  pool_idx receives up to cap node
+ * indices in ascending key order; *n_pool the count; *ambiguous as in plane_info.    */
+int str_er_nms_tree(str_er_ctx *ctx, const str_er_node *nodes, int32_t n_nodes,
+                    int32_t rows, int32_t cols, int32_t *pool_idx, int32_t cap,
+                    int32_t *n_pool, int32_t *ambiguous);
+
+/* Build-defined pyramid primitive (no reference counterpart): fixed-point bilinear
+ * resize of one host plane, same arithmetic as cv::resize INTER_LINEAR 8UC1.         */
+int str_er_resize_plane(str_er_ctx *ctx, const uint8_t *src, int32_t sw, int32_t sh,
+                        int64_t sstride, uint8_t *dst, int32_t dw, int32_t dh);
+
+/* ---- results (owned by the library until str_er_result_free) ----------------------- */
+int32_t str_er_result_n_planes(const str_er_result *r);
+int     str_er_result_plane_info(const str_er_result *r, int32_t plane, str_er_plane_info *info);
+/* All candidates of the call, ordered by (plane, key). */
+const str_er_cand *str_er_result_cands(const str_er_result *r, int32_t *n);
+/* Candidates of one plane (a slice of the array above). */
+const str_er_cand *str_er_result_plane_cands(const str_er_result *r, int32_t plane, int32_t *n);
+/* Kept-node table of one plane, ascending (key, level); NULL unless STR_ER_WANT_NODES. */
+const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n);
+/* times[7] = {extract, nms, classify, track, group, ocr, total} seconds, the contract of
+ * ERFilter::text_detect's return value (src/ER.cpp:99-110); track/group/ocr are 0 here.
+ * extract/nms/classify are GPU stage times for the whole batch (HIP events).          */
+const double *str_er_result_times(const str_er_result *r);
+/* Device copy of the candidate array (for an RCCL gather without a host round trip):
+ * copies min(n, cap) records to dst_dev on the context's stream and synchronises.     */
+int  str_er_result_cands_to_device(str_er_ctx *ctx, const str_er_result *r, void *dst_dev,
+                                   int32_t cap, int32_t *n);
+void str_er_result_free(str_er_result *r);
+
+/* ---- introspection / measurement --------------------------------------------------- */
+/* Per-kernel-group GPU time of the LAST detect call, measured with HIP events on the
+ * context's stream.  names[i] are static strings.  Returns the number of groups.      */
+int str_er_last_profile(const str_er_ctx *ctx, const char **names, double *ms, int32_t cap);
+/* Enable (1) / disable (0) the per-group events above (default 0: two events per call). */
+int str_er_set_profiling(str_er_ctx *ctx, int enable);
+/* Bytes of device workspace held by the context. */
+int64_t str_er_workspace_bytes(const str_er_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STR_ER_H */

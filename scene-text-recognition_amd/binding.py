@@ -1,0 +1,381 @@
+"""ctypes binding of include/str_er.h.
+
+`ERFilter` mirrors the reference's `class ERFilter` (inc/ER.h:110-169) for the hot path:
+same constructor arguments and method names (`text_detect`, `compute_channels`,
+`er_tree_extract`, `non_maximum_supression`, `classify`, `make_LBP_hist`,
+`set_thresh_step`, `set_min_area`), results as numpy structured arrays instead of
+heap `ER*` trees.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, WANT_NODES = 1, 2, 4, 7, 16
+CLS_POOL, CLS_STRONG, CLS_WEAK = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+
+NODE_DTYPE = np.dtype([("key", "<u4"), ("parent", "<i4"), ("area", "<i4"), ("x", "<u2"), ("y", "<u2"),
+                       ("w", "<u2"), ("h", "<u2"), ("level", "u1"), ("flags", "u1"), ("reserved", "<u2")])
+CAND_DTYPE = np.dtype([("frame", "<u4"), ("ch", "u1"), ("pyr", "u1"), ("level", "u1"), ("cls", "u1"),
+                       ("x", "<u2"), ("y", "<u2"), ("w", "<u2"), ("h", "<u2"), ("area", "<u4"), ("key", "<u4"),
+                       ("node", "<i4"), ("plane", "<u4"), ("score_strong", "<f8"), ("score_weak", "<f8")])
+assert NODE_DTYPE.itemsize == 24 and CAND_DTYPE.itemsize == 48
+
+
+class StrErError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"str_er error {code}: {msg}")
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("thresh_step", C.c_int32), ("min_area", C.c_int32), ("max_area", C.c_int32),
+                ("stability_t", C.c_int32), ("overlap_coef", C.c_double), ("n_pyr_levels", C.c_int32),
+                ("channel_mask", C.c_uint32), ("device", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_frames", C.c_int32), ("kept_cap", C.c_int32),
+                ("pool_cap", C.c_int32), ("sibling_order", C.c_int32), ("stream", C.c_void_p)]
+
+
+class _PlaneInfo(C.Structure):
+    _fields_ = [("frame", C.c_uint32), ("ch", C.c_uint8), ("pyr", C.c_uint8), ("r0", C.c_uint8), ("r1", C.c_uint8),
+                ("width", C.c_int32), ("height", C.c_int32), ("n_created", C.c_int32), ("n_kept", C.c_int32),
+                ("n_pool", C.c_int32), ("n_strong", C.c_int32), ("n_weak", C.c_int32), ("ambiguous", C.c_int32),
+                ("root", C.c_int32)]
+
+
+@dataclass
+class Params:
+    """Constructor arguments of ERFilter (inc/ER.h:113; src/main.cpp:22) + capacity."""
+    thresh_step: int = 8
+    min_area: int = 120
+    max_area: int = 900000
+    stability_t: int = 2
+    overlap_coef: float = 0.7
+    n_pyr_levels: int = 1
+    channel_mask: int = 0x3F
+    device: int = 0
+    max_width: int = 1920
+    max_height: int = 1080
+    max_frames: int = 8
+    kept_cap: int = 0
+    pool_cap: int = 0
+    sibling_order: int = 0
+    stream: Optional[int] = None
+
+
+_LIB = None
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "lib", "libstr_er_hip.so")
+
+
+def load_library():
+    """Load libstr_er_hip.so; raises if it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: run `python scene-text-recognition_amd/build.py` (hipcc, gfx950). "
+            "There is no CPU implementation of this path.")
+    L = C.CDLL(path)
+    u8p, i32p, f64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.str_er_abi_version.restype = C.c_int
+    L.str_er_default_params.argtypes = [C.POINTER(_Params)]
+    L.str_er_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]
+    L.str_er_destroy.argtypes = [vp]
+    L.str_er_last_error.argtypes = [vp]
+    L.str_er_last_error.restype = C.c_char_p
+    L.str_er_strerror.argtypes = [C.c_int]
+    L.str_er_strerror.restype = C.c_char_p
+    L.str_er_set_thresh_step.argtypes = [vp, C.c_int32]
+    L.str_er_set_min_area.argtypes = [vp, C.c_int32]
+    L.str_er_load_cascade.argtypes = [vp, C.c_int, C.c_char_p]
+    L.str_er_load_cascade_mem.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    L.str_er_cascade_info.argtypes = [vp, C.c_int, i32p, i32p]
+    L.str_er_detect_bgr.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int,
+                                    C.c_uint32, C.POINTER(vp)]
+    L.str_er_detect_planes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int,
+                                       C.c_uint32, C.POINTER(vp)]
+    L.str_er_compute_channels.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]
+    L.str_er_classify_boxes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
+    L.str_er_lbp_hist.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp]
+    L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
+    L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
+    L.str_er_result_n_planes.argtypes = [vp]
+    L.str_er_result_n_planes.restype = C.c_int32
+    L.str_er_result_plane_info.argtypes = [vp, C.c_int32, C.POINTER(_PlaneInfo)]
+    L.str_er_result_cands.argtypes = [vp, i32p]
+    L.str_er_result_cands.restype = vp
+    L.str_er_result_plane_cands.argtypes = [vp, C.c_int32, i32p]
+    L.str_er_result_plane_cands.restype = vp
+    L.str_er_result_plane_nodes.argtypes = [vp, C.c_int32, i32p]
+    L.str_er_result_plane_nodes.restype = vp
+    L.str_er_result_times.argtypes = [vp]
+    L.str_er_result_times.restype = f64p
+    L.str_er_result_cands_to_device.argtypes = [vp, vp, vp, C.c_int32, i32p]
+    L.str_er_result_free.argtypes = [vp]
+    L.str_er_last_profile.argtypes = [vp, C.POINTER(C.c_char_p), f64p, C.c_int32]
+    L.str_er_set_profiling.argtypes = [vp, C.c_int]
+    L.str_er_workspace_bytes.argtypes = [vp]
+    L.str_er_workspace_bytes.restype = C.c_int64
+    if L.str_er_abi_version() != 1:
+        raise RuntimeError("libstr_er_hip.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+@dataclass
+class PlaneResult:
+    frame: int
+    ch: int
+    pyr: int
+    width: int
+    height: int
+    n_created: int
+    n_kept: int
+    n_pool: int
+    n_strong: int
+    n_weak: int
+    ambiguous: int
+    root: int
+    cands: np.ndarray                      # CAND_DTYPE, ascending key
+    nodes: Optional[np.ndarray] = None     # NODE_DTYPE, ascending (key, level)
+
+    @property
+    def pool(self) -> np.ndarray:
+        return self.cands
+
+    @property
+    def strong(self) -> np.ndarray:
+        return self.cands[self.cands["cls"] == CLS_STRONG]
+
+    @property
+    def weak(self) -> np.ndarray:
+        return self.cands[self.cands["cls"] == CLS_WEAK]
+
+
+@dataclass
+class Result:
+    planes: List[PlaneResult]
+    cands: np.ndarray
+    times: np.ndarray                      # 7 slots, ERFilter::text_detect's return value
+    profile: dict = field(default_factory=dict)
+
+
+def _np_ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+class ERFilter:
+    """Drop-in for the hot-path surface of the reference's ERFilter (inc/ER.h:110-136)."""
+
+    def __init__(self, thresh_step: int = 2, min_area: int = 100, max_area: int = 100000, stability_t: int = 2,
+                 overlap_coef: float = 0.7, min_ocr_prob: float = 0.01, *, params: Optional[Params] = None, **cap):
+        # positional defaults are the reference's (inc/ER.h:113); src/main.cpp:22 passes 8,120,900000,2,0.7,0.15
+        self.L = load_library()
+        p = params or Params(thresh_step=thresh_step, min_area=min_area, max_area=max_area, stability_t=stability_t,
+                             overlap_coef=overlap_coef, **cap)
+        self.params = p
+        self.min_ocr_prob = min_ocr_prob
+        cp = _Params(p.thresh_step, p.min_area, p.max_area, p.stability_t, p.overlap_coef, p.n_pyr_levels,
+                     p.channel_mask, p.device, p.max_width, p.max_height, p.max_frames, p.kept_cap, p.pool_cap,
+                     p.sibling_order, p.stream)
+        h = C.c_void_p()
+        rc = self.L.str_er_create(C.byref(cp), C.byref(h))
+        if rc != 0:
+            raise StrErError(rc, (self.L.str_er_last_error(None) or b"").decode())
+        self.h = h
+        self.stc = None  # names of the reference's public members (inc/ER.h:117-118)
+        self.wtc = None
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.str_er_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise StrErError(rc, (self.L.str_er_last_error(self.h) or b"").decode())
+
+    # ---- models: stc / wtc = new CascadeBoost(file)  (src/main.cpp:23-24) ------------------
+    def load_cascade(self, which: int, path: str) -> None:
+        self._check(self.L.str_er_load_cascade(self.h, which, path.encode()))
+        if which == 0:
+            self.stc = path
+        else:
+            self.wtc = path
+
+    def load_cascade_text(self, which: int, text: str) -> None:
+        b = text.encode()
+        self._check(self.L.str_er_load_cascade_mem(self.h, which, b, len(b)))
+
+    def cascade_info(self, which: int):
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self.L.str_er_cascade_info(self.h, which, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_thresh_step(self, t: int) -> None:      # src/ER.cpp:21-24
+        self._check(self.L.str_er_set_thresh_step(self.h, t))
+        self.params.thresh_step = t
+
+    def set_min_area(self, m: int) -> None:         # src/ER.cpp:27-30
+        self._check(self.L.str_er_set_min_area(self.h, m))
+        self.params.min_area = m
+
+    # ---- results ------------------------------------------------------------------------------
+    def _collect(self, rh: C.c_void_p) -> Result:
+        L = self.L
+        try:
+            n = C.c_int32()
+            ptr = L.str_er_result_cands(rh, C.byref(n))
+            if n.value:
+                cands = np.frombuffer((C.c_char * (48 * n.value)).from_address(ptr), dtype=CAND_DTYPE).copy()
+            else:
+                cands = np.zeros(0, CAND_DTYPE)
+            planes = []
+            off = 0
+            for i in range(L.str_er_result_n_planes(rh)):
+                pi = _PlaneInfo()
+                L.str_er_result_plane_info(rh, i, C.byref(pi))
+                nn = C.c_int32()
+                nptr = L.str_er_result_plane_nodes(rh, i, C.byref(nn))
+                nodes = None
+                if nptr:
+                    nodes = np.frombuffer((C.c_char * (24 * nn.value)).from_address(nptr), dtype=NODE_DTYPE).copy()
+                planes.append(PlaneResult(pi.frame, pi.ch, pi.pyr, pi.width, pi.height, pi.n_created, pi.n_kept,
+                                          pi.n_pool, pi.n_strong, pi.n_weak, pi.ambiguous, pi.root,
+                                          cands[off:off + pi.n_pool], nodes))
+                off += pi.n_pool
+            t = L.str_er_result_times(rh)
+            times = np.array([t[i] for i in range(7)])
+            return Result(planes, cands, times, self.last_profile())
+        finally:
+            L.str_er_result_free(rh)
+
+    def last_profile(self) -> dict:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        k = self.L.str_er_last_profile(self.h, names, ms, 16)
+        return {names[i].decode(): ms[i] for i in range(min(k, 16))}
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def text_detect(self, src: np.ndarray, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:
+        """ERFilter::text_detect up to classify (src/ER.cpp:33-60) for one BGR frame (H,W,3)
+        or a batch (F,H,W,3) of uint8."""
+        a = np.ascontiguousarray(src, dtype=np.uint8)
+        if a.ndim == 3:
+            a = a[None]
+        if a.ndim != 4 or a.shape[3] != 3:
+            raise ValueError("expected (H,W,3) or (F,H,W,3) uint8 BGR")
+        f, h, w, _ = a.shape
+        rh = C.c_void_p()
+        self._check(self.L.str_er_detect_bgr(self.h, _np_ptr(a), w, h, 3 * w, 3 * w * h, f, MEM_HOST,
+                                             stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
+        return self._collect(rh)
+
+    def detect_bgr_device(self, dptr: int, w: int, h: int, n_frames: int, stages: int = STAGE_ALL,
+                          stride: Optional[int] = None, frame_pitch: Optional[int] = None) -> Result:
+        """Same, for frames already resident in HBM (dptr = device address)."""
+        stride = stride or 3 * w
+        frame_pitch = frame_pitch or stride * h
+        rh = C.c_void_p()
+        self._check(self.L.str_er_detect_bgr(self.h, dptr, w, h, stride, frame_pitch, n_frames, MEM_DEVICE, stages,
+                                             C.byref(rh)))
+        return self._collect(rh)
+
+    def detect_planes(self, planes: np.ndarray, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:
+        """The loop body at src/ER.cpp:52-59 for (H,W) or (N,H,W) uint8 planes."""
+        a = np.ascontiguousarray(planes, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[None]
+        n, h, w = a.shape
+        rh = C.c_void_p()
+        self._check(self.L.str_er_detect_planes(self.h, _np_ptr(a), w, h, w, w * h, n, MEM_HOST,
+                                                stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
+        return self._collect(rh)
+
+    def detect_planes_device(self, dptr: int, w: int, h: int, n_planes: int, stages: int = STAGE_ALL,
+                             stride: Optional[int] = None, plane_pitch: Optional[int] = None) -> Result:
+        stride = stride or w
+        plane_pitch = plane_pitch or stride * h
+        rh = C.c_void_p()
+        self._check(self.L.str_er_detect_planes(self.h, dptr, w, h, stride, plane_pitch, n_planes, MEM_DEVICE, stages,
+                                                C.byref(rh)))
+        return self._collect(rh)
+
+    # ---- single stages ---------------------------------------------------------------------------
+    def compute_channels(self, src: np.ndarray) -> np.ndarray:
+        """ERFilter::compute_channels (src/ER.cpp:114-128) -> (6,H,W) uint8."""
+        a = np.ascontiguousarray(src, dtype=np.uint8)
+        h, w, _ = a.shape
+        out = np.empty((6, h, w), np.uint8)
+        self._check(self.L.str_er_compute_channels(self.h, _np_ptr(a), w, h, 3 * w, _np_ptr(out)))
+        return out
+
+    def er_tree_extract(self, plane: np.ndarray) -> PlaneResult:
+        """ERFilter::er_tree_extract (src/ER.cpp:240-374): the kept tree as a node table."""
+        return self.detect_planes(plane, STAGE_EXTRACT, want_nodes=True).planes[0]
+
+    def non_maximum_supression(self, nodes: np.ndarray, rows: int, cols: int):
+        """ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a node table.
+        Returns (pool indices in ascending key order, ambiguous count)."""
+        nd = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        cap = max(1, len(nd))
+        pool = np.zeros(cap, np.int32)
+        n, amb = C.c_int32(), C.c_int32()
+        self._check(self.L.str_er_nms_tree(self.h, _np_ptr(nd), len(nd), rows, cols, _np_ptr(pool), cap, C.byref(n),
+                                           C.byref(amb)))
+        return pool[:n.value].copy(), amb.value
+
+    def classify(self, plane: np.ndarray, boxes_xywh: np.ndarray):
+        """ERFilter::classify (src/ER.cpp:507-528): (cls, score_strong, score_weak) per box."""
+        a = np.ascontiguousarray(plane, dtype=np.uint8)
+        b = np.ascontiguousarray(boxes_xywh, dtype=np.int32).reshape(-1, 4)
+        n = len(b)
+        cls = np.zeros(n, np.uint8)
+        ss = np.zeros(n, np.float64)
+        sw = np.zeros(n, np.float64)
+        self._check(self.L.str_er_classify_boxes(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), n,
+                                                 _np_ptr(cls), _np_ptr(ss), _np_ptr(sw)))
+        return cls, ss, sw
+
+    def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):
+        """ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816).  With no boxes the whole
+        plane is the ROI (what the reference's get_lbp_data does, src/utils.cpp:1451-1470)."""
+        a = np.ascontiguousarray(plane, dtype=np.uint8)
+        if boxes_xywh is None:
+            boxes_xywh = np.array([[0, 0, a.shape[1], a.shape[0]]], np.int32)
+        b = np.ascontiguousarray(boxes_xywh, dtype=np.int32).reshape(-1, 4)
+        n = len(b)
+        hist = np.zeros((n, 1024), np.float64)
+        tiles = np.zeros((n, 26, 26), np.uint8) if return_tiles else None
+        self._check(self.L.str_er_lbp_hist(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), n,
+                                           _np_ptr(hist), _np_ptr(tiles) if return_tiles else None))
+        return (hist, tiles) if return_tiles else hist
+
+    def resize_plane(self, src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+        a = np.ascontiguousarray(src, dtype=np.uint8)
+        out = np.empty((dh, dw), np.uint8)
+        self._check(self.L.str_er_resize_plane(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(out), dw, dh))
+        return out
+
+    def workspace_bytes(self) -> int:
+        return int(self.L.str_er_workspace_bytes(self.h))

@@ -1,0 +1,54 @@
+// er_kernels.h -- host-callable launchers of the gfx950 kernels in er_kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "er_types.h"
+
+namespace str_er {
+
+struct BatchDev {
+    const PlaneDesc *planes;   // device array [n_planes]
+    PlaneCtr        *ctr;      // device array [n_planes]
+    int32_t          n_planes;
+    uint32_t         n_tiles;  // batch-wide
+    uint32_t         n_pairs;  // batch-wide seam pixel pairs
+    uint32_t         max_nodes_plane; // largest plane capacity (w*h)
+    NodeArrays       na;
+    KeptArrays       ka;
+    uint32_t        *seam;     // node id of every tile-border pixel
+    uint32_t        *pool;     // kept slots chosen by NMS, ascending key
+    uint32_t        *pool_tmp;
+    CandRec         *cands;    // packed, ordered by (plane, key)
+    uint32_t        *total_cands;
+};
+
+// compute_channels (src/ER.cpp:114-128): interleaved BGR -> Y, Cr, Cb planes.
+void launch_bgr_to_ycrcb(hipStream_t s, const uint8_t *bgr, int w, int h, int64_t stride,
+                         int64_t frame_pitch, int n_frames, uint8_t *y, uint8_t *cr, uint8_t *cb,
+                         int dstride, int64_t dst_frame_pitch);
+// 255 - x for the single-stage compute_channels entry point.
+void launch_invert(hipStream_t s, const uint8_t *src, uint8_t *dst, size_t n);
+// cv::resize INTER_LINEAR 8UC1 semantics; z planes with the given pitches.
+void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, int64_t splane_pitch,
+                   int64_t sframe_pitch, uint8_t *dst, int dw, int dh, int dstride, int64_t dplane_pitch,
+                   int64_t dframe_pitch, int planes_per_frame, int n_frames);
+
+void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p);
+void launch_seam(hipStream_t s, const BatchDev &b);
+void launch_resolve(hipStream_t s, const BatchDev &b);
+void launch_accumulate(hipStream_t s, const BatchDev &b, int level);
+void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p);
+void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p);
+void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);
+void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p);
+void launch_cand_prefix(hipStream_t s, const BatchDev &b);
+// classify (src/ER.cpp:507-528) over the packed pool of the batch.
+void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong,
+                     CascadeDev weak, int run_cascades);
+
+// Stand-alone classify chain on explicit boxes of one device plane (single-stage API).
+void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int stride, const int32_t *boxes,
+                      int n, double *hist /*n*1024 or null*/, uint8_t *tiles /*n*676 or null*/, uint8_t *cls,
+                      double *s_strong, double *s_weak, CascadeDev strong, CascadeDev weak, int run_cascades);
+
+} // namespace str_er

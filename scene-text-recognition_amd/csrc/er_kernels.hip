@@ -1,0 +1,1053 @@
+// er_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the extremal-region
+// hot path.  One kernel per function of the reference's per-plane loop
+// (src/ER.cpp:50-60); citations are to /root/reference.
+//
+//   k_bgr_to_ycrcb   compute_channels                 src/ER.cpp:114-128
+//   k_resize         cv::resize (pyramid + ARAN)      src/OCR.cpp:401
+//   k_tile_tree      er_tree_extract inside a tile    src/ER.cpp:240-413
+//   k_seam           ... across tile borders
+//   k_resolve / k_accumulate / k_root / k_select / k_kept
+//                    er_accumulate + er_merge + pruning   src/ER.cpp:131-191
+//   k_nms            non_maximum_supression           src/ER.cpp:416-505
+//   k_classify       classify -> make_LBP_hist -> calc_LBP -> ARAN -> CascadeBoost::predict
+//                                                     src/ER.cpp:507-528, 789-845
+//
+// The component tree is NOT computed by the reference's sequential flood.  Each
+// 64x32 tile builds its tree in LDS with a lock-free "connect" (merge of two sorted
+// root paths, LDS compare-and-swap); tile trees are then joined along the seams with
+// the same connect on global memory (agent-scope atomics).  The node set, levels,
+// boxes and areas of a component tree do not depend on the order in which it is
+// built, so the result equals the flood's (tests/ check this bit for bit).
+//
+// Compile with -ffp-contract=off: the resize coefficients must be computed with the
+// same IEEE operations as the host statement of cv::resize.
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <stdint.h>
+
+#include "er_kernels.h"
+
+namespace str_er {
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+#define LD_AGENT(p)      __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ST_AGENT(p, v)   __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LD_WG(p)         __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+__device__ __forceinline__ int find_plane_by_tile(const PlaneDesc *pl, int n, uint32_t tile)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pl[mid].tile_base <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int find_plane_by_pair(const PlaneDesc *pl, int n, uint32_t pair)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pl[mid].pair_base <= pair) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int find_plane_by_cand(const PlaneCtr *ctr, int n, uint32_t c)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ctr[mid].cand_base <= c) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------
+// compute_channels (src/ER.cpp:114-128): OpenCV 8-bit BGR2YCrCb, yuv_shift = 14.
+// One lane converts 4 pixels: 12 bytes in (three dwords), three dwords out.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void ycrcb_px(int B, int G, int R, int &Y, int &Cr, int &Cb)
+{
+    Y  = (1868 * B + 9617 * G + 4899 * R + 8192) >> 14;
+    Cr = ((R - Y) * 11682 + (128 << 14) + 8192) >> 14;
+    Cb = ((B - Y) * 9241 + (128 << 14) + 8192) >> 14;
+    Y  = min(max(Y, 0), 255);
+    Cr = min(max(Cr, 0), 255);
+    Cb = min(max(Cb, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_bgr_to_ycrcb(const uint8_t *__restrict__ bgr, int w, int h,
+                                                      int64_t stride, int64_t frame_pitch,
+                                                      uint8_t *__restrict__ yp, uint8_t *__restrict__ crp,
+                                                      uint8_t *__restrict__ cbp, int dstride,
+                                                      int64_t dst_frame_pitch, int aligned)
+{
+    const int quad = blockIdx.x * blockDim.x + threadIdx.x; // 4-pixel group in the row
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int x = quad * 4;
+    if (x >= w) return;
+    const uint8_t *src = bgr + (size_t)f * frame_pitch + (size_t)y * stride + (size_t)x * 3;
+    const size_t   dof = (size_t)f * dst_frame_pitch + (size_t)y * dstride + x;
+    if (aligned && x + 4 <= w) {
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        const uint32_t a = s32[0], b = s32[1], c = s32[2];
+        // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        int Y[4], Cr[4], Cb[4];
+        ycrcb_px(a & 255, (a >> 8) & 255, (a >> 16) & 255, Y[0], Cr[0], Cb[0]);
+        ycrcb_px(a >> 24, b & 255, (b >> 8) & 255, Y[1], Cr[1], Cb[1]);
+        ycrcb_px((b >> 16) & 255, b >> 24, c & 255, Y[2], Cr[2], Cb[2]);
+        ycrcb_px((c >> 8) & 255, (c >> 16) & 255, c >> 24, Y[3], Cr[3], Cb[3]);
+        *reinterpret_cast<uint32_t *>(yp + dof)  = Y[0] | (Y[1] << 8) | (Y[2] << 16) | (Y[3] << 24);
+        *reinterpret_cast<uint32_t *>(crp + dof) = Cr[0] | (Cr[1] << 8) | (Cr[2] << 16) | (Cr[3] << 24);
+        *reinterpret_cast<uint32_t *>(cbp + dof) = Cb[0] | (Cb[1] << 8) | (Cb[2] << 16) | (Cb[3] << 24);
+    } else {
+        for (int k = 0; k < 4 && x + k < w; ++k) {
+            int Y, Cr, Cb;
+            ycrcb_px(src[3 * k], src[3 * k + 1], src[3 * k + 2], Y, Cr, Cb);
+            yp[dof + k] = (uint8_t)Y; crp[dof + k] = (uint8_t)Cr; cbp[dof + k] = (uint8_t)Cb;
+        }
+    }
+}
+
+void launch_bgr_to_ycrcb(hipStream_t s, const uint8_t *bgr, int w, int h, int64_t stride, int64_t frame_pitch,
+                         int n_frames, uint8_t *y, uint8_t *cr, uint8_t *cb, int dstride, int64_t dst_frame_pitch)
+{
+    const int quads = (w + 3) / 4;
+    const int aligned = ((reinterpret_cast<uintptr_t>(bgr) | (uintptr_t)stride | (uintptr_t)frame_pitch) % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(cr) |
+                          reinterpret_cast<uintptr_t>(cb) | (uintptr_t)dstride | (uintptr_t)dst_frame_pitch) % 4 == 0);
+    dim3 grid((quads + 255) / 256, h, n_frames);
+    hipLaunchKernelGGL(k_bgr_to_ycrcb, grid, dim3(256), 0, s, bgr, w, h, stride, frame_pitch, y, cr, cb, dstride,
+                       dst_frame_pitch, aligned);
+}
+
+__global__ __launch_bounds__(256) void k_invert(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) dst[i] = (uint8_t)(255 - src[i]);
+}
+
+void launch_invert(hipStream_t s, const uint8_t *src, uint8_t *dst, size_t n)
+{
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_invert, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, dst, n);
+}
+
+// ------------------------------------------------------------------------------------
+// cv::resize, INTER_LINEAR, 8UC1 (OpenCV 4.x semantics; see oracle/er_oracle.c for the
+// statement this follows).  `inv` is xor-ed into every tap so an inverted channel is
+// resized exactly like the materialised 255-x plane would be.
+// ------------------------------------------------------------------------------------
+struct ResizeGeom {
+    int    sw, sh, dw, dh;
+    int    mode;          // 0 copy, 1 exact 2x2 area, 2 fixed-point bilinear
+    double scale_x, scale_y;
+};
+
+__device__ __forceinline__ ResizeGeom resize_geom(int sw, int sh, int dw, int dh)
+{
+    ResizeGeom g;
+    g.sw = sw; g.sh = sh; g.dw = dw; g.dh = dh;
+    g.scale_x = 1.0 / ((double)dw / sw);
+    g.scale_y = 1.0 / ((double)dh / sh);
+    if (dw == sw && dh == sh) { g.mode = 0; return g; }
+    const int isx = (int)rint(g.scale_x), isy = (int)rint(g.scale_y);
+    const bool fast = fabs(g.scale_x - isx) < DBL_EPSILON && fabs(g.scale_y - isy) < DBL_EPSILON;
+    g.mode = (fast && isx == 2 && isy == 2) ? 1 : 2;
+    return g;
+}
+
+__device__ __forceinline__ int resize_px(const ResizeGeom &g, const uint8_t *__restrict__ src, int sstride, int inv,
+                                         int dx, int dy)
+{
+    if (g.mode == 0) return src[(size_t)dy * sstride + dx] ^ inv;
+    if (g.mode == 1) {
+        const uint8_t *r0 = src + (size_t)(2 * dy) * sstride + 2 * dx, *r1 = r0 + sstride;
+        return ((r0[0] ^ inv) + (r0[1] ^ inv) + (r1[0] ^ inv) + (r1[1] ^ inv) + 2) >> 2;
+    }
+    float fx = (float)((dx + 0.5) * g.scale_x - 0.5);
+    int   sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= g.sw - 1) { fx = 0.f; sx = g.sw - 1; }
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+    int   sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+    const int y0 = min(max(sy, 0), g.sh - 1), y1 = min(max(sy + 1, 0), g.sh - 1);
+    const int sx1 = (sx + 1 < g.sw) ? sx + 1 : sx;
+    const uint8_t *p0 = src + (size_t)y0 * sstride, *p1 = src + (size_t)y1 * sstride;
+    const int r0 = (p0[sx] ^ inv) * a0 + (p0[sx1] ^ inv) * a1;
+    const int r1 = (p1[sx] ^ inv) * a0 + (p1[sx1] ^ inv) * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return min(max(v, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sw, int sh, int sstride,
+                                                int64_t splane_pitch, int64_t sframe_pitch,
+                                                uint8_t *__restrict__ dst, int dw, int dh, int dstride,
+                                                int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dy = blockIdx.y;
+    if (dx >= dw) return;
+    const int f = blockIdx.z / planes_per_frame, c = blockIdx.z % planes_per_frame;
+    const uint8_t *s = src + (size_t)f * sframe_pitch + (size_t)c * splane_pitch;
+    uint8_t       *d = dst + (size_t)f * dframe_pitch + (size_t)c * dplane_pitch;
+    const ResizeGeom g = resize_geom(sw, sh, dw, dh);
+    d[(size_t)dy * dstride + dx] = (uint8_t)resize_px(g, s, sstride, 0, dx, dy);
+}
+
+void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, int64_t splane_pitch,
+                   int64_t sframe_pitch, uint8_t *dst, int dw, int dh, int dstride, int64_t dplane_pitch,
+                   int64_t dframe_pitch, int planes_per_frame, int n_frames)
+{
+    dim3 grid((dw + 255) / 256, dh, planes_per_frame * n_frames);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, sw, sh, sstride, splane_pitch, sframe_pitch, dst, dw, dh,
+                       dstride, dplane_pitch, dframe_pitch, planes_per_frame);
+}
+
+// ------------------------------------------------------------------------------------
+// Component tree, part 1: one workgroup builds the tree of one 64x32 tile in LDS.
+//
+// LDS state per pixel p:  s_lev[p]  quantised level (0xFFFF = wall: outside the image or
+//                                   at the sentinel level the reference never floods)
+//                         s_par[p]  NONE, or (level of q << 16 | q): q is a pixel of the
+//                                   same node (same level, q < p) or of the parent node.
+// A pixel whose s_par is NONE or points to a higher level is the "level root" of its
+// node; the level root of node (t, C) ends up being the smallest-index pixel of level
+// t in C, which is also the node's canonical key.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t WALL = 0xFFFFu;
+
+// Join pixels a and b (4-neighbours, both not walls): afterwards the root paths of a
+// and b are merged into one path sorted by level.  Lock-free; every change is one CAS
+// on the parent word of a level root, conditional on the value that was read.
+__device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_lev, uint32_t a, uint32_t b)
+{
+    uint32_t la = s_lev[a], lb = s_lev[b];
+    for (;;) {
+        uint32_t wa = LD_WG(&s_par[a]);
+        while (wa != NONE && (wa >> 16) == la) { a = wa & 0xFFFFu; wa = LD_WG(&s_par[a]); }
+        uint32_t wb = LD_WG(&s_par[b]);
+        while (wb != NONE && (wb >> 16) == lb) { b = wb & 0xFFFFu; wb = LD_WG(&s_par[b]); }
+        if (a == b) return;
+        if (la > lb || (la == lb && a < b)) {
+            uint32_t t;
+            t = a; a = b; b = t;
+            t = la; la = lb; lb = t;
+            t = wa; wa = wb; wb = t;
+        }
+        // now a must end up below b: either in the same node (equal levels, a > b) or
+        // as a descendant.  If a's current parent is higher than b, b slots in between.
+        if (la == lb || wa == NONE || (wa >> 16) > lb) {
+            const uint32_t old = atomicCAS(&s_par[a], wa, (lb << 16) | b);
+            if (old != wa) continue;   // somebody else moved a: re-read
+            if (wa == NONE) return;    // a was a tree root: nothing left to merge
+            a = wa & 0xFFFFu;          // a's former parent still has to be merged with b
+            la = wa >> 16;
+        } else {
+            a = wa & 0xFFFFu;          // climb
+            la = wa >> 16;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectParams prm)
+{
+    __shared__ unsigned long long s_col[TILE_PX];
+    __shared__ uint32_t s_par[TILE_PX];
+    __shared__ uint32_t s_cnt[TILE_PX];
+    __shared__ uint32_t s_row[TILE_PX];
+    __shared__ uint16_t s_lev[TILE_PX];
+    __shared__ uint16_t s_nid[TILE_PX];
+    __shared__ uint32_t s_wsum[TILE_THREADS / 64];
+    __shared__ uint32_t s_base, s_walls;
+
+    const int       tid = threadIdx.x;
+    const int       pi = find_plane_by_tile(b.planes, b.n_planes, blockIdx.x);
+    const PlaneDesc pd = b.planes[pi];
+    const uint32_t  tl = blockIdx.x - pd.tile_base;
+    const int       tx = tl % pd.tiles_x, ty = tl / pd.tiles_x;
+    const int       ox = tx * TILE_W, oy = ty * TILE_H;
+    const int       ly = tid >> 3, lx = (tid & 7) * TILE_PPT;
+    const uint32_t  p0 = (uint32_t)tid * TILE_PPT;
+    const int       gx = ox + lx, gy = oy + ly;
+
+    if (tid == 0) s_walls = 0;
+
+    // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
+    uint32_t lev[TILE_PPT];
+    {
+        uint8_t px[TILE_PPT];
+        int     nvalid = 0;
+        if (gy < pd.h && gx < pd.w) {
+            const uint8_t *row = pd.pix + (size_t)gy * pd.stride + gx;
+            nvalid = min(TILE_PPT, pd.w - gx);
+            if (nvalid == TILE_PPT && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(row);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { px[k] = (v.x >> (8 * k)) & 255; px[4 + k] = (v.y >> (8 * k)) & 255; }
+            } else {
+                for (int k = 0; k < nvalid; ++k) px[k] = row[k];
+            }
+        }
+        uint32_t walls = 0;
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k) {
+            uint32_t q = WALL;
+            if (k < nvalid) {
+                q = (uint32_t)__float2int_rn((float)(px[k] ^ pd.invert) * prm.qscale);
+                if (q >= (uint32_t)prm.hi) { q = WALL; ++walls; }
+            }
+            lev[k] = q;
+            s_lev[p0 + k] = (uint16_t)q;
+            s_par[p0 + k] = NONE;
+            s_cnt[p0 + k] = 0;
+            s_row[p0 + k] = 0;
+            s_col[p0 + k] = 0ull;
+        }
+        __syncthreads();
+        if (walls) atomicAdd(&s_walls, walls);
+    }
+
+    // ---- connect every in-tile edge (right, bottom) -----------------------------------
+#pragma unroll 1
+    for (int k = 0; k < TILE_PPT; ++k) {
+        if (lev[k] == WALL) continue;
+        const uint32_t p = p0 + k;
+        if (lx + k + 1 < TILE_W && s_lev[p + 1] != WALL) tile_connect(s_par, s_lev, p, p + 1);
+        if (ly + 1 < TILE_H && s_lev[p + TILE_W] != WALL) tile_connect(s_par, s_lev, p, p + TILE_W);
+    }
+    __syncthreads();
+
+    // ---- flatten: every pixel points straight at its level root ----------------------
+    uint32_t rootmask = 0;
+#pragma unroll 1
+    for (int k = 0; k < TILE_PPT; ++k) {
+        if (lev[k] == WALL) continue;
+        const uint32_t p = p0 + k, l = lev[k];
+        uint32_t w = LD_WG(&s_par[p]);
+        if (w != NONE && (w >> 16) == l) {
+            uint32_t r = w & 0xFFFFu;
+            for (;;) {
+                const uint32_t w2 = LD_WG(&s_par[r]);
+                if (w2 == NONE || (w2 >> 16) != l) break;
+                r = w2 & 0xFFFFu;
+            }
+            s_par[p] = (l << 16) | r;
+        } else {
+            rootmask |= 1u << k;
+        }
+    }
+    __syncthreads();
+    // level roots: make the parent word point at the parent node's level root
+#pragma unroll 1
+    for (int k = 0; k < TILE_PPT; ++k) {
+        if (!((rootmask >> k) & 1)) continue;
+        const uint32_t p = p0 + k;
+        const uint32_t w = s_par[p];
+        if (w == NONE) continue;
+        uint32_t       q = w & 0xFFFFu;
+        const uint32_t wq = LD_WG(&s_par[q]);
+        if (wq != NONE && (wq >> 16) == (w >> 16)) q = wq & 0xFFFFu;
+        s_par[p] = (w & 0xFFFF0000u) | q;
+    }
+
+    // ---- dense ids for the level roots (pixel order), one allocation per tile --------
+    const uint32_t mycount = __popc(rootmask);
+    const uint32_t incl = wave_incl_scan(mycount);
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < TILE_THREADS / 64; ++i) {
+        if (i < (tid >> 6)) wave_off += s_wsum[i];
+        total += s_wsum[i];
+    }
+    if (tid == 0) {
+        s_base = atomicAdd(&b.ctr[pi].n_nodes, total);
+        if (s_walls) atomicAdd(&b.ctr[pi].n_walls, s_walls);
+    }
+    {
+        uint32_t id = wave_off + incl - mycount;
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k)
+            if ((rootmask >> k) & 1) s_nid[p0 + k] = (uint16_t)id++;
+    }
+
+    // ---- own statistics of every node: pixel count, row set, column set ---------------
+#pragma unroll 1
+    for (int k = 0; k < TILE_PPT; ++k) {
+        if (lev[k] == WALL) continue;
+        const uint32_t p = p0 + k;
+        const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[p] & 0xFFFFu);
+        atomicAdd(&s_cnt[r], 1u);
+        atomicOr(&s_row[r], 1u << ly);
+        atomicOr(&s_col[r], 1ull << (lx + k));
+    }
+    __syncthreads();
+
+    // ---- export the nodes ----------------------------------------------------------------
+    const uint32_t base = s_base;
+    const size_t   nb = pd.node_base;
+#pragma unroll 1
+    for (int k = 0; k < TILE_PPT; ++k) {
+        if (!((rootmask >> k) & 1)) continue;
+        const uint32_t p = p0 + k;
+        const size_t   id = nb + base + s_nid[p];
+        const uint32_t w = s_par[p];
+        b.na.par[id] = (w == NONE) ? NONE : base + s_nid[w & 0xFFFFu];
+        b.na.lvl[id] = (uint8_t)lev[k];
+        b.na.dead[id] = 0;
+        b.na.cnt[id] = s_cnt[p];
+        b.na.nod[id] = 1;
+        const unsigned long long cm = s_col[p];
+        const uint32_t           rm = s_row[p];
+        b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
+        b.na.x1[id] = ox + 63 - __clzll((long long)cm);
+        b.na.y0[id] = oy + __ffs((int)rm) - 1;
+        b.na.y1[id] = oy + 31 - __clz((int)rm);
+        b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+    }
+
+    // ---- node id of every tile-border pixel, for the seam pass ---------------------------
+    // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
+    // of w ids (pixel row j*TH-1, then j*TH); then for every vertical boundary i two
+    // columns of h ids (pixel column i*TW-1, then i*TW).
+    uint32_t *seam = b.seam + pd.seam_base;
+    const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
+    for (int i = tid; i < 2 * TILE_W + 2 * TILE_H; i += TILE_THREADS) {
+        int      sx, sy;
+        uint32_t *dst = nullptr;
+        if (i < TILE_W) {                       // top row -> lower side of boundary ty
+            sx = i; sy = 0;
+            if (ty > 0 && ox + sx < pd.w) dst = seam + ((size_t)(ty - 1) * 2 + 1) * pd.w + ox + sx;
+        } else if (i < 2 * TILE_W) {            // bottom row -> upper side of boundary ty+1
+            sx = i - TILE_W; sy = TILE_H - 1;
+            if (ty + 1 < pd.tiles_y && ox + sx < pd.w) dst = seam + ((size_t)ty * 2) * pd.w + ox + sx;
+        } else if (i < 2 * TILE_W + TILE_H) {   // left column -> right side of boundary tx
+            sx = 0; sy = i - 2 * TILE_W;
+            if (tx > 0 && oy + sy < pd.h) dst = seam + voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + oy + sy;
+        } else {                                // right column -> left side of boundary tx+1
+            sx = TILE_W - 1; sy = i - 2 * TILE_W - TILE_H;
+            if (tx + 1 < pd.tiles_x && oy + sy < pd.h) dst = seam + voff + ((size_t)tx * 2) * pd.h + oy + sy;
+        }
+        if (!dst) continue;
+        const uint32_t p = sy * TILE_W + sx;
+        const uint32_t l = s_lev[p];
+        uint32_t       id = NONE;
+        if (l != WALL) {
+            const uint32_t w = s_par[p];
+            const uint32_t r = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : p;
+            id = base + s_nid[r];
+        }
+        *dst = id;
+    }
+
+    // ---- the flood's start pixel: pixel 0, else pixel 1, else pixel w --------
+    if (tl == 0 && tid == 0) {
+        int sp = -1;
+        if (s_lev[0] != WALL) sp = 0;
+        else if (pd.w > 1 && s_lev[1] != WALL) sp = 1;
+        else if (pd.h > 1 && s_lev[TILE_W] != WALL) sp = TILE_W;
+        uint32_t id = NONE;
+        if (sp >= 0) {
+            const uint32_t l = s_lev[sp], w = s_par[sp];
+            const uint32_t r = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : (uint32_t)sp;
+            id = base + s_nid[r];
+        }
+        b.ctr[pi].start_node = id;
+    }
+}
+
+void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p)
+{
+    if (!b.n_tiles) return;
+    hipLaunchKernelGGL(k_tile_tree, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
+}
+
+// ------------------------------------------------------------------------------------
+// Component tree, part 2: join the tile trees along every seam.  Same connect as in
+// the tile kernel, on the global node arrays, with agent-scope atomics (the per-XCD L2s
+// are not coherent with each other, so every access to `par` that may race goes through
+// an agent-scope atomic).  Levels are immutable here and read with plain loads.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, uint32_t a, uint32_t b)
+{
+    uint32_t la = lvl[a], lb = lvl[b];
+    for (;;) {
+        uint32_t wa = LD_AGENT(&par[a]);
+        while (wa != NONE && lvl[wa] == la) { a = wa; wa = LD_AGENT(&par[a]); }
+        uint32_t wb = LD_AGENT(&par[b]);
+        while (wb != NONE && lvl[wb] == lb) { b = wb; wb = LD_AGENT(&par[b]); }
+        if (a == b) return;
+        if (la > lb || (la == lb && a < b)) {
+            uint32_t t;
+            t = a; a = b; b = t;
+            t = la; la = lb; lb = t;
+            t = wa; wa = wb; wb = t;
+        }
+        if (la == lb || wa == NONE || lvl[wa] > lb) {
+            const uint32_t old = atomicCAS(&par[a], wa, b);
+            if (old != wa) continue;
+            if (wa == NONE) return;
+            a = wa;
+            la = lvl[a];
+        } else {
+            a = wa;
+            la = lvl[a];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seam(BatchDev b)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       na = NONE, nbn = NONE;
+    int            pi = 0;
+    if (g < b.n_pairs) {
+        pi = find_plane_by_pair(b.planes, b.n_planes, g);
+        const PlaneDesc &pd = b.planes[pi];
+        const uint32_t   i = g - pd.pair_base;
+        const uint32_t  *seam = b.seam + pd.seam_base;
+        if (i < pd.n_hpairs) {
+            const uint32_t j = i / pd.w, x = i - j * pd.w;
+            na = seam[((size_t)j * 2) * pd.w + x];
+            nbn = seam[((size_t)j * 2 + 1) * pd.w + x];
+        } else {
+            const uint32_t i2 = i - pd.n_hpairs;
+            const uint32_t k = i2 / pd.h, y = i2 - k * pd.h;
+            const size_t   voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
+            na = seam[voff + ((size_t)k * 2) * pd.h + y];
+            nbn = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
+        }
+    }
+    // neighbouring lanes very often carry the same pair (a flat region crossing the seam):
+    // only the first lane of a run does the work.
+    const uint32_t pa = __shfl_up(na, 1), pb = __shfl_up(nbn, 1);
+    const int      pp = __shfl_up(pi, 1);
+    const bool     dup = (threadIdx.x & 63) != 0 && pa == na && pb == nbn && pp == pi;
+    if (na == NONE || nbn == NONE || dup) return;
+    const size_t nb = b.planes[pi].node_base;
+    node_connect(b.na.par + nb, b.na.lvl + nb, na, nbn);
+}
+
+void launch_seam(hipStream_t s, const BatchDev &b)
+{
+    if (!b.n_pairs) return;
+    hipLaunchKernelGGL(k_seam, dim3((b.n_pairs + 255) / 256), dim3(256), 0, s, b);
+}
+
+// ------------------------------------------------------------------------------------
+// Part 3: per-node passes.  Grid = (blocks, planes); lanes stride over the plane's nodes.
+// ------------------------------------------------------------------------------------
+constexpr int NODE_BLOCKS = 96;  // blocks per plane for the per-node passes
+
+// Nodes that were unified into another node of the same level hand their own
+// statistics to the surviving level root; surviving nodes get a canonical parent.
+__global__ __launch_bounds__(256) void k_resolve(BatchDev b)
+{
+    const int       pi = blockIdx.y;
+    const uint32_t  n = b.ctr[pi].n_nodes;
+    const size_t    nb = b.planes[pi].node_base;
+    uint32_t       *par = b.na.par + nb;
+    const uint8_t  *lvl = b.na.lvl + nb;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        const uint32_t w = LD_AGENT(&par[x]);
+        const uint32_t l = lvl[x];
+        if (w != NONE && lvl[w] == l) {
+            uint32_t r = w;
+            for (;;) {
+                const uint32_t w2 = LD_AGENT(&par[r]);
+                if (w2 == NONE || lvl[w2] != l) break;
+                r = w2;
+            }
+            b.na.dead[nb + x] = 1;
+            atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
+            atomicMin(&b.na.x0[nb + r], b.na.x0[nb + x]);
+            atomicMin(&b.na.y0[nb + r], b.na.y0[nb + x]);
+            atomicMax(&b.na.x1[nb + r], b.na.x1[nb + x]);
+            atomicMax(&b.na.y1[nb + r], b.na.y1[nb + x]);
+            atomicMin(&b.na.key[nb + r], b.na.key[nb + x]);
+        } else if (w != NONE) {
+            uint32_t q = w;
+            const uint32_t lq = lvl[q];
+            for (;;) {
+                const uint32_t w2 = LD_AGENT(&par[q]);
+                if (w2 == NONE || lvl[w2] != lq) break;
+                q = w2;
+            }
+            if (q != w) ST_AGENT(&par[x], q);
+        }
+    }
+}
+
+void launch_resolve(hipStream_t s, const BatchDev &b)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_resolve, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b);
+}
+
+// er_merge's accumulation (src/ER.cpp:153-165), one level per launch: every live node
+// of level t adds its (now final) totals to its parent.  Children are always at lower
+// levels than their parent, so launching t = 0,1,2,... in order is a topological order.
+__global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
+{
+    const int      pi = blockIdx.y;
+    const uint32_t n = b.ctr[pi].n_nodes;
+    const size_t   nb = b.planes[pi].node_base;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        if (b.na.lvl[nb + x] != level || b.na.dead[nb + x]) continue;
+        const uint32_t p = b.na.par[nb + x];
+        if (p == NONE) continue;
+        atomicAdd(&b.na.cnt[nb + p], b.na.cnt[nb + x]);
+        atomicAdd(&b.na.nod[nb + p], b.na.nod[nb + x]);
+        atomicMin(&b.na.x0[nb + p], b.na.x0[nb + x]);
+        atomicMin(&b.na.y0[nb + p], b.na.y0[nb + x]);
+        atomicMax(&b.na.x1[nb + p], b.na.x1[nb + x]);
+        atomicMax(&b.na.y1[nb + p], b.na.y1[nb + x]);
+    }
+}
+
+void launch_accumulate(hipStream_t s, const BatchDev &b, int level)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b, level);
+}
+
+// Root of the tree that holds the flood's start pixel (er_stack.back(), src/ER.cpp:346).
+// If the start pixel and its two candidates are all at the sentinel level the reference
+// returns one childless node {level hi, area 2, bound (0,0,1,1)}.
+__global__ void k_root(BatchDev b, DetectParams prm)
+{
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= b.n_planes) return;
+    PlaneCtr       &c = b.ctr[pi];
+    const PlaneDesc &pd = b.planes[pi];
+    const size_t    nb = pd.node_base;
+    const uint32_t *par = b.na.par + nb;
+    const uint8_t  *lvl = b.na.lvl + nb;
+    uint32_t        x = c.start_node;
+    if (x == NONE) {
+        const size_t kb = pd.kept_base;
+        b.ka.node[kb] = NONE;
+        b.ka.key[kb] = 0;
+        b.ka.area[kb] = 2;
+        b.ka.parent[kb] = 0;
+        b.ka.box[4 * kb + 0] = 0; b.ka.box[4 * kb + 1] = 0; b.ka.box[4 * kb + 2] = 1; b.ka.box[4 * kb + 3] = 1;
+        b.ka.level[kb] = (uint8_t)prm.hi;
+        c.root_node = NONE;
+        c.n_kept = 1;
+        c.root_slot = 0;
+        c.n_created = 1;
+        c.max_level = prm.hi;
+        return;
+    }
+    for (;;) { const uint32_t w = par[x]; if (w == NONE || lvl[w] != lvl[x]) break; x = w; }
+    for (;;) { const uint32_t w = par[x]; if (w == NONE) break; x = w; }
+    c.root_node = x;
+    c.n_created = b.na.nod[nb + x];
+    c.max_level = lvl[x];
+}
+
+void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_root, dim3((b.n_planes + 63) / 64), dim3(64), 0, s, b, p);
+}
+
+// Pruning (src/ER.cpp:167-180): a node survives iff area > MIN_AREA (area = pixels +
+// nodes of the subtree, because ER::ER starts area at 1), plus the root.  Nodes of other
+// trees (regions sealed off by sentinel-level pixels) were never visited by the flood.
+__global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
+{
+    const int       pi = blockIdx.y;
+    PlaneCtr       &c = b.ctr[pi];
+    const uint32_t  root = c.root_node;
+    if (root == NONE) return;
+    const uint32_t  n = c.n_nodes;
+    const PlaneDesc &pd = b.planes[pi];
+    const size_t    nb = pd.node_base;
+    const uint32_t *par = b.na.par + nb;
+    const bool      walls = c.n_walls != 0;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        if (b.na.dead[nb + x]) continue;
+        if (x != root) {
+            const uint32_t area = b.na.cnt[nb + x] + b.na.nod[nb + x];
+            if ((int64_t)area <= (int64_t)prm.min_area) continue;
+            if (walls) {
+                uint32_t y = x;
+                for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = w; }
+                if (y != root) continue;
+            }
+        }
+        const uint32_t slot = atomicAdd(&c.n_kept, 1u);
+        if (slot < (uint32_t)prm.kept_cap) {
+            b.ka.node[pd.kept_base + slot] = x;
+            b.na.kmap[nb + x] = slot;
+        } else {
+            atomicOr(&c.overflow, 1u);
+        }
+    }
+}
+
+void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_select, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b, p);
+}
+
+// Kept-node records (flat form of struct ER, inc/ER.h:42-80).
+__global__ __launch_bounds__(256) void k_kept(BatchDev b, DetectParams prm)
+{
+    const int       pi = blockIdx.y;
+    PlaneCtr       &c = b.ctr[pi];
+    if (c.root_node == NONE) return;
+    const uint32_t  n = min(c.n_kept, (uint32_t)prm.kept_cap);
+    const PlaneDesc &pd = b.planes[pi];
+    const size_t    nb = pd.node_base, kb = pd.kept_base;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        const uint32_t x = b.ka.node[kb + s];
+        const uint32_t p = b.na.par[nb + x];
+        b.ka.key[kb + s] = b.na.key[nb + x];
+        b.ka.area[kb + s] = b.na.cnt[nb + x] + b.na.nod[nb + x];
+        b.ka.level[kb + s] = b.na.lvl[nb + x];
+        const uint32_t x0 = b.na.x0[nb + x], y0 = b.na.y0[nb + x];
+        b.ka.box[4 * (kb + s) + 0] = (uint16_t)x0;
+        b.ka.box[4 * (kb + s) + 1] = (uint16_t)y0;
+        b.ka.box[4 * (kb + s) + 2] = (uint16_t)(b.na.x1[nb + x] - x0 + 1);
+        b.ka.box[4 * (kb + s) + 3] = (uint16_t)(b.na.y1[nb + x] - y0 + 1);
+        if (x == c.root_node) {
+            b.ka.parent[kb + s] = (int32_t)s;
+            c.root_slot = s;
+        } else {
+            b.ka.parent[kb + s] = (int32_t)b.na.kmap[nb + p];
+        }
+    }
+}
+
+void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_kept, dim3(16, b.n_planes), dim3(256), 0, s, b, p);
+}
+
+// ------------------------------------------------------------------------------------
+// non_maximum_supression (src/ER.cpp:416-505), one workgroup per plane.
+//
+// The reference walks the tree in post-order and lets every not-yet-claimed node X
+// climb while bboxarea(X)/bboxarea(parent) > OVERLAP_COEF and the parent is unclaimed.
+// Equivalent bottom-up form: start(P) = start(c) for the child c whose chain passes the
+// overlap test on P, or P itself if no child chain does.  If two or more child chains
+// pass, the reference's answer depends on its flood's sibling order; here
+// the child with the extreme key wins and the plane is flagged (n_amb).
+// ------------------------------------------------------------------------------------
+constexpr int NMS_THREADS = 512;
+
+__global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm)
+{
+    __shared__ uint32_t s_npool;
+    const int        pi = blockIdx.x;
+    PlaneCtr        &c = b.ctr[pi];
+    const PlaneDesc &pd = b.planes[pi];
+    const size_t     kb = pd.kept_base, pb = pd.pool_base;
+    const uint32_t   K = min(c.n_kept, (uint32_t)prm.kept_cap);
+    const int        tid = threadIdx.x;
+    const uint8_t   *klev = b.ka.level + kb;
+    const int32_t   *kpar = b.ka.parent + kb;
+    const uint16_t  *kbox = b.ka.box + 4 * kb;
+    uint32_t        *kstart = b.ka.start + kb;
+    uint32_t        *kncand = b.ka.ncand + kb;
+    unsigned long long *kbest = b.ka.best + kb;
+    const uint32_t  *kkey = b.ka.key + kb;
+    const int        maxl = (int)c.max_level;
+    const uint32_t   root = c.root_slot;
+
+    for (uint32_t i = tid; i < K; i += NMS_THREADS) { kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull; }
+    if (tid == 0) s_npool = 0;
+    __syncthreads();
+
+    for (int t = 0; t <= maxl; ++t) {
+        // settle the nodes of level t: all their children (lower levels) have proposed
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            if (klev[i] != t) continue;
+            const uint32_t nc = LD_AGENT(&kncand[i]);
+            if (nc) {
+                const uint32_t child = (uint32_t)(LD_AGENT(&kbest[i]) & 0xFFFFFFFFull);
+                kstart[i] = kstart[child];
+                if (nc > 1) atomicAdd(&c.n_amb, 1u);
+            }
+        }
+        __syncthreads();
+        // propose to the parent
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            if (klev[i] != t || i == root) continue;
+            const uint32_t P = (uint32_t)kpar[i], s = kstart[i];
+            const int as = (int)kbox[4 * s + 2] * (int)kbox[4 * s + 3];
+            const int ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
+            if ((double)as / (double)ap > prm.overlap_coef) {
+                atomicAdd(&kncand[P], 1u);
+                const uint32_t ord = prm.sibling_order == 0 ? ~kkey[i] : kkey[i];
+                atomicMin(&kbest[P], ((unsigned long long)ord << 32) | i);
+            }
+        }
+        __syncthreads();
+    }
+
+    // evaluate every chain from its start (src/ER.cpp:464-497)
+    const int T = prm.stability_t;
+    for (uint32_t X = tid; X < K; X += NMS_THREADS) {
+        if (kstart[X] != X) continue;
+        int      len = 1;
+        uint32_t p = X;
+        while (p != root && kstart[kpar[p]] == X) { p = (uint32_t)kpar[p]; ++len; }
+        if (len < 1 + T) continue;
+        uint32_t trail = X, lead = X;
+        for (int i = 0; i < T; ++i) lead = (uint32_t)kpar[lead];
+        uint32_t best = X;
+        double   best_st = 0;
+        int      best_a = 0;
+        for (int i = 0; i < len - T; ++i) {
+            const int a = (int)kbox[4 * trail + 2] * (int)kbox[4 * trail + 3];
+            const int bb = (int)kbox[4 * lead + 2] * (int)kbox[4 * lead + 3];
+            const double st = (double)a / (double)(bb - a);   // 0 denominator -> +inf, as in the reference
+            if (i == 0 || st > best_st) { best = trail; best_st = st; best_a = a; }
+            else if (st == best_st && a < best_a) { best = trail; best_a = a; }
+            trail = (uint32_t)kpar[trail];
+            lead = (uint32_t)kpar[lead];
+        }
+        const int    bw = kbox[4 * best + 2], bh = kbox[4 * best + 3];
+        const double ar = (double)bw / (double)bh;
+        const int    area = (int)b.ka.area[kb + best];
+        if (ar < 2.0 && ar > 0.10 && area < prm.max_area && area > prm.min_area && bh < pd.h * 0.8 && bw < pd.w * 0.8) {
+            const uint32_t slot = atomicAdd(&s_npool, 1u);
+            if (slot < (uint32_t)prm.pool_cap) b.pool_tmp[pb + slot] = best;
+        }
+    }
+    __syncthreads();
+    uint32_t np = s_npool;
+    if (np > (uint32_t)prm.pool_cap) {
+        if (tid == 0) atomicOr(&c.overflow, 2u);
+        np = prm.pool_cap;
+    }
+    // order the pool by key (keys are unique inside a plane)
+    for (uint32_t i = tid; i < np; i += NMS_THREADS) {
+        const uint32_t me = b.pool_tmp[pb + i], mk = kkey[me];
+        uint32_t       rank = 0;
+        for (uint32_t j = 0; j < np; ++j) rank += kkey[b.pool_tmp[pb + j]] < mk;
+        b.pool[pb + rank] = me;
+    }
+    if (tid == 0) c.n_pool = np;
+}
+
+void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p);
+}
+
+// exclusive prefix of the pool sizes: where every plane's candidates go in the packed array
+__global__ void k_cand_prefix(BatchDev b)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < b.n_planes; ++i) { b.ctr[i].cand_base = acc; acc += b.ctr[i].n_pool; }
+        *b.total_cands = acc;
+    }
+}
+
+void launch_cand_prefix(hipStream_t s, const BatchDev &b)
+{
+    hipLaunchKernelGGL(k_cand_prefix, dim3(1), dim3(64), 0, s, b);
+}
+
+// ------------------------------------------------------------------------------------
+// classify (src/ER.cpp:507-528): ARAN(26) -> Mean-LBP 24x24 -> 2x2x256 histogram ->
+// strong cascade, then weak cascade if rejected.  One workgroup per candidate.
+// ------------------------------------------------------------------------------------
+constexpr int CLS_THREADS = 256;
+constexpr int CLS_CHUNK = 1024;
+
+struct ClsShared {
+    uint32_t hist[1024];
+    double   vals[CLS_CHUNK];
+    double   acc;
+    uint8_t  tile[26 * 26 + 4];
+};
+
+// make_LBP_hist (src/ER.cpp:789-816) + calc_LBP (:819-845) + OCR::ARAN (src/OCR.cpp:394-430)
+__device__ void block_lbp_hist(ClsShared &sh, const uint8_t *__restrict__ pix, int stride, int inv, int bx, int by,
+                               int bw, int bh)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 1024; i += CLS_THREADS) sh.hist[i] = 0;
+    for (int i = tid; i < 26 * 26; i += CLS_THREADS) sh.tile[i] = 0;
+    __syncthreads();
+    const double R1 = (bw > bh) ? (double)bh / bw : (double)bw / bh;
+    const int    k = (int)(26.0 * sqrt(R1));   // (int)(L * pow(R1, 0.5))
+    const int    dw = (bw > bh) ? 26 : k, dh = (bw > bh) ? k : 26;
+    if (dw > 0 && dh > 0) {
+        const int offy = (dw > dh) ? (26 - dh) / 2 : 0;
+        const int offx = (dw > dh) ? 0 : (26 - dw) / 2;
+        const ResizeGeom g = resize_geom(bw, bh, dw, dh);
+        const uint8_t *roi = pix + (size_t)by * stride + bx;
+        for (int i = tid; i < dw * dh; i += CLS_THREADS) {
+            const int dy = i / dw, dx = i - dy * dw;
+            sh.tile[(dy + offy) * 26 + dx + offx] = (uint8_t)resize_px(g, roi, stride, inv, dx, dy);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 24 * 24; idx += CLS_THREADS) {
+        const int i = idx / 24, j = idx - i * 24;
+        const int cpos = (i + 1) * 26 + (j + 1);
+        // the reference indexes the 26-wide tile with a row stride of 24
+        const int v0 = sh.tile[cpos - 25], v1 = sh.tile[cpos - 24], v2 = sh.tile[cpos - 23], v3 = sh.tile[cpos + 1];
+        const int v4 = sh.tile[cpos + 25], v5 = sh.tile[cpos + 24], v6 = sh.tile[cpos + 23], v7 = sh.tile[cpos - 1];
+        const int sum = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;   // v > sum/8.0  <=>  8v > sum
+        const int code = (8 * v0 > sum) | ((8 * v1 > sum) << 1) | ((8 * v2 > sum) << 2) | ((8 * v3 > sum) << 3) |
+                         ((8 * v4 > sum) << 4) | ((8 * v5 > sum) << 5) | ((8 * v6 > sum) << 6) | ((8 * v7 > sum) << 7);
+        atomicAdd(&sh.hist[(i / 12) * 512 + (j / 12) * 256 + code], 1u);
+    }
+    __syncthreads();
+}
+
+// CascadeBoost::predict (src/adaboost.cpp:507-542).  Stump outputs are produced by all
+// lanes; the stage sum is formed by one lane in file order so it is bit-identical to the
+// reference's sequential `score_stage += ...`.
+__device__ double block_cascade(ClsShared &sh, const CascadeDev &c)
+{
+    const int tid = threadIdx.x;
+    int       off = 0;
+    double    score = 0;
+    for (int s = 0; s < c.n_stages; ++s) {
+        const int n = c.stage_n[s];
+        if (tid == 0) sh.acc = 0;
+        for (int base = 0; base < n; base += CLS_CHUNK) {
+            const int m = min(CLS_CHUNK, n - base);
+            for (int j = tid; j < m; j += CLS_THREADS) {
+                const int st = off + base + j;
+                double    v = 0;
+                if (st < c.n_stumps) {
+                    const double fv = (double)sh.hist[c.dim[st]], d = c.dir[st];
+                    v = (fv * d < c.thr[st] * d) ? c.vp[st] : c.vn[st];
+                }
+                sh.vals[j] = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double a = sh.acc;
+                const int mm = min(m, max(0, c.n_stumps - off - base));
+                for (int j = 0; j < mm; ++j) a += sh.vals[j];
+                sh.acc = a;
+            }
+            __syncthreads();
+        }
+        score = sh.acc;
+        __syncthreads();
+        if (score < (double)c.stage_thresh[s]) return -DBL_MAX;
+        off += n;
+    }
+    return score;
+}
+
+__global__ __launch_bounds__(CLS_THREADS) void k_classify(BatchDev b, DetectParams prm, CascadeDev strong,
+                                                          CascadeDev weak, int run_cascades)
+{
+    __shared__ ClsShared sh;
+    const uint32_t total = *b.total_cands;
+    for (uint32_t cidx = blockIdx.x; cidx < total; cidx += gridDim.x) {
+        const int        pi = find_plane_by_cand(b.ctr, b.n_planes, cidx);
+        const PlaneDesc &pd = b.planes[pi];
+        const uint32_t   i = cidx - b.ctr[pi].cand_base;
+        const uint32_t   slot = b.pool[pd.pool_base + i];
+        const size_t     ks = pd.kept_base + slot;
+        const int bx = b.ka.box[4 * ks], by = b.ka.box[4 * ks + 1], bw = b.ka.box[4 * ks + 2], bh = b.ka.box[4 * ks + 3];
+        int    cls = 0;
+        double ss = -DBL_MAX, sw = 0;
+        if (run_cascades) {
+            block_lbp_hist(sh, pd.pix, pd.stride, pd.invert, bx, by, bw, bh);
+            ss = block_cascade(sh, strong);
+            if (ss > -DBL_MAX) cls = 1;
+            else {
+                sw = block_cascade(sh, weak);
+                if (sw > -DBL_MAX) cls = 2;
+            }
+        }
+        if (threadIdx.x == 0) {
+            CandRec r;
+            r.frame = pd.frame; r.ch = pd.ch; r.pyr = pd.pyr; r.level = b.ka.level[ks]; r.cls = (uint8_t)cls;
+            r.x = (uint16_t)bx; r.y = (uint16_t)by; r.w = (uint16_t)bw; r.h = (uint16_t)bh;
+            r.area = b.ka.area[ks]; r.key = b.ka.key[ks]; r.node = (int32_t)slot; r.plane = (uint32_t)pi;
+            r.score_strong = ss; r.score_weak = sw;
+            b.cands[cidx] = r;
+            if (cls == 1) atomicAdd(&b.ctr[pi].n_strong, 1u);
+            if (cls == 2) atomicAdd(&b.ctr[pi].n_weak, 1u);
+        }
+        __syncthreads();
+    }
+}
+
+void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong, CascadeDev weak,
+                     int run_cascades)
+{
+    hipLaunchKernelGGL(k_classify, dim3(2048), dim3(CLS_THREADS), 0, s, b, p, strong, weak, run_cascades);
+}
+
+// Single-stage entry points (str_er_classify_boxes / str_er_lbp_hist): explicit boxes.
+__global__ __launch_bounds__(CLS_THREADS) void k_lbp_boxes(const uint8_t *__restrict__ plane, int w, int h, int stride,
+                                                           const int32_t *__restrict__ boxes, int n, double *hist,
+                                                           uint8_t *tiles, uint8_t *cls_out, double *s_strong,
+                                                           double *s_weak, CascadeDev strong, CascadeDev weak,
+                                                           int run_cascades)
+{
+    __shared__ ClsShared sh;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int bx = boxes[4 * i], by = boxes[4 * i + 1], bw = boxes[4 * i + 2], bh = boxes[4 * i + 3];
+        block_lbp_hist(sh, plane, stride, 0, bx, by, bw, bh);
+        if (hist)
+            for (int k = threadIdx.x; k < 1024; k += CLS_THREADS) hist[(size_t)i * 1024 + k] = (double)sh.hist[k];
+        if (tiles)
+            for (int k = threadIdx.x; k < 676; k += CLS_THREADS) tiles[(size_t)i * 676 + k] = sh.tile[k];
+        if (run_cascades) {
+            int    cls = 0;
+            double ss = block_cascade(sh, strong), sw = 0;
+            if (ss > -DBL_MAX) cls = 1;
+            else {
+                sw = block_cascade(sh, weak);
+                if (sw > -DBL_MAX) cls = 2;
+            }
+            if (threadIdx.x == 0) { cls_out[i] = (uint8_t)cls; s_strong[i] = ss; s_weak[i] = sw; }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int stride, const int32_t *boxes, int n,
+                      double *hist, uint8_t *tiles, uint8_t *cls, double *s_strong, double *s_weak, CascadeDev strong,
+                      CascadeDev weak, int run_cascades)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_lbp_boxes, dim3(n < 2048 ? n : 2048), dim3(CLS_THREADS), 0, s, plane, w, h, stride, boxes, n,
+                       hist, tiles, cls, s_strong, s_weak, strong, weak, run_cascades);
+}
+
+} // namespace str_er

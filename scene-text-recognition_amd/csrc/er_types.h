@@ -1,0 +1,116 @@
+// er_types.h -- structures shared by the host API (str_er_api.cpp) and the gfx950
+// kernels (er_kernels.hip).  Internal; the public boundary is include/str_er.h.
+#pragma once
+#include <stdint.h>
+
+namespace str_er {
+
+// Tile of the in-LDS component-tree kernel.  64 pixels wide so a tile row is one
+// 64-byte scanline segment and the per-node column set fits one 64-bit mask;
+// 32 rows so the row set fits one 32-bit mask.
+constexpr int      TILE_W   = 64;
+constexpr int      TILE_H   = 32;
+constexpr int      TILE_PX  = TILE_W * TILE_H;   // 2048
+constexpr int      TILE_THREADS = 256;           // 4 wavefronts of 64
+constexpr int      TILE_PPT = TILE_PX / TILE_THREADS; // 8 consecutive pixels per lane
+constexpr uint32_t NONE     = 0xFFFFFFFFu;
+
+// One logical plane = one (frame, channel, pyramid level): the unit the reference
+// loops over at src/ER.cpp:50-60.  Inverted channels (255-x, src/ER.cpp:125-127) share
+// the physical plane of their source and set `invert`.
+struct PlaneDesc {
+    const uint8_t *pix;     // device pointer, top-left pixel of the physical plane
+    int32_t  w, h, stride;
+    int32_t  invert;        // 0 or 0xFF (xor mask)
+    int32_t  tiles_x, tiles_y;
+    uint32_t tile_base;     // first tile of this plane in the batch-wide tile numbering
+    uint32_t pair_base;     // first seam pixel-pair of this plane (batch-wide numbering)
+    uint32_t n_hpairs;      // w * (tiles_y - 1)
+    uint32_t n_pairs;       // n_hpairs + h * (tiles_x - 1)
+    uint32_t node_base;     // offset of this plane in the node arrays (capacity w*h)
+    uint32_t seam_base;     // offset in the seam map (u32 units)
+    uint32_t kept_base;     // offset in the kept-node arrays (capacity kept_cap)
+    uint32_t pool_base;     // offset in the pool arrays (capacity pool_cap)
+    uint32_t frame;
+    uint8_t  ch, pyr, pad0, pad1;
+};
+
+// Per-plane device counters, zeroed before every batch.
+struct PlaneCtr {
+    uint32_t n_nodes;       // tile-local nodes allocated (before cross-tile unification)
+    uint32_t n_walls;       // in-image pixels at the sentinel level
+    uint32_t start_node;    // node of the flood's start pixel, NONE if none (A.2)
+    uint32_t root_node;     // root of the start pixel's tree
+    uint32_t n_kept;
+    uint32_t n_pool;
+    uint32_t n_amb;
+    uint32_t overflow;      // bit0 kept table, bit1 pool
+    uint32_t n_strong;
+    uint32_t n_weak;
+    uint32_t cand_base;     // exclusive prefix of n_pool over planes
+    uint32_t n_created;     // live nodes inside the start pixel's tree
+    uint32_t root_slot;     // kept slot of the root
+    uint32_t max_level;     // highest level among kept nodes (bounds the NMS sweep)
+};
+
+// Structure-of-arrays node storage (index = PlaneDesc::node_base + plane-local id).
+struct NodeArrays {
+    uint32_t *par;          // parent node id (plane-local), NONE for a tree root
+    uint8_t  *lvl;          // quantised level (immutable after the tile kernel)
+    uint32_t *cnt;          // pixels:  own -> subtree total
+    uint32_t *nod;          // nodes:   1   -> subtree total (pruned ones included)
+    uint32_t *x0, *y0, *x1, *y1; // bbox: own -> subtree
+    uint32_t *key;          // min linear pixel index of the node's own-level pixels
+    uint32_t *kmap;         // node id -> kept slot
+    uint8_t  *dead;         // 1 = unified into another node of the same level
+};
+
+// Kept-node storage (index = PlaneDesc::kept_base + slot).
+struct KeptArrays {
+    uint32_t *node;         // plane-local node id
+    uint32_t *key;
+    uint32_t *area;         // reference "quirk" area = cnt + nod
+    int32_t  *parent;       // kept slot of the parent; root -> itself
+    uint16_t *box;          // 4 per slot: x, y, w, h
+    uint8_t  *level;
+    uint32_t *start;        // NMS: chain start of the chain that owns this node
+    uint32_t *ncand;        // NMS: number of child chains that want this node
+    unsigned long long *best; // NMS: (order key << 32 | child slot), minimum wins
+};
+
+// Cascade tables on the device (CascadeBoost, inc/adaboost.h:158-185).
+struct CascadeDev {
+    const uint16_t *dim;
+    const double   *thr;
+    const double   *dir;    // +1 for REAL; DecisionStump::dir for DISCRETE
+    const double   *vp;     // value when fv*dir <  thr*dir (REAL: cp; DISCRETE: +weight)
+    const double   *vn;     // value otherwise              (REAL: cn; DISCRETE: -weight)
+    const int32_t  *stage_n;
+    const int32_t  *stage_thresh;
+    int32_t n_stages;
+    int32_t n_stumps;
+    int32_t max_stage;
+};
+
+struct DetectParams {
+    int32_t thresh_step, min_area, max_area, stability_t;
+    double  overlap_coef;
+    int32_t hi;             // highest_level = 255/step + 1 (src/ER.cpp:247)
+    float   qscale;         // float(1.0/step): the convertTo scale (src/ER.cpp:250)
+    int32_t kept_cap, pool_cap;
+    int32_t sibling_order;
+};
+
+// Matches str_er_cand in include/str_er.h (48 bytes).
+struct CandRec {
+    uint32_t frame;
+    uint8_t  ch, pyr, level, cls;
+    uint16_t x, y, w, h;
+    uint32_t area, key;
+    int32_t  node;
+    uint32_t plane;
+    double   score_strong, score_weak;
+};
+static_assert(sizeof(CandRec) == 48, "CandRec must match str_er_cand");
+
+} // namespace str_er

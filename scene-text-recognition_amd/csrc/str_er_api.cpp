@@ -1,0 +1,917 @@
+// str_er_api.cpp -- implementation of the C ABI in include/str_er.h.
+//
+// Host side of the hot path: owns the device workspace, lays out one batch of planes
+// (frames x channels x pyramid levels), enqueues the gfx950 kernels of er_kernels.hip on
+// one HIP stream with no host synchronisation in between, then copies back the per-plane
+// counters and the packed candidate records.  No computation of the path happens on the
+// host; if the device or a kernel fails the call fails (there is no CPU fallback).
+#include "../../include/str_er.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "er_kernels.h"
+
+using namespace str_er;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostCascade {
+    bool loaded = false;
+    bool real = true;
+    std::vector<int32_t> stage_n, stage_thresh;
+    std::vector<uint16_t> dim;
+    std::vector<double> thr, dir, vp, vn;
+    void *d_blob = nullptr;
+    CascadeDev dev{};
+};
+
+struct NodeRec { // == str_er_node
+    uint32_t key; int32_t parent; int32_t area; uint16_t x, y, w, h; uint8_t level, flags; uint16_t reserved;
+};
+static_assert(sizeof(NodeRec) == sizeof(str_er_node), "node layout");
+static_assert(sizeof(CandRec) == sizeof(str_er_cand), "cand layout");
+
+struct PlaneGeom { int w, h, stride; size_t off; }; // physical planes of one pyramid level
+
+} // namespace
+
+struct str_er_result {
+    std::vector<str_er_plane_info> planes;
+    std::vector<str_er_cand> cands;
+    std::vector<uint32_t> cand_off;          // n_planes + 1
+    std::vector<std::vector<str_er_node>> nodes;
+    bool have_nodes = false;
+    double times[7] = {0, 0, 0, 0, 0, 0, 0};
+};
+
+struct str_er_ctx {
+    str_er_params prm{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int ppf = 0;                     // logical planes per frame
+    std::vector<int> chans;          // channel indices selected by the mask
+    size_t slots = 0;                // node slots (== plane pixels) the workspace can hold
+    int max_planes = 0;
+    int kept_cap = 0, pool_cap = 0;
+    int64_t ws_bytes = 0;
+
+    // device workspace
+    uint8_t *d_in = nullptr;  size_t in_bytes = 0;    // staging for host inputs
+    uint8_t *d_pix = nullptr; size_t pix_bytes = 0;   // physical planes (Y,Cr,Cb per level)
+    PlaneDesc *d_planes = nullptr;
+    PlaneCtr *d_ctr = nullptr;
+    NodeArrays na{};
+    KeptArrays ka{};
+    uint32_t *d_seam = nullptr; size_t seam_slots = 0;
+    uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
+    CandRec *d_cands = nullptr;
+    uint32_t *d_total = nullptr;
+    NodeRec *d_nodes = nullptr;
+    void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    std::vector<void *> allocs;
+
+    // pinned host mirrors
+    PlaneDesc *h_planes = nullptr;
+    PlaneCtr *h_ctr = nullptr;
+    uint32_t *h_total = nullptr;
+
+    HostCascade casc[2];
+    hipEvent_t ev[16]{};
+    int n_ev = 0;
+    bool profiling = false;
+    std::vector<std::pair<const char *, double>> profile;
+};
+
+namespace {
+
+int fail(str_er_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((ctx), (e_ == hipErrorOutOfMemory) ? STR_ER_ENOMEM : STR_ER_EHIP,          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+template <typename T> int dev_alloc(str_er_ctx *c, T *&p, size_t n)
+{
+    void *v = nullptr;
+    const size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+    hipError_t e = hipMalloc(&v, bytes);
+    if (e != hipSuccess) return fail(c, STR_ER_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    c->allocs.push_back(v);
+    c->ws_bytes += (int64_t)bytes;
+    p = static_cast<T *>(v);
+    return STR_ER_OK;
+}
+
+int ensure_scratch(str_er_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return STR_ER_OK;
+    if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
+    hipError_t e = hipMalloc(&c->d_scratch, bytes);
+    if (e != hipSuccess) return fail(c, STR_ER_ENOMEM, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
+    c->scratch_bytes = bytes;
+    return STR_ER_OK;
+}
+
+void pyr_dims(int w0, int h0, int level, int &w, int &h)
+{
+    const double s = std::pow(2.0, -0.5 * level);
+    w = std::max(1, (int)std::floor(w0 * s + 0.5));
+    h = std::max(1, (int)std::floor(h0 * s + 0.5));
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+DetectParams make_dp(const str_er_ctx *c)
+{
+    DetectParams d{};
+    d.thresh_step = c->prm.thresh_step; d.min_area = c->prm.min_area; d.max_area = c->prm.max_area;
+    d.stability_t = c->prm.stability_t; d.overlap_coef = c->prm.overlap_coef;
+    d.hi = 255 / c->prm.thresh_step + 1;
+    d.qscale = (float)(1.0 / (double)c->prm.thresh_step);
+    d.kept_cap = c->kept_cap; d.pool_cap = c->pool_cap; d.sibling_order = c->prm.sibling_order;
+    return d;
+}
+
+// ---- cascade text (format: SURVEY.md Appendix C; CascadeBoost::load_classifier,
+// ---- src/adaboost.cpp:873-951) ---------------------------------------------------------------
+bool parse_number(const std::string &t, double &v)
+{
+    if (t.empty()) return false;
+    char *end = nullptr;
+    v = std::strtod(t.c_str(), &end);
+    return end != t.c_str();
+}
+
+int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
+{
+    std::vector<std::string> tok;
+    {
+        size_t i = 0;
+        while (i < len) {
+            while (i < len && (text[i] == ' ' || text[i] == '\t' || text[i] == '\r' || text[i] == '\n')) ++i;
+            size_t j = i;
+            while (j < len && !(text[j] == ' ' || text[j] == '\t' || text[j] == '\r' || text[j] == '\n')) ++j;
+            if (j > i) tok.emplace_back(text + i, j - i);
+            i = j;
+        }
+    }
+    size_t k = 0;
+    auto next = [&]() -> const std::string * { return k < tok.size() ? &tok[k++] : nullptr; };
+    HostCascade n;
+    const std::string *t = next();
+    if (!t || *t != "boost_type") return fail(c, STR_ER_EFORMAT, "cascade: missing boost_type");
+    t = next();
+    if (!t) return fail(c, STR_ER_EFORMAT, "cascade: truncated header");
+    n.real = (*t != "DISCRETE");
+    t = next();
+    if (!t || *t != "base_type") return fail(c, STR_ER_EFORMAT, "cascade: missing base_type");
+    t = next();
+    t = next();
+    if (!t || *t != "num_of_iter") return fail(c, STR_ER_EFORMAT, "cascade: missing num_of_iter");
+    for (;;) {
+        t = next();
+        double v;
+        if (!t || !parse_number(*t, v)) break;
+        n.stage_n.push_back((int32_t)v);
+    }
+    if (!t || *t != "threshold" || n.stage_n.empty()) return fail(c, STR_ER_EFORMAT, "cascade: missing threshold");
+    for (size_t j = 0; j < n.stage_n.size(); ++j) {
+        t = next();
+        double v;
+        if (!t || !parse_number(*t, v)) return fail(c, STR_ER_EFORMAT, "cascade: short threshold list");
+        n.stage_thresh.push_back((int32_t)v); // (int)stod(...), src/adaboost.cpp:919
+    }
+    const int per = n.real ? 5 : 4;
+    for (;;) {
+        double v[5];
+        int got = 0;
+        for (; got < per; ++got) {
+            t = next();
+            if (!t || !parse_number(*t, v[got])) break;
+        }
+        if (got == 0) break;
+        if (got < per) return fail(c, STR_ER_EFORMAT, "cascade: incomplete stump row");
+        const int d = (int)v[1];
+        if (d < 0 || d >= 1024) return fail(c, STR_ER_EFORMAT, "cascade: feature index outside the 1024-bin histogram");
+        n.dim.push_back((uint16_t)d);
+        if (n.real) { n.thr.push_back(v[2]); n.dir.push_back(1.0); n.vp.push_back(v[3]); n.vn.push_back(v[4]); }
+        else { n.dir.push_back((double)(int)v[2]); n.thr.push_back(v[3]); n.vp.push_back(1.0 * v[0]); n.vn.push_back(-1.0 * v[0]); }
+    }
+    long long total = 0;
+    for (int32_t s : n.stage_n) { if (s < 0) return fail(c, STR_ER_EFORMAT, "cascade: negative stage size"); total += s; }
+    if (total > (long long)n.dim.size()) return fail(c, STR_ER_EFORMAT, "cascade: fewer stump rows than num_of_iter announces");
+    // upload: one blob
+    const size_t ns = n.dim.size(), nst = n.stage_n.size();
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return o; };
+    const size_t o_thr = take(ns * 8), o_dir = take(ns * 8), o_vp = take(ns * 8), o_vn = take(ns * 8), o_dim = take(ns * 2),
+                 o_sn = take(nst * 4), o_st = take(nst * 4);
+    std::vector<uint8_t> blob(off ? off : 16);
+    std::memcpy(&blob[o_thr], n.thr.data(), ns * 8); std::memcpy(&blob[o_dir], n.dir.data(), ns * 8);
+    std::memcpy(&blob[o_vp], n.vp.data(), ns * 8); std::memcpy(&blob[o_vn], n.vn.data(), ns * 8);
+    std::memcpy(&blob[o_dim], n.dim.data(), ns * 2); std::memcpy(&blob[o_sn], n.stage_n.data(), nst * 4);
+    std::memcpy(&blob[o_st], n.stage_thresh.data(), nst * 4);
+    void *d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, blob.size()));
+    hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(c, STR_ER_EHIP, std::string("cascade upload: ") + hipGetErrorString(e)); }
+    if (hc.d_blob) (void)hipFree(hc.d_blob);
+    n.d_blob = d;
+    const uint8_t *b = static_cast<const uint8_t *>(d);
+    n.dev.thr = reinterpret_cast<const double *>(b + o_thr); n.dev.dir = reinterpret_cast<const double *>(b + o_dir);
+    n.dev.vp = reinterpret_cast<const double *>(b + o_vp); n.dev.vn = reinterpret_cast<const double *>(b + o_vn);
+    n.dev.dim = reinterpret_cast<const uint16_t *>(b + o_dim);
+    n.dev.stage_n = reinterpret_cast<const int32_t *>(b + o_sn); n.dev.stage_thresh = reinterpret_cast<const int32_t *>(b + o_st);
+    n.dev.n_stages = (int32_t)nst; n.dev.n_stumps = (int32_t)ns;
+    n.dev.max_stage = 0;
+    for (int32_t s : n.stage_n) n.dev.max_stage = std::max(n.dev.max_stage, s);
+    n.loaded = true;
+    hc = std::move(n);
+    return STR_ER_OK;
+}
+
+// ---- batch layout -------------------------------------------------------------------------------
+struct Batch {
+    std::vector<PlaneDesc> planes;
+    uint32_t n_tiles = 0, n_pairs = 0, max_nodes_plane = 0;
+    size_t slots = 0, seam = 0;
+};
+
+void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int invert, uint32_t frame, int ch, int pyr,
+               int kept_cap, int pool_cap)
+{
+    PlaneDesc d{};
+    d.pix = pix; d.w = w; d.h = h; d.stride = stride; d.invert = invert ? 0xFF : 0;
+    d.tiles_x = (w + TILE_W - 1) / TILE_W; d.tiles_y = (h + TILE_H - 1) / TILE_H;
+    d.tile_base = b.n_tiles; b.n_tiles += (uint32_t)d.tiles_x * d.tiles_y;
+    d.n_hpairs = (uint32_t)w * (d.tiles_y - 1);
+    d.n_pairs = d.n_hpairs + (uint32_t)h * (d.tiles_x - 1);
+    d.pair_base = b.n_pairs; b.n_pairs += d.n_pairs;
+    d.node_base = (uint32_t)b.slots; b.slots += (size_t)w * h;
+    d.seam_base = (uint32_t)b.seam; b.seam += 2 * (size_t)d.n_pairs;
+    d.kept_base = (uint32_t)(b.planes.size() * (size_t)kept_cap);
+    d.pool_base = (uint32_t)(b.planes.size() * (size_t)pool_cap);
+    d.frame = frame; d.ch = (uint8_t)ch; d.pyr = (uint8_t)pyr;
+    b.max_nodes_plane = std::max<uint32_t>(b.max_nodes_plane, (uint32_t)w * h);
+    b.planes.push_back(d);
+}
+
+BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
+{
+    BatchDev d{};
+    d.planes = c->d_planes; d.ctr = c->d_ctr; d.n_planes = (int32_t)b.planes.size();
+    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.max_nodes_plane = b.max_nodes_plane;
+    d.na = c->na; d.ka = c->ka; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
+    d.cands = c->d_cands; d.total_cands = c->d_total;
+    return d;
+}
+
+void rec(str_er_ctx *c, const char *name)
+{
+    if (c->n_ev < 16) {
+        (void)hipEventRecord(c->ev[c->n_ev], c->stream);
+        c->profile.emplace_back(name, 0.0);
+        ++c->n_ev;
+    }
+}
+
+// Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
+int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **out,
+              std::chrono::steady_clock::time_point t_start, bool pre_recorded)
+{
+    const int np = (int)b.planes.size();
+    if (np == 0) return fail(c, STR_ER_EINVAL, "no planes");
+    if (np > c->max_planes) return fail(c, STR_ER_ECAPACITY, "more planes than the context was created for");
+    if (b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "planes exceed the pixel capacity of the context");
+    if (b.seam > c->seam_slots) return fail(c, STR_ER_ECAPACITY, "seam map capacity exceeded");
+    if ((stages & STR_ER_STAGE_CLASSIFY) && !(c->casc[0].loaded && c->casc[1].loaded))
+        return fail(c, STR_ER_ESTATE, "classify needs both cascades (str_er_load_cascade)");
+    if (!(stages & STR_ER_STAGE_EXTRACT)) return fail(c, STR_ER_EINVAL, "stages must include STR_ER_STAGE_EXTRACT");
+    if ((stages & STR_ER_STAGE_CLASSIFY) && !(stages & STR_ER_STAGE_NMS))
+        return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_CLASSIFY needs STR_ER_STAGE_NMS");
+
+    const DetectParams dp = make_dp(c);
+    hipStream_t s = c->stream;
+    std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
+    HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+    const BatchDev bd = make_batchdev(c, b);
+    if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
+
+    launch_tile_tree(s, bd, dp);                      rec(c, "tile_tree");
+    launch_seam(s, bd);                               rec(c, "seam");
+    launch_resolve(s, bd);                            rec(c, "resolve");
+    for (int t = 0; t < dp.hi; ++t) launch_accumulate(s, bd, t);
+    rec(c, "accumulate");
+    launch_root(s, bd, dp);
+    launch_select(s, bd, dp);
+    launch_kept(s, bd, dp);                           rec(c, "select");
+    const int i_extract = c->n_ev - 1;
+    if (stages & STR_ER_STAGE_NMS) launch_nms(s, bd, dp);
+    rec(c, "nms");
+    const int i_nms = c->n_ev - 1;
+    if (stages & STR_ER_STAGE_NMS) {
+        launch_cand_prefix(s, bd);
+        launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
+    }
+    rec(c, "classify");
+    const int i_cls = c->n_ev - 1;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    for (int i = 0; i < np; ++i) {
+        if (c->h_ctr[i].overflow & 1u)
+            return fail(c, STR_ER_ECAPACITY, "kept-node table overflow: plane " + std::to_string(i) + " has " +
+                        std::to_string(c->h_ctr[i].n_kept) + " kept nodes, kept_cap = " + std::to_string(c->kept_cap));
+        if (c->h_ctr[i].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
+    }
+    str_er_result *r = new (std::nothrow) str_er_result();
+    if (!r) return fail(c, STR_ER_ENOMEM, "result allocation");
+    const uint32_t total = *c->h_total;
+    r->cands.resize(total);
+    r->cand_off.assign(np + 1, 0);
+    r->planes.resize(np);
+    if (total)
+        if (hipMemcpyAsync(r->cands.data(), c->d_cands, sizeof(CandRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
+            delete r; return fail(c, STR_ER_EHIP, "candidate copy failed");
+        }
+    const bool want_nodes = (stages & STR_ER_WANT_NODES) != 0;
+    if (want_nodes) {
+        r->nodes.resize(np);
+        for (int i = 0; i < np; ++i) {
+            const PlaneDesc &pd = b.planes[i];
+            const uint32_t nk = c->h_ctr[i].n_kept;
+            r->nodes[i].resize(nk);
+            // gather the SoA kept arrays into records on the host side of the copy
+            std::vector<uint32_t> key(nk), area(nk); std::vector<int32_t> par(nk); std::vector<uint16_t> box(4 * (size_t)nk);
+            std::vector<uint8_t> lev(nk);
+            hipError_t e = hipSuccess;
+            if (nk) {
+                e = hipMemcpyAsync(key.data(), c->ka.key + pd.kept_base, 4 * (size_t)nk, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(area.data(), c->ka.area + pd.kept_base, 4 * (size_t)nk, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(par.data(), c->ka.parent + pd.kept_base, 4 * (size_t)nk, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(box.data(), c->ka.box + 4 * (size_t)pd.kept_base, 8 * (size_t)nk, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(lev.data(), c->ka.level + pd.kept_base, (size_t)nk, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+            }
+            if (e != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, std::string("node copy: ") + hipGetErrorString(e)); }
+            // order by (key, level) so the table is deterministic; remap parents and the root
+            std::vector<uint32_t> order(nk), rank(nk);
+            for (uint32_t k = 0; k < nk; ++k) order[k] = k;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t bb) {
+                return key[a] != key[bb] ? key[a] < key[bb] : lev[a] < lev[bb]; });
+            for (uint32_t k = 0; k < nk; ++k) rank[order[k]] = k;
+            for (uint32_t k = 0; k < nk; ++k) {
+                const uint32_t o = order[k];
+                str_er_node &n = r->nodes[i][k];
+                n.key = key[o]; n.parent = (int32_t)rank[(uint32_t)par[o]]; n.area = (int32_t)area[o];
+                n.x = box[4 * o]; n.y = box[4 * o + 1]; n.w = box[4 * o + 2]; n.h = box[4 * o + 3];
+                n.level = lev[o]; n.flags = (o == c->h_ctr[i].root_slot) ? 1 : 0; n.reserved = 0;
+            }
+            c->h_ctr[i].root_slot = nk ? rank[c->h_ctr[i].root_slot] : 0;
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    uint32_t off = 0;
+    for (int i = 0; i < np; ++i) {
+        const PlaneDesc &pd = b.planes[i];
+        const PlaneCtr &pc = c->h_ctr[i];
+        str_er_plane_info &pi = r->planes[i];
+        pi.frame = pd.frame; pi.ch = pd.ch; pi.pyr = pd.pyr; pi.reserved0 = pi.reserved1 = 0;
+        pi.width = pd.w; pi.height = pd.h;
+        pi.n_created = (int32_t)pc.n_created; pi.n_kept = (int32_t)pc.n_kept;
+        pi.n_pool = (int32_t)pc.n_pool; pi.n_strong = (int32_t)pc.n_strong; pi.n_weak = (int32_t)pc.n_weak;
+        pi.ambiguous = (int32_t)pc.n_amb; pi.root = want_nodes ? (int32_t)pc.root_slot : -1;
+        r->cand_off[i] = off;
+        off += pc.n_pool;
+    }
+    r->cand_off[np] = off;
+    if (want_nodes) {
+        // candidates carry the device kept slot; translate to the sorted table through (key, level)
+        for (int i = 0; i < np; ++i) {
+            const auto &tbl = r->nodes[i];
+            for (uint32_t k = r->cand_off[i]; k < r->cand_off[i + 1]; ++k) {
+                str_er_cand &cd = r->cands[k];
+                auto it = std::lower_bound(tbl.begin(), tbl.end(), cd, [](const str_er_node &n, const str_er_cand &q) {
+                    return n.key != q.key ? n.key < q.key : n.level < q.level; });
+                cd.node = (it != tbl.end() && it->key == cd.key && it->level == cd.level) ? (int32_t)(it - tbl.begin()) : -1;
+            }
+        }
+        r->have_nodes = true;
+    } else {
+        for (auto &cd : r->cands) cd.node = -1;
+    }
+
+    float ms = 0;
+    double stage_s[3] = {0, 0, 0};
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[i_extract]) == hipSuccess) stage_s[0] = ms * 1e-3;
+    if (hipEventElapsedTime(&ms, c->ev[i_extract], c->ev[i_nms]) == hipSuccess) stage_s[1] = ms * 1e-3;
+    if (hipEventElapsedTime(&ms, c->ev[i_nms], c->ev[i_cls]) == hipSuccess) stage_s[2] = ms * 1e-3;
+    for (int i = 1; i < c->n_ev; ++i)
+        if (hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) == hipSuccess) c->profile[i].second = ms;
+    r->times[0] = stage_s[0]; r->times[1] = stage_s[1]; r->times[2] = stage_s[2];
+    r->times[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    *out = r;
+    return STR_ER_OK;
+}
+
+int stage_input(str_er_ctx *c, const uint8_t *src, size_t bytes, int mem_kind, const uint8_t **dev)
+{
+    if (mem_kind == STR_ER_MEM_DEVICE) { *dev = src; return STR_ER_OK; }
+    if (bytes > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "host input larger than the staging buffer");
+    HIP_TRY(c, hipMemcpyAsync(c->d_in, src, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = c->d_in;
+    return STR_ER_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int str_er_abi_version(void) { return STR_ER_ABI_VERSION; }
+
+const char *str_er_strerror(int code)
+{
+    switch (code) {
+    case STR_ER_OK: return "ok";
+    case STR_ER_EINVAL: return "invalid argument";
+    case STR_ER_ENOMEM: return "out of memory";
+    case STR_ER_EHIP: return "HIP runtime error";
+    case STR_ER_EIO: return "I/O error";
+    case STR_ER_EFORMAT: return "bad classifier format";
+    case STR_ER_ESTATE: return "cascades not loaded";
+    case STR_ER_ECAPACITY: return "capacity exceeded";
+    default: return "unknown error";
+    }
+}
+
+void str_er_default_params(str_er_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->thresh_step = 8; p->min_area = 120; p->max_area = 900000; p->stability_t = 2; p->overlap_coef = 0.7;
+    p->n_pyr_levels = 1; p->channel_mask = 0x3F; p->device = 0;
+    p->max_width = 1920; p->max_height = 1080; p->max_frames = 8;
+    p->kept_cap = 0; p->pool_cap = 0; p->sibling_order = 0; p->stream = nullptr;
+}
+
+const char *str_er_last_error(const str_er_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void str_er_destroy(str_er_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->prm.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
+    if (c->h_planes) (void)hipHostFree(c->h_planes);
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int str_er_create(const str_er_params *p, str_er_ctx **out)
+{
+    if (!p || !out) return fail(nullptr, STR_ER_EINVAL, "null argument");
+    *out = nullptr;
+    if (p->thresh_step < 1 || p->thresh_step > 255) return fail(nullptr, STR_ER_EINVAL, "thresh_step must be in [1,255]");
+    if (p->stability_t < 0 || p->stability_t > 255) return fail(nullptr, STR_ER_EINVAL, "stability_t must be in [0,255]");
+    if (p->n_pyr_levels < 1 || p->n_pyr_levels > 32) return fail(nullptr, STR_ER_EINVAL, "n_pyr_levels must be in [1,32]");
+    if (!(p->channel_mask & 0x3F) || (p->channel_mask & ~0x3Fu)) return fail(nullptr, STR_ER_EINVAL, "channel_mask must select planes 0..5");
+    if (p->max_width < 1 || p->max_height < 1 || p->max_frames < 1) return fail(nullptr, STR_ER_EINVAL, "capacity must be positive");
+    if (p->max_width > 65535 || p->max_height > 65535) return fail(nullptr, STR_ER_EINVAL, "planes are limited to 65535 x 65535");
+    if ((size_t)p->max_width * p->max_height > (1u << 24)) return fail(nullptr, STR_ER_EINVAL, "planes are limited to 2^24 pixels");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, STR_ER_EHIP, "no HIP device available: this library has no CPU path");
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, STR_ER_EINVAL, "device ordinal out of range");
+    if (hipSetDevice(p->device) != hipSuccess) return fail(nullptr, STR_ER_EHIP, "hipSetDevice failed");
+
+    str_er_ctx *c = new (std::nothrow) str_er_ctx();
+    if (!c) return fail(nullptr, STR_ER_ENOMEM, "context allocation");
+    c->prm = *p;
+    for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
+    c->ppf = (int)c->chans.size() * p->n_pyr_levels;
+    c->max_planes = c->ppf * p->max_frames;
+    size_t px_frame = 0, phys_frame = 0;
+    for (int l = 0; l < p->n_pyr_levels; ++l) {
+        int w, h; pyr_dims(p->max_width, p->max_height, l, w, h);
+        px_frame += (size_t)w * h * c->chans.size();
+        phys_frame += 3 * align_up((size_t)align_up(w, 64) * h, 256);
+    }
+    c->slots = px_frame * p->max_frames;
+    if (c->slots >= 0xFFFF0000ull) { delete c; return fail(nullptr, STR_ER_ECAPACITY, "batch too large: more than 2^32 pixels per call"); }
+    const size_t plane_px = (size_t)p->max_width * p->max_height;
+    c->kept_cap = p->kept_cap > 0 ? p->kept_cap : (int)std::max<size_t>(4096, plane_px / 64);
+    c->pool_cap = p->pool_cap > 0 ? p->pool_cap : std::max(256, c->kept_cap / 4);
+    c->seam_slots = c->slots / 8 + 4096;
+
+    int rc = STR_ER_OK;
+    auto A = [&](int r) { if (rc == STR_ER_OK && r != STR_ER_OK) rc = r; };
+    if (p->stream) c->stream = static_cast<hipStream_t>(p->stream);
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, STR_ER_EHIP, "hipStreamCreate failed"); }
+        c->own_stream = true;
+    }
+    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { A(fail(nullptr, STR_ER_EHIP, "hipEventCreate failed")); break; }
+    c->in_bytes = std::max((size_t)p->max_frames * plane_px * 3, c->slots);
+    c->pix_bytes = std::max(phys_frame * p->max_frames, c->slots + 4096);
+    const size_t S = c->slots, KP = (size_t)c->max_planes * c->kept_cap, PP = (size_t)c->max_planes * c->pool_cap;
+    A(dev_alloc(c, c->d_in, c->in_bytes));
+    A(dev_alloc(c, c->d_pix, c->pix_bytes));
+    A(dev_alloc(c, c->d_planes, (size_t)c->max_planes));
+    A(dev_alloc(c, c->d_ctr, (size_t)c->max_planes));
+    A(dev_alloc(c, c->na.par, S)); A(dev_alloc(c, c->na.lvl, S)); A(dev_alloc(c, c->na.dead, S));
+    A(dev_alloc(c, c->na.cnt, S)); A(dev_alloc(c, c->na.nod, S));
+    A(dev_alloc(c, c->na.x0, S)); A(dev_alloc(c, c->na.y0, S)); A(dev_alloc(c, c->na.x1, S)); A(dev_alloc(c, c->na.y1, S));
+    A(dev_alloc(c, c->na.key, S)); A(dev_alloc(c, c->na.kmap, S));
+    A(dev_alloc(c, c->ka.node, KP)); A(dev_alloc(c, c->ka.key, KP)); A(dev_alloc(c, c->ka.area, KP));
+    A(dev_alloc(c, c->ka.parent, KP)); A(dev_alloc(c, c->ka.box, 4 * KP)); A(dev_alloc(c, c->ka.level, KP));
+    A(dev_alloc(c, c->ka.start, KP)); A(dev_alloc(c, c->ka.ncand, KP)); A(dev_alloc(c, c->ka.best, KP));
+    A(dev_alloc(c, c->d_seam, c->seam_slots));
+    A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
+    A(dev_alloc(c, c->d_cands, PP));
+    A(dev_alloc(c, c->d_total, 4));
+    if (rc == STR_ER_OK) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&c->h_total), 64) != hipSuccess)
+            rc = fail(nullptr, STR_ER_ENOMEM, "hipHostMalloc failed");
+    }
+    if (rc != STR_ER_OK) { std::string keep = g_create_error.empty() ? c->err : g_create_error; str_er_destroy(c); g_create_error = keep; return rc; }
+    *out = c;
+    return STR_ER_OK;
+}
+
+int str_er_set_thresh_step(str_er_ctx *c, int32_t t)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (t < 1 || t > 255) return fail(c, STR_ER_EINVAL, "thresh_step must be in [1,255]");
+    c->prm.thresh_step = t;
+    return STR_ER_OK;
+}
+
+int str_er_set_min_area(str_er_ctx *c, int32_t m)
+{
+    if (!c) return STR_ER_EINVAL;
+    c->prm.min_area = m;
+    return STR_ER_OK;
+}
+
+int str_er_load_cascade_mem(str_er_ctx *c, int which, const char *text, size_t len)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!text || (which != STR_ER_CASCADE_STRONG && which != STR_ER_CASCADE_WEAK)) return fail(c, STR_ER_EINVAL, "bad cascade argument");
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    return parse_cascade(c, c->casc[which], text, len);
+}
+
+int str_er_load_cascade(str_er_ctx *c, int which, const char *path)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!path) return fail(c, STR_ER_EINVAL, "null path");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(c, STR_ER_EIO, std::string("cannot open ") + path);
+    std::string buf;
+    char tmp[65536];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n);
+    std::fclose(f);
+    return str_er_load_cascade_mem(c, which, buf.data(), buf.size());
+}
+
+int str_er_cascade_info(const str_er_ctx *c, int which, int32_t *n_stages, int32_t *n_stumps)
+{
+    if (!c || (which != 0 && which != 1)) return STR_ER_EINVAL;
+    if (n_stages) *n_stages = c->casc[which].loaded ? c->casc[which].dev.n_stages : 0;
+    if (n_stumps) *n_stumps = c->casc[which].loaded ? c->casc[which].dev.n_stumps : 0;
+    return STR_ER_OK;
+}
+
+int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                      int32_t n_frames, int mem_kind, uint32_t stages, str_er_result **out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!bgr || !out || w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3) return fail(c, STR_ER_EINVAL, "bad frame arguments");
+    if (n_frames > 1 && frame_pitch < stride * (int64_t)h) return fail(c, STR_ER_EINVAL, "frame_pitch smaller than a frame");
+    if (w > c->prm.max_width || h > c->prm.max_height || n_frames > c->prm.max_frames)
+        return fail(c, STR_ER_ECAPACITY, "frame larger than / more frames than the context capacity");
+    *out = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const uint8_t *dbgr = nullptr;
+    int64_t dstride = stride, dpitch = frame_pitch;
+    if (mem_kind == STR_ER_MEM_HOST) {
+        // pack rows tightly while staging
+        dstride = (int64_t)w * 3; dpitch = dstride * h;
+        if ((size_t)dpitch * n_frames > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "staging buffer too small");
+        for (int f = 0; f < n_frames; ++f)
+            HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)f * dpitch, (size_t)dstride, bgr + (size_t)f * frame_pitch, (size_t)stride,
+                                        (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        dbgr = c->d_in;
+    } else if (mem_kind == STR_ER_MEM_DEVICE) dbgr = bgr;
+    else return fail(c, STR_ER_EINVAL, "bad mem_kind");
+
+    // physical planes: per level, [Y, Cr, Cb], row stride padded to 64 bytes
+    const int nl = c->prm.n_pyr_levels;
+    std::vector<PlaneGeom> geo(nl);
+    size_t frame_bytes = 0;
+    for (int l = 0; l < nl; ++l) {
+        pyr_dims(w, h, l, geo[l].w, geo[l].h);
+        geo[l].stride = (int)align_up(geo[l].w, 64);
+        geo[l].off = frame_bytes;
+        frame_bytes += 3 * align_up((size_t)geo[l].stride * geo[l].h, 256);
+    }
+    if (frame_bytes * n_frames > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
+    auto plane_sz = [&](int l) { return align_up((size_t)geo[l].stride * geo[l].h, 256); };
+    c->n_ev = 0; c->profile.clear(); rec(c, "begin");
+    launch_bgr_to_ycrcb(c->stream, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
+                        c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);
+    rec(c, "channels");
+    for (int l = 1; l < nl; ++l)
+        launch_resize(c->stream, c->d_pix + geo[l - 1].off, geo[l - 1].w, geo[l - 1].h, geo[l - 1].stride, (int64_t)plane_sz(l - 1),
+                      (int64_t)frame_bytes, c->d_pix + geo[l].off, geo[l].w, geo[l].h, geo[l].stride, (int64_t)plane_sz(l),
+                      (int64_t)frame_bytes, 3, n_frames);
+    rec(c, "pyramid");
+
+    Batch b;
+    for (int f = 0; f < n_frames; ++f)
+        for (int l = 0; l < nl; ++l)
+            for (int ch : c->chans) {
+                const uint8_t *pix = c->d_pix + (size_t)f * frame_bytes + geo[l].off + (size_t)(ch % 3) * plane_sz(l);
+                add_plane(b, pix, geo[l].w, geo[l].h, geo[l].stride, ch >= 3, (uint32_t)f, ch, l, c->kept_cap, c->pool_cap);
+            }
+    return run_batch(c, b, stages, out, t0, true);
+}
+
+int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_t h, int64_t stride, int64_t plane_pitch,
+                         int32_t n_planes, int mem_kind, uint32_t stages, str_er_result **out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!planes || !out || w < 1 || h < 1 || n_planes < 1 || stride < w) return fail(c, STR_ER_EINVAL, "bad plane arguments");
+    if (n_planes > 1 && plane_pitch < stride * (int64_t)h) return fail(c, STR_ER_EINVAL, "plane_pitch smaller than a plane");
+    if (w > c->prm.max_width || h > c->prm.max_height || n_planes > c->max_planes)
+        return fail(c, STR_ER_ECAPACITY, "plane larger than / more planes than the context capacity");
+    if (stride > 0x7FFFFFFF) return fail(c, STR_ER_EINVAL, "stride too large");
+    *out = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const uint8_t *dp = nullptr;
+    int dstride = (int)stride;
+    int64_t dpitch = plane_pitch;
+    if (mem_kind == STR_ER_MEM_HOST) {
+        dstride = (int)align_up(w, 64); dpitch = (int64_t)align_up((size_t)dstride * h, 256);
+        if ((size_t)dpitch * n_planes > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
+        for (int i = 0; i < n_planes; ++i)
+            HIP_TRY(c, hipMemcpy2DAsync(c->d_pix + (size_t)i * dpitch, (size_t)dstride, planes + (size_t)i * plane_pitch, (size_t)stride,
+                                        (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        dp = c->d_pix;
+    } else if (mem_kind == STR_ER_MEM_DEVICE) dp = planes;
+    else return fail(c, STR_ER_EINVAL, "bad mem_kind");
+    Batch b;
+    for (int i = 0; i < n_planes; ++i)
+        add_plane(b, dp + (size_t)i * dpitch, w, h, dstride, 0, 0, i & 255, 0, c->kept_cap, c->pool_cap);
+    return run_batch(c, b, stages, out, t0, false);
+}
+
+int str_er_compute_channels(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, uint8_t *planes6)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!bgr || !planes6 || w < 1 || h < 1 || stride < (int64_t)w * 3) return fail(c, STR_ER_EINVAL, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const size_t n = (size_t)w * h;
+    if (n * 3 > c->in_bytes || n * 6 > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)w * 3, bgr, (size_t)stride, (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    uint8_t *d = c->d_pix;
+    launch_bgr_to_ycrcb(c->stream, c->d_in, w, h, (int64_t)w * 3, 0, 1, d, d + n, d + 2 * n, w, 0);
+    launch_invert(c->stream, d, d + 3 * n, 3 * n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(planes6, d, 6 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return STR_ER_OK;
+}
+
+static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
+                      double *hist, uint8_t *tiles, uint8_t *cls, double *ss, double *sw, bool cascades)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (cascades && !(c->casc[0].loaded && c->casc[1].loaded)) return fail(c, STR_ER_ESTATE, "classify needs both cascades");
+    if (cascades && (!cls || !ss || !sw)) return fail(c, STR_ER_EINVAL, "null output");
+    for (int i = 0; i < n; ++i) {
+        const int32_t *b = boxes + 4 * (size_t)i;
+        if (b[2] < 1 || b[3] < 1 || b[0] < 0 || b[1] < 0 || (int64_t)b[0] + b[2] > w || (int64_t)b[1] + b[3] > h)
+            return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " outside the plane");
+    }
+    if (n == 0) return STR_ER_OK;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const size_t np = (size_t)w * h;
+    if (np > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    const size_t o_box = 0, o_hist = align_up(16 * (size_t)n, 256), o_tile = o_hist + 8192 * (size_t)n,
+                 o_cls = align_up(o_tile + 676 * (size_t)n, 256), o_ss = align_up(o_cls + (size_t)n, 256), o_sw = o_ss + 8 * (size_t)n,
+                 total = o_sw + 8 * (size_t)n;
+    int rc = ensure_scratch(c, total);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    launch_lbp_boxes(c->stream, c->d_pix, w, h, w, reinterpret_cast<const int32_t *>(s + o_box), n,
+                     hist ? reinterpret_cast<double *>(s + o_hist) : nullptr, tiles ? s + o_tile : nullptr, s + o_cls,
+                     reinterpret_cast<double *>(s + o_ss), reinterpret_cast<double *>(s + o_sw), c->casc[0].dev, c->casc[1].dev,
+                     cascades ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    if (hist) HIP_TRY(c, hipMemcpyAsync(hist, s + o_hist, 8192 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (tiles) HIP_TRY(c, hipMemcpyAsync(tiles, s + o_tile, 676 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (cascades) {
+        HIP_TRY(c, hipMemcpyAsync(cls, s + o_cls, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(ss, s + o_ss, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(sw, s + o_sw, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return STR_ER_OK;
+}
+
+int str_er_classify_boxes(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes,
+                          int32_t n, uint8_t *cls, double *score_strong, double *score_weak)
+{
+    return boxes_call(c, plane, w, h, stride, boxes, n, nullptr, nullptr, cls, score_strong, score_weak, true);
+}
+
+int str_er_lbp_hist(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
+                    double *hist, uint8_t *tiles26)
+{
+    if (c && !hist) return fail(c, STR_ER_EINVAL, "null hist");
+    return boxes_call(c, plane, w, h, stride, boxes, n, hist, tiles26, nullptr, nullptr, nullptr, false);
+}
+
+int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
+                    int32_t cap, int32_t *n_pool, int32_t *ambiguous)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!nodes || n_nodes < 1 || rows < 1 || cols < 1 || !n_pool || (cap > 0 && !pool_idx) || cap < 0)
+        return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (n_nodes > c->kept_cap) return fail(c, STR_ER_ECAPACITY, "tree larger than kept_cap");
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    std::vector<uint32_t> key(n_nodes), area(n_nodes); std::vector<int32_t> par(n_nodes);
+    std::vector<uint16_t> box(4 * (size_t)n_nodes); std::vector<uint8_t> lev(n_nodes);
+    int root = -1, maxl = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        const str_er_node &n = nodes[i];
+        int p = n.parent;
+        if (p < 0 || p == i) { if (root >= 0) return fail(c, STR_ER_EINVAL, "tree has more than one root"); root = i; p = i; }
+        if (p >= n_nodes) return fail(c, STR_ER_EINVAL, "parent index out of range");
+        if (n.w < 1 || n.h < 1) return fail(c, STR_ER_EINVAL, "empty box");
+        key[i] = n.key; area[i] = (uint32_t)n.area; par[i] = p; lev[i] = n.level;
+        box[4 * (size_t)i] = n.x; box[4 * (size_t)i + 1] = n.y; box[4 * (size_t)i + 2] = n.w; box[4 * (size_t)i + 3] = n.h;
+        maxl = std::max(maxl, (int)n.level);
+    }
+    if (root < 0) return fail(c, STR_ER_EINVAL, "tree has no root");
+    for (int i = 0; i < n_nodes; ++i)
+        if (i != root && lev[par[i]] <= lev[i]) return fail(c, STR_ER_EINVAL, "parent level must exceed child level");
+    hipStream_t s = c->stream;
+    Batch b;
+    add_plane(b, c->d_pix, cols, rows, cols, 0, 0, 0, 0, c->kept_cap, c->pool_cap);
+    std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc));
+    PlaneCtr pc{};
+    pc.n_kept = (uint32_t)n_nodes; pc.root_slot = (uint32_t)root; pc.max_level = (uint32_t)maxl;
+    c->h_ctr[0] = pc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_ctr, c->h_ctr, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->ka.key, key.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->ka.area, area.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->ka.parent, par.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->ka.box, box.data(), 8 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->ka.level, lev.data(), (size_t)n_nodes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s)); // host vectors go out of scope after this call
+    const BatchDev bd = make_batchdev(c, b);
+    launch_nms(s, bd, make_dp(c));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_ctr[0].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
+    const int np = (int)c->h_ctr[0].n_pool;
+    *n_pool = np;
+    if (ambiguous) *ambiguous = (int32_t)c->h_ctr[0].n_amb;
+    const int ncopy = std::min(np, cap);
+    if (ncopy > 0) {
+        HIP_TRY(c, hipMemcpyAsync(pool_idx, c->d_pool, 4 * (size_t)ncopy, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    return STR_ER_OK;
+}
+
+int str_er_resize_plane(str_er_ctx *c, const uint8_t *src, int32_t sw, int32_t sh, int64_t sstride, uint8_t *dst, int32_t dw,
+                        int32_t dh)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw) return fail(c, STR_ER_EINVAL, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const size_t ns = (size_t)sw * sh, nd = (size_t)dw * dh;
+    if (ns > c->in_bytes || nd > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)sw, src, (size_t)sstride, (size_t)sw, (size_t)sh, hipMemcpyHostToDevice, c->stream));
+    launch_resize(c->stream, c->d_in, sw, sh, sw, 0, 0, c->d_pix, dw, dh, dw, 0, 0, 1, 1);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(dst, c->d_pix, nd, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return STR_ER_OK;
+}
+
+// ---- results ---------------------------------------------------------------------------------
+int32_t str_er_result_n_planes(const str_er_result *r) { return r ? (int32_t)r->planes.size() : 0; }
+
+int str_er_result_plane_info(const str_er_result *r, int32_t plane, str_er_plane_info *info)
+{
+    if (!r || !info || plane < 0 || plane >= (int32_t)r->planes.size()) return STR_ER_EINVAL;
+    *info = r->planes[plane];
+    return STR_ER_OK;
+}
+
+const str_er_cand *str_er_result_cands(const str_er_result *r, int32_t *n)
+{
+    if (!r) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->cands.size();
+    return r->cands.data();
+}
+
+const str_er_cand *str_er_result_plane_cands(const str_er_result *r, int32_t plane, int32_t *n)
+{
+    if (!r || plane < 0 || plane >= (int32_t)r->planes.size()) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)(r->cand_off[plane + 1] - r->cand_off[plane]);
+    return r->cands.data() + r->cand_off[plane];
+}
+
+const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n)
+{
+    if (!r || !r->have_nodes || plane < 0 || plane >= (int32_t)r->planes.size()) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->nodes[plane].size();
+    return r->nodes[plane].data();
+}
+
+const double *str_er_result_times(const str_er_result *r) { return r ? r->times : nullptr; }
+
+int str_er_result_cands_to_device(str_er_ctx *c, const str_er_result *r, void *dst_dev, int32_t cap, int32_t *n)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!r || !dst_dev || cap < 0 || !n) return fail(c, STR_ER_EINVAL, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const int32_t m = std::min<int32_t>((int32_t)r->cands.size(), cap);
+    *n = (int32_t)r->cands.size();
+    if (m > 0) {
+        HIP_TRY(c, hipMemcpyAsync(dst_dev, r->cands.data(), sizeof(str_er_cand) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return STR_ER_OK;
+}
+
+void str_er_result_free(str_er_result *r) { delete r; }
+
+int str_er_last_profile(const str_er_ctx *c, const char **names, double *ms, int32_t cap)
+{
+    if (!c) return 0;
+    int k = 0;
+    for (size_t i = 1; i < c->profile.size(); ++i, ++k)
+        if (k < cap) { if (names) names[k] = c->profile[i].first; if (ms) ms[k] = c->profile[i].second; }
+    return k;
+}
+
+int str_er_set_profiling(str_er_ctx *c, int enable)
+{
+    if (!c) return STR_ER_EINVAL;
+    c->profiling = enable != 0;
+    return STR_ER_OK;
+}
+
+int64_t str_er_workspace_bytes(const str_er_ctx *c) { return c ? c->ws_bytes : 0; }
+
+} // extern "C"

@@ -1,0 +1,97 @@
+"""Deterministic synthetic frames for tests and bench.py.
+
+All randomness comes from splitmix64 used as a counter-based hash, so a frame is a pure
+function of (kind, seed, width, height) and can be regenerated anywhere with numpy alone:
+
+  S-text  : smooth ramp 96 + 64x/W + 32y/H with +-4 noise, plus W*H/2500 glyph-like hollow
+            boxes with a centre bar (dark 20-59 or bright 200-239, +-3 noise), drawn with
+            independent per-colour offsets.  Never reaches the sentinel level (p >= 252).
+  S-noise : iid uniform 0..255 (stress; hits the level-32 sentinel of SURVEY A.2 constantly).
+  S-flat  : constant 128.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """One splitmix64 output step applied element-wise to uint64 states."""
+    with np.errstate(over="ignore"):
+        z = (x + _GOLD).astype(np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _hash(seed: int, idx: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        return splitmix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx.astype(np.uint64) * _GOLD)
+
+
+def frame_seed(frame_index: int) -> int:
+    return 0x5EED0000 + int(frame_index)
+
+
+def snoise_bgr(seed: int, w: int, h: int) -> np.ndarray:
+    idx = np.arange(w * h * 3, dtype=np.uint64)
+    return (_hash(seed, idx) >> np.uint64(56)).astype(np.uint8).reshape(h, w, 3)
+
+
+def sflat_bgr(seed: int, w: int, h: int, value: int = 128) -> np.ndarray:
+    return np.full((h, w, 3), value, np.uint8)
+
+
+def stext_bgr(seed: int, w: int, h: int) -> np.ndarray:
+    n = w * h
+    yy, xx = np.mgrid[0:h, 0:w]
+    ramp = (96 + (64 * xx) // max(w, 1) + (32 * yy) // max(h, 1)).astype(np.int32)
+    img = np.empty((h, w, 3), np.int32)
+    for c in range(3):
+        nz = (_hash(seed, np.arange(n, dtype=np.uint64) + np.uint64(c * n)) % np.uint64(9)).astype(np.int32) - 4
+        img[:, :, c] = ramp + nz.reshape(h, w)
+    n_glyph = n // 2500
+    g = _hash(seed ^ 0xA5A5A5A5, np.arange(n_glyph * 12, dtype=np.uint64)).reshape(n_glyph, 12)
+    for i in range(n_glyph):
+        r = [int(v) for v in g[i]]
+        gw = 6 + r[0] % 60
+        gh = 10 + r[1] % 80
+        if gw >= w or gh >= h:
+            continue
+        st = 2 + r[2] % 6
+        st = max(1, min(st, gw // 3, gh // 3))
+        x0 = r[3] % (w - gw)
+        y0 = r[4] % (h - gh)
+        base = (20 + r[5] % 40) if (r[6] & 1) else (200 + r[5] % 40)
+        mask = np.zeros((gh, gw), bool)
+        mask[:st, :] = True
+        mask[-st:, :] = True
+        mask[:, :st] = True
+        mask[:, -st:] = True
+        mid = gh // 2
+        mask[mid - st // 2: mid - st // 2 + st, :] = True
+        pn = (_hash(seed ^ (0x1234 + i), np.arange(gw * gh * 3, dtype=np.uint64)) % np.uint64(7)).astype(np.int32) - 3
+        pn = pn.reshape(gh, gw, 3)
+        for c in range(3):
+            off = (r[7 + c] % 17) - 8
+            val = np.clip(base + off + pn[:, :, c], 0, 251)
+            sub = img[y0:y0 + gh, x0:x0 + gw, c]
+            sub[mask] = val[mask]
+    return np.clip(img, 0, 251).astype(np.uint8)
+
+
+KINDS = {"text": stext_bgr, "noise": snoise_bgr, "flat": sflat_bgr}
+
+
+def frames_bgr(kind: str, first_frame: int, n_frames: int, w: int, h: int) -> np.ndarray:
+    """(n_frames, h, w, 3) uint8, frame i uses seed 0x5EED0000 + first_frame + i."""
+    fn = KINDS[kind]
+    return np.stack([fn(frame_seed(first_frame + i), w, h) for i in range(n_frames)])
+
+
+def gray(bgr: np.ndarray) -> np.ndarray:
+    """Cheap deterministic grey plane for single-plane tests: the G channel."""
+    return np.ascontiguousarray(bgr[..., 1])
