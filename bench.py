@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the ER hot path (extract + NMS + 2-stage classify) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu F]
+                    [--workload pyr3x8|native6] [--kind text|noise] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path over one batch of F synthetic 1920x1080 BGR frames per
+GPU that are ALREADY RESIDENT IN HBM: compute_channels (+ pyramid) -> per-plane component
+tree -> NMS -> LBP + strong/weak cascades -> candidate records copied back to the host
+(and, for N > 1, gathered across ranks with RCCL).  Frames are dealt out to ranks, so per-GPU
+work is fixed as N grows ("weak" scaling) and `value` = all frames processed by all ranks
+per second.
+
+Workloads (BASELINE.json `configs`):
+  pyr3x8  : configs[1]/[2]: planes {Y,Cr,Cb} x 8 pyramid levels (24 planes, 12.40 Mpx/frame)
+  native6 : what the reference's text_detect really runs: {Y,Cr,Cb,255-Y,255-Cr,255-Cb} at
+            native resolution (6 planes, 12.44 Mpx/frame; src/ER.cpp:114-128)
+
+Extra objects on the JSON line:
+  roofline     : HBM roofline of the dominant kernel (k_tile_tree), from HIP events recorded
+                 by the library on the stream the kernels run on.
+  cpu_baseline : the oracle (a plain-C port of the reference's CPU algorithm) timed on this
+                 box's host cores on a bounded sample, threads over planes like the
+                 reference's `#pragma omp parallel for` (src/ER.cpp:50).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+WORKLOADS = {
+    "pyr3x8": dict(n_pyr_levels=8, channel_mask=0x07, label="1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels (BASELINE configs[1]/[2])"),
+    "native6": dict(n_pyr_levels=1, channel_mask=0x3F, label="1920x1080 BGR, reference-native 6 planes x 1 level"),
+}
+
+
+def plane_pixels(workload: str) -> int:
+    """Sum of plane pixels per frame (12 395 367 for pyr3x8, 12 441 600 for native6)."""
+    cfg = WORKLOADS[workload]
+    nch = bin(cfg["channel_mask"]).count("1")
+    tot = 0
+    for k in range(cfg["n_pyr_levels"]):
+        s = 2.0 ** (-0.5 * k)
+        tot += max(1, int(np.floor(W * s + 0.5))) * max(1, int(np.floor(H * s + 0.5))) * nch
+    return tot
+
+
+def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 20.0):
+    """Oracle on host cores: per frame compute_channels (+pyramid) then one thread per plane."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import Oracle
+
+    S = importlib.import_module("scene-text-recognition_amd")
+    cfg = WORKLOADS[workload]
+    o = Oracle()
+    cs, cw = o.cascade_load(cascades[0]), o.cascade_load(cascades[1])
+    ncores = os.cpu_count() or 1
+
+    def planes_of(frame):
+        six = o.compute_channels(frame)
+        out = []
+        for ch in range(6):
+            if cfg["channel_mask"] & (1 << ch):
+                out.extend(o.pyramid(six[ch], cfg["n_pyr_levels"]))
+        return out
+
+    def run_plane(p):
+        r = o.detect_plane(p, cs, cw)
+        return len(r["pool"])
+
+    frames_done, t_total, pooled = 0, 0.0, 0
+    nthreads = 1
+    while t_total < budget_s and frames_done < 4:
+        frame = S.synth.KINDS[kind](S.synth.frame_seed(frames_done), W, H)
+        t0 = time.perf_counter()
+        planes = planes_of(frame)
+        nthreads = max(1, min(len(planes), ncores))
+        with ThreadPoolExecutor(nthreads) as ex:
+            pooled += sum(ex.map(run_plane, planes))
+        t_total += time.perf_counter() - t0
+        frames_done += 1
+    return {"value": round(frames_done / t_total, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": f"{frames_done} S-{kind} 1920x1080 frame(s), workload {workload}, {t_total:.1f} s of CPU wall time, "
+                      f"oracle/er_oracle.c -O2, one thread per plane ({nthreads} threads on {ncores} host cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=16)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
+    ap.add_argument("--kind", choices=["text", "noise"], default="text")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    S = importlib.import_module("scene-text-recognition_amd")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path to measure)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = WORKLOADS[args.workload]
+    F = args.frames_per_gpu
+    tmp = tempfile.mkdtemp()
+    cascades = S.cascade_io.write_golden(tmp)
+    f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
+                                   channel_mask=cfg["channel_mask"], device=local_rank))
+    f.load_cascade(0, cascades[0])
+    f.load_cascade(1, cascades[1])
+
+    # synthetic frames of this rank's shard: global frame index = rank*F + i
+    n_distinct = min(F, 4)
+    src = S.synth.frames_bgr(args.kind, rank * F, n_distinct, W, H)
+    frames = np.stack([src[i % n_distinct] for i in range(F)])
+    d_frames = torch.from_numpy(frames).to(device)
+    torch.cuda.synchronize()
+
+    def step():
+        r = f.detect_bgr_device(d_frames.data_ptr(), W, H, F)
+        if world > 1:
+            S.dist.gather_candidates(r.cands, device, frame_offset=rank * F)
+        return r
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof_sum = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+        for k, v in r.profile.items():
+            prof_sum[k] = prof_sum.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = F * world * args.steps
+        fps = total_frames / elapsed
+        px = plane_pixels(args.workload)
+        n_pool = len(r.cands)
+        # algorithmic bytes per frame, SURVEY.md 8(d): 3WH (BGR read) + 2*sum(plane px) (each 8-bit
+        # plane written once, read once) + N_pool*(2704+48)
+        b_alg = 3 * W * H + 2 * px + (n_pool / F) * (2704 + 48)
+        # dominant kernel: k_tile_tree reads every plane pixel once -> px bytes per frame
+        tile_ms = prof_sum.get("tile_tree", 0.0) / max(args.steps, 1)
+        tile_bytes = px * F
+        achieved = tile_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_tile_tree.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as fh:
+                    j = json.load(fh)
+                if j.get("workload") == args.workload and j.get("frames_per_launch"):
+                    traffic = j["hbm_bytes_per_launch"] * F / j["frames_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec (ER extract + 2-stage classify), 1920x1080",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['label']}; S-{args.kind} frames", "frames_per_gpu_per_step": F,
+                       "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
+                       "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
+                       "pooled_per_frame": round(n_pool / F, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "bytes_per_launch": tile_bytes, "avg_launch_ms": round(tile_ms, 4),
+                         "path_bytes_per_frame": int(b_alg), "path_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)},
+            "gpu_ms_per_step_by_kernel_group": {k: round(v / args.steps, 4) for k, v in prof_sum.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

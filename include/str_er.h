@@ -189,6 +189,11 @@ int str_er_lbp_hist(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h,
                     int64_t stride, const int32_t *boxes_xywh, int32_t n,
                     double *hist, uint8_t *tiles26);
 
+/* AdaBoost::predict(vector<double> fv) (inc/adaboost.h:131; CascadeBoost::predict,
+ * src/adaboost.cpp:507-542) for n caller-supplied 1024-element feature vectors:
+ * out[i] = last stage score, or -DBL_MAX if a stage rejected.                       */
+int str_er_cascade_predict(str_er_ctx *ctx, int which, const double *fv, int32_t n, double *out);
+
 /* ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a caller-supplied kept tree
  * (parent indices; root points to itself or -1).  pool_idx receives up to cap node
  * indices in ascending key order; *n_pool the count; *ambiguous as in plane_info.    */

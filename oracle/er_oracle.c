@@ -583,6 +583,27 @@ void ero_aran26(const uint8_t *roi, int stride, int w, int h, uint8_t tile[26 * 
     }
 }
 
+/* Size OCR::ARAN resizes to (src/OCR.cpp:396-397), and a self-test used by tests/: the HIP
+ * kernel computes (int)(26*sqrt(R1)) where the reference writes (int)(26*pow(R1,0.5)); this
+ * counts the (w,h) pairs up to maxdim for which this libm's pow() disagrees with sqrt(). */
+void ero_aran_dims(int w, int h, int *dw, int *dh)
+{
+    const double R1 = (w > h) ? (double)h / w : (double)w / h;
+    if (w > h) { *dw = 26; *dh = (int)(26 * pow(R1, 0.5)); }
+    else       { *dw = (int)(26 * pow(R1, 0.5)); *dh = 26; }
+}
+
+long ero_selftest_pow_vs_sqrt(int maxdim)
+{
+    long bad = 0;
+    for (int w = 1; w <= maxdim; ++w)
+        for (int h = 1; h <= maxdim; ++h) {
+            volatile double r = (w > h) ? (double)h / w : (double)w / h;
+            if ((int)(26 * pow(r, 0.5)) != (int)(26 * sqrt(r))) ++bad;
+        }
+    return bad;
+}
+
 /* ERFilter::calc_LBP (src/ER.cpp:819-845): neighbour offsets are written with
  * `size` (24) although the tile is 26 wide -- kept as is. */
 void ero_lbp24(const uint8_t tile[26 * 26], uint8_t lbp[24 * 24])

@@ -101,6 +101,8 @@ int  ero_nms(const ero_tree *t, int rows, int cols, const ero_params *p,
 /* ---- classify chain (src/ER.cpp:507-528, 789-845; src/OCR.cpp:394-430) --- */
 /* ARAN(L=26) of a w*h ROI into a zeroed 26*26 tile. */
 void ero_aran26(const uint8_t *roi, int stride, int w, int h, uint8_t tile[26 * 26]);
+void ero_aran_dims(int w, int h, int *dw, int *dh);
+long ero_selftest_pow_vs_sqrt(int maxdim);
 /* calc_LBP on the 26*26 tile -> 24*24 codes (stride-24-on-26 quirk kept). */
 void ero_lbp24(const uint8_t tile[26 * 26], uint8_t lbp[24 * 24]);
 /* make_LBP_hist: 2x2 blocks x 256 bins, counts as doubles. */

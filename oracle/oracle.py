@@ -80,6 +80,9 @@ class Oracle:
                               C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.ero_aran26.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.ero_lbp24.argtypes = [u8p, u8p]
+        L.ero_aran_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ero_selftest_pow_vs_sqrt.argtypes = [C.c_int]
+        L.ero_selftest_pow_vs_sqrt.restype = C.c_long
         L.ero_lbp_hist.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.ero_cascade_load.argtypes = [C.c_char_p]
         L.ero_cascade_load.restype = C.c_void_p
@@ -174,6 +177,11 @@ class Oracle:
         p = C.POINTER(C.c_uint8)
         self.lib.ero_aran26(roi.ctypes.data_as(p), roi.shape[1], roi.shape[1], roi.shape[0], tile.ctypes.data_as(p))
         return tile
+
+    def aran_dims(self, w: int, h: int):
+        dw, dh = C.c_int(), C.c_int()
+        self.lib.ero_aran_dims(w, h, C.byref(dw), C.byref(dh))
+        return dw.value, dh.value
 
     def lbp24(self, tile: np.ndarray) -> np.ndarray:
         tile = _u8(tile)

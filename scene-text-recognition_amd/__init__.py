@@ -20,3 +20,11 @@ from . import cascade_io, synth  # noqa: F401
 
 __all__ = ["ERFilter", "Params", "Result", "StrErError", "load_library", "lib_path", "cascade_io", "synth",
            "CAND_DTYPE", "NODE_DTYPE"]
+
+
+def __getattr__(name):
+    # `dist` pulls in torch; load it only when somebody asks for it
+    if name == "dist":
+        import importlib
+        return importlib.import_module(__name__ + ".dist")
+    raise AttributeError(name)

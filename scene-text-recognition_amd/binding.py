@@ -110,6 +110,7 @@ def load_library():
     L.str_er_compute_channels.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]
     L.str_er_classify_boxes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
     L.str_er_lbp_hist.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp]
+    L.str_er_cascade_predict.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
@@ -356,6 +357,13 @@ class ERFilter:
         self._check(self.L.str_er_classify_boxes(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), n,
                                                  _np_ptr(cls), _np_ptr(ss), _np_ptr(sw)))
         return cls, ss, sw
+
+    def predict(self, which: int, fv: np.ndarray) -> np.ndarray:
+        """stc->predict(fv) / wtc->predict(fv) (inc/adaboost.h:131) for (n,1024) feature vectors."""
+        a = np.ascontiguousarray(fv, dtype=np.float64).reshape(-1, 1024)
+        out = np.zeros(len(a), np.float64)
+        self._check(self.L.str_er_cascade_predict(self.h, which, _np_ptr(a), len(a), _np_ptr(out)))
+        return out
 
     def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):
         """ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816).  With no boxes the whole

@@ -51,4 +51,7 @@ void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int str
                       int n, double *hist /*n*1024 or null*/, uint8_t *tiles /*n*676 or null*/, uint8_t *cls,
                       double *s_strong, double *s_weak, CascadeDev strong, CascadeDev weak, int run_cascades);
 
+// CascadeBoost::predict on explicit feature vectors (n x 1024 doubles).
+void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, CascadeDev c);
+
 } // namespace str_er

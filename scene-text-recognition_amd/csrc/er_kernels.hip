@@ -1050,4 +1050,56 @@ void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int str
                        hist, tiles, cls, s_strong, s_weak, strong, weak, run_cascades);
 }
 
+// CascadeBoost::predict (src/adaboost.cpp:507-542) on caller-supplied feature vectors.
+__global__ __launch_bounds__(CLS_THREADS) void k_cascade_fv(const double *__restrict__ fv, int n, double *out, CascadeDev c)
+{
+    __shared__ double s_fv[1024];
+    __shared__ double s_vals[CLS_CHUNK];
+    __shared__ double s_acc;
+    const int tid = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        for (int k = tid; k < 1024; k += CLS_THREADS) s_fv[k] = fv[(size_t)i * 1024 + k];
+        __syncthreads();
+        int    off = 0;
+        double score = 0;
+        bool   rejected = false;
+        for (int s = 0; s < c.n_stages && !rejected; ++s) {
+            const int nst = c.stage_n[s];
+            if (tid == 0) s_acc = 0;
+            for (int base = 0; base < nst; base += CLS_CHUNK) {
+                const int m = min(CLS_CHUNK, nst - base);
+                for (int j = tid; j < m; j += CLS_THREADS) {
+                    const int st = off + base + j;
+                    double    v = 0;
+                    if (st < c.n_stumps) {
+                        const double f = s_fv[c.dim[st]], d = c.dir[st];
+                        v = (f * d < c.thr[st] * d) ? c.vp[st] : c.vn[st];
+                    }
+                    s_vals[j] = v;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    double a = s_acc;
+                    const int mm = min(m, max(0, c.n_stumps - off - base));
+                    for (int j = 0; j < mm; ++j) a += s_vals[j];
+                    s_acc = a;
+                }
+                __syncthreads();
+            }
+            score = s_acc;
+            __syncthreads();
+            if (score < (double)c.stage_thresh[s]) rejected = true;
+            off += nst;
+        }
+        if (tid == 0) out[i] = rejected ? -DBL_MAX : score;
+        __syncthreads();
+    }
+}
+
+void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, CascadeDev c)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cascade_fv, dim3(n < 2048 ? n : 2048), dim3(CLS_THREADS), 0, s, fv, n, out, c);
+}
+
 } // namespace str_er

@@ -775,6 +775,25 @@ int str_er_lbp_hist(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, i
     return boxes_call(c, plane, w, h, stride, boxes, n, hist, tiles26, nullptr, nullptr, nullptr, false);
 }
 
+int str_er_cascade_predict(str_er_ctx *c, int which, const double *fv, int32_t n, double *out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if ((which != 0 && which != 1) || n < 0 || (n > 0 && (!fv || !out))) return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (!c->casc[which].loaded) return fail(c, STR_ER_ESTATE, "cascade not loaded");
+    if (n == 0) return STR_ER_OK;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const size_t in_b = 8192 * (size_t)n, total = in_b + 8 * (size_t)n;
+    int rc = ensure_scratch(c, total);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(s, fv, in_b, hipMemcpyHostToDevice, c->stream));
+    launch_cascade_fv(c->stream, reinterpret_cast<const double *>(s), n, reinterpret_cast<double *>(s + in_b), c->casc[which].dev);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, s + in_b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return STR_ER_OK;
+}
+
 int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
                     int32_t cap, int32_t *n_pool, int32_t *ambiguous)
 {

@@ -1,0 +1,343 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle on the same
+inputs.  Integer/index outputs (node tables, pools, classes) are compared bit for bit; the
+cascade scores are compared EXACTLY as well (the kernel adds stump outputs in file order),
+which is stricter than the 1e-4 tolerance BASELINE.json allows."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import check_plane_against_oracle, gpu_tree_canon, oracle_tree_canon
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+def _planes(rng, shapes):
+    for k, (h, w) in enumerate(shapes):
+        mode = k % 5
+        if mode == 0:
+            yield "noise", rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif mode == 1:
+            yield "4lev", (rng.integers(0, 4, (h, w)) * 60).astype(np.uint8)
+        elif mode == 2:
+            yield "sentinel", rng.integers(200, 256, (h, w)).astype(np.uint8)
+        elif mode == 3:
+            yield "ramp", (np.add.outer(np.arange(h) * 3, np.arange(w) * 5) % 256).astype(np.uint8)
+        else:
+            yield "blocks", np.kron(rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8), dtype=np.uint8), np.ones((8, 8), np.uint8))[:h, :w]
+
+
+SHAPES = [(1, 1), (1, 17), (23, 1), (2, 2), (31, 63), (32, 64), (33, 65), (64, 128), (65, 129), (70, 130), (97, 211),
+          (128, 64), (5, 300), (300, 5), (200, 333)]
+
+
+@pytest.mark.parametrize("min_area", [0, 120])
+def test_planes_small_all_nodes(erf, oracle, oracle_cascades, min_area):
+    """Ragged sizes around the 64x32 tile; min_area=0 keeps (and so checks) every tree node."""
+    rng = np.random.default_rng(100 + min_area)
+    erf.set_min_area(min_area)
+    try:
+        for name, img in _planes(rng, SHAPES):
+            res = erf.detect_planes(img, want_nodes=True)
+            check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades, min_area=min_area)
+    finally:
+        erf.set_min_area(120)
+
+
+def test_known_answers(erf):
+    """SURVEY.md Appendix B known-answer runs of the unmodified reference."""
+    p = erf.er_tree_extract(np.full((10, 10), 100, np.uint8))
+    n = p.nodes
+    assert len(n) == 1 and (n[0]["level"], n[0]["area"], n[0]["w"], n[0]["h"]) == (12, 101, 10, 10)
+    p = erf.er_tree_extract(np.full((10, 10), 252, np.uint8))
+    n = p.nodes
+    assert len(n) == 1 and (n[0]["level"], n[0]["area"], n[0]["x"], n[0]["y"], n[0]["w"], n[0]["h"]) == (32, 2, 0, 0, 1, 1)
+    m = np.full((6, 6), 40, np.uint8)
+    m[0, 0] = 255
+    assert erf.er_tree_extract(m).nodes[0]["area"] == 36
+    m[0, 1] = 255
+    assert erf.er_tree_extract(m).nodes[0]["area"] == 35
+    m[1, 0] = 255
+    n = erf.er_tree_extract(m).nodes
+    assert (n[0]["level"], n[0]["area"], n[0]["w"], n[0]["h"]) == (32, 2, 1, 1)
+
+
+def test_sentinel_walls(erf, oracle, oracle_cascades):
+    """Closed curves of >=252 pixels hide what is behind them, across tiles."""
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 250, (150, 260), dtype=np.uint8)
+    img[20:130, 40] = 255; img[20:130, 200] = 253; img[20, 40:201] = 252; img[129, 40:201] = 254   # sealed box
+    img[60:90, 100:140] = rng.integers(0, 250, (30, 40))
+    erf.set_min_area(0)
+    try:
+        res = erf.detect_planes(img, want_nodes=True)
+        ref = check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades, min_area=0)
+        assert int(ref["tree"].nodes[ref["tree"].root]["npix"]) < img.size - 110 * 160 + 1000
+        img[0, 0] = 255                                           # start pixel itself is a wall
+        res = erf.detect_planes(img, want_nodes=True)
+        check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades, min_area=0)
+        img[0, 1] = 255
+        img[1, 0] = 255                                           # ... and both candidates: single node
+        res = erf.detect_planes(img, want_nodes=True)
+        assert res.planes[0].n_kept == 1
+        check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades, min_area=0)
+    finally:
+        erf.set_min_area(120)
+
+
+@pytest.mark.parametrize("step,min_area", [(1, 30), (2, 50), (9, 20), (16, 200)])
+def test_other_thresh_steps(S, cascade_paths, oracle, oracle_cascades, step, min_area):
+    """THRESH_STEP and MIN_AREA are run-time parameters (src/utils.cpp:680, 716, 940, 1090)."""
+    f = S.ERFilter(step, min_area, 900000, 2, 0.7, max_width=256, max_height=256, max_frames=1)
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    rng = np.random.default_rng(step)
+    for img in (rng.integers(0, 256, (90, 150), dtype=np.uint8), S.synth.gray(S.synth.stext_bgr(step, 256, 200))):
+        res = f.detect_planes(img, want_nodes=True)
+        check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades, step=step, min_area=min_area)
+    f.close()
+
+
+def test_nms_parameters(S, cascade_paths, oracle, oracle_cascades):
+    f = S.ERFilter(8, 40, 5000, 3, 0.6, max_width=320, max_height=240, max_frames=1)
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    img = S.synth.gray(S.synth.stext_bgr(21, 320, 240))
+    res = f.detect_planes(img, want_nodes=True)
+    check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades, min_area=40, max_area=5000, stability_t=3,
+                               overlap_coef=0.6)
+    f.close()
+
+
+def test_batch_of_planes_is_independent(erf, oracle, oracle_cascades, S):
+    imgs = np.stack([S.synth.gray(S.synth.stext_bgr(30 + i, 320, 240)) for i in range(5)])
+    res = erf.detect_planes(imgs, want_nodes=True)
+    assert len(res.planes) == 5
+    for p, img in zip(res.planes, imgs):
+        check_plane_against_oracle(oracle, p, img, oracle_cascades)
+    single = erf.detect_planes(imgs[3], want_nodes=True).planes[0]
+    assert single.cands.tobytes() == res.planes[3].cands.tobytes() or \
+        [tuple(c)[1:12] for c in single.cands.tolist()] == [tuple(c)[1:12] for c in res.planes[3].cands.tolist()]
+
+
+def test_bgr_frame_all_six_planes(erf, oracle, oracle_cascades, S):
+    """ERFilter::text_detect up to classify on a 640x480 frame (src/ER.cpp:39-60)."""
+    frame = S.synth.stext_bgr(S.synth.frame_seed(1), 640, 480)
+    res = erf.text_detect(frame, want_nodes=True)
+    planes = oracle.compute_channels(frame)
+    assert [p.ch for p in res.planes] == [0, 1, 2, 3, 4, 5]
+    for p in res.planes:
+        check_plane_against_oracle(oracle, p, planes[p.ch], oracle_cascades)
+    assert sum(p.n_strong + p.n_weak for p in res.planes) > 0
+    assert res.times.shape == (7,) and res.times[0] > 0 and res.times[6] >= res.times[0]
+
+
+def test_compute_channels(erf, oracle, S):
+    rng = np.random.default_rng(3)
+    for shape in ((1, 1, 3), (7, 13, 3), (48, 64, 3), (33, 101, 3)):
+        bgr = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert (erf.compute_channels(bgr) == oracle.compute_channels(bgr)).all()
+    corners = np.array([[[b, g, r] for b in (0, 255) for g in (0, 255) for r in (0, 255)]], np.uint8)
+    assert (erf.compute_channels(corners) == oracle.compute_channels(corners)).all()
+
+
+def test_resize_plane(erf, oracle):
+    rng = np.random.default_rng(4)
+    for (sh, sw), (dh, dw) in (((108, 192), (76, 136)), ((52, 52), (26, 26)), ((52, 48), (26, 24)), ((30, 30), (30, 30)),
+                               ((9, 200), (26, 5)), ((200, 9), (8, 26)), ((3, 3), (26, 26)), ((1, 1), (7, 5))):
+        src = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        assert (erf.resize_plane(src, dw, dh) == oracle.resize(src, dw, dh)).all(), (sh, sw, dh, dw)
+
+
+def test_pyramid_planes(S, cascade_paths, oracle, oracle_cascades):
+    """Build-defined pyramid: level k = resize_linear(level k-1); every level is checked as a plane."""
+    f = S.ERFilter(params=S.Params(max_width=320, max_height=240, max_frames=1, n_pyr_levels=4, channel_mask=0x0B))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    frame = S.synth.stext_bgr(9, 320, 240)
+    res = f.text_detect(frame, want_nodes=True)
+    six = oracle.compute_channels(frame)
+    assert [(p.pyr, p.ch) for p in res.planes] == [(l, c) for l in range(4) for c in (0, 1, 3)]
+    pyr = {c: oracle.pyramid(six[c], 4) for c in (0, 1, 3)}
+    for p in res.planes:
+        img = pyr[p.ch][p.pyr]
+        assert (p.height, p.width) == img.shape
+        check_plane_against_oracle(oracle, p, img, oracle_cascades)
+    f.close()
+
+
+def test_inverted_channel_equals_materialised_inverse(erf, S):
+    frame = S.synth.stext_bgr(12, 320, 240)
+    res = erf.text_detect(frame, want_nodes=True)
+    six = erf.compute_channels(frame)
+    for ch in (3, 4, 5):
+        direct = erf.detect_planes(six[ch], want_nodes=True).planes[0]
+        assert gpu_tree_canon(direct.nodes) == gpu_tree_canon(res.planes[ch].nodes)
+        a = [tuple(c)[2:11] + tuple(c)[13:] for c in direct.cands.tolist()]
+        b = [tuple(c)[2:11] + tuple(c)[13:] for c in res.planes[ch].cands.tolist()]
+        assert a == b
+
+
+# ---- single stages --------------------------------------------------------------------------------
+def _boxes(rng, h, w, n):
+    out = [(0, 0, 52, 52), (3, 2, 48, 52), (0, 0, w, h), (5, 5, 26, 26), (1, 1, 3, 3), (0, 0, 1, 1), (10, 0, 200, 21), (0, 10, 9, 88)]
+    for _ in range(n):
+        bw, bh = int(rng.integers(1, min(w, 230))), int(rng.integers(1, min(h, 230)))
+        out.append((int(rng.integers(0, w - bw + 1)), int(rng.integers(0, h - bh + 1)), bw, bh))
+    return np.array([b for b in out if b[0] + b[2] <= w and b[1] + b[3] <= h], np.int32)
+
+
+def test_lbp_hist_and_tiles(erf, oracle):
+    """make_LBP_hist / calc_LBP / ARAN (src/ER.cpp:789-845, src/OCR.cpp:394-430) on assorted ROIs,
+    including the exact-2x (52x52, 48x52) resize path and extreme aspect ratios."""
+    rng = np.random.default_rng(5)
+    plane = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    boxes = _boxes(rng, 240, 320, 120)
+    hist, tiles = erf.make_LBP_hist(plane, boxes, return_tiles=True)
+    for b, h, t in zip(boxes, hist, tiles):
+        roi = plane[b[1]:b[1] + b[3], b[0]:b[0] + b[2]]
+        assert (t == oracle.aran26(roi)).all(), b
+        assert (h == oracle.lbp_hist(roi)).all(), b
+    whole = erf.make_LBP_hist(plane)
+    assert (whole[0] == oracle.lbp_hist(plane)).all()
+
+
+def test_classify_boxes(erf, oracle, oracle_cascades, S):
+    img = S.synth.gray(S.synth.stext_bgr(14, 640, 480))
+    rng = np.random.default_rng(6)
+    boxes = _boxes(rng, 480, 640, 150)
+    cls, ss, sw = erf.classify(img, boxes)
+    ecls, ess, esw = oracle.classify(img, boxes, *oracle_cascades)
+    assert (cls == ecls).all() and (ss == ess).all() and (sw == esw).all()
+
+
+def test_cascade_predict_matches_reference_vectors(erf):
+    """tests/golden/cascade_vectors.npz = outputs of the reference's own CascadeBoost::predict."""
+    z = np.load(os.path.join(GOLDEN, "cascade_vectors.npz"))
+    fv = z["hist"].astype(np.float64)
+    assert (erf.predict(0, fv) == z["strong"]).all()
+    assert (erf.predict(1, fv) == z["weak"]).all()
+
+
+def test_cascade_predict_matches_reference_library(erf, cascade_paths):
+    from oracle.oracle import RefCascade
+    if not RefCascade.available():
+        pytest.skip("oracle/_ref/libref_adaboost.so not present")
+    rs, rw = RefCascade(cascade_paths[0]), RefCascade(cascade_paths[1])
+    rng = np.random.default_rng(8)
+    fv = np.stack([np.concatenate([np.bincount(rng.integers(0, 256, 144) // rng.integers(1, 40), minlength=256)
+                                   for _ in range(4)]) for _ in range(300)]).astype(np.float64)
+    gs, gw = erf.predict(0, fv), erf.predict(1, fv)
+    assert (gs == np.array([rs.predict(v) for v in fv])).all()
+    assert (gw == np.array([rw.predict(v) for v in fv])).all()
+    assert (gs > -DBL_MAX).any()
+
+
+def _to_node_table(S, tree):
+    n = tree.nodes
+    out = np.zeros(len(n), S.NODE_DTYPE)
+    out["key"], out["area"], out["level"] = n["key"], n["area"], n["level"]
+    out["x"], out["y"], out["w"], out["h"] = n["x"], n["y"], n["w"], n["h"]
+    out["parent"] = np.where(n["parent"] < 0, np.arange(len(n)), n["parent"])
+    return out
+
+
+def test_nms_tree(erf, oracle, S):
+    """non_maximum_supression on uploaded trees, incl. a hand-made ambiguous one."""
+    for seed, kind in ((1, "text"), (2, "noise"), (3, "text")):
+        img = S.synth.gray(S.synth.KINDS[kind](seed, 400, 300))
+        t = oracle.tree_extract(img, 8, 120)
+        pool, amb = erf.non_maximum_supression(_to_node_table(S, t), 300, 400)
+        ref, ramb = oracle.nms(t, 300, 400)
+        assert (amb == 0) == (ramb == 0)
+        if ramb:
+            ref, _ = oracle.nms(t, 300, 400, sibling_mode=2)
+        assert sorted(pool.tolist()) == sorted(ref.tolist())
+        assert [int(t.nodes[i]["key"]) for i in pool] == sorted(int(t.nodes[i]["key"]) for i in pool)
+    # two children whose boxes both cover > 0.7 of the parent: the answer depends on sibling order
+    from oracle.oracle import NODE_DTYPE, Tree
+    n = np.zeros(5, NODE_DTYPE)
+    #        level area   x  y  w   h  parent child next key
+    n[0] = (1, 500, 0, 0, 30, 28, 2, -1, 1, 5, 0, 0)
+    n[1] = (1, 500, 0, 0, 28, 30, 2, -1, -1, 9, 0, 0)
+    n[2] = (2, 1100, 0, 0, 30, 30, 3, 0, -1, 2, 0, 0)
+    n[3] = (3, 1300, 0, 0, 31, 31, 4, 2, -1, 1, 0, 0)
+    n[4] = (4, 9000, 0, 0, 90, 90, -1, 3, -1, 0, 0, 0)
+    t = Tree(n, 4, 5, 0)
+    for order, mode in ((0, 2), (1, 1)):
+        f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=128, max_height=128, max_frames=1, sibling_order=order)
+        pool, amb = f.non_maximum_supression(_to_node_table(S, t), 100, 100)
+        ref, ramb = oracle.nms(t, 100, 100, sibling_mode=mode)
+        assert amb >= 1 and ramb >= 1 and sorted(pool.tolist()) == sorted(ref.tolist())
+        f.close()
+
+
+# ---- full size ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["text", "noise"])
+def test_full_hd_plane(erf, oracle, oracle_cascades, S, kind):
+    img = S.synth.gray(S.synth.KINDS[kind](S.synth.frame_seed(5), 1920, 1080))
+    res = erf.detect_planes(img, want_nodes=True)
+    check_plane_against_oracle(oracle, res.planes[0], img, oracle_cascades)
+
+
+def test_full_hd_frame_two_frames(erf, oracle, oracle_cascades, S):
+    """BASELINE configs: 1920x1080 BGR, the reference's six planes; 2 frames in one call."""
+    frames = S.synth.frames_bgr("text", 0, 2, 1920, 1080)
+    res = erf.text_detect(frames)
+    assert len(res.planes) == 12
+    for p in res.planes:
+        if p.frame == 1 or p.ch in (0, 3):        # every plane of frame 1, the luma planes of frame 0
+            check_plane_against_oracle(oracle, p, oracle.compute_channels(frames[p.frame])[p.ch], oracle_cascades)
+    again = erf.text_detect(frames)
+    assert again.cands.tobytes() == res.cands.tobytes()        # deterministic
+
+
+def test_properties_full_size(erf, S):
+    """Size-independent checks at 1920x1080: area bookkeeping and tree shape."""
+    img = S.synth.gray(S.synth.snoise_bgr(77, 1920, 1080))
+    p = erf.er_tree_extract(img)
+    n = p.nodes
+    root = n[p.root]
+    assert root["parent"] == p.root and (n["flags"] & 1).sum() == 1
+    others = np.arange(len(n)) != p.root
+    par = n[n["parent"]]
+    assert (par["level"][others] > n["level"][others]).all()           # levels strictly increase upward
+    assert (par["area"][others] > n["area"][others]).all()             # areas grow upward
+    assert (n["area"][others] > 120).all()
+    assert (par["x"] <= n["x"]).all() and (par["y"] <= n["y"]).all()   # boxes nest
+    assert (par["x"].astype(int) + par["w"] >= n["x"].astype(int) + n["w"]).all()
+    assert (par["y"].astype(int) + par["h"] >= n["y"].astype(int) + n["h"]).all()
+    assert len(np.unique(n[["key", "level"]])) == len(n)
+
+
+# ---- error behaviour -------------------------------------------------------------------------------------
+def test_errors(S, cascade_paths):
+    f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=128, max_height=96, max_frames=1)
+    img = np.zeros((96, 128), np.uint8)
+    with pytest.raises(S.StrErError) as e:
+        f.detect_planes(img)                                   # classify without cascades
+    assert e.value.code == -6
+    f.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS)        # fine without classify
+    with pytest.raises(S.StrErError) as e:
+        f.detect_planes(np.zeros((97, 128), np.uint8), S.STAGE_EXTRACT)
+    assert e.value.code == -7
+    with pytest.raises(S.StrErError) as e:
+        f.load_cascade(0, "/nonexistent/strong.classifier")
+    assert e.value.code == -4                                  # reference: prints and returns false
+    with pytest.raises(S.StrErError) as e:
+        f.load_cascade_text(0, "boost_type REAL\nbase_type DECISION_STUMP\nnum_of_iter 2\nthreshold 0\n1 5 3 0.1 0.2 \n")
+    assert e.value.code == -5
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    assert f.cascade_info(0) == (4, 2660) and f.cascade_info(1) == (6, 1354)
+    with pytest.raises(S.StrErError) as e:
+        f.classify(img, np.array([[100, 0, 40, 10]], np.int32))   # box sticks out of the plane
+    assert e.value.code == -1
+    f.close()
+
+
+def test_kept_table_overflow_is_reported(S):
+    f = S.ERFilter(8, 2, 900000, 2, 0.7, max_width=256, max_height=256, max_frames=1, kept_cap=64)
+    img = np.random.default_rng(0).integers(0, 256, (256, 256), dtype=np.uint8)
+    with pytest.raises(S.StrErError) as e:
+        f.detect_planes(img, S.STAGE_EXTRACT)
+    assert e.value.code == -7 and "kept" in str(e.value)
+    f.close()
