@@ -71,8 +71,9 @@ typedef struct str_er_params {
     int32_t  stability_t;     /* STABILITY_T   default 2                              */
     double   overlap_coef;    /* OVERLAP_COEF  default 0.7                            */
     int32_t  n_pyr_levels;    /* 1 = native resolution only (the reference);
-                                 level k>=1 is resize_linear(level k-1) to
-                                 (lround(w*2^(-k/2)), lround(h*2^(-k/2)))             */
+                                 level k>=1 of Y/Cr/Cb is resize_linear(level k-1)
+                                 to (lround(w*2^(-k/2)), lround(h*2^(-k/2)));
+                                 inverted channels are 255 - that level               */
     uint32_t channel_mask;    /* bit i = plane i of [Y,Cr,Cb,255-Y,255-Cr,255-Cb]
                                  (src/ER.cpp:122-127); 0x3F = the reference           */
     int32_t  device;          /* HIP device ordinal                                   */

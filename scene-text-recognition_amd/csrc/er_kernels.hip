@@ -79,6 +79,14 @@ __device__ __forceinline__ void ycrcb_px(int B, int G, int R, int &Y, int &Cr, i
     Y  = min(max(Y, 0), 255);
     Cr = min(max(Cr, 0), 255);
     Cb = min(max(Cb, 0), 255);
+    // Toolchain hazard (ROCm 7.2 hipcc, gfx950): when two such clamped shifts are packed into
+    // bytes, LLVM fuses them into v_ashr_pk_u8_i32 and then ORs further bytes into the result
+    // assuming bits 31:16 are zero -- on MI355X they keep the old register contents, which
+    // corrupted byte 2 of every packed Cr/Cb dword.  The empty asm makes each value opaque so
+    // the fusion cannot happen.
+    asm volatile("" : "+v"(Y));
+    asm volatile("" : "+v"(Cr));
+    asm volatile("" : "+v"(Cb));
 }
 
 __global__ __launch_bounds__(256) void k_bgr_to_ycrcb(const uint8_t *__restrict__ bgr, int w, int h,
@@ -95,13 +103,17 @@ __global__ __launch_bounds__(256) void k_bgr_to_ycrcb(const uint8_t *__restrict_
     const size_t   dof = (size_t)f * dst_frame_pitch + (size_t)y * dstride + x;
     if (aligned && x + 4 <= w) {
         const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-        const uint32_t a = s32[0], b = s32[1], c = s32[2];
+        const uint32_t wd[3] = {s32[0], s32[1], s32[2]};
         // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
         int Y[4], Cr[4], Cb[4];
-        ycrcb_px(a & 255, (a >> 8) & 255, (a >> 16) & 255, Y[0], Cr[0], Cb[0]);
-        ycrcb_px(a >> 24, b & 255, (b >> 8) & 255, Y[1], Cr[1], Cb[1]);
-        ycrcb_px((b >> 16) & 255, b >> 24, c & 255, Y[2], Cr[2], Cb[2]);
-        ycrcb_px((c >> 8) & 255, (c >> 16) & 255, c >> 24, Y[3], Cr[3], Cb[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i0 = 3 * k, i1 = 3 * k + 1, i2 = 3 * k + 2;
+            const int B = (int)((wd[i0 >> 2] >> (8 * (i0 & 3))) & 255u);
+            const int G = (int)((wd[i1 >> 2] >> (8 * (i1 & 3))) & 255u);
+            const int R = (int)((wd[i2 >> 2] >> (8 * (i2 & 3))) & 255u);
+            ycrcb_px(B, G, R, Y[k], Cr[k], Cb[k]);
+        }
         *reinterpret_cast<uint32_t *>(yp + dof)  = Y[0] | (Y[1] << 8) | (Y[2] << 16) | (Y[3] << 24);
         *reinterpret_cast<uint32_t *>(crp + dof) = Cr[0] | (Cr[1] << 8) | (Cr[2] << 16) | (Cr[3] << 24);
         *reinterpret_cast<uint32_t *>(cbp + dof) = Cb[0] | (Cb[1] << 8) | (Cb[2] << 16) | (Cb[3] << 24);
