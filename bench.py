@@ -56,7 +56,7 @@ def plane_pixels(workload: str) -> int:
     return tot
 
 
-def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 20.0):
+def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
     """Oracle on host cores: per frame compute_channels (+pyramid) then one thread per plane."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle.oracle import Oracle
@@ -81,8 +81,9 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 20.0):
 
     frames_done, t_total, pooled = 0, 0.0, 0
     nthreads = 1
-    while t_total < budget_s and frames_done < 4:
-        frame = S.synth.KINDS[kind](S.synth.frame_seed(frames_done), W, H)
+    while t_total < budget_s and frames_done < 64:
+        frame = S.synth.KINDS[kind](S.synth.frame_seed(frames_done % 4), W, H) if frames_done >= 4 else \
+            S.synth.KINDS[kind](S.synth.frame_seed(frames_done), W, H)
         t0 = time.perf_counter()
         planes = planes_of(frame)
         nthreads = max(1, min(len(planes), ncores))

@@ -210,6 +210,8 @@ int str_er_resize_plane(str_er_ctx *ctx, const uint8_t *src, int32_t sw, int32_t
 /* ---- results (owned by the library until str_er_result_free) ----------------------- */
 int32_t str_er_result_n_planes(const str_er_result *r);
 int     str_er_result_plane_info(const str_er_result *r, int32_t plane, str_er_plane_info *info);
+/* All plane records of the call as one array (n = str_er_result_n_planes). */
+const str_er_plane_info *str_er_result_plane_infos(const str_er_result *r, int32_t *n);
 /* All candidates of the call, ordered by (plane, key). */
 const str_er_cand *str_er_result_cands(const str_er_result *r, int32_t *n);
 /* Candidates of one plane (a slice of the array above). */

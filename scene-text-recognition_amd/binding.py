@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional
 
 import numpy as np
@@ -26,7 +26,10 @@ NODE_DTYPE = np.dtype([("key", "<u4"), ("parent", "<i4"), ("area", "<i4"), ("x",
 CAND_DTYPE = np.dtype([("frame", "<u4"), ("ch", "u1"), ("pyr", "u1"), ("level", "u1"), ("cls", "u1"),
                        ("x", "<u2"), ("y", "<u2"), ("w", "<u2"), ("h", "<u2"), ("area", "<u4"), ("key", "<u4"),
                        ("node", "<i4"), ("plane", "<u4"), ("score_strong", "<f8"), ("score_weak", "<f8")])
-assert NODE_DTYPE.itemsize == 24 and CAND_DTYPE.itemsize == 48
+PLANE_DTYPE = np.dtype([("frame", "<u4"), ("ch", "u1"), ("pyr", "u1"), ("r0", "u1"), ("r1", "u1"), ("width", "<i4"),
+                        ("height", "<i4"), ("n_created", "<i4"), ("n_kept", "<i4"), ("n_pool", "<i4"), ("n_strong", "<i4"),
+                        ("n_weak", "<i4"), ("ambiguous", "<i4"), ("root", "<i4")])
+assert NODE_DTYPE.itemsize == 24 and CAND_DTYPE.itemsize == 48 and PLANE_DTYPE.itemsize == 44
 
 
 class StrErError(RuntimeError):
@@ -116,6 +119,8 @@ def load_library():
     L.str_er_result_n_planes.argtypes = [vp]
     L.str_er_result_n_planes.restype = C.c_int32
     L.str_er_result_plane_info.argtypes = [vp, C.c_int32, C.POINTER(_PlaneInfo)]
+    L.str_er_result_plane_infos.argtypes = [vp, i32p]
+    L.str_er_result_plane_infos.restype = vp
     L.str_er_result_cands.argtypes = [vp, i32p]
     L.str_er_result_cands.restype = vp
     L.str_er_result_plane_cands.argtypes = [vp, C.c_int32, i32p]
@@ -166,12 +171,27 @@ class PlaneResult:
         return self.cands[self.cands["cls"] == CLS_WEAK]
 
 
-@dataclass
 class Result:
-    planes: List[PlaneResult]
-    cands: np.ndarray
-    times: np.ndarray                      # 7 slots, ERFilter::text_detect's return value
-    profile: dict = field(default_factory=dict)
+    """Outcome of one detect call.  `info` (PLANE_DTYPE) and `cands` (CAND_DTYPE) are flat arrays;
+    `planes` builds one PlaneResult per plane on first use."""
+
+    def __init__(self, info: np.ndarray, cands: np.ndarray, times: np.ndarray, profile: dict, nodes=None):
+        self.info, self.cands, self.times, self.profile, self._nodes = info, cands, times, profile, nodes
+        self._planes = None
+
+    @property
+    def planes(self) -> List[PlaneResult]:
+        if self._planes is None:
+            out, off = [], 0
+            for i, pi in enumerate(self.info):
+                n = int(pi["n_pool"])
+                out.append(PlaneResult(int(pi["frame"]), int(pi["ch"]), int(pi["pyr"]), int(pi["width"]), int(pi["height"]),
+                                       int(pi["n_created"]), int(pi["n_kept"]), n, int(pi["n_strong"]), int(pi["n_weak"]),
+                                       int(pi["ambiguous"]), int(pi["root"]), self.cands[off:off + n],
+                                       self._nodes[i] if self._nodes is not None else None))
+                off += n
+            self._planes = out
+        return self._planes
 
 
 def _np_ptr(a: np.ndarray) -> int:
@@ -251,23 +271,19 @@ class ERFilter:
                 cands = np.frombuffer((C.c_char * (48 * n.value)).from_address(ptr), dtype=CAND_DTYPE).copy()
             else:
                 cands = np.zeros(0, CAND_DTYPE)
-            planes = []
-            off = 0
-            for i in range(L.str_er_result_n_planes(rh)):
-                pi = _PlaneInfo()
-                L.str_er_result_plane_info(rh, i, C.byref(pi))
-                nn = C.c_int32()
-                nptr = L.str_er_result_plane_nodes(rh, i, C.byref(nn))
-                nodes = None
-                if nptr:
-                    nodes = np.frombuffer((C.c_char * (24 * nn.value)).from_address(nptr), dtype=NODE_DTYPE).copy()
-                planes.append(PlaneResult(pi.frame, pi.ch, pi.pyr, pi.width, pi.height, pi.n_created, pi.n_kept,
-                                          pi.n_pool, pi.n_strong, pi.n_weak, pi.ambiguous, pi.root,
-                                          cands[off:off + pi.n_pool], nodes))
-                off += pi.n_pool
+            ptr = L.str_er_result_plane_infos(rh, C.byref(n))
+            info = np.frombuffer((C.c_char * (44 * n.value)).from_address(ptr), dtype=PLANE_DTYPE).copy()
+            nodes = None
+            nn = C.c_int32()
+            if n.value and L.str_er_result_plane_nodes(rh, 0, C.byref(nn)):
+                nodes = []
+                for i in range(n.value):
+                    nptr = L.str_er_result_plane_nodes(rh, i, C.byref(nn))
+                    nodes.append(np.frombuffer((C.c_char * (24 * nn.value)).from_address(nptr), dtype=NODE_DTYPE).copy()
+                                 if nn.value else np.zeros(0, NODE_DTYPE))
             t = L.str_er_result_times(rh)
             times = np.array([t[i] for i in range(7)])
-            return Result(planes, cands, times, self.last_profile())
+            return Result(info, cands, times, self.last_profile(), nodes)
         finally:
             L.str_er_result_free(rh)
 

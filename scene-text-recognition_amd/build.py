@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libstr_er_hip.so")
 SOURCES = ["er_kernels.hip", "str_er_api.cpp"]
 DEPS = SOURCES + ["er_kernels.h", "er_types.h", os.path.join("..", "..", "include", "str_er.h")]
+EXTRA = os.environ.get("STR_ER_EXTRA_FLAGS", "").split()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -41,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc(), *FLAGS, *EXTRA, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

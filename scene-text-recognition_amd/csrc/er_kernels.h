@@ -15,6 +15,13 @@ struct BatchDev {
     uint32_t         max_nodes_plane; // largest plane capacity (w*h)
     NodeArrays       na;
     KeptArrays       ka;
+    const uint16_t  *tile_plane;        // plane of every tile
+    const uint16_t  *seam_block_plane;  // plane of every k_seam workgroup
+    const uint32_t  *seam_block_first;  // its first pair inside that plane
+    uint32_t         n_seam_blocks;
+    uint32_t        *tile_cnt; // nodes per tile (batch-wide tile numbering)
+    uint8_t         *tile_lo;  // lowest / highest node level of the tile
+    uint8_t         *tile_hi;
     uint32_t        *seam;     // node id of every tile-border pixel
     uint32_t        *pool;     // kept slots chosen by NMS, ascending key
     uint32_t        *pool_tmp;

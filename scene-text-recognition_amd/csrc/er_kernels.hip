@@ -239,17 +239,58 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 // ------------------------------------------------------------------------------------
 constexpr uint32_t WALL = 0xFFFFu;
 
+// Developer aid: build with -DSTR_ER_PHASE_PROF to accumulate per-phase cycle counts of
+// k_tile_tree (lane 0 of every block) into g_tile_phase[]; read with str_er_debug_phase_cycles().
+#ifdef STR_ER_PHASE_PROF
+__device__ unsigned long long g_tile_phase[16];
+#define PHASE_MARK(i)                                                                  \
+    do {                                                                               \
+        if (threadIdx.x == 0) {                                                        \
+            const unsigned long long t_now = wall_clock64();                           \
+            atomicAdd(&g_tile_phase[i], t_now - t_prev);                               \
+            t_prev = t_now;                                                            \
+        }                                                                              \
+    } while (0)
+#define PHASE_INIT() unsigned long long t_prev = wall_clock64()
+#ifdef STR_ER_COUNT_PROF
+#define CNT(i, v) atomicAdd(&g_tile_phase[8 + (i)], (unsigned long long)(v))
+#else
+#define CNT(i, v) do { } while (0)
+#endif
+#else
+#define CNT(i, v) do { } while (0)
+#define PHASE_MARK(i) do { } while (0)
+#define PHASE_INIT() do { } while (0)
+#endif
+
 // Join pixels a and b (4-neighbours, both not walls): afterwards the root paths of a
 // and b are merged into one path sorted by level.  Lock-free; every change is one CAS
 // on the parent word of a level root, conditional on the value that was read.
+// Level root of pixel a (level la), with path halving: every same-level hop re-points the
+// pixel at its grandparent.  Only non-roots are rewritten, and only with another pixel of
+// the same node, so racing with the CAS in tile_connect (which targets level roots) is benign.
+__device__ __forceinline__ uint32_t tile_find(uint32_t *s_par, uint32_t &a, uint32_t la)
+{
+    uint32_t wa = LD_WG(&s_par[a]);
+    while (wa != NONE && (wa >> 16) == la) {
+        const uint32_t nx = wa & 0xFFFFu;
+        const uint32_t w2 = LD_WG(&s_par[nx]);
+        if (w2 != NONE && (w2 >> 16) == la) s_par[a] = w2;
+        a = nx;
+        wa = w2;
+        CNT(2, 1);
+    }
+    return wa;
+}
+
 __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_lev, uint32_t a, uint32_t b)
 {
     uint32_t la = s_lev[a], lb = s_lev[b];
+    CNT(0, 1);
     for (;;) {
-        uint32_t wa = LD_WG(&s_par[a]);
-        while (wa != NONE && (wa >> 16) == la) { a = wa & 0xFFFFu; wa = LD_WG(&s_par[a]); }
-        uint32_t wb = LD_WG(&s_par[b]);
-        while (wb != NONE && (wb >> 16) == lb) { b = wb & 0xFFFFu; wb = LD_WG(&s_par[b]); }
+        CNT(1, 1);
+        uint32_t wa = tile_find(s_par, a, la);
+        uint32_t wb = tile_find(s_par, b, lb);
         if (a == b) return;
         if (la > lb || (la == lb && a < b)) {
             uint32_t t;
@@ -261,7 +302,8 @@ __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_
         // as a descendant.  If a's current parent is higher than b, b slots in between.
         if (la == lb || wa == NONE || (wa >> 16) > lb) {
             const uint32_t old = atomicCAS(&s_par[a], wa, (lb << 16) | b);
-            if (old != wa) continue;   // somebody else moved a: re-read
+            CNT(3, 1);
+            if (old != wa) { CNT(4, 1); continue; }   // somebody else moved a: re-read
             if (wa == NONE) return;    // a was a tree root: nothing left to merge
             a = wa & 0xFFFFu;          // a's former parent still has to be merged with b
             la = wa >> 16;
@@ -283,19 +325,39 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
+// Block-wide exclusive prefix sum of one value per lane (256 lanes = 4 waves).
+// Returns the lane's offset; *total receives the block sum.  Contains two barriers.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wsum, uint32_t *total)
+{
+    const int      tid = threadIdx.x;
+    const uint32_t incl = wave_incl_scan(v);
+    __syncthreads();                     // s_wsum may still be read from the previous scan
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < TILE_THREADS / 64; ++i) {
+        if (i < (tid >> 6)) off += s_wsum[i];
+        tot += s_wsum[i];
+    }
+    *total = tot;
+    return off + incl - v;
+}
+
+constexpr int STAT_CHUNK = 512;   // nodes whose statistics are accumulated per pass
+
 __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectParams prm)
 {
-    __shared__ unsigned long long s_col[TILE_PX];
+    // 24.1 KB of LDS -> 6 workgroups (24 waves) per CU
     __shared__ uint32_t s_par[TILE_PX];
-    __shared__ uint32_t s_cnt[TILE_PX];
-    __shared__ uint32_t s_row[TILE_PX];
+    __shared__ uint32_t s_work[TILE_PX];   // edge worklist, later the statistics of one node chunk
     __shared__ uint16_t s_lev[TILE_PX];
     __shared__ uint16_t s_nid[TILE_PX];
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_base, s_walls;
+    __shared__ uint32_t s_walls, s_lmin, s_lmax;
 
     const int       tid = threadIdx.x;
-    const int       pi = find_plane_by_tile(b.planes, b.n_planes, blockIdx.x);
+    const int       pi = b.tile_plane[blockIdx.x];
     const PlaneDesc pd = b.planes[pi];
     const uint32_t  tl = blockIdx.x - pd.tile_base;
     const int       tx = tl % pd.tiles_x, ty = tl / pd.tiles_x;
@@ -304,7 +366,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     const uint32_t  p0 = (uint32_t)tid * TILE_PPT;
     const int       gx = ox + lx, gy = oy + ly;
 
-    if (tid == 0) s_walls = 0;
+    if (tid == 0) { s_walls = 0; s_lmin = 0xFFFFFFFFu; s_lmax = 0; }
+    PHASE_INIT();
 
     // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
     uint32_t lev[TILE_PPT];
@@ -332,28 +395,63 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             }
             lev[k] = q;
             s_lev[p0 + k] = (uint16_t)q;
-            s_par[p0 + k] = NONE;
-            s_cnt[p0 + k] = 0;
-            s_row[p0 + k] = 0;
-            s_col[p0 + k] = 0ull;
+        }
+        // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; point every
+        // pixel of a run at the run's first pixel
+        uint32_t head = p0;
+        s_par[p0] = NONE;
+#pragma unroll
+        for (int k = 1; k < TILE_PPT; ++k) {
+            if (lev[k] != WALL && lev[k] == lev[k - 1]) s_par[p0 + k] = (lev[k] << 16) | head;
+            else { head = p0 + k; s_par[p0 + k] = NONE; }
         }
         __syncthreads();
         if (walls) atomicAdd(&s_walls, walls);
     }
+    PHASE_MARK(0);
 
-    // ---- connect every in-tile edge (right, bottom) -----------------------------------
-#pragma unroll 1
-    for (int k = 0; k < TILE_PPT; ++k) {
-        if (lev[k] == WALL) continue;
-        const uint32_t p = p0 + k;
-        if (lx + k + 1 < TILE_W && s_lev[p + 1] != WALL) tile_connect(s_par, s_lev, p, p + 1);
-        if (ly + 1 < TILE_H && s_lev[p + TILE_W] != WALL) tile_connect(s_par, s_lev, p, p + TILE_W);
+    // ---- connect the in-tile edges, in two balanced rounds -------------------------------------
+    // Each lane lists the edges that still need a connect (horizontal: level changes and lane
+    // boundaries; vertical: the first column of a pair of runs -- the other columns join the same
+    // two nodes); the list is compacted into LDS and dealt out evenly, so a lane whose pixels
+    // happen to need many connects does not hold its whole wave back.
+    for (int round = 0; round < 2; ++round) {
+        uint32_t emask = 0;
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k) {
+            if (lev[k] == WALL) continue;
+            const uint32_t p = p0 + k;
+            if (round == 0) {
+                if (k == 0) { if (lx > 0 && s_lev[p - 1] != WALL) emask |= 1u; }
+                else if (lev[k - 1] != WALL && lev[k - 1] != lev[k]) emask |= 1u << k;
+            } else if (ly + 1 < TILE_H) {
+                const uint32_t lq = s_lev[p + TILE_W];
+                if (lq != WALL) {
+                    const bool covered = k > 0 && lev[k - 1] == lev[k] && s_lev[p + TILE_W - 1] == lq;
+                    if (!covered) emask |= 1u << k;
+                }
+            }
+        }
+        uint32_t n_edges;
+        uint32_t off = block_excl_scan(__popc(emask), s_wsum, &n_edges);
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k)
+            if ((emask >> k) & 1) {
+                const uint32_t p = p0 + k;
+                s_work[off++] = round == 0 ? ((p - 1) | (p << 16)) : (p | ((p + TILE_W) << 16));
+            }
+        __syncthreads();
+        for (uint32_t e = tid; e < n_edges; e += TILE_THREADS) {
+            const uint32_t w = s_work[e];
+            tile_connect(s_par, s_lev, w & 0xFFFFu, w >> 16);
+        }
+        __syncthreads();
+        PHASE_MARK(1 + round);
     }
-    __syncthreads();
 
-    // ---- flatten: every pixel points straight at its level root ----------------------
+    // ---- flatten: every pixel points straight at its level root ----------------------------
     uint32_t rootmask = 0;
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < TILE_PPT; ++k) {
         if (lev[k] == WALL) continue;
         const uint32_t p = p0 + k, l = lev[k];
@@ -372,74 +470,99 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     }
     __syncthreads();
     // level roots: make the parent word point at the parent node's level root
-#pragma unroll 1
-    for (int k = 0; k < TILE_PPT; ++k) {
-        if (!((rootmask >> k) & 1)) continue;
-        const uint32_t p = p0 + k;
-        const uint32_t w = s_par[p];
-        if (w == NONE) continue;
-        uint32_t       q = w & 0xFFFFu;
-        const uint32_t wq = LD_WG(&s_par[q]);
-        if (wq != NONE && (wq >> 16) == (w >> 16)) q = wq & 0xFFFFu;
-        s_par[p] = (w & 0xFFFF0000u) | q;
-    }
-
-    // ---- dense ids for the level roots (pixel order), one allocation per tile --------
-    const uint32_t mycount = __popc(rootmask);
-    const uint32_t incl = wave_incl_scan(mycount);
-    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < TILE_THREADS / 64; ++i) {
-        if (i < (tid >> 6)) wave_off += s_wsum[i];
-        total += s_wsum[i];
-    }
-    if (tid == 0) {
-        s_base = atomicAdd(&b.ctr[pi].n_nodes, total);
-        if (s_walls) atomicAdd(&b.ctr[pi].n_walls, s_walls);
-    }
     {
-        uint32_t id = wave_off + incl - mycount;
+        uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k) {
+            if (!((rootmask >> k) & 1)) continue;
+            lmin = min(lmin, lev[k]); lmax = max(lmax, lev[k]);
+            const uint32_t p = p0 + k;
+            const uint32_t w = s_par[p];
+            if (w == NONE) continue;
+            uint32_t       q = w & 0xFFFFu;
+            const uint32_t wq = LD_WG(&s_par[q]);
+            if (wq != NONE && (wq >> 16) == (w >> 16)) q = wq & 0xFFFFu;
+            s_par[p] = (w & 0xFFFF0000u) | q;
+        }
+        if (rootmask) { atomicMin(&s_lmin, lmin); atomicMax(&s_lmax, lmax); }
+    }
+    PHASE_MARK(3);
+
+    // ---- dense ids for the level roots, in pixel order.  Node id = tile * 2048 + dense id: no
+    // allocation, and ids do not depend on the order in which tiles happen to run. -------------
+    uint32_t total;
+    {
+        uint32_t id = block_excl_scan(__popc(rootmask), s_wsum, &total);
 #pragma unroll
         for (int k = 0; k < TILE_PPT; ++k)
             if ((rootmask >> k) & 1) s_nid[p0 + k] = (uint16_t)id++;
     }
-
-    // ---- own statistics of every node: pixel count, row set, column set ---------------
-#pragma unroll 1
-    for (int k = 0; k < TILE_PPT; ++k) {
-        if (lev[k] == WALL) continue;
-        const uint32_t p = p0 + k;
-        const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[p] & 0xFFFFu);
-        atomicAdd(&s_cnt[r], 1u);
-        atomicOr(&s_row[r], 1u << ly);
-        atomicOr(&s_col[r], 1ull << (lx + k));
-    }
     __syncthreads();
-
-    // ---- export the nodes ----------------------------------------------------------------
-    const uint32_t base = s_base;
-    const size_t   nb = pd.node_base;
-#pragma unroll 1
-    for (int k = 0; k < TILE_PPT; ++k) {
-        if (!((rootmask >> k) & 1)) continue;
-        const uint32_t p = p0 + k;
-        const size_t   id = nb + base + s_nid[p];
-        const uint32_t w = s_par[p];
-        b.na.par[id] = (w == NONE) ? NONE : base + s_nid[w & 0xFFFFu];
-        b.na.lvl[id] = (uint8_t)lev[k];
-        b.na.dead[id] = 0;
-        b.na.cnt[id] = s_cnt[p];
-        b.na.nod[id] = 1;
-        const unsigned long long cm = s_col[p];
-        const uint32_t           rm = s_row[p];
-        b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
-        b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-        b.na.y0[id] = oy + __ffs((int)rm) - 1;
-        b.na.y1[id] = oy + 31 - __clz((int)rm);
-        b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+    if (tid == 0) {
+        b.tile_cnt[blockIdx.x] = total;
+        b.tile_lo[blockIdx.x] = (uint8_t)min(s_lmin, 255u);
+        b.tile_hi[blockIdx.x] = (uint8_t)s_lmax;
+        if (s_walls) atomicAdd(&b.ctr[pi].n_walls, s_walls);
     }
+    PHASE_MARK(4);
+
+    // ---- own statistics (pixel count, row set, column set) and export, STAT_CHUNK nodes per pass
+    const uint32_t base = tl * (uint32_t)TILE_PX;
+    const size_t   nb = pd.node_base;
+    uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
+    uint32_t            *s_row = s_work + STAT_CHUNK;          // [STAT_CHUNK]
+    unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * STAT_CHUNK); // [STAT_CHUNK]
+    for (uint32_t c0 = 0; c0 < total; c0 += STAT_CHUNK) {
+        for (int i = tid; i < TILE_PX; i += TILE_THREADS) s_work[i] = 0;
+        __syncthreads();
+        {   // the lane's pixels form runs with a common root: one set of atomics per run
+            uint32_t cur = NONE, cnt = 0;
+            unsigned long long col = 0;
+#pragma unroll
+            for (int k = 0; k <= TILE_PPT; ++k) {
+                uint32_t id = NONE;
+                if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL) {
+                    const uint32_t p = p0 + k;
+                    const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[p] & 0xFFFFu);
+                    id = (uint32_t)s_nid[r] - c0;
+                    if (id >= (uint32_t)STAT_CHUNK) id = NONE;
+                }
+                if (id != cur) {
+                    if (cur != NONE) {
+                        atomicAdd(&s_cnt[cur], cnt);
+                        atomicOr(&s_row[cur], 1u << ly);
+                        atomicOr(&s_col[cur], col);
+                    }
+                    cur = id; cnt = 0; col = 0;
+                }
+                if (id != NONE) { ++cnt; col |= 1ull << (lx + k); }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < TILE_PPT; ++k) {
+            if (!((rootmask >> k) & 1)) continue;
+            const uint32_t p = p0 + k;
+            const uint32_t li = (uint32_t)s_nid[p] - c0;
+            if (li >= (uint32_t)STAT_CHUNK) continue;
+            const size_t   id = nb + base + s_nid[p];
+            const uint32_t w = s_par[p];
+            b.na.par[id] = (w == NONE) ? NONE : base + s_nid[w & 0xFFFFu];
+            b.na.lvl[id] = (uint8_t)lev[k];
+            b.na.dead[id] = 0;
+            b.na.cnt[id] = s_cnt[li];
+            b.na.nod[id] = 1;
+            const unsigned long long cm = s_col[li];
+            const uint32_t           rm = s_row[li];
+            b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
+            b.na.x1[id] = ox + 63 - __clzll((long long)cm);
+            b.na.y0[id] = oy + __ffs((int)rm) - 1;
+            b.na.y1[id] = oy + 31 - __clz((int)rm);
+            b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+        }
+        __syncthreads();
+    }
+    PHASE_MARK(5);
 
     // ---- node id of every tile-border pixel, for the seam pass ---------------------------
     // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
@@ -474,6 +597,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         }
         *dst = id;
     }
+    PHASE_MARK(6);
 
     // ---- the flood's start pixel: pixel 0, else pixel 1, else pixel w --------
     if (tl == 0 && tid == 0) {
@@ -491,6 +615,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     }
 }
 
+#ifdef STR_ER_PHASE_PROF
+extern "C" void str_er_debug_phase_cycles(unsigned long long *out16, int reset)
+{
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tile_phase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_phase), z, sizeof(z));
+    }
+}
+#endif
+
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p)
 {
     if (!b.n_tiles) return;
@@ -503,14 +638,24 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // are not coherent with each other, so every access to `par` that may race goes through
 // an agent-scope atomic).  Levels are immutable here and read with plain loads.
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t node_find(uint32_t *par, const uint8_t *lvl, uint32_t &a, uint32_t la)
+{
+    uint32_t wa = LD_AGENT(&par[a]);
+    while (wa != NONE && lvl[wa] == la) {
+        const uint32_t w2 = LD_AGENT(&par[wa]);
+        if (w2 != NONE && lvl[w2] == la) ST_AGENT(&par[a], w2);   // path halving, same node
+        a = wa;
+        wa = w2;
+    }
+    return wa;
+}
+
 __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, uint32_t a, uint32_t b)
 {
     uint32_t la = lvl[a], lb = lvl[b];
     for (;;) {
-        uint32_t wa = LD_AGENT(&par[a]);
-        while (wa != NONE && lvl[wa] == la) { a = wa; wa = LD_AGENT(&par[a]); }
-        uint32_t wb = LD_AGENT(&par[b]);
-        while (wb != NONE && lvl[wb] == lb) { b = wb; wb = LD_AGENT(&par[b]); }
+        uint32_t wa = node_find(par, lvl, a, la);
+        uint32_t wb = node_find(par, lvl, b, lb);
         if (a == b) return;
         if (la > lb || (la == lb && a < b)) {
             uint32_t t;
@@ -533,14 +678,13 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
 
 __global__ __launch_bounds__(256) void k_seam(BatchDev b)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t       na = NONE, nbn = NONE;
-    int            pi = 0;
-    if (g < b.n_pairs) {
-        pi = find_plane_by_pair(b.planes, b.n_planes, g);
-        const PlaneDesc &pd = b.planes[pi];
-        const uint32_t   i = g - pd.pair_base;
-        const uint32_t  *seam = b.seam + pd.seam_base;
+    // a block never straddles two planes: the host lists (plane, first pair) per block
+    const int        pi = b.seam_block_plane[blockIdx.x];
+    const PlaneDesc &pd = b.planes[pi];
+    const uint32_t   i = b.seam_block_first[blockIdx.x] + threadIdx.x;
+    uint32_t         na = NONE, nbn = NONE;
+    if (i < pd.n_pairs) {
+        const uint32_t *seam = b.seam + pd.seam_base;
         if (i < pd.n_hpairs) {
             const uint32_t j = i / pd.w, x = i - j * pd.w;
             na = seam[((size_t)j * 2) * pd.w + x];
@@ -556,67 +700,99 @@ __global__ __launch_bounds__(256) void k_seam(BatchDev b)
     // neighbouring lanes very often carry the same pair (a flat region crossing the seam):
     // only the first lane of a run does the work.
     const uint32_t pa = __shfl_up(na, 1), pb = __shfl_up(nbn, 1);
-    const int      pp = __shfl_up(pi, 1);
-    const bool     dup = (threadIdx.x & 63) != 0 && pa == na && pb == nbn && pp == pi;
+    const bool     dup = (threadIdx.x & 63) != 0 && pa == na && pb == nbn;
     if (na == NONE || nbn == NONE || dup) return;
-    const size_t nb = b.planes[pi].node_base;
+    const size_t nb = pd.node_base;
     node_connect(b.na.par + nb, b.na.lvl + nb, na, nbn);
 }
 
 void launch_seam(hipStream_t s, const BatchDev &b)
 {
-    if (!b.n_pairs) return;
-    hipLaunchKernelGGL(k_seam, dim3((b.n_pairs + 255) / 256), dim3(256), 0, s, b);
+    if (!b.n_seam_blocks) return;
+    hipLaunchKernelGGL(k_seam, dim3(b.n_seam_blocks), dim3(256), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------
 // Part 3: per-node passes.  Grid = (blocks, planes); lanes stride over the plane's nodes.
 // ------------------------------------------------------------------------------------
-constexpr int NODE_BLOCKS = 96;  // blocks per plane for the per-node passes
+// Per-node passes run one wavefront per tile: lane i handles node i of the tile (tile_cnt nodes,
+// ids tile*2048 + i).  A fixed grid of workgroups strides over the batch's tiles.
+constexpr int NODE_GRID = 4096;
+
+#define FOR_EACH_TILE_WAVE(b, T, PI, ND, BASE)                                                      \
+    for (uint32_t T = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); T < (b).n_tiles;        \
+         T += gridDim.x * (blockDim.x >> 6))
 
 // Nodes that were unified into another node of the same level hand their own
 // statistics to the surviving level root; surviving nodes get a canonical parent.
 __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 {
-    const int       pi = blockIdx.y;
-    const uint32_t  n = b.ctr[pi].n_nodes;
-    const size_t    nb = b.planes[pi].node_base;
-    uint32_t       *par = b.na.par + nb;
-    const uint8_t  *lvl = b.na.lvl + nb;
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
-        const uint32_t w = LD_AGENT(&par[x]);
-        const uint32_t l = lvl[x];
-        if (w != NONE && lvl[w] == l) {
-            uint32_t r = w;
-            for (;;) {
-                const uint32_t w2 = LD_AGENT(&par[r]);
-                if (w2 == NONE || lvl[w2] != l) break;
-                r = w2;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
+        const uint32_t n = b.tile_cnt[t];
+        if (!n) continue;
+        const int       pi = b.tile_plane[t];
+        const PlaneDesc &pd = b.planes[pi];
+        const size_t    nb = pd.node_base;
+        const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
+        uint32_t       *par = b.na.par + nb;
+        const uint8_t  *lvl = b.na.lvl + nb;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t x = base + i;
+            const uint32_t w = LD_AGENT(&par[x]);
+            const uint32_t l = lvl[x];
+            if (w != NONE && lvl[w] == l) {
+                uint32_t r = w;
+                for (;;) {
+                    const uint32_t w2 = LD_AGENT(&par[r]);
+                    if (w2 == NONE || lvl[w2] != l) break;
+                    r = w2;
+                }
+                b.na.dead[nb + x] = 1;
+                atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
+                atomicMin(&b.na.x0[nb + r], b.na.x0[nb + x]);
+                atomicMin(&b.na.y0[nb + r], b.na.y0[nb + x]);
+                atomicMax(&b.na.x1[nb + r], b.na.x1[nb + x]);
+                atomicMax(&b.na.y1[nb + r], b.na.y1[nb + x]);
+                atomicMin(&b.na.key[nb + r], b.na.key[nb + x]);
+            } else if (w != NONE) {
+                uint32_t q = w;
+                const uint32_t lq = lvl[q];
+                for (;;) {
+                    const uint32_t w2 = LD_AGENT(&par[q]);
+                    if (w2 == NONE || lvl[w2] != lq) break;
+                    q = w2;
+                }
+                if (q != w) ST_AGENT(&par[x], q);
             }
-            b.na.dead[nb + x] = 1;
-            atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
-            atomicMin(&b.na.x0[nb + r], b.na.x0[nb + x]);
-            atomicMin(&b.na.y0[nb + r], b.na.y0[nb + x]);
-            atomicMax(&b.na.x1[nb + r], b.na.x1[nb + x]);
-            atomicMax(&b.na.y1[nb + r], b.na.y1[nb + x]);
-            atomicMin(&b.na.key[nb + r], b.na.key[nb + x]);
-        } else if (w != NONE) {
-            uint32_t q = w;
-            const uint32_t lq = lvl[q];
-            for (;;) {
-                const uint32_t w2 = LD_AGENT(&par[q]);
-                if (w2 == NONE || lvl[w2] != lq) break;
-                q = w2;
-            }
-            if (q != w) ST_AGENT(&par[x], q);
         }
     }
 }
 
 void launch_resolve(hipStream_t s, const BatchDev &b)
 {
-    if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_resolve, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b);
+    if (!b.n_tiles) return;
+    const uint32_t blocks = (b.n_tiles + 3) / 4;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+    return v;
 }
 
 // er_merge's accumulation (src/ER.cpp:153-165), one level per launch: every live node
@@ -624,26 +800,61 @@ void launch_resolve(hipStream_t s, const BatchDev &b)
 // levels than their parent, so launching t = 0,1,2,... in order is a topological order.
 __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
 {
-    const int      pi = blockIdx.y;
-    const uint32_t n = b.ctr[pi].n_nodes;
-    const size_t   nb = b.planes[pi].node_base;
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
-        if (b.na.lvl[nb + x] != level || b.na.dead[nb + x]) continue;
-        const uint32_t p = b.na.par[nb + x];
-        if (p == NONE) continue;
-        atomicAdd(&b.na.cnt[nb + p], b.na.cnt[nb + x]);
-        atomicAdd(&b.na.nod[nb + p], b.na.nod[nb + x]);
-        atomicMin(&b.na.x0[nb + p], b.na.x0[nb + x]);
-        atomicMin(&b.na.y0[nb + p], b.na.y0[nb + x]);
-        atomicMax(&b.na.x1[nb + p], b.na.x1[nb + x]);
-        atomicMax(&b.na.y1[nb + p], b.na.y1[nb + x]);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
+        const uint32_t n = b.tile_cnt[t];
+        if (!n || level < (int)b.tile_lo[t] || level > (int)b.tile_hi[t]) continue;
+        const int       pi = b.tile_plane[t];
+        const PlaneDesc &pd = b.planes[pi];
+        const size_t    nb = pd.node_base;
+        const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {          // uniform trip count: ballots below
+            const uint32_t x = base + i0 + lane;
+            uint32_t p = NONE;
+            if (i0 + lane < n && b.na.lvl[nb + x] == level && !b.na.dead[nb + x]) p = b.na.par[nb + x];
+            const bool act = p != NONE;
+            unsigned long long todo = __ballot(act);
+            if (!todo) continue;
+            uint32_t c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
+            if (act) {
+                c = b.na.cnt[nb + x]; nd = b.na.nod[nb + x];
+                bx0 = b.na.x0[nb + x]; by0 = b.na.y0[nb + x]; bx1 = b.na.x1[nb + x]; by1 = b.na.y1[nb + x];
+            }
+            // children of one parent sit next to each other (nodes are numbered in pixel order
+            // inside a tile): combine them in the wave and issue ONE set of atomics per distinct
+            // parent instead of one per child (the big background nodes have thousands).
+            while (todo) {
+                const int      leader = __ffsll((long long)todo) - 1;
+                const uint32_t lp = __shfl(p, leader);
+                const bool     mine = act && p == lp;
+                const unsigned long long m = __ballot(mine);
+                if (__popcll(m) == 1) {
+                    if (mine) {
+                        atomicAdd(&b.na.cnt[nb + lp], c); atomicAdd(&b.na.nod[nb + lp], nd);
+                        atomicMin(&b.na.x0[nb + lp], bx0); atomicMin(&b.na.y0[nb + lp], by0);
+                        atomicMax(&b.na.x1[nb + lp], bx1); atomicMax(&b.na.y1[nb + lp], by1);
+                    }
+                } else {
+                    const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
+                    const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
+                    const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
+                    if (lane == leader) {
+                        atomicAdd(&b.na.cnt[nb + lp], sc); atomicAdd(&b.na.nod[nb + lp], sn);
+                        atomicMin(&b.na.x0[nb + lp], mx0); atomicMin(&b.na.y0[nb + lp], my0);
+                        atomicMax(&b.na.x1[nb + lp], mx1); atomicMax(&b.na.y1[nb + lp], my1);
+                    }
+                }
+                todo &= ~m;
+            }
+        }
     }
 }
 
 void launch_accumulate(hipStream_t s, const BatchDev &b, int level)
 {
-    if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b, level);
+    if (!b.n_tiles) return;
+    const uint32_t blocks = (b.n_tiles + 3) / 4;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b, level);
 }
 
 // Root of the tree that holds the flood's start pixel (er_stack.back(), src/ER.cpp:346).
@@ -692,40 +903,47 @@ void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // trees (regions sealed off by sentinel-level pixels) were never visited by the flood.
 __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 {
-    const int       pi = blockIdx.y;
-    PlaneCtr       &c = b.ctr[pi];
-    const uint32_t  root = c.root_node;
-    if (root == NONE) return;
-    const uint32_t  n = c.n_nodes;
-    const PlaneDesc &pd = b.planes[pi];
-    const size_t    nb = pd.node_base;
-    const uint32_t *par = b.na.par + nb;
-    const bool      walls = c.n_walls != 0;
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
-        if (b.na.dead[nb + x]) continue;
-        if (x != root) {
-            const uint32_t area = b.na.cnt[nb + x] + b.na.nod[nb + x];
-            if ((int64_t)area <= (int64_t)prm.min_area) continue;
-            if (walls) {
-                uint32_t y = x;
-                for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = w; }
-                if (y != root) continue;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
+        const uint32_t n = b.tile_cnt[t];
+        if (!n) continue;
+        const int       pi = b.tile_plane[t];
+        PlaneCtr       &c = b.ctr[pi];
+        const uint32_t  root = c.root_node;
+        if (root == NONE) continue;
+        const PlaneDesc &pd = b.planes[pi];
+        const size_t    nb = pd.node_base;
+        const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
+        const uint32_t *par = b.na.par + nb;
+        const bool      walls = c.n_walls != 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t x = base + i;
+            if (b.na.dead[nb + x]) continue;
+            if (x != root) {
+                const uint32_t area = b.na.cnt[nb + x] + b.na.nod[nb + x];
+                if ((int64_t)area <= (int64_t)prm.min_area) continue;
+                if (walls) {
+                    uint32_t y = x;
+                    for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = w; }
+                    if (y != root) continue;
+                }
             }
-        }
-        const uint32_t slot = atomicAdd(&c.n_kept, 1u);
-        if (slot < (uint32_t)prm.kept_cap) {
-            b.ka.node[pd.kept_base + slot] = x;
-            b.na.kmap[nb + x] = slot;
-        } else {
-            atomicOr(&c.overflow, 1u);
+            const uint32_t slot = atomicAdd(&c.n_kept, 1u);
+            if (slot < (uint32_t)prm.kept_cap) {
+                b.ka.node[pd.kept_base + slot] = x;
+                b.na.kmap[nb + x] = slot;
+            } else {
+                atomicOr(&c.overflow, 1u);
+            }
         }
     }
 }
 
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p)
 {
-    if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_select, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b, p);
+    if (!b.n_tiles) return;
+    const uint32_t blocks = (b.n_tiles + 3) / 4;
+    hipLaunchKernelGGL(k_select, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b, p);
 }
 
 // Kept-node records (flat form of struct ER, inc/ER.h:42-80).

@@ -27,7 +27,7 @@ struct PlaneDesc {
     uint32_t pair_base;     // first seam pixel-pair of this plane (batch-wide numbering)
     uint32_t n_hpairs;      // w * (tiles_y - 1)
     uint32_t n_pairs;       // n_hpairs + h * (tiles_x - 1)
-    uint32_t node_base;     // offset of this plane in the node arrays (capacity w*h)
+    uint32_t node_base;     // offset of this plane in the node arrays (capacity tiles * 2048)
     uint32_t seam_base;     // offset in the seam map (u32 units)
     uint32_t kept_base;     // offset in the kept-node arrays (capacity kept_cap)
     uint32_t pool_base;     // offset in the pool arrays (capacity pool_cap)
@@ -37,7 +37,7 @@ struct PlaneDesc {
 
 // Per-plane device counters, zeroed before every batch.
 struct PlaneCtr {
-    uint32_t n_nodes;       // tile-local nodes allocated (before cross-tile unification)
+    uint32_t n_nodes;       // (unused; nodes are counted per tile)
     uint32_t n_walls;       // in-image pixels at the sentinel level
     uint32_t start_node;    // node of the flood's start pixel, NONE if none (A.2)
     uint32_t root_node;     // root of the start pixel's tree

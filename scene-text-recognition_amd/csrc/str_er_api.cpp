@@ -76,6 +76,10 @@ struct str_er_ctx {
     NodeArrays na{};
     KeptArrays ka{};
     uint32_t *d_seam = nullptr; size_t seam_slots = 0;
+    uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
+    std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
+    std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
+    uint32_t *d_tile_cnt = nullptr; uint8_t *d_tile_lo = nullptr, *d_tile_hi = nullptr; size_t tile_slots = 0;
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
     uint32_t *d_total = nullptr;
@@ -268,12 +272,12 @@ void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int inver
     d.n_hpairs = (uint32_t)w * (d.tiles_y - 1);
     d.n_pairs = d.n_hpairs + (uint32_t)h * (d.tiles_x - 1);
     d.pair_base = b.n_pairs; b.n_pairs += d.n_pairs;
-    d.node_base = (uint32_t)b.slots; b.slots += (size_t)w * h;
+    d.node_base = (uint32_t)b.slots; b.slots += (size_t)d.tiles_x * d.tiles_y * TILE_PX;
     d.seam_base = (uint32_t)b.seam; b.seam += 2 * (size_t)d.n_pairs;
     d.kept_base = (uint32_t)(b.planes.size() * (size_t)kept_cap);
     d.pool_base = (uint32_t)(b.planes.size() * (size_t)pool_cap);
     d.frame = frame; d.ch = (uint8_t)ch; d.pyr = (uint8_t)pyr;
-    b.max_nodes_plane = std::max<uint32_t>(b.max_nodes_plane, (uint32_t)w * h);
+    b.max_nodes_plane = std::max<uint32_t>(b.max_nodes_plane, (uint32_t)d.tiles_x * d.tiles_y * TILE_PX);
     b.planes.push_back(d);
 }
 
@@ -282,7 +286,9 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     BatchDev d{};
     d.planes = c->d_planes; d.ctr = c->d_ctr; d.n_planes = (int32_t)b.planes.size();
     d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.max_nodes_plane = b.max_nodes_plane;
-    d.na = c->na; d.ka = c->ka; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
+    d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
+    d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
+    d.na = c->na; d.ka = c->ka; d.tile_cnt = c->d_tile_cnt; d.tile_lo = c->d_tile_lo; d.tile_hi = c->d_tile_hi; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total;
     return d;
 }
@@ -305,6 +311,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if (np > c->max_planes) return fail(c, STR_ER_ECAPACITY, "more planes than the context was created for");
     if (b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "planes exceed the pixel capacity of the context");
     if (b.seam > c->seam_slots) return fail(c, STR_ER_ECAPACITY, "seam map capacity exceeded");
+    if (b.n_tiles > c->tile_slots) return fail(c, STR_ER_ECAPACITY, "tile table capacity exceeded");
     if ((stages & STR_ER_STAGE_CLASSIFY) && !(c->casc[0].loaded && c->casc[1].loaded))
         return fail(c, STR_ER_ESTATE, "classify needs both cascades (str_er_load_cascade)");
     if (!(stages & STR_ER_STAGE_EXTRACT)) return fail(c, STR_ER_EINVAL, "stages must include STR_ER_STAGE_EXTRACT");
@@ -317,6 +324,28 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
     HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+    {   // tile -> plane and seam-block -> (plane, first pair) tables; re-uploaded only when the layout changes
+        std::vector<uint32_t> key;
+        key.reserve(np * 2 + 1);
+        key.push_back((uint32_t)np);
+        for (const PlaneDesc &pd : b.planes) { key.push_back((uint32_t)pd.w); key.push_back((uint32_t)pd.h); }
+        if (key != c->layout_key) {
+            c->h_tile_plane.clear(); c->h_sb_plane.clear(); c->h_sb_first.clear();
+            for (int i = 0; i < np; ++i) {
+                const PlaneDesc &pd = b.planes[i];
+                c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
+                for (uint32_t f0 = 0; f0 < pd.n_pairs; f0 += 256) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
+            }
+            if (c->h_sb_plane.size() > c->sb_slots) return fail(c, STR_ER_ECAPACITY, "seam block table capacity exceeded");
+            HIP_TRY(c, hipMemcpyAsync(c->d_tile_plane, c->h_tile_plane.data(), 2 * c->h_tile_plane.size(), hipMemcpyHostToDevice, s));
+            if (!c->h_sb_plane.empty()) {
+                HIP_TRY(c, hipMemcpyAsync(c->d_sb_plane, c->h_sb_plane.data(), 2 * c->h_sb_plane.size(), hipMemcpyHostToDevice, s));
+                HIP_TRY(c, hipMemcpyAsync(c->d_sb_first, c->h_sb_first.data(), 4 * c->h_sb_first.size(), hipMemcpyHostToDevice, s));
+            }
+            HIP_TRY(c, hipStreamSynchronize(s));   // pageable host vectors: make sure the copies are done
+            c->layout_key = key;
+        }
+    }
     const BatchDev bd = make_batchdev(c, b);
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
 
@@ -527,7 +556,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     size_t px_frame = 0, phys_frame = 0;
     for (int l = 0; l < p->n_pyr_levels; ++l) {
         int w, h; pyr_dims(p->max_width, p->max_height, l, w, h);
-        px_frame += (size_t)w * h * c->chans.size();
+        px_frame += (size_t)((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * TILE_PX * c->chans.size();
         phys_frame += 3 * align_up((size_t)align_up(w, 64) * h, 256);
     }
     c->slots = px_frame * p->max_frames;
@@ -560,6 +589,10 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->ka.parent, KP)); A(dev_alloc(c, c->ka.box, 4 * KP)); A(dev_alloc(c, c->ka.level, KP));
     A(dev_alloc(c, c->ka.start, KP)); A(dev_alloc(c, c->ka.ncand, KP)); A(dev_alloc(c, c->ka.best, KP));
     A(dev_alloc(c, c->d_seam, c->seam_slots));
+    c->tile_slots = c->slots / TILE_PX + 16;
+    c->sb_slots = c->seam_slots / 512 + (size_t)c->max_planes + 16;
+    A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
+    A(dev_alloc(c, c->d_tile_cnt, c->tile_slots)); A(dev_alloc(c, c->d_tile_lo, c->tile_slots)); A(dev_alloc(c, c->d_tile_hi, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
     A(dev_alloc(c, c->d_cands, PP));
     A(dev_alloc(c, c->d_total, 4));
@@ -833,7 +866,8 @@ int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, in
     HIP_TRY(c, hipMemcpyAsync(c->ka.box, box.data(), 8 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->ka.level, lev.data(), (size_t)n_nodes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s)); // host vectors go out of scope after this call
-    const BatchDev bd = make_batchdev(c, b);
+    BatchDev bd = make_batchdev(c, b);
+    bd.n_seam_blocks = 0;
     launch_nms(s, bd, make_dp(c));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
@@ -874,6 +908,13 @@ int str_er_result_plane_info(const str_er_result *r, int32_t plane, str_er_plane
     if (!r || !info || plane < 0 || plane >= (int32_t)r->planes.size()) return STR_ER_EINVAL;
     *info = r->planes[plane];
     return STR_ER_OK;
+}
+
+const str_er_plane_info *str_er_result_plane_infos(const str_er_result *r, int32_t *n)
+{
+    if (!r) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->planes.size();
+    return r->planes.data();
 }
 
 const str_er_cand *str_er_result_cands(const str_er_result *r, int32_t *n)
