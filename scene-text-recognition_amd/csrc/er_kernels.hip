@@ -238,6 +238,11 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 // t in C, which is also the node's canonical key.
 // ------------------------------------------------------------------------------------
 constexpr uint32_t WALL = 0xFFFFu;
+// LDS placement of pixel p: k-major ("transposed"), so that when every lane touches the k-th of
+// its 8 consecutive pixels (p = 8*lane + k) the wave hits 64 consecutive words -- no bank
+// conflicts.  Stored pointers stay logical pixel numbers; only the addressing goes through LX.
+#define LX(p)  ((((uint32_t)(p)) & 7u) << 8 | (((uint32_t)(p)) >> 3))
+#define OWN(k) ((uint32_t)((k) << 8) + (uint32_t)threadIdx.x)
 
 // Developer aid: build with -DSTR_ER_PHASE_PROF to accumulate per-phase cycle counts of
 // k_tile_tree (lane 0 of every block) into g_tile_phase[]; read with str_er_debug_phase_cycles().
@@ -271,11 +276,11 @@ __device__ unsigned long long g_tile_phase[16];
 // the same node, so racing with the CAS in tile_connect (which targets level roots) is benign.
 __device__ __forceinline__ uint32_t tile_find(uint32_t *s_par, uint32_t &a, uint32_t la)
 {
-    uint32_t wa = LD_WG(&s_par[a]);
+    uint32_t wa = LD_WG(&s_par[LX(a)]);
     while (wa != NONE && (wa >> 16) == la) {
         const uint32_t nx = wa & 0xFFFFu;
-        const uint32_t w2 = LD_WG(&s_par[nx]);
-        if (w2 != NONE && (w2 >> 16) == la) s_par[a] = w2;
+        const uint32_t w2 = LD_WG(&s_par[LX(nx)]);
+        if (w2 != NONE && (w2 >> 16) == la) s_par[LX(a)] = w2;
         a = nx;
         wa = w2;
         CNT(2, 1);
@@ -285,7 +290,7 @@ __device__ __forceinline__ uint32_t tile_find(uint32_t *s_par, uint32_t &a, uint
 
 __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_lev, uint32_t a, uint32_t b)
 {
-    uint32_t la = s_lev[a], lb = s_lev[b];
+    uint32_t la = s_lev[LX(a)], lb = s_lev[LX(b)];
     CNT(0, 1);
     for (;;) {
         CNT(1, 1);
@@ -301,7 +306,7 @@ __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_
         // now a must end up below b: either in the same node (equal levels, a > b) or
         // as a descendant.  If a's current parent is higher than b, b slots in between.
         if (la == lb || wa == NONE || (wa >> 16) > lb) {
-            const uint32_t old = atomicCAS(&s_par[a], wa, (lb << 16) | b);
+            const uint32_t old = atomicCAS(&s_par[LX(a)], wa, (lb << 16) | b);
             CNT(3, 1);
             if (old != wa) { CNT(4, 1); continue; }   // somebody else moved a: re-read
             if (wa == NONE) return;    // a was a tree root: nothing left to merge
@@ -344,17 +349,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wsum
     return off + incl - v;
 }
 
-constexpr int STAT_CHUNK = 512;   // nodes whose statistics are accumulated per pass
+constexpr int STAT_CHUNK = 512;   // dense tiles: nodes whose statistics are accumulated per pass
+constexpr int FOLD_CAP = 896;     // tiles with at most this many nodes fold their closed nodes in LDS
 
 __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectParams prm)
 {
-    // 24.1 KB of LDS -> 6 workgroups (24 waves) per CU
+    // 26.6 KB of LDS -> 6 workgroups (24 waves) per CU
     __shared__ uint32_t s_par[TILE_PX];
-    __shared__ uint32_t s_work[TILE_PX];   // edge worklist, later the statistics of one node chunk
-    __shared__ uint16_t s_lev[TILE_PX];
-    __shared__ uint16_t s_nid[TILE_PX];
+    __shared__ uint32_t s_work[4 * FOLD_CAP]; // edge worklist, later the per-node statistics
+    __shared__ uint16_t s_lev[TILE_PX];      // levels; once the connects are done the same array
+    uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_walls, s_lmin, s_lmax;
+    __shared__ uint32_t s_walls, s_lmin, s_lmax, s_lmin2, s_lmax2, s_start;
 
     const int       tid = threadIdx.x;
     const int       pi = b.tile_plane[blockIdx.x];
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     const uint32_t  p0 = (uint32_t)tid * TILE_PPT;
     const int       gx = ox + lx, gy = oy + ly;
 
-    if (tid == 0) { s_walls = 0; s_lmin = 0xFFFFFFFFu; s_lmax = 0; }
+    if (tid == 0) { s_walls = 0; s_lmin = 0xFFFFFFFFu; s_lmax = 0; s_lmin2 = 0xFFFFFFFFu; s_lmax2 = 0; }
     PHASE_INIT();
 
     // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
@@ -394,16 +400,16 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 if (q >= (uint32_t)prm.hi) { q = WALL; ++walls; }
             }
             lev[k] = q;
-            s_lev[p0 + k] = (uint16_t)q;
+            s_lev[OWN(k)] = (uint16_t)q;
         }
         // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; point every
         // pixel of a run at the run's first pixel
         uint32_t head = p0;
-        s_par[p0] = NONE;
+        s_par[OWN(0)] = NONE;
 #pragma unroll
         for (int k = 1; k < TILE_PPT; ++k) {
-            if (lev[k] != WALL && lev[k] == lev[k - 1]) s_par[p0 + k] = (lev[k] << 16) | head;
-            else { head = p0 + k; s_par[p0 + k] = NONE; }
+            if (lev[k] != WALL && lev[k] == lev[k - 1]) s_par[OWN(k)] = (lev[k] << 16) | head;
+            else { head = p0 + k; s_par[OWN(k)] = NONE; }
         }
         __syncthreads();
         if (walls) atomicAdd(&s_walls, walls);
@@ -422,12 +428,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             if (lev[k] == WALL) continue;
             const uint32_t p = p0 + k;
             if (round == 0) {
-                if (k == 0) { if (lx > 0 && s_lev[p - 1] != WALL) emask |= 1u; }
+                if (k == 0) { if (lx > 0 && s_lev[LX(p - 1)] != WALL) emask |= 1u; }
                 else if (lev[k - 1] != WALL && lev[k - 1] != lev[k]) emask |= 1u << k;
             } else if (ly + 1 < TILE_H) {
-                const uint32_t lq = s_lev[p + TILE_W];
+                const uint32_t lq = s_lev[LX(p + TILE_W)];
                 if (lq != WALL) {
-                    const bool covered = k > 0 && lev[k - 1] == lev[k] && s_lev[p + TILE_W - 1] == lq;
+                    const bool covered = k > 0 && lev[k - 1] == lev[k] && s_lev[LX(p + TILE_W - 1)] == lq;
                     if (!covered) emask |= 1u << k;
                 }
             }
@@ -455,15 +461,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     for (int k = 0; k < TILE_PPT; ++k) {
         if (lev[k] == WALL) continue;
         const uint32_t p = p0 + k, l = lev[k];
-        uint32_t w = LD_WG(&s_par[p]);
+        uint32_t w = LD_WG(&s_par[LX(p)]);
         if (w != NONE && (w >> 16) == l) {
             uint32_t r = w & 0xFFFFu;
             for (;;) {
-                const uint32_t w2 = LD_WG(&s_par[r]);
+                const uint32_t w2 = LD_WG(&s_par[LX(r)]);
                 if (w2 == NONE || (w2 >> 16) != l) break;
                 r = w2 & 0xFFFFu;
             }
-            s_par[p] = (l << 16) | r;
+            s_par[LX(p)] = (l << 16) | r;
         } else {
             rootmask |= 1u << k;
         }
@@ -477,45 +483,65 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             if (!((rootmask >> k) & 1)) continue;
             lmin = min(lmin, lev[k]); lmax = max(lmax, lev[k]);
             const uint32_t p = p0 + k;
-            const uint32_t w = s_par[p];
+            const uint32_t w = s_par[LX(p)];
             if (w == NONE) continue;
             uint32_t       q = w & 0xFFFFu;
-            const uint32_t wq = LD_WG(&s_par[q]);
+            const uint32_t wq = LD_WG(&s_par[LX(q)]);
             if (wq != NONE && (wq >> 16) == (w >> 16)) q = wq & 0xFFFFu;
-            s_par[p] = (w & 0xFFFF0000u) | q;
+            s_par[LX(p)] = (w & 0xFFFF0000u) | q;
         }
         if (rootmask) { atomicMin(&s_lmin, lmin); atomicMax(&s_lmax, lmax); }
     }
     PHASE_MARK(3);
 
-    // ---- dense ids for the level roots, in pixel order.  Node id = tile * 2048 + dense id: no
-    // allocation, and ids do not depend on the order in which tiles happen to run. -------------
-    uint32_t total;
+    // ---- the flood's start pixel: pixel 0, else pixel 1, else pixel w (read the
+    // levels now: s_lev is about to be reused for node ids) -----------------------------------------
+    if (tid == 0) {
+        if (s_walls) atomicAdd(&b.ctr[pi].n_walls, s_walls);
+        uint32_t sr = NONE;
+        if (tl == 0) {
+            int sp = -1;
+            if (s_lev[LX(0)] != WALL) sp = 0;
+            else if (pd.w > 1 && s_lev[LX(1)] != WALL) sp = 1;
+            else if (pd.h > 1 && s_lev[LX(TILE_W)] != WALL) sp = TILE_W;
+            if (sp >= 0) {
+                const uint32_t l = s_lev[LX(sp)], w = s_par[LX(sp)];
+                sr = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : (uint32_t)sp;
+            }
+        }
+        s_start = sr;
+    }
+    // ---- dense ids for ALL level roots of the tile, in pixel order ---------------------------------
+    uint32_t total_all;
+    const uint32_t aid0 = block_excl_scan(__popc(rootmask), s_wsum, &total_all);
     {
-        uint32_t id = block_excl_scan(__popc(rootmask), s_wsum, &total);
+        uint32_t id = aid0;
 #pragma unroll
         for (int k = 0; k < TILE_PPT; ++k)
-            if ((rootmask >> k) & 1) s_nid[p0 + k] = (uint16_t)id++;
+            if ((rootmask >> k) & 1) s_nid[OWN(k)] = (uint16_t)id++;
     }
     __syncthreads();
-    if (tid == 0) {
-        b.tile_cnt[blockIdx.x] = total;
-        b.tile_lo[blockIdx.x] = (uint8_t)min(s_lmin, 255u);
-        b.tile_hi[blockIdx.x] = (uint8_t)s_lmax;
-        if (s_walls) atomicAdd(&b.ctr[pi].n_walls, s_walls);
-    }
     PHASE_MARK(4);
 
-    // ---- own statistics (pixel count, row set, column set) and export, STAT_CHUNK nodes per pass
     const uint32_t base = tl * (uint32_t)TILE_PX;
     const size_t   nb = pd.node_base;
-    uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
-    uint32_t            *s_row = s_work + STAT_CHUNK;          // [STAT_CHUNK]
-    unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * STAT_CHUNK); // [STAT_CHUNK]
-    for (uint32_t c0 = 0; c0 < total; c0 += STAT_CHUNK) {
-        for (int i = tid; i < TILE_PX; i += TILE_THREADS) s_work[i] = 0;
+    uint32_t total = 0;     // nodes exported by this tile
+
+    if (total_all <= (uint32_t)FOLD_CAP) {
+        // ---- fold path.  Statistics of every node of the tile live in LDS:
+        //   s_w0[a]  = pixels (bits 0-11) | nodes (bits 12-23) | open (bit 31)
+        //   s_row[a] = set of tile rows, s_col[a] = set of tile columns the component touches.
+        // "open" = the component reaches a pixel that has a neighbour in another tile, so seam
+        // merging may still change it.  Everything else ("closed") is final inside this tile: a
+        // closed node adds its totals to its parent here in LDS and is exported only if the
+        // reference would keep it (area > MIN_AREA); the thousands of small speckle nodes never
+        // reach global memory, yet they are counted (ER::area includes the node count).
+        uint32_t           *s_w0 = s_work;                                   // [FOLD_CAP]
+        uint32_t           *s_row = s_work + FOLD_CAP;                       // [FOLD_CAP]
+        unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * FOLD_CAP); // [FOLD_CAP]
+        for (int i = tid; i < 4 * FOLD_CAP; i += TILE_THREADS) s_work[i] = 0;
         __syncthreads();
-        {   // the lane's pixels form runs with a common root: one set of atomics per run
+        {
             uint32_t cur = NONE, cnt = 0;
             unsigned long long col = 0;
 #pragma unroll
@@ -523,13 +549,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 uint32_t id = NONE;
                 if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL) {
                     const uint32_t p = p0 + k;
-                    const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[p] & 0xFFFFu);
-                    id = (uint32_t)s_nid[r] - c0;
-                    if (id >= (uint32_t)STAT_CHUNK) id = NONE;
+                    const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
+                    id = s_nid[LX(r)];
                 }
                 if (id != cur) {
                     if (cur != NONE) {
-                        atomicAdd(&s_cnt[cur], cnt);
+                        atomicAdd(&s_w0[cur], cnt);
                         atomicOr(&s_row[cur], 1u << ly);
                         atomicOr(&s_col[cur], col);
                     }
@@ -538,81 +563,201 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 if (id != NONE) { ++cnt; col |= 1ull << (lx + k); }
             }
         }
-        __syncthreads();
-#pragma unroll 1
+        // (open bits are OR-ed separately: an add could carry)
+#pragma unroll
         for (int k = 0; k < TILE_PPT; ++k) {
-            if (!((rootmask >> k) & 1)) continue;
+            if (lev[k] == WALL) continue;
+            const int  xx = lx + k;
+            const bool on_seam = (ly == 0 && ty > 0) || (ly == TILE_H - 1 && ty + 1 < pd.tiles_y) ||
+                                 (xx == 0 && tx > 0) || (xx == TILE_W - 1 && tx + 1 < pd.tiles_x);
+            if (!on_seam) continue;
             const uint32_t p = p0 + k;
-            const uint32_t li = (uint32_t)s_nid[p] - c0;
-            if (li >= (uint32_t)STAT_CHUNK) continue;
-            const size_t   id = nb + base + s_nid[p];
-            const uint32_t w = s_par[p];
-            b.na.par[id] = (w == NONE) ? NONE : base + s_nid[w & 0xFFFFu];
-            b.na.lvl[id] = (uint8_t)lev[k];
-            b.na.dead[id] = 0;
-            b.na.cnt[id] = s_cnt[li];
-            b.na.nod[id] = 1;
-            const unsigned long long cm = s_col[li];
-            const uint32_t           rm = s_row[li];
-            b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
-            b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-            b.na.y0[id] = oy + __ffs((int)rm) - 1;
-            b.na.y1[id] = oy + 31 - __clz((int)rm);
-            b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+            const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
+            atomicOr(&s_w0[s_nid[LX(r)]], 0x80000000u);
+        }
+        {
+            uint32_t id = aid0;
+#pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k)
+                if ((rootmask >> k) & 1) atomicAdd(&s_w0[id++], 1u << 12);     // the node itself
         }
         __syncthreads();
+        // bottom-up over the levels present in the tile: children are at lower levels than parents
+        const uint32_t lmin = s_lmin, lmax = s_lmax;
+        for (uint32_t t = lmin; t <= lmax && lmin != 0xFFFFFFFFu; ++t) {
+            uint32_t id = aid0;
+#pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k) {
+                if (!((rootmask >> k) & 1)) continue;
+                const uint32_t a = id++;
+                if (lev[k] != t) continue;
+                const uint32_t w = s_par[OWN(k)];
+                if (w == NONE) continue;
+                const uint32_t pa = s_nid[LX(w & 0xFFFFu)];
+                const uint32_t v = s_w0[a];
+                if (v >> 31) atomicOr(&s_w0[pa], 0x80000000u);
+                else {
+                    atomicAdd(&s_w0[pa], v & 0xFFFFFFu);
+                    atomicOr(&s_row[pa], s_row[a]);
+                    atomicOr(&s_col[pa], s_col[a]);
+                }
+            }
+            __syncthreads();
+        }
+        // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
+        // node of the flood's start pixel
+        uint32_t expmask = 0, openmask = 0;
+        {
+            uint32_t id = aid0;
+            const uint32_t sroot = s_start;
+#pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k) {
+                if (!((rootmask >> k) & 1)) continue;
+                const uint32_t v = s_w0[id++];
+                const uint32_t area = (v & 0xFFFu) + ((v >> 12) & 0xFFFu);
+                const bool     open = (v >> 31) != 0;
+                if (open) openmask |= 1u << k;
+                if (open || (int64_t)area > (int64_t)prm.min_area || s_par[OWN(k)] == NONE || p0 + k == sroot) expmask |= 1u << k;
+            }
+        }
+        const uint32_t eid0 = block_excl_scan(__popc(expmask), s_wsum, &total);
+        // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
+        {
+            uint32_t id = eid0;
+#pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k)
+                if ((rootmask >> k) & 1) s_nid[OWN(k)] = ((expmask >> k) & 1) ? (uint16_t)id++ : (uint16_t)0xFFFFu;
+        }
+        __syncthreads();
+        {
+            uint32_t aid = aid0, lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll 1
+            for (int k = 0; k < TILE_PPT; ++k) {
+                if (!((rootmask >> k) & 1)) continue;
+                const uint32_t a = aid++;
+                if (!((expmask >> k) & 1)) continue;
+                const uint32_t p = p0 + k;
+                const size_t   id = nb + base + s_nid[LX(p)];
+                uint32_t       q = s_par[LX(p)];
+                q = (q == NONE) ? NONE : (q & 0xFFFFu);
+                while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
+                    const uint32_t w2 = s_par[LX(q)];
+                    q = (w2 == NONE) ? NONE : (w2 & 0xFFFFu);
+                }
+                const uint32_t v = s_w0[a];
+                const bool     open = (openmask >> k) & 1;
+                if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
+                b.na.par[id] = (q == NONE) ? NONE : base + s_nid[LX(q)];
+                b.na.lvl[id] = (uint8_t)lev[k];
+                b.na.dead[id] = open ? 0 : 2;                    // 2 = closed: totals are final
+                b.na.cnt[id] = v & 0xFFFu;
+                b.na.nod[id] = (v >> 12) & 0xFFFu;
+                const unsigned long long cm = s_col[a];
+                const uint32_t           rm = s_row[a];
+                b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
+                b.na.x1[id] = ox + 63 - __clzll((long long)cm);
+                b.na.y0[id] = oy + __ffs((int)rm) - 1;
+                b.na.y1[id] = oy + 31 - __clz((int)rm);
+                b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+            }
+            if (lo != 0xFFFFFFFFu) { atomicMin(&s_lmin2, lo); atomicMax(&s_lmax2, hi); }
+        }
+    } else {
+        // ---- dense tile (more than FOLD_CAP nodes): export every node with its own statistics,
+        // STAT_CHUNK nodes per pass; the global passes do all the accumulation.
+        total = total_all;
+        uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
+        uint32_t            *s_row = s_work + STAT_CHUNK;          // [STAT_CHUNK]
+        unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * STAT_CHUNK); // [STAT_CHUNK]
+        for (uint32_t c0 = 0; c0 < total; c0 += STAT_CHUNK) {
+            for (int i = tid; i < 4 * STAT_CHUNK; i += TILE_THREADS) s_work[i] = 0;
+            __syncthreads();
+            {   // the lane's pixels form runs with a common root: one set of atomics per run
+                uint32_t cur = NONE, cnt = 0;
+                unsigned long long col = 0;
+#pragma unroll
+                for (int k = 0; k <= TILE_PPT; ++k) {
+                    uint32_t id = NONE;
+                    if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL) {
+                        const uint32_t p = p0 + k;
+                        const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
+                        id = (uint32_t)s_nid[LX(r)] - c0;
+                        if (id >= (uint32_t)STAT_CHUNK) id = NONE;
+                    }
+                    if (id != cur) {
+                        if (cur != NONE) {
+                            atomicAdd(&s_cnt[cur], cnt);
+                            atomicOr(&s_row[cur], 1u << ly);
+                            atomicOr(&s_col[cur], col);
+                        }
+                        cur = id; cnt = 0; col = 0;
+                    }
+                    if (id != NONE) { ++cnt; col |= 1ull << (lx + k); }
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < TILE_PPT; ++k) {
+                if (!((rootmask >> k) & 1)) continue;
+                const uint32_t p = p0 + k;
+                const uint32_t li = (uint32_t)s_nid[LX(p)] - c0;
+                if (li >= (uint32_t)STAT_CHUNK) continue;
+                const size_t   id = nb + base + s_nid[LX(p)];
+                const uint32_t w = s_par[LX(p)];
+                b.na.par[id] = (w == NONE) ? NONE : base + s_nid[LX(w & 0xFFFFu)];
+                b.na.lvl[id] = (uint8_t)lev[k];
+                b.na.dead[id] = 0;
+                b.na.cnt[id] = s_cnt[li];
+                b.na.nod[id] = 1;
+                const unsigned long long cm = s_col[li];
+                const uint32_t           rm = s_row[li];
+                b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
+                b.na.x1[id] = ox + 63 - __clzll((long long)cm);
+                b.na.y0[id] = oy + __ffs((int)rm) - 1;
+                b.na.y1[id] = oy + 31 - __clz((int)rm);
+                b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { s_lmin2 = s_lmin; s_lmax2 = s_lmax; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        b.tile_cnt[blockIdx.x] = total;
+        b.tile_lo[blockIdx.x] = (uint8_t)min(s_lmin2, 255u);
+        b.tile_hi[blockIdx.x] = (uint8_t)min(s_lmax2, 255u);
+        if (tl == 0) b.ctr[pi].start_node = (s_start == NONE) ? NONE : base + s_nid[LX(s_start)];
     }
     PHASE_MARK(5);
 
     // ---- node id of every tile-border pixel, for the seam pass ---------------------------
     // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
     // of w ids (pixel row j*TH-1, then j*TH); then for every vertical boundary i two
-    // columns of h ids (pixel column i*TW-1, then i*TW).
-    uint32_t *seam = b.seam + pd.seam_base;
-    const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
-    for (int i = tid; i < 2 * TILE_W + 2 * TILE_H; i += TILE_THREADS) {
-        int      sx, sy;
-        uint32_t *dst = nullptr;
-        if (i < TILE_W) {                       // top row -> lower side of boundary ty
-            sx = i; sy = 0;
-            if (ty > 0 && ox + sx < pd.w) dst = seam + ((size_t)(ty - 1) * 2 + 1) * pd.w + ox + sx;
-        } else if (i < 2 * TILE_W) {            // bottom row -> upper side of boundary ty+1
-            sx = i - TILE_W; sy = TILE_H - 1;
-            if (ty + 1 < pd.tiles_y && ox + sx < pd.w) dst = seam + ((size_t)ty * 2) * pd.w + ox + sx;
-        } else if (i < 2 * TILE_W + TILE_H) {   // left column -> right side of boundary tx
-            sx = 0; sy = i - 2 * TILE_W;
-            if (tx > 0 && oy + sy < pd.h) dst = seam + voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + oy + sy;
-        } else {                                // right column -> left side of boundary tx+1
-            sx = TILE_W - 1; sy = i - 2 * TILE_W - TILE_H;
-            if (tx + 1 < pd.tiles_x && oy + sy < pd.h) dst = seam + voff + ((size_t)tx * 2) * pd.h + oy + sy;
+    // columns of h ids (pixel column i*TW-1, then i*TW).  Each lane writes its own pixels.
+    {
+        uint32_t *seam = b.seam + pd.seam_base;
+        const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
+        const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k) {
+            const int  xx = lx + k;
+            const bool lef = xx == 0 && tx > 0, rig = xx == TILE_W - 1 && tx + 1 < pd.tiles_x;
+            if (!(top || bot || lef || rig)) continue;
+            if (gx + k >= pd.w || gy >= pd.h) continue;
+            uint32_t id = NONE;
+            if (lev[k] != WALL) {
+                const uint32_t p = p0 + k;
+                const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
+                id = base + s_nid[LX(r)];
+            }
+            if (top) seam[((size_t)(ty - 1) * 2 + 1) * pd.w + gx + k] = id;
+            if (bot) seam[((size_t)ty * 2) * pd.w + gx + k] = id;
+            if (lef) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = id;
+            if (rig) seam[voff + ((size_t)tx * 2) * pd.h + gy] = id;
         }
-        if (!dst) continue;
-        const uint32_t p = sy * TILE_W + sx;
-        const uint32_t l = s_lev[p];
-        uint32_t       id = NONE;
-        if (l != WALL) {
-            const uint32_t w = s_par[p];
-            const uint32_t r = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : p;
-            id = base + s_nid[r];
-        }
-        *dst = id;
     }
     PHASE_MARK(6);
 
-    // ---- the flood's start pixel: pixel 0, else pixel 1, else pixel w --------
-    if (tl == 0 && tid == 0) {
-        int sp = -1;
-        if (s_lev[0] != WALL) sp = 0;
-        else if (pd.w > 1 && s_lev[1] != WALL) sp = 1;
-        else if (pd.h > 1 && s_lev[TILE_W] != WALL) sp = TILE_W;
-        uint32_t id = NONE;
-        if (sp >= 0) {
-            const uint32_t l = s_lev[sp], w = s_par[sp];
-            const uint32_t r = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : (uint32_t)sp;
-            id = base + s_nid[r];
-        }
-        b.ctr[pi].start_node = id;
-    }
 }
 
 #ifdef STR_ER_PHASE_PROF
@@ -750,6 +895,7 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
                 }
                 b.na.dead[nb + x] = 1;
                 atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
+                if (b.na.nod[nb + x] > 1) atomicAdd(&b.na.nod[nb + r], b.na.nod[nb + x] - 1);   // folded descendants
                 atomicMin(&b.na.x0[nb + r], b.na.x0[nb + x]);
                 atomicMin(&b.na.y0[nb + r], b.na.y0[nb + x]);
                 atomicMax(&b.na.x1[nb + r], b.na.x1[nb + x]);
@@ -918,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
         const bool      walls = c.n_walls != 0;
         for (uint32_t i = lane; i < n; i += 64) {
             const uint32_t x = base + i;
-            if (b.na.dead[nb + x]) continue;
+            if (b.na.dead[nb + x] == 1) continue;
             if (x != root) {
                 const uint32_t area = b.na.cnt[nb + x] + b.na.nod[nb + x];
                 if ((int64_t)area <= (int64_t)prm.min_area) continue;

@@ -1,0 +1,249 @@
+// er_filter_hip.hpp -- C++ host-side mirror of the reference's `class ERFilter` hot-path
+// surface (inc/ER.h:110-136), implemented on top of the C ABI in include/str_er.h.
+//
+// The reference keeps its host code in C++ and so does this: the class below has the same
+// constructor arguments, public members and method names as the reference for the path
+//
+//     text_detect -> compute_channels -> er_tree_extract -> non_maximum_supression -> classify
+//
+// but takes plain 8-bit buffers instead of cv::Mat (OpenCV is not a dependency of this
+// library).  A maintainer of the reference wraps `cv::Mat::data/step` in the `Image8` view
+// below (see INTEGRATION.md for the exact patch).  `struct ER` / `ERs` keep the reference's
+// field names (inc/ER.h:42-82) so downstream code (er_track, er_grouping, er_ocr,
+// src/ER.cpp:532-786) compiles against it unchanged.
+//
+// Header-only; link with -lstr_er_hip.  Errors are reported the way the reference does for
+// CV_Assert (src/ER.cpp:242): by throwing (std::runtime_error instead of cv::Exception).
+#pragma once
+
+#include <cfloat>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/str_er.h"
+
+namespace str_er_host {
+
+// Borrowed view of an 8-bit image: what cv::Mat gives through .data/.cols/.rows/.step.
+struct Image8 {
+    const uint8_t *data = nullptr;
+    int cols = 0, rows = 0;
+    int64_t step = 0;      // bytes per row
+    int channels = 1;      // 1 (8UC1 plane) or 3 (8UC3, BGR)
+    Image8() = default;
+    Image8(const uint8_t *d, int c, int r, int64_t s, int ch) : data(d), cols(c), rows(r), step(s), channels(ch) {}
+};
+
+struct Rect { int x = 0, y = 0, width = 0, height = 0; int area() const { return width * height; } };
+
+// Field-for-field the hot-path part of the reference's struct ER (inc/ER.h:42-80).
+struct ER {
+    int pixel = 0, level = 0, x = 0, y = 0;
+    int area = 0;
+    Rect bound;
+    bool done = false;
+    double stability = 0;
+    ER *parent = nullptr, *child = nullptr, *next = nullptr;
+    int ch = 0;
+    // set by classify on pooled ERs (not in the reference, where strong/weak are separate lists)
+    double score_strong = -DBL_MAX, score_weak = 0;
+    uint32_t key = 0;
+};
+typedef std::vector<ER *> ERs;
+
+// Owns the nodes of one plane's tree (the reference leaks them in image_mode and frees them
+// with ERFilter::er_delete in video_mode, src/ER.cpp:194-233, src/utils.cpp:212-213).
+struct ERTree {
+    std::vector<ER> nodes;
+    ER *root = nullptr;
+};
+
+class AdaBoostHandle {   // stands for `AdaBoost *stc, *wtc` (inc/ER.h:117-118): a loaded cascade file
+public:
+    explicit AdaBoostHandle(std::string path) : path_(std::move(path)) {}
+    const std::string &path() const { return path_; }
+private:
+    std::string path_;
+};
+
+class ERFilter {
+public:
+    // inc/ER.h:113 -- same argument order and defaults
+    ERFilter(int thresh_step = 2, int min_area = 100, int max_area = 100000, int stability_t = 2,
+             double overlap_coef = 0.7, double min_ocr_prob = 0.01, int max_width = 1920, int max_height = 1080,
+             int max_frames = 1, int device = 0)
+        : MIN_OCR_PROB(min_ocr_prob)
+    {
+        str_er_params p;
+        str_er_default_params(&p);
+        p.thresh_step = thresh_step; p.min_area = min_area; p.max_area = max_area; p.stability_t = stability_t;
+        p.overlap_coef = overlap_coef; p.max_width = max_width; p.max_height = max_height; p.max_frames = max_frames;
+        p.device = device;
+        str_er_ctx *c = nullptr;
+        const int rc = str_er_create(&p, &c);
+        if (rc != STR_ER_OK) throw std::runtime_error(std::string("str_er_create: ") + str_er_last_error(nullptr));
+        ctx_.reset(c, str_er_destroy);
+    }
+
+    //! modules (inc/ER.h:116-119): assigning a cascade file loads it onto the GPU
+    std::shared_ptr<AdaBoostHandle> stc, wtc;
+    void set_stc(const std::string &file) { load(STR_ER_CASCADE_STRONG, file); stc = std::make_shared<AdaBoostHandle>(file); }
+    void set_wtc(const std::string &file) { load(STR_ER_CASCADE_WEAK, file); wtc = std::make_shared<AdaBoostHandle>(file); }
+
+    void set_thresh_step(int t) { check(str_er_set_thresh_step(ctx_.get(), t)); }   // src/ER.cpp:21-24
+    void set_min_area(int m) { check(str_er_set_min_area(ctx_.get(), m)); }         // src/ER.cpp:27-30
+
+    // ERFilter::text_detect up to classify (src/ER.cpp:33-60).  root/pool/strong/weak are resized to
+    // the number of channels exactly like the reference does (:42-46); `all` stays empty unless
+    // GET_ALL_ER semantics are wanted (inc/ER.h:24).  Returns the 7-slot times vector (:99-110).
+    std::vector<double> text_detect(const Image8 &src, std::vector<ERTree> &trees, ERs &root, std::vector<ERs> &all,
+                                    std::vector<ERs> &pool, std::vector<ERs> &strong, std::vector<ERs> &weak)
+    {
+        if (src.channels != 3) throw std::runtime_error("text_detect expects an 8UC3 BGR image");
+        str_er_result *r = nullptr;
+        check(str_er_detect_bgr(ctx_.get(), src.data, src.cols, src.rows, src.step, src.step * (int64_t)src.rows, 1,
+                                STR_ER_MEM_HOST, STR_ER_STAGE_ALL | STR_ER_WANT_NODES, &r));
+        std::unique_ptr<str_er_result, void (*)(str_er_result *)> guard(r, str_er_result_free);
+        const int n = str_er_result_n_planes(r);
+        trees.assign(n, ERTree());
+        root.assign(n, nullptr); all.assign(n, ERs()); pool.assign(n, ERs()); strong.assign(n, ERs()); weak.assign(n, ERs());
+        for (int i = 0; i < n; ++i) unpack_plane(r, i, trees[i], pool[i], strong[i], weak[i]), root[i] = trees[i].root;
+        const double *t = str_er_result_times(r);
+        return std::vector<double>(t, t + 7);
+    }
+
+    // ER* ERFilter::er_tree_extract(Mat input) (src/ER.cpp:240-374); input must be 8UC1 (:242)
+    ER *er_tree_extract(const Image8 &input, ERTree &tree)
+    {
+        if (input.channels != 1) throw std::runtime_error("er_tree_extract: input.type() == CV_8UC1");
+        str_er_result *r = nullptr;
+        check(str_er_detect_planes(ctx_.get(), input.data, input.cols, input.rows, input.step, 0, 1, STR_ER_MEM_HOST,
+                                   STR_ER_STAGE_EXTRACT | STR_ER_WANT_NODES, &r));
+        std::unique_ptr<str_er_result, void (*)(str_er_result *)> guard(r, str_er_result_free);
+        ERs p, s, w;
+        unpack_plane(r, 0, tree, p, s, w);
+        return tree.root;
+    }
+
+    // void ERFilter::non_maximum_supression(ER *er, ERs &all, ERs &pool, Mat input) (src/ER.cpp:416-505);
+    // `tree` is the table er_tree_extract filled.  pool comes back in ascending key order.
+    void non_maximum_supression(ERTree &tree, ERs &all, ERs &pool, const Image8 &input, int *ambiguous = nullptr)
+    {
+        (void)all;
+        std::vector<str_er_node> tab(tree.nodes.size());
+        for (size_t i = 0; i < tab.size(); ++i) {
+            const ER &e = tree.nodes[i];
+            str_er_node &n = tab[i];
+            n.key = e.key; n.parent = e.parent ? (int32_t)(e.parent - tree.nodes.data()) : (int32_t)i; n.area = e.area;
+            n.x = (uint16_t)e.bound.x; n.y = (uint16_t)e.bound.y; n.w = (uint16_t)e.bound.width; n.h = (uint16_t)e.bound.height;
+            n.level = (uint8_t)e.level; n.flags = (&e == tree.root) ? 1 : 0; n.reserved = 0;
+            if (&e == tree.root) n.parent = (int32_t)i;
+        }
+        std::vector<int32_t> idx(tab.size());
+        int32_t np = 0, amb = 0;
+        check(str_er_nms_tree(ctx_.get(), tab.data(), (int32_t)tab.size(), input.rows, input.cols, idx.data(),
+                              (int32_t)idx.size(), &np, &amb));
+        pool.clear();
+        for (int i = 0; i < np; ++i) pool.push_back(&tree.nodes[idx[i]]);
+        if (ambiguous) *ambiguous = amb;
+    }
+
+    // void ERFilter::classify(ERs &pool, ERs &strong, ERs &weak, Mat input) (src/ER.cpp:507-528)
+    void classify(ERs &pool, ERs &strong, ERs &weak, const Image8 &input)
+    {
+        const int n = (int)pool.size();
+        std::vector<int32_t> boxes(4 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            boxes[4 * i] = pool[i]->bound.x; boxes[4 * i + 1] = pool[i]->bound.y;
+            boxes[4 * i + 2] = pool[i]->bound.width; boxes[4 * i + 3] = pool[i]->bound.height;
+        }
+        std::vector<uint8_t> cls(n);
+        std::vector<double> ss(n), sw(n);
+        check(str_er_classify_boxes(ctx_.get(), input.data, input.cols, input.rows, input.step, boxes.data(), n, cls.data(),
+                                    ss.data(), sw.data()));
+        for (int i = 0; i < n; ++i) {
+            pool[i]->score_strong = ss[i]; pool[i]->score_weak = sw[i];
+            if (cls[i] == STR_ER_CLS_STRONG) strong.push_back(pool[i]);
+            else if (cls[i] == STR_ER_CLS_WEAK) weak.push_back(pool[i]);
+        }
+    }
+
+    // void ERFilter::compute_channels(Mat &src, Mat &YCrcb, vector<Mat> &channels) (src/ER.cpp:114-128):
+    // six tightly packed planes [Y, Cr, Cb, 255-Y, 255-Cr, 255-Cb]
+    void compute_channels(const Image8 &src, std::vector<std::vector<uint8_t>> &channels)
+    {
+        std::vector<uint8_t> six((size_t)6 * src.cols * src.rows);
+        check(str_er_compute_channels(ctx_.get(), src.data, src.cols, src.rows, src.step, six.data()));
+        const size_t n = (size_t)src.cols * src.rows;
+        channels.assign(6, std::vector<uint8_t>());
+        for (int i = 0; i < 6; ++i) channels[i].assign(six.begin() + i * n, six.begin() + (i + 1) * n);
+    }
+
+    // vector<double> ERFilter::make_LBP_hist(Mat input, N = 2, normalize_size = 24) (src/ER.cpp:789-816)
+    std::vector<double> make_LBP_hist(const Image8 &input)
+    {
+        const int32_t box[4] = {0, 0, input.cols, input.rows};
+        std::vector<double> h(1024);
+        check(str_er_lbp_hist(ctx_.get(), input.data, input.cols, input.rows, input.step, box, 1, h.data(), nullptr));
+        return h;
+    }
+
+    // void ERFilter::er_delete(ER *er) (src/ER.cpp:194-233): the table owns the nodes
+    void er_delete(ERTree &tree) { tree.nodes.clear(); tree.root = nullptr; }
+
+    str_er_ctx *handle() const { return ctx_.get(); }
+
+private:
+    double MIN_OCR_PROB;
+    std::shared_ptr<str_er_ctx> ctx_;
+
+    void check(int rc) const
+    {
+        if (rc != STR_ER_OK) throw std::runtime_error(std::string(str_er_strerror(rc)) + ": " + str_er_last_error(ctx_.get()));
+    }
+    void load(int which, const std::string &file)
+    {
+        // the reference prints and returns false (src/adaboost.cpp:877-881); callers ignore it (src/main.cpp:23-24).
+        check(str_er_load_cascade(ctx_.get(), which, file.c_str()));
+    }
+
+    // node table -> intrusive tree with the reference's parent/child/next links; children are
+    // prepended like er_merge does (src/ER.cpp:183-185), in ascending key order overall.
+    static void unpack_plane(const str_er_result *r, int plane, ERTree &tree, ERs &pool, ERs &strong, ERs &weak)
+    {
+        int32_t nn = 0, nc = 0;
+        const str_er_node *nodes = str_er_result_plane_nodes(r, plane, &nn);
+        const str_er_cand *cands = str_er_result_plane_cands(r, plane, &nc);
+        str_er_plane_info info;
+        str_er_result_plane_info(r, plane, &info);
+        tree.nodes.assign((size_t)nn, ER());
+        tree.root = nn ? &tree.nodes[info.root] : nullptr;
+        for (int i = 0; i < nn; ++i) {
+            ER &e = tree.nodes[i];
+            const str_er_node &n = nodes[i];
+            e.level = n.level; e.area = n.area; e.key = n.key; e.ch = info.ch;
+            e.bound.x = n.x; e.bound.y = n.y; e.bound.width = n.w; e.bound.height = n.h;
+            e.pixel = (int)n.key; e.x = (int)(n.key % (uint32_t)info.width); e.y = (int)(n.key / (uint32_t)info.width);
+        }
+        for (int i = nn - 1; i >= 0; --i) {       // descending index + prepend = ascending child lists
+            if (i == info.root) continue;
+            ER &e = tree.nodes[i];
+            ER &p = tree.nodes[nodes[i].parent];
+            e.parent = &p; e.next = p.child; p.child = &e;
+        }
+        for (int i = 0; i < nc; ++i) {
+            const str_er_cand &c = cands[i];
+            if (c.node < 0) continue;
+            ER *e = &tree.nodes[c.node];
+            e->score_strong = c.score_strong; e->score_weak = c.score_weak;
+            pool.push_back(e);
+            if (c.cls == STR_ER_CLS_STRONG) strong.push_back(e);
+            else if (c.cls == STR_ER_CLS_WEAK) weak.push_back(e);
+        }
+    }
+};
+
+} // namespace str_er_host

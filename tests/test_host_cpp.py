@@ -1,0 +1,51 @@
+"""The C++ host-side mirror of the reference's ERFilter (scene-text-recognition_amd/host):
+compiles everywhere; on a GPU box the example runs and must agree with the Python path."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "scene-text-recognition_amd", "host")
+
+
+def _build(S, tmp_path):
+    exe = str(tmp_path / "example_text_detect")
+    libdir = os.path.dirname(S.lib_path())
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", os.path.join(HOST, "example_text_detect.cpp"),
+                    "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lstr_er_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    return exe
+
+
+def test_host_mirror_compiles(S, tmp_path):
+    assert os.path.exists(_build(S, tmp_path))
+
+
+def test_host_mirror_has_the_reference_surface():
+    txt = open(os.path.join(HOST, "er_filter_hip.hpp")).read()
+    for name in ("text_detect", "compute_channels", "er_tree_extract", "non_maximum_supression", "classify", "er_delete",
+                 "make_LBP_hist", "set_thresh_step", "set_min_area", "stc", "wtc"):
+        assert name in txt, name
+
+
+@pytest.mark.gpu
+def test_host_mirror_runs_and_matches_python(S, cascade_paths, tmp_path):
+    exe = _build(S, tmp_path)
+    frame = S.synth.stext_bgr(S.synth.frame_seed(2), 640, 480)
+    raw = tmp_path / "frame.bgr"
+    raw.write_bytes(frame.tobytes())
+    out = subprocess.run([exe, cascade_paths[0], cascade_paths[1], str(raw), "640", "480"], check=True, capture_output=True,
+                         text=True).stdout.splitlines()
+    assert out[-1] == "staged == fused on plane 0: yes"
+    f = S.ERFilter(8, 120, 900000, 2, 0.7, 0.15, max_width=640, max_height=480, max_frames=1)
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    res = f.text_detect(frame)
+    planes = [l.split() for l in out if l.startswith("plane")]
+    assert [(int(p[3]), int(p[5]), int(p[7]), int(p[9])) for p in planes] == \
+        [(p.n_kept, p.n_pool, p.n_strong, p.n_weak) for p in res.planes]
+    got = sorted((l.split()[0], int(l.split()[1]), int(l.split()[7]), float(l.split()[8])) for l in out if l[:2] in ("S ", "W "))
+    exp = sorted([("S", int(c["ch"]), int(c["key"]), float(c["score_strong"])) for c in res.cands if c["cls"] == 1] +
+                 [("W", int(c["ch"]), int(c["key"]), float(c["score_weak"])) for c in res.cands if c["cls"] == 2])
+    assert got == exp and len(got) > 0
+    f.close()
