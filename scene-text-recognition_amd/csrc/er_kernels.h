@@ -27,6 +27,7 @@ struct BatchDev {
     uint32_t        *pool_tmp;
     CandRec         *cands;    // packed, ordered by (plane, key)
     uint32_t        *total_cands;
+    uint16_t        *cand_plane; // plane of every packed candidate
 };
 
 // compute_channels (src/ER.cpp:114-128): interleaved BGR -> Y, Cr, Cb planes.

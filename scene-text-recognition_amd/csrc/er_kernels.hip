@@ -57,7 +57,7 @@ __device__ __forceinline__ int find_plane_by_pair(const PlaneDesc *pl, int n, ui
     return lo;
 }
 
-__device__ __forceinline__ int find_plane_by_cand(const PlaneCtr *ctr, int n, uint32_t c)
+__device__ __forceinline__ int find_plane_by_cand_unused(const PlaneCtr *ctr, int n, uint32_t c)
 {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -1241,19 +1241,38 @@ void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p)
     hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p);
 }
 
-// exclusive prefix of the pool sizes: where every plane's candidates go in the packed array
-__global__ void k_cand_prefix(BatchDev b)
+// exclusive prefix of the pool sizes: where every plane's candidates go in the packed array;
+// also the candidate -> plane table, so k_classify does not have to search.
+__global__ __launch_bounds__(1024) void k_cand_prefix(BatchDev b)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int i = 0; i < b.n_planes; ++i) { b.ctr[i].cand_base = acc; acc += b.ctr[i].n_pool; }
-        *b.total_cands = acc;
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < b.n_planes; base += 1024) {
+        const int      i = base + tid;
+        const uint32_t n = i < b.n_planes ? b.ctr[i].n_pool : 0;
+        const uint32_t incl = wave_incl_scan(n);
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < wv) off += s_w[k]; tot += s_w[k]; }
+        const uint32_t mine = off + incl - n;
+        if (i < b.n_planes) {
+            b.ctr[i].cand_base = mine;
+            for (uint32_t k = 0; k < n; ++k) b.cand_plane[mine + k] = (uint16_t)i;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
     }
+    if (tid == 0) *b.total_cands = s_carry;
 }
 
 void launch_cand_prefix(hipStream_t s, const BatchDev &b)
 {
-    hipLaunchKernelGGL(k_cand_prefix, dim3(1), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_cand_prefix, dim3(1), dim3(1024), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1345,38 +1364,264 @@ __device__ double block_cascade(ClsShared &sh, const CascadeDev &c)
     return score;
 }
 
-__global__ __launch_bounds__(CLS_THREADS) void k_classify(BatchDev b, DetectParams prm, CascadeDev strong,
-                                                          CascadeDev weak, int run_cascades)
+// Batched classify: one workgroup takes 64 pooled ERs.
+//   phase 1: each of the 16 waves builds the LBP histograms of 4 of them (wave per ER) and stores
+//            them as 1028-byte rows of 8-bit counts in LDS (1028 = 1024 + 4: lane j reading
+//            row j, column d hits bank (257 j + d/4) mod 32 -- conflict free);
+//   phase 2: ONE wave scores all 64 with one ER per lane: every lane walks the stumps in file
+//            order and adds in that order, so each stage sum is bit-identical to the
+//            reference's sequential `score_stage +=` (src/adaboost.cpp:526-541), while the stump
+//            parameters are wave-uniform (scalar loads).
+constexpr int CLS_ROW = 1028;
+constexpr int CLS_PER_BLOCK = 64;
+
+constexpr int CLS64_WAVES = 16;
+constexpr int CLS64_THREADS = CLS64_WAVES * 64;
+
+struct Cls64Scratch {
+    uint32_t hist[CLS64_WAVES][1024];
+    uint8_t  tile[CLS64_WAVES][26 * 26 + 4];
+};
+struct Cls64Shared {
+    uint8_t rows[CLS_PER_BLOCK * CLS_ROW];
+    union {                              // phase 1 scratch, then the (A,B) tables of both cascades
+        Cls64Scratch p1;
+        double       ab[sizeof(Cls64Scratch) / sizeof(double)];
+    } u;
+};
+constexpr int CLS_AB_CAP = (int)(sizeof(Cls64Scratch) / (2 * sizeof(double)));   // stumps that fit
+
+__device__ __forceinline__ double readlane_f64(double v, int j)
 {
-    __shared__ ClsShared sh;
-    const uint32_t total = *b.total_cands;
-    for (uint32_t cidx = blockIdx.x; cidx < total; cidx += gridDim.x) {
-        const int        pi = find_plane_by_cand(b.ctr, b.n_planes, cidx);
-        const PlaneDesc &pd = b.planes[pi];
-        const uint32_t   i = cidx - b.ctr[pi].cand_base;
-        const uint32_t   slot = b.pool[pd.pool_base + i];
-        const size_t     ks = pd.kept_base + slot;
-        const int bx = b.ka.box[4 * ks], by = b.ka.box[4 * ks + 1], bw = b.ka.box[4 * ks + 2], bh = b.ka.box[4 * ks + 3];
-        int    cls = 0;
-        double ss = -DBL_MAX, sw = 0;
-        if (run_cascades) {
-            block_lbp_hist(sh, pd.pix, pd.stride, pd.invert, bx, by, bw, bh);
-            ss = block_cascade(sh, strong);
-            if (ss > -DBL_MAX) cls = 1;
-            else {
-                sw = block_cascade(sh, weak);
-                if (sw > -DBL_MAX) cls = 2;
+    const unsigned long long u = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), j);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// One ER per lane.  The parameters of 64 stumps at a time are fetched with one coalesced vector
+// load per field (lane i holds stump i) and broadcast with v_readlane; the lane's histogram bytes
+// for 8 stumps are gathered from LDS together, so only the 8 adds are serial.
+__device__ __forceinline__ double lane_cascade_generic(const CascadeDev &c, const uint8_t *row, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    int    off = 0;
+    bool   alive = valid;
+    double score = 0;
+    for (int s = 0; s < c.n_stages; ++s) {
+        const int n = c.stage_n[s];
+        double    acc = 0;
+        const int m = min(n, max(0, c.n_stumps - off));
+        for (int base = 0; base < m; base += 64) {
+            const int  st = off + base + lane;
+            const bool have = base + lane < m;
+            StumpRec   r;
+            r.dim = 0; r.mode = 0; r.thr = 0; r.vp = 0; r.vn = 0;
+            if (have) r = c.rec[st];
+            const double pr = (have && r.mode == 2) ? c.dir[st] : 1.0;
+            const int    pd = r.dim | (r.mode << 16);
+            const int    cnt = min(64, m - base);
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                int    dj[8];
+                double fv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { dj[u] = __builtin_amdgcn_readlane(pd, j + u); fv[u] = (double)row[dj[u] & 0xFFFF]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double t = readlane_f64(r.thr, j + u), vp = readlane_f64(r.vp, j + u), vn = readlane_f64(r.vn, j + u);
+                    const int    mode = dj[u] >> 16;
+                    bool         lt;
+                    if (mode == 0) lt = fv[u] < t;
+                    else if (mode == 1) lt = fv[u] > t;
+                    else { const double d = readlane_f64(pr, j + u); lt = fv[u] * d < t * d; }
+                    acc += lt ? vp : vn;
+                }
+            }
+            for (; j < cnt; ++j) {
+                const int    dw = __builtin_amdgcn_readlane(pd, j);
+                const double fv = (double)row[dw & 0xFFFF];
+                const double t = readlane_f64(r.thr, j), vp = readlane_f64(r.vp, j), vn = readlane_f64(r.vn, j);
+                const int    mode = dw >> 16;
+                bool         lt;
+                if (mode == 0) lt = fv < t;
+                else if (mode == 1) lt = fv > t;
+                else { const double d = readlane_f64(pr, j); lt = fv * d < t * d; }
+                acc += lt ? vp : vn;
             }
         }
-        if (threadIdx.x == 0) {
-            CandRec r;
-            r.frame = pd.frame; r.ch = pd.ch; r.pyr = pd.pyr; r.level = b.ka.level[ks]; r.cls = (uint8_t)cls;
-            r.x = (uint16_t)bx; r.y = (uint16_t)by; r.w = (uint16_t)bw; r.h = (uint16_t)bh;
-            r.area = b.ka.area[ks]; r.key = b.ka.key[ks]; r.node = (int32_t)slot; r.plane = (uint32_t)pi;
-            r.score_strong = ss; r.score_weak = sw;
-            b.cands[cidx] = r;
-            if (cls == 1) atomicAdd(&b.ctr[pi].n_strong, 1u);
-            if (cls == 2) atomicAdd(&b.ctr[pi].n_weak, 1u);
+        if (alive) {
+            if (acc < (double)c.stage_thresh[s]) alive = false;
+            else score = acc;
+        }
+        off += n;
+        if (!__any(alive)) break;
+    }
+    return alive ? score : -DBL_MAX;
+}
+
+// Fast form for dir = +-1 cascades: histogram counts are integers, so `fv*dir < thr*dir` is the
+// integer test h < T (T = ceil(thr), or floor(thr)+1 with the two outputs swapped for dir = -1).
+// The (A,B) output pairs of all stumps sit in LDS (s_ab); the packed (dim, T) words of 64 stumps
+// are fetched with one vector load and broadcast with v_readlane.  Adds stay in file order.
+__device__ __forceinline__ double lane_cascade_fast(const CascadeDev &c, const uint8_t *row, const double *s_ab, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    int    off = 0;
+    bool   alive = valid;
+    double score = 0;
+    for (int s = 0; s < c.n_stages; ++s) {
+        const int n = c.stage_n[s];
+        double    acc = 0;
+        const int m = min(n, max(0, c.n_stumps - off));
+        for (int base = 0; base < m; base += 64) {
+            const int pw = (base + lane < m) ? (int)c.w[off + base + lane] : 0;
+            const int cnt = min(64, m - base);
+            const double *ab = s_ab + 2 * (size_t)(off + base);
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, j + u);
+                    const uint32_t h = row[w & 1023u];
+                    v[u] = ab[2 * (j + u) + (h < (w >> 10) ? 0 : 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; j < cnt; ++j) {
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, j);
+                const uint32_t h = row[w & 1023u];
+                acc += ab[2 * j + (h < (w >> 10) ? 0 : 1)];
+            }
+        }
+        if (alive) {
+            if (acc < (double)c.stage_thresh[s]) alive = false;
+            else score = acc;
+        }
+        off += n;
+        if (!__any(alive)) break;
+    }
+    return alive ? score : -DBL_MAX;
+}
+
+__global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectParams prm, CascadeDev strong,
+                                                          CascadeDev weak, int run_cascades)
+{
+    __shared__ Cls64Shared sh;
+    const uint32_t total = *b.total_cands;
+    const int      tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t c0 = blockIdx.x * CLS_PER_BLOCK; c0 < total; c0 += gridDim.x * CLS_PER_BLOCK) {
+#ifdef STR_ER_PHASE_PROF
+        const unsigned long long tp0 = wall_clock64();
+#endif
+        // ---- phase 1: histograms --------------------------------------------------------------
+        if (run_cascades) {
+            for (int it = 0; it < CLS_PER_BLOCK / CLS64_WAVES; ++it) {
+                const uint32_t cidx = c0 + it * CLS64_WAVES + wv;
+                const bool     ok = cidx < total;
+                int bx = 0, by = 0, bw = 1, bh = 1, stride = 0, inv = 0;
+                const uint8_t *pix = nullptr;
+                if (ok) {
+                    const int        pi = b.cand_plane[cidx];
+                    const PlaneDesc &pd = b.planes[pi];
+                    const uint32_t   slot = b.pool[pd.pool_base + (cidx - b.ctr[pi].cand_base)];
+                    const size_t     ks = pd.kept_base + slot;
+                    bx = b.ka.box[4 * ks]; by = b.ka.box[4 * ks + 1]; bw = b.ka.box[4 * ks + 2]; bh = b.ka.box[4 * ks + 3];
+                    pix = pd.pix; stride = pd.stride; inv = pd.invert;
+                }
+                uint32_t *hist = sh.u.p1.hist[wv];
+                uint8_t  *tile = sh.u.p1.tile[wv];
+                for (int i = lane; i < 1024; i += 64) hist[i] = 0;
+                for (int i = lane; i < 26 * 26; i += 64) tile[i] = 0;
+                __syncthreads();
+                if (ok) {
+                    const double R1 = (bw > bh) ? (double)bh / bw : (double)bw / bh;
+                    const int    k = (int)(26.0 * sqrt(R1));
+                    const int    dw = (bw > bh) ? 26 : k, dh = (bw > bh) ? k : 26;
+                    if (dw > 0 && dh > 0) {
+                        const int offy = (dw > dh) ? (26 - dh) / 2 : 0;
+                        const int offx = (dw > dh) ? 0 : (26 - dw) / 2;
+                        const ResizeGeom g = resize_geom(bw, bh, dw, dh);
+                        const uint8_t *roi = pix + (size_t)by * stride + bx;
+                        for (int i = lane; i < dw * dh; i += 64) {
+                            const int dy = i / dw, dx = i - dy * dw;
+                            tile[(dy + offy) * 26 + dx + offx] = (uint8_t)resize_px(g, roi, stride, inv, dx, dy);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (ok) {
+                    for (int idx = lane; idx < 24 * 24; idx += 64) {
+                        const int i = idx / 24, j = idx - i * 24;
+                        const int cpos = (i + 1) * 26 + (j + 1);
+                        const int v0 = tile[cpos - 25], v1 = tile[cpos - 24], v2 = tile[cpos - 23], v3 = tile[cpos + 1];
+                        const int v4 = tile[cpos + 25], v5 = tile[cpos + 24], v6 = tile[cpos + 23], v7 = tile[cpos - 1];
+                        const int sum = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+                        const int code = (8 * v0 > sum) | ((8 * v1 > sum) << 1) | ((8 * v2 > sum) << 2) | ((8 * v3 > sum) << 3) |
+                                         ((8 * v4 > sum) << 4) | ((8 * v5 > sum) << 5) | ((8 * v6 > sum) << 6) | ((8 * v7 > sum) << 7);
+                        atomicAdd(&hist[(i / 12) * 512 + (j / 12) * 256 + code], 1u);
+                    }
+                }
+                __syncthreads();
+                if (ok) {
+                    uint8_t *row = sh.rows + (size_t)(it * CLS64_WAVES + wv) * CLS_ROW;
+                    for (int i = lane; i < 256; i += 64) {     // 4 bins per lane per step, one 32-bit store
+                        const uint32_t v = hist[4 * i] | (hist[4 * i + 1] << 8) | (hist[4 * i + 2] << 16) | (hist[4 * i + 3] << 24);
+                        *reinterpret_cast<uint32_t *>(row + 4 * i) = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#ifdef STR_ER_PHASE_PROF
+        unsigned long long tp1 = wall_clock64();
+        if (tid == 0) atomicAdd(&g_tile_phase[12], tp1 - tp0);
+#endif
+        // ---- phase 2: cascades, one ER per lane ---------------------------------------------------
+        const bool fast = run_cascades && strong.all_unit && weak.all_unit && strong.n_stumps + weak.n_stumps <= CLS_AB_CAP;
+        if (fast) {     // phase 1 is over (barrier above): reuse its scratch for the output tables
+            for (int i = tid; i < 2 * strong.n_stumps; i += CLS64_THREADS) sh.u.ab[i] = strong.ab[i];
+            for (int i = tid; i < 2 * weak.n_stumps; i += CLS64_THREADS) sh.u.ab[2 * strong.n_stumps + i] = weak.ab[i];
+            __syncthreads();
+        }
+        if (wv == 0) {
+            const uint32_t cidx = c0 + lane;
+            const bool     ok = cidx < total;
+            int    cls = 0;
+            double ss = -DBL_MAX, sw = 0;
+            if (run_cascades) {
+                const uint8_t *row = sh.rows + (size_t)lane * CLS_ROW;
+                ss = fast ? lane_cascade_fast(strong, row, sh.u.ab, ok) : lane_cascade_generic(strong, row, ok);
+#ifdef STR_ER_PHASE_PROF
+                if (tid == 0) { const unsigned long long t2 = wall_clock64(); atomicAdd(&g_tile_phase[13], t2 - tp1); tp1 = t2; atomicAdd(&g_tile_phase[15], 1ull); }
+#endif
+                const bool need_weak = ok && !(ss > -DBL_MAX);
+                if (ss > -DBL_MAX) cls = 1;
+                if (__any(need_weak)) {
+                    const double w = fast ? lane_cascade_fast(weak, row, sh.u.ab + 2 * strong.n_stumps, need_weak)
+                                          : lane_cascade_generic(weak, row, need_weak);
+                    if (need_weak) { sw = w; if (sw > -DBL_MAX) cls = 2; }
+                }
+#ifdef STR_ER_PHASE_PROF
+                if (tid == 0) { const unsigned long long t2 = wall_clock64(); atomicAdd(&g_tile_phase[14], t2 - tp1); }
+#endif
+            }
+            if (ok) {
+                const int        pi = b.cand_plane[cidx];
+                const PlaneDesc &pd = b.planes[pi];
+                const uint32_t   slot = b.pool[pd.pool_base + (cidx - b.ctr[pi].cand_base)];
+                const size_t     ks = pd.kept_base + slot;
+                CandRec r;
+                r.frame = pd.frame; r.ch = pd.ch; r.pyr = pd.pyr; r.level = b.ka.level[ks]; r.cls = (uint8_t)cls;
+                r.x = b.ka.box[4 * ks]; r.y = b.ka.box[4 * ks + 1]; r.w = b.ka.box[4 * ks + 2]; r.h = b.ka.box[4 * ks + 3];
+                r.area = b.ka.area[ks]; r.key = b.ka.key[ks]; r.node = (int32_t)slot; r.plane = (uint32_t)pi;
+                r.score_strong = ss; r.score_weak = sw;
+                b.cands[cidx] = r;
+                if (cls == 1) atomicAdd(&b.ctr[pi].n_strong, 1u);
+                if (cls == 2) atomicAdd(&b.ctr[pi].n_weak, 1u);
+            }
         }
         __syncthreads();
     }
@@ -1385,7 +1630,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(BatchDev b, DetectPara
 void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong, CascadeDev weak,
                      int run_cascades)
 {
-    hipLaunchKernelGGL(k_classify, dim3(2048), dim3(CLS_THREADS), 0, s, b, p, strong, weak, run_cascades);
+    hipLaunchKernelGGL(k_classify, dim3(1024), dim3(CLS64_THREADS), 0, s, b, p, strong, weak, run_cascades);
 }
 
 // Single-stage entry points (str_er_classify_boxes / str_er_lbp_hist): explicit boxes.

@@ -79,7 +79,20 @@ struct KeptArrays {
 };
 
 // Cascade tables on the device (CascadeBoost, inc/adaboost.h:158-185).
+// One stump, 32 bytes, laid out so a wave-uniform read of a whole stump is one s_load_dwordx8.
+struct StumpRec {
+    int32_t dim;
+    int32_t mode;   // 0: fv < thr ? vp : vn (dir = +1)   1: fv > thr ? vp : vn (dir = -1)   2: general, see dir[]
+    double  thr, vp, vn;
+};
+
 struct CascadeDev {
+    const StumpRec *rec;    // same stumps as the arrays below, array-of-structures
+    // integer form for 8-bit histogram counts h (valid when every dir is +1 or -1):
+    //   value = (h < T) ? ab[2i] : ab[2i+1],  w[i] = dim | T << 10
+    const uint32_t *w;
+    const double   *ab;
+    int32_t         all_unit;
     const uint16_t *dim;
     const double   *thr;
     const double   *dir;    // +1 for REAL; DecisionStump::dir for DISCRETE

@@ -83,6 +83,7 @@ struct str_er_ctx {
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
     uint32_t *d_total = nullptr;
+    uint16_t *d_cand_plane = nullptr;
     NodeRec *d_nodes = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
     std::vector<void *> allocs;
@@ -230,12 +231,32 @@ int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return o; };
     const size_t o_thr = take(ns * 8), o_dir = take(ns * 8), o_vp = take(ns * 8), o_vn = take(ns * 8), o_dim = take(ns * 2),
-                 o_sn = take(nst * 4), o_st = take(nst * 4);
+                 o_sn = take(nst * 4), o_st = take(nst * 4), o_rec = take(ns * sizeof(StumpRec)), o_w = take(ns * 4), o_ab = take(ns * 16);
     std::vector<uint8_t> blob(off ? off : 16);
     std::memcpy(&blob[o_thr], n.thr.data(), ns * 8); std::memcpy(&blob[o_dir], n.dir.data(), ns * 8);
     std::memcpy(&blob[o_vp], n.vp.data(), ns * 8); std::memcpy(&blob[o_vn], n.vn.data(), ns * 8);
     std::memcpy(&blob[o_dim], n.dim.data(), ns * 2); std::memcpy(&blob[o_sn], n.stage_n.data(), nst * 4);
     std::memcpy(&blob[o_st], n.stage_thresh.data(), nst * 4);
+    int32_t all_unit = 1;
+    for (size_t i = 0; i < ns; ++i) {
+        StumpRec r;
+        r.dim = n.dim[i]; r.thr = n.thr[i]; r.vp = n.vp[i]; r.vn = n.vn[i];
+        r.mode = n.dir[i] == 1.0 ? 0 : (n.dir[i] == -1.0 ? 1 : 2);
+        std::memcpy(&blob[o_rec + i * sizeof(StumpRec)], &r, sizeof(r));
+        // integer form for 8-bit counts: (h < T) ? A : B
+        double T = 0, A = n.vn[i], B = n.vn[i];
+        if (r.mode == 0) {            // h < thr  <=>  h < ceil(thr)
+            A = n.vp[i]; B = n.vn[i];
+            T = std::isnan(n.thr[i]) ? 0.0 : std::ceil(n.thr[i]);
+        } else if (r.mode == 1) {     // h > thr  <=>  !(h < floor(thr)+1)
+            A = n.vn[i]; B = n.vp[i];
+            T = std::isnan(n.thr[i]) ? 1e9 : std::floor(n.thr[i]) + 1.0;   // NaN: h > NaN is false -> always vn = A
+        } else all_unit = 0;
+        const uint32_t Ti = (uint32_t)std::min(std::max(T, 0.0), 300.0);
+        const uint32_t wv = (uint32_t)n.dim[i] | (Ti << 10);
+        std::memcpy(&blob[o_w + i * 4], &wv, 4);
+        std::memcpy(&blob[o_ab + i * 16], &A, 8); std::memcpy(&blob[o_ab + i * 16 + 8], &B, 8);
+    }
     void *d = nullptr;
     HIP_TRY(c, hipMalloc(&d, blob.size()));
     hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
@@ -246,6 +267,9 @@ int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
     n.dev.thr = reinterpret_cast<const double *>(b + o_thr); n.dev.dir = reinterpret_cast<const double *>(b + o_dir);
     n.dev.vp = reinterpret_cast<const double *>(b + o_vp); n.dev.vn = reinterpret_cast<const double *>(b + o_vn);
     n.dev.dim = reinterpret_cast<const uint16_t *>(b + o_dim);
+    n.dev.rec = reinterpret_cast<const StumpRec *>(b + o_rec);
+    n.dev.w = reinterpret_cast<const uint32_t *>(b + o_w); n.dev.ab = reinterpret_cast<const double *>(b + o_ab);
+    n.dev.all_unit = all_unit;
     n.dev.stage_n = reinterpret_cast<const int32_t *>(b + o_sn); n.dev.stage_thresh = reinterpret_cast<const int32_t *>(b + o_st);
     n.dev.n_stages = (int32_t)nst; n.dev.n_stumps = (int32_t)ns;
     n.dev.max_stage = 0;
@@ -289,7 +313,7 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
     d.na = c->na; d.ka = c->ka; d.tile_cnt = c->d_tile_cnt; d.tile_lo = c->d_tile_lo; d.tile_hi = c->d_tile_hi; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
-    d.cands = c->d_cands; d.total_cands = c->d_total;
+    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane;
     return d;
 }
 
@@ -594,7 +618,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     A(dev_alloc(c, c->d_tile_cnt, c->tile_slots)); A(dev_alloc(c, c->d_tile_lo, c->tile_slots)); A(dev_alloc(c, c->d_tile_hi, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
-    A(dev_alloc(c, c->d_cands, PP));
+    A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
     A(dev_alloc(c, c->d_total, 4));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||

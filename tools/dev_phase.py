@@ -28,3 +28,6 @@ for i, n in enumerate(names):
 
 for i, n in enumerate(['connects', 'loop iters', 'find hops', 'cas', 'cas fail']):
     print(f'  {n:12s} {out[8+i]/ntiles:10.1f} per tile')
+
+nb = max(out[15], 1)
+print(f'classify: blocks {out[15]}  phase1 {out[12]/nb/100:.1f} us  strong {out[13]/nb/100:.1f} us  weak {out[14]/nb/100:.1f} us  (classify ms {r.profile["classify"]:.3f})')
