@@ -99,9 +99,9 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=16)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
     ap.add_argument("--kind", choices=["text", "noise"], default="text")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <float.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "er_kernels.h"
@@ -202,28 +203,50 @@ __device__ __forceinline__ int resize_px(const ResizeGeom &g, const uint8_t *__r
     return min(max(v, 0), 255);
 }
 
-__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sw, int sh, int sstride,
-                                                int64_t splane_pitch, int64_t sframe_pitch,
-                                                uint8_t *__restrict__ dst, int dw, int dh, int dstride,
-                                                int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame)
+// Pyramid level: every lane produces 4 consecutive output pixels (one dword store); the
+// geometry (mode, scales) is computed once on the host with the same IEEE operations.
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride, int64_t splane_pitch,
+                                                int64_t sframe_pitch, uint8_t *__restrict__ dst, int dstride,
+                                                int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame,
+                                                ResizeGeom g)
 {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int dy = blockIdx.y;
-    if (dx >= dw) return;
+    if (dx0 >= g.dw) return;
     const int f = blockIdx.z / planes_per_frame, c = blockIdx.z % planes_per_frame;
     const uint8_t *s = src + (size_t)f * sframe_pitch + (size_t)c * splane_pitch;
-    uint8_t       *d = dst + (size_t)f * dframe_pitch + (size_t)c * dplane_pitch;
-    const ResizeGeom g = resize_geom(sw, sh, dw, dh);
-    d[(size_t)dy * dstride + dx] = (uint8_t)resize_px(g, s, sstride, 0, dx, dy);
+    uint8_t       *d = dst + (size_t)f * dframe_pitch + (size_t)c * dplane_pitch + (size_t)dy * dstride + dx0;
+    if (dx0 + 4 <= g.dw && (dstride & 3) == 0) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)resize_px(g, s, sstride, 0, dx0 + k, dy) << (8 * k);
+        *reinterpret_cast<uint32_t *>(d) = v;
+    } else {
+        for (int k = 0; k < 4 && dx0 + k < g.dw; ++k) d[k] = (uint8_t)resize_px(g, s, sstride, 0, dx0 + k, dy);
+    }
+}
+
+static ResizeGeom host_resize_geom(int sw, int sh, int dw, int dh)
+{
+    ResizeGeom g;
+    g.sw = sw; g.sh = sh; g.dw = dw; g.dh = dh;
+    g.scale_x = 1.0 / ((double)dw / sw);
+    g.scale_y = 1.0 / ((double)dh / sh);
+    if (dw == sw && dh == sh) { g.mode = 0; return g; }
+    const int isx = (int)rint(g.scale_x), isy = (int)rint(g.scale_y);
+    const bool fast = fabs(g.scale_x - isx) < DBL_EPSILON && fabs(g.scale_y - isy) < DBL_EPSILON;
+    g.mode = (fast && isx == 2 && isy == 2) ? 1 : 2;
+    return g;
 }
 
 void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, int64_t splane_pitch,
                    int64_t sframe_pitch, uint8_t *dst, int dw, int dh, int dstride, int64_t dplane_pitch,
                    int64_t dframe_pitch, int planes_per_frame, int n_frames)
 {
-    dim3 grid((dw + 255) / 256, dh, planes_per_frame * n_frames);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, sw, sh, sstride, splane_pitch, sframe_pitch, dst, dw, dh,
-                       dstride, dplane_pitch, dframe_pitch, planes_per_frame);
+    const int quads = (dw + 3) / 4;
+    dim3 grid((quads + 255) / 256, dh, planes_per_frame * n_frames);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, sstride, splane_pitch, sframe_pitch, dst, dstride,
+                       dplane_pitch, dframe_pitch, planes_per_frame, host_resize_geom(sw, sh, dw, dh));
 }
 
 // ------------------------------------------------------------------------------------
@@ -862,7 +885,7 @@ void launch_seam(hipStream_t s, const BatchDev &b)
 // ------------------------------------------------------------------------------------
 // Per-node passes run one wavefront per tile: lane i handles node i of the tile (tile_cnt nodes,
 // ids tile*2048 + i).  A fixed grid of workgroups strides over the batch's tiles.
-constexpr int NODE_GRID = 4096;
+constexpr int NODE_GRID = 65536;
 
 #define FOR_EACH_TILE_WAVE(b, T, PI, ND, BASE)                                                      \
     for (uint32_t T = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); T < (b).n_tiles;        \
@@ -1142,6 +1165,7 @@ constexpr int NMS_THREADS = 512;
 __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm)
 {
     __shared__ uint32_t s_npool;
+    __shared__ uint32_t s_levels[8];
     const int        pi = blockIdx.x;
     PlaneCtr        &c = b.ctr[pi];
     const PlaneDesc &pd = b.planes[pi];
@@ -1158,26 +1182,32 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     const int        maxl = (int)c.max_level;
     const uint32_t   root = c.root_slot;
 
-    for (uint32_t i = tid; i < K; i += NMS_THREADS) { kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull; }
+    for (int i = tid; i < 8; i += NMS_THREADS) s_levels[i] = 0;
     if (tid == 0) s_npool = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+        kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull;
+        atomicOr(&s_levels[klev[i] >> 5], 1u << (klev[i] & 31));
+    }
     __syncthreads();
 
     for (int t = 0; t <= maxl; ++t) {
-        // settle the nodes of level t: all their children (lower levels) have proposed
+        if (!((s_levels[t >> 5] >> (t & 31)) & 1)) continue;      // no kept node at this level
+        // settle the nodes of level t (all their children, at lower levels, have proposed), then
+        // let them propose to their parents; one barrier per level is enough because a node only
+        // reads what lower levels wrote and only writes to higher levels
         for (uint32_t i = tid; i < K; i += NMS_THREADS) {
             if (klev[i] != t) continue;
+            uint32_t s = i;
             const uint32_t nc = LD_AGENT(&kncand[i]);
             if (nc) {
                 const uint32_t child = (uint32_t)(LD_AGENT(&kbest[i]) & 0xFFFFFFFFull);
-                kstart[i] = kstart[child];
+                s = kstart[child];
+                kstart[i] = s;
                 if (nc > 1) atomicAdd(&c.n_amb, 1u);
             }
-        }
-        __syncthreads();
-        // propose to the parent
-        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
-            if (klev[i] != t || i == root) continue;
-            const uint32_t P = (uint32_t)kpar[i], s = kstart[i];
+            if (i == root) continue;
+            const uint32_t P = (uint32_t)kpar[i];
             const int as = (int)kbox[4 * s + 2] * (int)kbox[4 * s + 3];
             const int ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
             if ((double)as / (double)ap > prm.overlap_coef) {

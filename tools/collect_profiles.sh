@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on a GPU box (via gpurun) from the repo root: bench lines + rocprofv3 summaries for profiles/.
+# Usage: tools/collect_profiles.sh r01
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $ROOT/bench.py > $OUT/bench_${TAG}_pyr3x8_text.json 2> $OUT/bench_err.log
+python $ROOT/bench.py --workload native6 > $OUT/bench_${TAG}_native6_text.json 2>> $OUT/bench_err.log
+python $ROOT/bench.py --workload native6 --kind noise --frames-per-gpu 16 --no-cpu-baseline > $OUT/bench_${TAG}_native6_noise.json 2>> $OUT/bench_err.log
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $B > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $B > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq1 -o p -- $B > $OUT/pmc_sq1.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2 -o p -- $B > $OUT/pmc_sq2.log 2>&1
+rm -f $OUT/*/*kernel_trace.csv      # large; the stats and counter files are what we keep
+ls -R $OUT | head -40
