@@ -261,6 +261,13 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 // t in C, which is also the node's canonical key.
 // ------------------------------------------------------------------------------------
 constexpr uint32_t WALL = 0xFFFFu;
+// Global parent words: NONE, or (level of parent << 24 | parent id) -- ids are < 2^24 (planes are
+// limited to 2^24 pixels), and having the level in the word saves the dependent lvl[] load on every
+// hop of a find.
+#define PAR_ID(w)  ((w) & 0xFFFFFFu)
+#define PAR_LVL(w) ((w) >> 24)
+#define PAR_MAKE(l, id) (((uint32_t)(l) << 24) | (uint32_t)(id))
+
 // LDS placement of pixel p: k-major ("transposed"), so that when every lane touches the k-th of
 // its 8 consecutive pixels (p = 8*lane + k) the wave hits 64 consecutive words -- no bank
 // conflicts.  Stored pointers stay logical pixel numbers; only the addressing goes through LX.
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         uint32_t           *s_w0 = s_work;                                   // [FOLD_CAP]
         uint32_t           *s_row = s_work + FOLD_CAP;                       // [FOLD_CAP]
         unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * FOLD_CAP); // [FOLD_CAP]
-        for (int i = tid; i < 4 * FOLD_CAP; i += TILE_THREADS) s_work[i] = 0;
+        for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
         __syncthreads();
         {
             uint32_t cur = NONE, cnt = 0;
@@ -661,16 +668,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 if (!((expmask >> k) & 1)) continue;
                 const uint32_t p = p0 + k;
                 const size_t   id = nb + base + s_nid[LX(p)];
-                uint32_t       q = s_par[LX(p)];
-                q = (q == NONE) ? NONE : (q & 0xFFFFu);
+                uint32_t       q = s_par[LX(p)], ql = 0;
+                if (q != NONE) { ql = (q >> 16) & 0xFFu; q &= 0xFFFFu; }
                 while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
                     const uint32_t w2 = s_par[LX(q)];
-                    q = (w2 == NONE) ? NONE : (w2 & 0xFFFFu);
+                    if (w2 == NONE) q = NONE;
+                    else { ql = (w2 >> 16) & 0xFFu; q = w2 & 0xFFFFu; }
                 }
                 const uint32_t v = s_w0[a];
                 const bool     open = (openmask >> k) & 1;
                 if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
-                b.na.par[id] = (q == NONE) ? NONE : base + s_nid[LX(q)];
+                b.na.par[id] = (q == NONE) ? NONE : PAR_MAKE(ql, base + s_nid[LX(q)]);
                 b.na.lvl[id] = (uint8_t)lev[k];
                 b.na.dead[id] = open ? 0 : 2;                    // 2 = closed: totals are final
                 b.na.cnt[id] = v & 0xFFFu;
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 if (li >= (uint32_t)STAT_CHUNK) continue;
                 const size_t   id = nb + base + s_nid[LX(p)];
                 const uint32_t w = s_par[LX(p)];
-                b.na.par[id] = (w == NONE) ? NONE : base + s_nid[LX(w & 0xFFFFu)];
+                b.na.par[id] = (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, base + s_nid[LX(w & 0xFFFFu)]);
                 b.na.lvl[id] = (uint8_t)lev[k];
                 b.na.dead[id] = 0;
                 b.na.cnt[id] = s_cnt[li];
@@ -806,13 +814,14 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // are not coherent with each other, so every access to `par` that may race goes through
 // an agent-scope atomic).  Levels are immutable here and read with plain loads.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t node_find(uint32_t *par, const uint8_t *lvl, uint32_t &a, uint32_t la)
+__device__ __forceinline__ uint32_t node_find(uint32_t *par, uint32_t &a, uint32_t la)
 {
     uint32_t wa = LD_AGENT(&par[a]);
-    while (wa != NONE && lvl[wa] == la) {
-        const uint32_t w2 = LD_AGENT(&par[wa]);
-        if (w2 != NONE && lvl[w2] == la) ST_AGENT(&par[a], w2);   // path halving, same node
-        a = wa;
+    while (wa != NONE && PAR_LVL(wa) == la) {
+        const uint32_t nx = PAR_ID(wa);
+        const uint32_t w2 = LD_AGENT(&par[nx]);
+        if (w2 != NONE && PAR_LVL(w2) == la) ST_AGENT(&par[a], w2);   // path halving, same node
+        a = nx;
         wa = w2;
     }
     return wa;
@@ -822,8 +831,8 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
 {
     uint32_t la = lvl[a], lb = lvl[b];
     for (;;) {
-        uint32_t wa = node_find(par, lvl, a, la);
-        uint32_t wb = node_find(par, lvl, b, lb);
+        uint32_t wa = node_find(par, a, la);
+        uint32_t wb = node_find(par, b, lb);
         if (a == b) return;
         if (la > lb || (la == lb && a < b)) {
             uint32_t t;
@@ -831,15 +840,15 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
             t = la; la = lb; lb = t;
             t = wa; wa = wb; wb = t;
         }
-        if (la == lb || wa == NONE || lvl[wa] > lb) {
-            const uint32_t old = atomicCAS(&par[a], wa, b);
+        if (la == lb || wa == NONE || PAR_LVL(wa) > lb) {
+            const uint32_t old = atomicCAS(&par[a], wa, PAR_MAKE(lb, b));
             if (old != wa) continue;
             if (wa == NONE) return;
-            a = wa;
-            la = lvl[a];
+            a = PAR_ID(wa);
+            la = PAR_LVL(wa);
         } else {
-            a = wa;
-            la = lvl[a];
+            a = PAR_ID(wa);
+            la = PAR_LVL(wa);
         }
     }
 }
@@ -909,12 +918,12 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
             const uint32_t x = base + i;
             const uint32_t w = LD_AGENT(&par[x]);
             const uint32_t l = lvl[x];
-            if (w != NONE && lvl[w] == l) {
-                uint32_t r = w;
+            if (w != NONE && PAR_LVL(w) == l) {
+                uint32_t r = PAR_ID(w);
                 for (;;) {
                     const uint32_t w2 = LD_AGENT(&par[r]);
-                    if (w2 == NONE || lvl[w2] != l) break;
-                    r = w2;
+                    if (w2 == NONE || PAR_LVL(w2) != l) break;
+                    r = PAR_ID(w2);
                 }
                 b.na.dead[nb + x] = 1;
                 atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
@@ -925,14 +934,14 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
                 atomicMax(&b.na.y1[nb + r], b.na.y1[nb + x]);
                 atomicMin(&b.na.key[nb + r], b.na.key[nb + x]);
             } else if (w != NONE) {
-                uint32_t q = w;
-                const uint32_t lq = lvl[q];
+                uint32_t       q = PAR_ID(w);
+                const uint32_t lq = PAR_LVL(w);
                 for (;;) {
                     const uint32_t w2 = LD_AGENT(&par[q]);
-                    if (w2 == NONE || lvl[w2] != lq) break;
-                    q = w2;
+                    if (w2 == NONE || PAR_LVL(w2) != lq) break;
+                    q = PAR_ID(w2);
                 }
-                if (q != w) ST_AGENT(&par[x], q);
+                if (q != PAR_ID(w)) ST_AGENT(&par[x], PAR_MAKE(lq, q));
             }
         }
     }
@@ -982,6 +991,7 @@ __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
             uint32_t p = NONE;
             if (i0 + lane < n && b.na.lvl[nb + x] == level && !b.na.dead[nb + x]) p = b.na.par[nb + x];
             const bool act = p != NONE;
+            p = PAR_ID(p);     // (NONE & 0xFFFFFF never equals a real id of an active lane: act guards every use)
             unsigned long long todo = __ballot(act);
             if (!todo) continue;
             uint32_t c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
@@ -1054,8 +1064,8 @@ __global__ void k_root(BatchDev b, DetectParams prm)
         c.max_level = prm.hi;
         return;
     }
-    for (;;) { const uint32_t w = par[x]; if (w == NONE || lvl[w] != lvl[x]) break; x = w; }
-    for (;;) { const uint32_t w = par[x]; if (w == NONE) break; x = w; }
+    for (;;) { const uint32_t w = par[x]; if (w == NONE || PAR_LVL(w) != lvl[x]) break; x = PAR_ID(w); }
+    for (;;) { const uint32_t w = par[x]; if (w == NONE) break; x = PAR_ID(w); }
     c.root_node = x;
     c.n_created = b.na.nod[nb + x];
     c.max_level = lvl[x];
@@ -1093,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
                 if ((int64_t)area <= (int64_t)prm.min_area) continue;
                 if (walls) {
                     uint32_t y = x;
-                    for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = w; }
+                    for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = PAR_ID(w); }
                     if (y != root) continue;
                 }
             }
@@ -1139,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_kept(BatchDev b, DetectParams prm)
             b.ka.parent[kb + s] = (int32_t)s;
             c.root_slot = s;
         } else {
-            b.ka.parent[kb + s] = (int32_t)b.na.kmap[nb + p];
+            b.ka.parent[kb + s] = (int32_t)b.na.kmap[nb + PAR_ID(p)];
         }
     }
 }
