@@ -124,11 +124,18 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to measure)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # developer knobs (single-GPU boxes): run every rank on one device and gather over gloo
+    dev_index = int(os.environ.get("STR_ER_BENCH_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("STR_ER_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    gather_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = WORKLOADS[args.workload]
     F = args.frames_per_gpu
@@ -138,7 +145,7 @@ def main():
     filters = []
     for _ in range(P):
         f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
-                                       channel_mask=cfg["channel_mask"], device=local_rank))
+                                       channel_mask=cfg["channel_mask"], device=dev_index))
         f.load_cascade(0, cascades[0])
         f.load_cascade(1, cascades[1])
         filters.append(f)
@@ -161,7 +168,7 @@ def main():
         done = [threading.Event() for _ in range(n_batches)]
 
         def worker(p):
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(dev_index)
             for i in range(p, n_batches, P):
                 results[i] = filters[p].detect_bgr_device(d_frames.data_ptr(), W, H, F)
                 done[i].set()
@@ -175,7 +182,7 @@ def main():
             r = results[i]
             results[i] = None
             if world > 1:
-                S.dist.gather_candidates(r.cands, device, frame_offset=rank * F)
+                S.dist.gather_candidates(r.cands, gather_device, frame_offset=rank * F)
             for k, v in r.profile.items():
                 prof[k] = prof.get(k, 0.0) + v
             last = r
@@ -194,7 +201,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
