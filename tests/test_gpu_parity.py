@@ -341,3 +341,42 @@ def test_kept_table_overflow_is_reported(S):
         f.detect_planes(img, S.STAGE_EXTRACT)
     assert e.value.code == -7 and "kept" in str(e.value)
     f.close()
+
+
+# ---- config 5 geometry: 3840x2160, 12-level pyramid ------------------------------------------------------
+def test_4k_plane_and_pyramid_dims(S, cascade_paths, oracle, oracle_cascades):
+    f = S.ERFilter(params=S.Params(max_width=3840, max_height=2160, max_frames=1, n_pyr_levels=12, channel_mask=0x01))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    frame = S.synth.stext_bgr(S.synth.frame_seed(9), 3840, 2160)
+    res = f.text_detect(frame, want_nodes=True)
+    assert len(res.planes) == 12
+    assert [(p.width, p.height) for p in res.planes] == [oracle.pyr_dims(3840, 2160, k) for k in range(12)]
+    y = oracle.compute_channels(frame)[0]
+    pyr = oracle.pyramid(y, 12)
+    for p in res.planes:
+        if p.pyr in (0, 1, 5, 11):          # the full-size level, one odd level, two small ones
+            check_plane_against_oracle(oracle, p, pyr[p.pyr], oracle_cascades)
+    f.close()
+
+
+def test_random_small_planes_many(erf, oracle, oracle_cascades):
+    """200 random planes up to 96x160 in one go (batched call), several value distributions."""
+    rng = np.random.default_rng(2024)
+    erf.set_min_area(10)
+    try:
+        for trial in range(8):
+            h, w = int(rng.integers(1, 97)), int(rng.integers(1, 161))
+            imgs = []
+            for k in range(12):
+                if k % 3 == 0:
+                    imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+                elif k % 3 == 1:
+                    imgs.append((rng.integers(0, 3, (h, w)) * 100 + rng.integers(0, 3, (h, w))).astype(np.uint8))
+                else:
+                    base = np.add.outer(np.arange(h) * int(rng.integers(1, 9)), np.arange(w) * int(rng.integers(1, 9)))
+                    imgs.append(((base + rng.integers(0, 12, (h, w))) % 256).astype(np.uint8))
+            res = erf.detect_planes(np.stack(imgs), want_nodes=True)
+            for p, img in zip(res.planes, imgs):
+                check_plane_against_oracle(oracle, p, img, oracle_cascades, min_area=10)
+    finally:
+        erf.set_min_area(120)
