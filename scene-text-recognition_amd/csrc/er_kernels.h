@@ -22,6 +22,12 @@ struct BatchDev {
     uint32_t        *tile_cnt; // nodes per tile (batch-wide tile numbering)
     uint8_t         *tile_lo;  // lowest / highest node level of the tile
     uint8_t         *tile_hi;
+    uint32_t        *tile_off;  // exclusive prefix of tile_cnt
+    uint32_t        *chunk_sum; // scratch of the offset scan
+    uint32_t        *n_listed;  // total exported nodes of the batch
+    uint32_t        *node_list; // exported nodes (global slot index), tile after tile
+    uint16_t        *list_key;  // per list entry: level, or level | 0x100 for nodes that never push
+    uint32_t         node_list_cap;
     uint32_t        *seam;     // node id of every tile-border pixel
     uint32_t        *pool;     // kept slots chosen by NMS, ascending key
     uint32_t        *pool_tmp;
@@ -43,6 +49,7 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_seam(hipStream_t s, const BatchDev &b);
+void launch_level_prefix(hipStream_t s, const BatchDev &b);
 void launch_resolve(hipStream_t s, const BatchDev &b);
 void launch_accumulate(hipStream_t s, const BatchDev &b, int level);
 void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p);

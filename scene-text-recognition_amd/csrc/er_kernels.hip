@@ -892,16 +892,82 @@ void launch_seam(hipStream_t s, const BatchDev &b)
 // ------------------------------------------------------------------------------------
 // Part 3: per-node passes.  Grid = (blocks, planes); lanes stride over the plane's nodes.
 // ------------------------------------------------------------------------------------
-// Per-node passes run one wavefront per tile: lane i handles node i of the tile (tile_cnt nodes,
-// ids tile*2048 + i).  A fixed grid of workgroups strides over the batch's tiles.
+// Exported nodes are listed densely (tile after tile; offsets = exclusive prefix of tile_cnt), so the
+// level-by-level accumulation and the selection run with one lane per node instead of one sparse
+// wave per tile (a tile exports only ~10-15 nodes on text-like frames).
 constexpr int NODE_GRID = 65536;
+constexpr int SCAN_CHUNK = 1024;     // tiles per block of the offset scan
 
-#define FOR_EACH_TILE_WAVE(b, T, PI, ND, BASE)                                                      \
-    for (uint32_t T = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); T < (b).n_tiles;        \
-         T += gridDim.x * (blockDim.x >> 6))
+__global__ __launch_bounds__(256) void k_tile_scan1(BatchDev b)          // per-chunk sums
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t t0 = blockIdx.x * SCAN_CHUNK;
+    uint32_t sum = 0;
+    for (uint32_t t = t0 + threadIdx.x; t < min(t0 + (uint32_t)SCAN_CHUNK, b.n_tiles); t += 256) sum += b.tile_cnt[t];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) b.chunk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan2(BatchDev b, uint32_t n_chunks)   // scan of the chunk sums
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_chunks; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n_chunks ? b.chunk_sum[i] : 0;
+        const uint32_t incl = wave_incl_scan(v);
+        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+        if (i < n_chunks) b.chunk_sum[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *b.n_listed = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_tile_scan3(BatchDev b)          // offsets of the tiles of a chunk
+{
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    const int      tid = threadIdx.x;
+    const uint32_t t0 = blockIdx.x * SCAN_CHUNK;
+    if (tid == 0) s_carry = b.chunk_sum[blockIdx.x];
+    __syncthreads();
+    for (uint32_t base = 0; base < (uint32_t)SCAN_CHUNK; base += 256) {
+        const uint32_t t = t0 + base + tid;
+        const uint32_t v = t < b.n_tiles ? b.tile_cnt[t] : 0;
+        const uint32_t incl = wave_incl_scan(v);
+        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+        for (int k = 0; k < 4; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+        if (t < b.n_tiles) b.tile_off[t] = off + incl - v;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+}
+
+void launch_level_prefix(hipStream_t s, const BatchDev &b)
+{
+    if (!b.n_tiles) return;
+    const uint32_t n_chunks = (b.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(k_tile_scan1, dim3(n_chunks), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, s, b, n_chunks);
+    hipLaunchKernelGGL(k_tile_scan3, dim3(n_chunks), dim3(256), 0, s, b);
+}
 
 // Nodes that were unified into another node of the same level hand their own
 // statistics to the surviving level root; surviving nodes get a canonical parent.
+// Every exported node is also entered into the level-sorted list (global slot index).
 __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 {
     const int lane = threadIdx.x & 63;
@@ -914,10 +980,15 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
         const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
         uint32_t       *par = b.na.par + nb;
         const uint8_t  *lvl = b.na.lvl + nb;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t x = base + i;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool     have = i < n;
+            const uint32_t x = base + (have ? i : 0);
+            const uint32_t l = have ? lvl[x] : 0xFFFFFFFFu;
+            if (!have) continue;
+            const uint32_t at = b.tile_off[t] + i;
             const uint32_t w = LD_AGENT(&par[x]);
-            const uint32_t l = lvl[x];
+            uint32_t       skip = b.na.dead[nb + x] ? 0x100u : 0u;      // closed nodes never push (totals final)
             if (w != NONE && PAR_LVL(w) == l) {
                 uint32_t r = PAR_ID(w);
                 for (;;) {
@@ -926,6 +997,7 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
                     r = PAR_ID(w2);
                 }
                 b.na.dead[nb + x] = 1;
+                skip = 0x100u;
                 atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
                 if (b.na.nod[nb + x] > 1) atomicAdd(&b.na.nod[nb + r], b.na.nod[nb + x] - 1);   // folded descendants
                 atomicMin(&b.na.x0[nb + r], b.na.x0[nb + x]);
@@ -942,7 +1014,13 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
                     q = PAR_ID(w2);
                 }
                 if (q != PAR_ID(w)) ST_AGENT(&par[x], PAR_MAKE(lq, q));
+            } else {
+                skip = 0x100u;                                           // a tree root has nobody to push to
             }
+            if (at < b.node_list_cap) {
+                b.node_list[at] = (uint32_t)(nb + x);
+                b.list_key[at] = (uint16_t)(l | skip);                  // what k_accumulate tests: level, or "never"
+            } else atomicOr(&b.ctr[pi].overflow, 4u);
         }
     }
 }
@@ -973,58 +1051,61 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
-// er_merge's accumulation (src/ER.cpp:153-165), one level per launch: every live node
-// of level t adds its (now final) totals to its parent.  Children are always at lower
-// levels than their parent, so launching t = 0,1,2,... in order is a topological order.
+// er_merge's accumulation (src/ER.cpp:153-165), one level per launch: every live open node of
+// level t adds its (now final) totals to its parent.  Children are always at lower levels than
+// their parent, so launching t = 0,1,2,... in order is a topological order.
+constexpr int ACC_BLOCKS = 1024;
+
 __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
 {
-    const int lane = threadIdx.x & 63;
-    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
-        const uint32_t n = b.tile_cnt[t];
-        if (!n || level < (int)b.tile_lo[t] || level > (int)b.tile_hi[t]) continue;
-        const int       pi = b.tile_plane[t];
-        const PlaneDesc &pd = b.planes[pi];
-        const size_t    nb = pd.node_base;
-        const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
-        for (uint32_t i0 = 0; i0 < n; i0 += 64) {          // uniform trip count: ballots below
-            const uint32_t x = base + i0 + lane;
-            uint32_t p = NONE;
-            if (i0 + lane < n && b.na.lvl[nb + x] == level && !b.na.dead[nb + x]) p = b.na.par[nb + x];
-            const bool act = p != NONE;
-            p = PAR_ID(p);     // (NONE & 0xFFFFFF never equals a real id of an active lane: act guards every use)
-            unsigned long long todo = __ballot(act);
-            if (!todo) continue;
-            uint32_t c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
-            if (act) {
-                c = b.na.cnt[nb + x]; nd = b.na.nod[nb + x];
-                bx0 = b.na.x0[nb + x]; by0 = b.na.y0[nb + x]; bx1 = b.na.x1[nb + x]; by1 = b.na.y1[nb + x];
+    const uint32_t beg = 0, end = min(*b.n_listed, b.node_list_cap);
+    const int      lane = threadIdx.x & 63;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = beg + blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < end; i0 += stride) {
+        const uint32_t i = i0 + lane;
+        size_t   g = 0;
+        size_t   gp = (size_t)-1;          // global slot of the parent; all-ones = inactive lane
+        if (i < end) {
+            if (b.list_key[i] == (uint16_t)level) {
+                g = b.node_list[i];
+                const uint32_t w = b.na.par[g];
+                if (w != NONE) gp = (size_t)b.planes[b.tile_plane[g >> 11]].node_base + PAR_ID(w);
             }
-            // children of one parent sit next to each other (nodes are numbered in pixel order
-            // inside a tile): combine them in the wave and issue ONE set of atomics per distinct
-            // parent instead of one per child (the big background nodes have thousands).
-            while (todo) {
-                const int      leader = __ffsll((long long)todo) - 1;
-                const uint32_t lp = __shfl(p, leader);
-                const bool     mine = act && p == lp;
-                const unsigned long long m = __ballot(mine);
-                if (__popcll(m) == 1) {
-                    if (mine) {
-                        atomicAdd(&b.na.cnt[nb + lp], c); atomicAdd(&b.na.nod[nb + lp], nd);
-                        atomicMin(&b.na.x0[nb + lp], bx0); atomicMin(&b.na.y0[nb + lp], by0);
-                        atomicMax(&b.na.x1[nb + lp], bx1); atomicMax(&b.na.y1[nb + lp], by1);
-                    }
-                } else {
-                    const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
-                    const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
-                    const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
-                    if (lane == leader) {
-                        atomicAdd(&b.na.cnt[nb + lp], sc); atomicAdd(&b.na.nod[nb + lp], sn);
-                        atomicMin(&b.na.x0[nb + lp], mx0); atomicMin(&b.na.y0[nb + lp], my0);
-                        atomicMax(&b.na.x1[nb + lp], mx1); atomicMax(&b.na.y1[nb + lp], my1);
-                    }
+        }
+        const bool act = gp != (size_t)-1;
+        unsigned long long todo = __ballot(act);
+        if (!todo) continue;
+        uint32_t c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
+        if (act) {
+            c = b.na.cnt[g]; nd = b.na.nod[g];
+            bx0 = b.na.x0[g]; by0 = b.na.y0[g]; bx1 = b.na.x1[g]; by1 = b.na.y1[g];
+        }
+        const uint32_t plo = (uint32_t)gp, phi = (uint32_t)((unsigned long long)gp >> 32);
+        // lanes that share a parent combine first (ballot + butterfly): ONE set of atomics per
+        // distinct parent and wave instead of one per child
+        while (todo) {
+            const int      leader = __ffsll((long long)todo) - 1;
+            const uint32_t llo = __shfl(plo, leader), lhi = __shfl(phi, leader);
+            const bool     mine = act && plo == llo && phi == lhi;
+            const unsigned long long m = __ballot(mine);
+            const size_t   tp = ((size_t)lhi << 32) | llo;
+            if (__popcll(m) == 1) {
+                if (mine) {
+                    atomicAdd(&b.na.cnt[tp], c); atomicAdd(&b.na.nod[tp], nd);
+                    atomicMin(&b.na.x0[tp], bx0); atomicMin(&b.na.y0[tp], by0);
+                    atomicMax(&b.na.x1[tp], bx1); atomicMax(&b.na.y1[tp], by1);
                 }
-                todo &= ~m;
+            } else {
+                const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
+                const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
+                const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
+                if (lane == leader) {
+                    atomicAdd(&b.na.cnt[tp], sc); atomicAdd(&b.na.nod[tp], sn);
+                    atomicMin(&b.na.x0[tp], mx0); atomicMin(&b.na.y0[tp], my0);
+                    atomicMax(&b.na.x1[tp], mx1); atomicMax(&b.na.y1[tp], my1);
+                }
             }
+            todo &= ~m;
         }
     }
 }
@@ -1032,8 +1113,7 @@ __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
 void launch_accumulate(hipStream_t s, const BatchDev &b, int level)
 {
     if (!b.n_tiles) return;
-    const uint32_t blocks = (b.n_tiles + 3) / 4;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b, level);
+    hipLaunchKernelGGL(k_accumulate, dim3(ACC_BLOCKS), dim3(256), 0, s, b, level);
 }
 
 // Root of the tree that holds the flood's start pixel (er_stack.back(), src/ER.cpp:346).
@@ -1082,38 +1162,33 @@ void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // trees (regions sealed off by sentinel-level pixels) were never visited by the flood.
 __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 {
-    const int lane = threadIdx.x & 63;
-    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
-        const uint32_t n = b.tile_cnt[t];
-        if (!n) continue;
-        const int       pi = b.tile_plane[t];
+    const uint32_t end = min(*b.n_listed, b.node_list_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const size_t g = b.node_list[i];
+        if (b.na.dead[g] == 1) continue;
+        const int       pi = b.tile_plane[g >> 11];
         PlaneCtr       &c = b.ctr[pi];
         const uint32_t  root = c.root_node;
         if (root == NONE) continue;
         const PlaneDesc &pd = b.planes[pi];
         const size_t    nb = pd.node_base;
-        const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
-        const uint32_t *par = b.na.par + nb;
-        const bool      walls = c.n_walls != 0;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t x = base + i;
-            if (b.na.dead[nb + x] == 1) continue;
-            if (x != root) {
-                const uint32_t area = b.na.cnt[nb + x] + b.na.nod[nb + x];
-                if ((int64_t)area <= (int64_t)prm.min_area) continue;
-                if (walls) {
-                    uint32_t y = x;
-                    for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = PAR_ID(w); }
-                    if (y != root) continue;
-                }
+        const uint32_t  x = (uint32_t)(g - nb);
+        if (x != root) {
+            const uint32_t area = b.na.cnt[g] + b.na.nod[g];
+            if ((int64_t)area <= (int64_t)prm.min_area) continue;
+            if (c.n_walls != 0) {
+                const uint32_t *par = b.na.par + nb;
+                uint32_t y = x;
+                for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = PAR_ID(w); }
+                if (y != root) continue;
             }
-            const uint32_t slot = atomicAdd(&c.n_kept, 1u);
-            if (slot < (uint32_t)prm.kept_cap) {
-                b.ka.node[pd.kept_base + slot] = x;
-                b.na.kmap[nb + x] = slot;
-            } else {
-                atomicOr(&c.overflow, 1u);
-            }
+        }
+        const uint32_t slot = atomicAdd(&c.n_kept, 1u);
+        if (slot < (uint32_t)prm.kept_cap) {
+            b.ka.node[pd.kept_base + slot] = x;
+            b.na.kmap[g] = slot;
+        } else {
+            atomicOr(&c.overflow, 1u);
         }
     }
 }
@@ -1121,8 +1196,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p)
 {
     if (!b.n_tiles) return;
-    const uint32_t blocks = (b.n_tiles + 3) / 4;
-    hipLaunchKernelGGL(k_select, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b, p);
+    hipLaunchKernelGGL(k_select, dim3(2048), dim3(256), 0, s, b, p);
 }
 
 // Kept-node records (flat form of struct ER, inc/ER.h:42-80).

@@ -79,6 +79,8 @@ struct str_er_ctx {
     uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
     std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
     std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
+    uint32_t *d_lvl = nullptr, *d_node_list = nullptr, *d_tile_off = nullptr; size_t node_list_cap = 0;
+    uint16_t *d_list_key = nullptr;
     uint32_t *d_tile_cnt = nullptr; uint8_t *d_tile_lo = nullptr, *d_tile_hi = nullptr; size_t tile_slots = 0;
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
@@ -312,6 +314,8 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.max_nodes_plane = b.max_nodes_plane;
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
+    d.tile_off = c->d_tile_off; d.chunk_sum = c->d_lvl; d.n_listed = c->d_lvl + 8192; d.node_list = c->d_node_list; d.list_key = c->d_list_key;
+    d.node_list_cap = (uint32_t)c->node_list_cap;
     d.na = c->na; d.ka = c->ka; d.tile_cnt = c->d_tile_cnt; d.tile_lo = c->d_tile_lo; d.tile_hi = c->d_tile_hi; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane;
     return d;
@@ -375,6 +379,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
 
     launch_tile_tree(s, bd, dp);                      rec(c, "tile_tree");
     launch_seam(s, bd);                               rec(c, "seam");
+    launch_level_prefix(s, bd);
     launch_resolve(s, bd);                            rec(c, "resolve");
     for (int t = 0; t < dp.hi; ++t) launch_accumulate(s, bd, t);
     rec(c, "accumulate");
@@ -396,11 +401,21 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
 
+    if (std::getenv("STR_ER_DEBUG_STATS")) {     // developer aid: how many nodes left the tiles
+        std::vector<uint32_t> tc(b.n_tiles);
+        if (hipMemcpy(tc.data(), c->d_tile_cnt, 4 * (size_t)b.n_tiles, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long tot = 0, mx = 0, created = 0;
+            for (uint32_t v : tc) { tot += v; mx = std::max<unsigned long long>(mx, v); }
+            for (int i = 0; i < np; ++i) created += c->h_ctr[i].n_created;
+            std::fprintf(stderr, "[str_er] tiles %u exported nodes %llu (max/tile %llu) created %llu seam pairs %u\n", b.n_tiles, tot, mx, created, b.n_pairs);
+        }
+    }
     for (int i = 0; i < np; ++i) {
         if (c->h_ctr[i].overflow & 1u)
             return fail(c, STR_ER_ECAPACITY, "kept-node table overflow: plane " + std::to_string(i) + " has " +
                         std::to_string(c->h_ctr[i].n_kept) + " kept nodes, kept_cap = " + std::to_string(c->kept_cap));
         if (c->h_ctr[i].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
+        if (c->h_ctr[i].overflow & 4u) return fail(c, STR_ER_ECAPACITY, "exported-node list overflow (more than half of the pixels are open tree nodes)");
     }
     str_er_result *r = new (std::nothrow) str_er_result();
     if (!r) return fail(c, STR_ER_ENOMEM, "result allocation");
@@ -616,6 +631,9 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     c->tile_slots = c->slots / TILE_PX + 16;
     c->sb_slots = c->seam_slots / 512 + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
+    c->node_list_cap = c->slots / 2 + 4096;
+    A(dev_alloc(c, c->d_lvl, 8192 + 64)); A(dev_alloc(c, c->d_node_list, c->node_list_cap)); A(dev_alloc(c, c->d_list_key, c->node_list_cap));   // chunk sums of the offset scan + total
+    A(dev_alloc(c, c->d_tile_off, c->tile_slots));
     A(dev_alloc(c, c->d_tile_cnt, c->tile_slots)); A(dev_alloc(c, c->d_tile_lo, c->tile_slots)); A(dev_alloc(c, c->d_tile_hi, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
