@@ -579,7 +579,10 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     if (!(p->channel_mask & 0x3F) || (p->channel_mask & ~0x3Fu)) return fail(nullptr, STR_ER_EINVAL, "channel_mask must select planes 0..5");
     if (p->max_width < 1 || p->max_height < 1 || p->max_frames < 1) return fail(nullptr, STR_ER_EINVAL, "capacity must be positive");
     if (p->max_width > 65535 || p->max_height > 65535) return fail(nullptr, STR_ER_EINVAL, "planes are limited to 65535 x 65535");
-    if ((size_t)p->max_width * p->max_height > (1u << 24)) return fail(nullptr, STR_ER_EINVAL, "planes are limited to 2^24 pixels");
+    {   // node ids are 24-bit (PAR_ID in er_kernels.hip): tiles * 2048 of one plane must stay below 2^24
+        const size_t padded = (size_t)((p->max_width + TILE_W - 1) / TILE_W) * ((p->max_height + TILE_H - 1) / TILE_H) * TILE_PX;
+        if (padded > (1u << 24)) return fail(nullptr, STR_ER_EINVAL, "planes are limited to 2^24 pixels (after padding to 64x32 tiles)");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, STR_ER_EHIP, "no HIP device available: this library has no CPU path");
@@ -592,6 +595,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
     c->ppf = (int)c->chans.size() * p->n_pyr_levels;
     c->max_planes = c->ppf * p->max_frames;
+    if (c->max_planes > 65535) { delete c; return fail(nullptr, STR_ER_ECAPACITY, "more than 65535 planes per call (max_frames x channels x levels)"); }
     size_t px_frame = 0, phys_frame = 0;
     for (int l = 0; l < p->n_pyr_levels; ++l) {
         int w, h; pyr_dims(p->max_width, p->max_height, l, w, h);
