@@ -195,6 +195,19 @@ int str_er_lbp_hist(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h,
  * out[i] = last stage score, or -DBL_MAX if a stage rejected.                       */
 int str_er_cascade_predict(str_er_ctx *ctx, int which, const double *fv, int32_t n, double *out);
 
+/* ---- OCR scorer, SVM half (config 3) --------------------------------------
+ * svm_load_model (src/svm.cpp:2767-2982; OCR::OCR, src/OCR.cpp:19-22): a libsvm C-SVC / RBF text model
+ * with probability information (probA/probB).  dim = feature dimension (1800 = 8 x 15 x 15 for the
+ * reference's chain-code features, src/OCR.cpp:203-216); must exceed the largest SV index.           */
+int str_er_load_svm_model(str_er_ctx *ctx, const char *path, int32_t dim);
+int str_er_load_svm_model_mem(str_er_ctx *ctx, const char *text, size_t len, int32_t dim);
+int str_er_svm_info(const str_er_ctx *ctx, int32_t *nr_class, int32_t *total_sv, int32_t *dim);
+/* svm_predict_probability (inc/svm.h:88, src/svm.cpp:2592-2629) for n dense feature vectors x[n][dim]
+ * (zeros = absent svm_nodes): label[i] = model->label[argmax], prob[i][nr_class]; dec (optional, may
+ * be NULL) receives the nr_class*(nr_class-1)/2 decision values of svm_predict_values.              */
+int str_er_svm_predict_probability(str_er_ctx *ctx, const double *x, int32_t n, int32_t dim, int32_t *label, double *prob,
+                                   double *dec);
+
 /* ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a caller-supplied kept tree
  * (parent indices; root points to itself or -1).  pool_idx receives up to cap node
  * indices in ascending key order; *n_pool the count; *ambiguous as in plane_info.    */

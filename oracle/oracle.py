@@ -51,10 +51,10 @@ class Tree:
 def build(force: bool = False) -> None:
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
     so = os.path.join(HERE, "liber_oracle.so")
-    src = [os.path.join(HERE, f) for f in ("er_oracle.c", "er_oracle.h", "Makefile")]
+    src = [os.path.join(HERE, f) for f in ("er_oracle.c", "er_oracle.h", "svm_oracle.c", "svm_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
-    ref_missing = os.path.exists("/root/reference/src/adaboost.cpp") and not os.path.exists(
-        os.path.join(HERE, "_ref", "libref_adaboost.so"))
+    ref_missing = os.path.exists("/root/reference/src/adaboost.cpp") and not all(
+        os.path.exists(os.path.join(HERE, "_ref", f)) for f in ("libref_adaboost.so", "libref_svm.so", "svm-train"))
     if stale or ref_missing:
         subprocess.run(["make", "-s", "-C", HERE], check=True)
 
@@ -288,3 +288,70 @@ class RefCascade:
     def predict(self, fv: np.ndarray) -> float:
         fv = np.ascontiguousarray(fv, dtype=np.float64)
         return float(RefCascade._lib.ref_cascade_predict(self.h, fv.ctypes.data_as(C.POINTER(C.c_double)), fv.size))
+
+
+class OracleSVM:
+    """oracle/svm_oracle.c: plain-C restatement of the reference's libsvm inference."""
+
+    def __init__(self, o: Oracle, path: str) -> None:
+        L = o.lib
+        L.ero_svm_load.restype = C.c_void_p
+        L.ero_svm_load.argtypes = [C.c_char_p]
+        L.ero_svm_free.argtypes = [C.c_void_p]
+        for f in (L.ero_svm_nr_class, L.ero_svm_total_sv, L.ero_svm_max_index):
+            f.argtypes = [C.c_void_p]
+        L.ero_svm_predict_probability.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_double)]
+        self.L = L
+        self.h = L.ero_svm_load(path.encode())
+        if not self.h:
+            raise FileNotFoundError(path)
+        self.k, self.l = int(L.ero_svm_nr_class(self.h)), int(L.ero_svm_total_sv(self.h))
+
+    def predict_probability(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        dec = np.zeros(self.k * (self.k - 1) // 2)
+        prob = np.zeros(self.k)
+        p = C.POINTER(C.c_double)
+        lab = self.L.ero_svm_predict_probability(self.h, x.ctypes.data_as(p), x.size, dec.ctypes.data_as(p), prob.ctypes.data_as(p))
+        return int(lab), prob, dec
+
+
+class _SvmNode(C.Structure):
+    _fields_ = [("index", C.c_int), ("value", C.c_double)]
+
+
+class RefSVM:
+    """The reference's vendored libsvm 3.21 itself (oracle/_ref/libref_svm.so, its own extern "C" API)."""
+
+    @staticmethod
+    def available() -> bool:
+        build()
+        return os.path.exists(os.path.join(HERE, "_ref", "libref_svm.so"))
+
+    def __init__(self, path: str) -> None:
+        L = C.CDLL(os.path.join(HERE, "_ref", "libref_svm.so"))
+        L.svm_load_model.restype = C.c_void_p
+        L.svm_load_model.argtypes = [C.c_char_p]
+        L.svm_get_nr_class.argtypes = [C.c_void_p]
+        L.svm_predict_probability.restype = C.c_double
+        L.svm_predict_probability.argtypes = [C.c_void_p, C.POINTER(_SvmNode), C.POINTER(C.c_double)]
+        L.svm_predict_values.restype = C.c_double
+        L.svm_predict_values.argtypes = [C.c_void_p, C.POINTER(_SvmNode), C.POINTER(C.c_double)]
+        self.L = L
+        self.h = L.svm_load_model(path.encode())
+        if not self.h:
+            raise FileNotFoundError(path)
+        self.k = int(L.svm_get_nr_class(self.h))
+
+    def predict_probability(self, x: np.ndarray):
+        nz = np.nonzero(x)[0]
+        nodes = (_SvmNode * (len(nz) + 1))()
+        for j, i in enumerate(nz):
+            nodes[j].index, nodes[j].value = int(i), float(x[i])
+        nodes[len(nz)].index = -1
+        pv = (C.c_double * self.k)()
+        dv = (C.c_double * (self.k * (self.k - 1) // 2))()
+        lab = int(self.L.svm_predict_probability(self.h, nodes, pv))
+        self.L.svm_predict_values(self.h, nodes, dv)
+        return lab, np.array(list(pv)), np.array(list(dv))

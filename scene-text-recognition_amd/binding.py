@@ -114,6 +114,10 @@ def load_library():
     L.str_er_classify_boxes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
     L.str_er_lbp_hist.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp]
     L.str_er_cascade_predict.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
+    L.str_er_load_svm_model.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.str_er_load_svm_model_mem.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int32]
+    L.str_er_svm_info.argtypes = [vp, i32p, i32p, i32p]
+    L.str_er_svm_predict_probability.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
@@ -380,6 +384,32 @@ class ERFilter:
         out = np.zeros(len(a), np.float64)
         self._check(self.L.str_er_cascade_predict(self.h, which, _np_ptr(a), len(a), _np_ptr(out)))
         return out
+
+    # ---- OCR scorer, SVM half (config 3): OCR::OCR loads the model, chain_run calls svm_predict_probability ----
+    def load_svm_model(self, path: str, dim: int = 1800) -> None:
+        self._check(self.L.str_er_load_svm_model(self.h, path.encode(), dim))
+
+    def load_svm_model_text(self, text: bytes, dim: int = 1800) -> None:
+        self._check(self.L.str_er_load_svm_model_mem(self.h, text, len(text), dim))
+
+    def svm_info(self):
+        a, b, d = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.L.str_er_svm_info(self.h, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
+    def svm_predict_probability(self, x: np.ndarray, want_dec: bool = False):
+        """svm_predict_probability (src/svm.cpp:2592-2629) for dense (n, dim) features -> (label, prob[, dec])."""
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        if a.ndim == 1:
+            a = a[None]
+        n, dim = a.shape
+        k = self.svm_info()[0]
+        label = np.zeros(n, np.int32)
+        prob = np.zeros((n, k), np.float64)
+        dec = np.zeros((n, k * (k - 1) // 2), np.float64) if want_dec else None
+        self._check(self.L.str_er_svm_predict_probability(self.h, _np_ptr(a), n, dim, _np_ptr(label), _np_ptr(prob),
+                                                          _np_ptr(dec) if want_dec else None))
+        return (label, prob, dec) if want_dec else (label, prob)
 
     def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):
         """ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816).  With no boxes the whole

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "er_kernels.h"
+#include "svm_kernels.h"
 
 using namespace str_er;
 
@@ -96,6 +97,9 @@ struct str_er_ctx {
     uint32_t *h_total = nullptr;
 
     HostCascade casc[2];
+    bool svm_loaded = false;
+    SvmDev svm{};
+    void *d_svm_blob = nullptr;
     hipEvent_t ev[16]{};
     int n_ev = 0;
     bool profiling = false;
@@ -561,6 +565,7 @@ void str_er_destroy(str_er_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
+    if (c->d_svm_blob) (void)hipFree(c->d_svm_blob);
     if (c->h_planes) (void)hipHostFree(c->h_planes);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -870,6 +875,165 @@ int str_er_cascade_predict(str_er_ctx *c, int which, const double *fv, int32_t n
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, s + in_b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return STR_ER_OK;
+}
+
+// ---- libsvm text model (svm_save_model format, src/svm.cpp:2641-2736; reader :2767-2982) -------------
+int str_er_load_svm_model_mem(str_er_ctx *c, const char *text, size_t len, int32_t dim)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!text || dim < 1) return fail(c, STR_ER_EINVAL, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    std::string buf(text, len);
+    size_t pos = 0;
+    auto next_line = [&](std::string &out) -> bool {
+        if (pos >= buf.size()) return false;
+        size_t e = buf.find('\n', pos);
+        if (e == std::string::npos) e = buf.size();
+        out.assign(buf, pos, e - pos);
+        pos = e + 1;
+        return true;
+    };
+    auto numbers = [](const std::string &s, size_t from, std::vector<double> &out) {
+        const char *p = s.c_str() + from;
+        char *end;
+        for (;;) { double v = std::strtod(p, &end); if (end == p) break; out.push_back(v); p = end; }
+    };
+    int k = 0, l = 0;
+    double gamma = 0;
+    bool ok_type = false, ok_kernel = false, have_sv = false;
+    std::vector<double> rho, pa, pb, lab, nsv;
+    std::string line;
+    while (next_line(line)) {
+        const size_t sp = line.find(' ');
+        const std::string key = line.substr(0, sp);
+        const size_t from = sp == std::string::npos ? line.size() : sp;
+        if (key == "svm_type") ok_type = line.find("c_svc") != std::string::npos;
+        else if (key == "kernel_type") ok_kernel = line.find("rbf") != std::string::npos;
+        else if (key == "gamma") gamma = std::strtod(line.c_str() + from, nullptr);
+        else if (key == "nr_class") k = std::atoi(line.c_str() + from);
+        else if (key == "total_sv") l = std::atoi(line.c_str() + from);
+        else if (key == "rho") numbers(line, from, rho);
+        else if (key == "probA") numbers(line, from, pa);
+        else if (key == "probB") numbers(line, from, pb);
+        else if (key == "label") numbers(line, from, lab);
+        else if (key == "nr_sv") numbers(line, from, nsv);
+        else if (key == "SV") { have_sv = true; break; }
+    }
+    if (!ok_type || !ok_kernel) return fail(c, STR_ER_EFORMAT, "svm model: only svm_type c_svc with kernel_type rbf is supported");
+    const int np = k * (k - 1) / 2;
+    if (!have_sv || k < 2 || k > 128 || l < 1 || (int)rho.size() != np || (int)pa.size() != np || (int)pb.size() != np ||
+        (int)lab.size() != k || (int)nsv.size() != k)
+        return fail(c, STR_ER_EFORMAT, "svm model: incomplete header (need nr_class<=128, rho, label, probA, probB, nr_sv)");
+    const int dpad = (int)align_up((size_t)dim, 16), l_pad = (int)align_up((size_t)l, 64);
+    std::vector<float> sv((size_t)l_pad * dpad, 0.f);
+    std::vector<double> svnorm(l_pad, 0.0), coef((size_t)(k - 1) * l, 0.0);
+    for (int i = 0; i < l; ++i) {
+        if (!next_line(line)) return fail(c, STR_ER_EFORMAT, "svm model: fewer SV lines than total_sv");
+        const char *p = line.c_str();
+        char *end;
+        for (int j = 0; j < k - 1; ++j) { coef[(size_t)j * l + i] = std::strtod(p, &end); if (end == p) return fail(c, STR_ER_EFORMAT, "svm model: bad SV line"); p = end; }
+        double nrm = 0;
+        for (;;) {
+            const long idx = std::strtol(p, &end, 10);
+            if (end == p || *end != ':') break;
+            p = end + 1;
+            const double v = std::strtod(p, &end);
+            p = end;
+            if (idx < 0 || idx >= dim) return fail(c, STR_ER_EFORMAT, "svm model: SV feature index outside [0, dim)");
+            sv[(size_t)i * dpad + idx] = (float)v;
+            nrm += v * v;
+        }
+        svnorm[i] = nrm;
+    }
+    std::vector<int32_t> ilab(k), insv(k), start(k), pi(np), pj(np);
+    int tot = 0;
+    for (int i = 0; i < k; ++i) { ilab[i] = (int32_t)lab[i]; insv[i] = (int32_t)nsv[i]; start[i] = tot; tot += insv[i]; }
+    if (tot != l) return fail(c, STR_ER_EFORMAT, "svm model: nr_sv does not add up to total_sv");
+    for (int i = 0, p = 0; i < k; ++i) for (int j = i + 1; j < k; ++j, ++p) { pi[p] = i; pj[p] = j; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_rho = take(np * 8),
+                 o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4), o_pi = take(np * 4),
+                 o_pj = take(np * 4);
+    std::vector<uint8_t> blob(off);
+    std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
+    std::memcpy(&blob[o_coef], coef.data(), coef.size() * 8); std::memcpy(&blob[o_rho], rho.data(), np * 8);
+    std::memcpy(&blob[o_pa], pa.data(), np * 8); std::memcpy(&blob[o_pb], pb.data(), np * 8);
+    std::memcpy(&blob[o_lab], ilab.data(), k * 4); std::memcpy(&blob[o_nsv], insv.data(), k * 4); std::memcpy(&blob[o_start], start.data(), k * 4);
+    std::memcpy(&blob[o_pi], pi.data(), np * 4); std::memcpy(&blob[o_pj], pj.data(), np * 4);
+    void *d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, blob.size()));
+    hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(c, STR_ER_EHIP, std::string("svm upload: ") + hipGetErrorString(e)); }
+    if (c->d_svm_blob) (void)hipFree(c->d_svm_blob);
+    c->d_svm_blob = d;
+    const uint8_t *b = static_cast<const uint8_t *>(d);
+    SvmDev m{};
+    m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
+    m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
+    m.coef = reinterpret_cast<const double *>(b + o_coef); m.rho = reinterpret_cast<const double *>(b + o_rho);
+    m.probA = reinterpret_cast<const double *>(b + o_pa); m.probB = reinterpret_cast<const double *>(b + o_pb);
+    m.label = reinterpret_cast<const int32_t *>(b + o_lab); m.nsv = reinterpret_cast<const int32_t *>(b + o_nsv);
+    m.start = reinterpret_cast<const int32_t *>(b + o_start); m.pair_i = reinterpret_cast<const int32_t *>(b + o_pi);
+    m.pair_j = reinterpret_cast<const int32_t *>(b + o_pj);
+    c->svm = m;
+    c->svm_loaded = true;
+    return STR_ER_OK;
+}
+
+int str_er_load_svm_model(str_er_ctx *c, const char *path, int32_t dim)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!path) return fail(c, STR_ER_EINVAL, "null path");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(c, STR_ER_EIO, std::string("cannot open ") + path);      // reference: svm_load_model returns NULL (src/svm.cpp:2878-2879)
+    std::string buf;
+    char tmp[65536];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n);
+    std::fclose(f);
+    return str_er_load_svm_model_mem(c, buf.data(), buf.size(), dim);
+}
+
+int str_er_svm_info(const str_er_ctx *c, int32_t *nr_class, int32_t *total_sv, int32_t *dim)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (nr_class) *nr_class = c->svm_loaded ? c->svm.k : 0;
+    if (total_sv) *total_sv = c->svm_loaded ? c->svm.l : 0;
+    if (dim) *dim = c->svm_loaded ? c->svm.dim : 0;
+    return STR_ER_OK;
+}
+
+int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, int32_t dim, int32_t *label, double *prob, double *dec)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (n < 0 || (n > 0 && (!x || !label || !prob))) return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (!c->svm_loaded) return fail(c, STR_ER_ESTATE, "svm model not loaded");
+    if (dim != c->svm.dim) return fail(c, STR_ER_EINVAL, "feature dimension differs from the one the model was loaded with");
+    if (n == 0) return STR_ER_OK;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const SvmDev &m = c->svm;
+    const size_t n_pad = align_up((size_t)n, 64), np = (size_t)m.k * (m.k - 1) / 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_x = take((size_t)n * dim * 8), o_xf = take(n_pad * m.dpad * 4), o_xn = take(n_pad * 8), o_kv = take(n_pad * m.l_pad * 8),
+                 o_dec = take((size_t)n * np * 8), o_prob = take((size_t)n * m.k * 8), o_lab = take((size_t)n * 4);
+    int rc = ensure_scratch(c, off);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemsetAsync(s + o_xf, 0, n_pad * m.dpad * 4 + 256, st));
+    HIP_TRY(c, hipMemsetAsync(s + o_xn, 0, n_pad * 8, st));
+    HIP_TRY(c, hipMemcpyAsync(s + o_x, x, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
+    launch_svm_predict(st, reinterpret_cast<const double *>(s + o_x), n, dim, reinterpret_cast<float *>(s + o_xf),
+                       reinterpret_cast<double *>(s + o_xn), (int)n_pad, reinterpret_cast<double *>(s + o_kv),
+                       reinterpret_cast<double *>(s + o_dec), reinterpret_cast<double *>(s + o_prob), reinterpret_cast<int32_t *>(s + o_lab), m);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(prob, s + o_prob, (size_t)n * m.k * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(label, s + o_lab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (dec) HIP_TRY(c, hipMemcpyAsync(dec, s + o_dec, (size_t)n * np * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
     return STR_ER_OK;
 }
 

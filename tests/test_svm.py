@@ -1,0 +1,106 @@
+"""OCR scorer, SVM half (config 3): svm_predict_probability.
+
+The oracle (oracle/svm_oracle.c) is pinned bit for bit against the reference's own vendored libsvm
+(oracle/_ref/libref_svm.so = src/svm.cpp compiled unmodified); tests/golden/svm_vectors.npz stores that
+library's outputs so the comparison also works where /root/reference is absent.  The HIP path computes
+the RBF kernel matrix with an f32 MFMA GEMM, so it is compared with the tolerance BASELINE.json states
+for SVM scores (1e-4, absolute, on probabilities; labels must be equal)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def model_path(tmp_path_factory):
+    p = tmp_path_factory.mktemp("svm") / "ocr_synth.model"
+    p.write_bytes(gzip.open(os.path.join(GOLDEN, "ocr_synth.model.gz")).read())
+    return str(p)
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    z = np.load(os.path.join(GOLDEN, "svm_vectors.npz"))
+    return z["q"] / 255.0, z["label"], z["prob"], z["dec"]      # features are q/255.0 (src/OCR.cpp:211)
+
+
+def test_oracle_matches_reference_vectors(oracle, model_path, vectors):
+    from oracle.oracle import OracleSVM
+    m = OracleSVM(oracle, model_path)
+    assert (m.k, m.l) == (65, 319)
+    x, lab, prob, dec = vectors
+    for i in range(len(x)):
+        l, p, d = m.predict_probability(x[i])
+        assert l == lab[i] and np.array_equal(p, prob[i])
+        if i < len(dec):
+            assert np.array_equal(d, dec[i])
+    assert abs(prob.sum(axis=1) - 1).max() < 1e-9
+
+
+def test_oracle_matches_reference_library(oracle, model_path):
+    from oracle.oracle import OracleSVM, RefSVM
+    if not RefSVM.available():
+        pytest.skip("oracle/_ref/libref_svm.so not present")
+    m, r = OracleSVM(oracle, model_path), RefSVM(model_path)
+    rng = np.random.default_rng(14)
+    for _ in range(40):
+        x = np.zeros(1800)
+        nz = rng.choice(1800, size=int(rng.integers(0, 400)), replace=False)
+        x[nz] = rng.integers(1, 256, len(nz)) / 255.0
+        a, b = m.predict_probability(x), r.predict_probability(x)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+def test_gpu_svm_matches_reference_vectors(erf, model_path, vectors):
+    erf.load_svm_model(model_path, 1800)
+    assert erf.svm_info() == (65, 319, 1800)
+    x, lab, prob, dec = vectors
+    gl, gp, gd = erf.svm_predict_probability(x, want_dec=True)
+    assert (gl == lab).all()
+    assert np.abs(gp - prob).max() < TOL
+    assert np.abs(gd[:len(dec)] - dec).max() < TOL
+    assert np.abs(gp.sum(axis=1) - 1).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_svm_matches_oracle_on_many(erf, oracle, model_path):
+    from oracle.oracle import OracleSVM
+    erf.load_svm_model(model_path, 1800)
+    m = OracleSVM(oracle, model_path)
+    rng = np.random.default_rng(15)
+    n = 333                                                       # not a multiple of the 64-row GEMM tile
+    x = np.zeros((n, 1800))
+    for i in range(n):
+        nz = rng.choice(1800, size=int(rng.integers(0, 600)), replace=False)
+        x[i, nz] = rng.integers(1, 256, len(nz)) / 255.0
+    gl, gp, gd = erf.svm_predict_probability(x, want_dec=True)
+    for i in range(n):
+        l, p, d = m.predict_probability(x[i])
+        assert np.abs(gd[i] - d).max() < TOL and np.abs(gp[i] - p).max() < TOL
+        top2 = np.sort(p)[-2:]
+        if top2[1] - top2[0] > 10 * TOL:                          # skip near-ties of the arg max
+            assert gl[i] == l
+
+
+@pytest.mark.gpu
+def test_gpu_svm_errors(S, model_path):
+    f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=64, max_height=64, max_frames=1)
+    with pytest.raises(S.StrErError) as e:
+        f.svm_predict_probability(np.zeros((1, 1800)))
+    assert e.value.code == -6
+    with pytest.raises(S.StrErError) as e:
+        f.load_svm_model("/nonexistent/OCR.model")            # reference: svm_load_model returns NULL
+    assert e.value.code == -4
+    with pytest.raises(S.StrErError) as e:
+        f.load_svm_model(model_path, 100)                        # SV indices exceed the declared dimension
+    assert e.value.code == -5
+    f.load_svm_model(model_path, 1800)
+    with pytest.raises(S.StrErError) as e:
+        f.svm_predict_probability(np.zeros((1, 900)))
+    assert e.value.code == -1
+    f.close()

@@ -1,0 +1,18 @@
+import gzip, os, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import str_er_amd as S
+tmp = tempfile.mkdtemp(); mp = os.path.join(tmp, 'm'); open(mp, 'wb').write(gzip.open(os.path.join(ROOT, 'tests/golden/ocr_synth.model.gz')).read())
+z = np.load(os.path.join(ROOT, 'tests/golden/svm_vectors.npz'))
+f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=64, max_height=64, max_frames=1)
+f.load_svm_model(mp, 1800)
+x = z['q'] / 255.0
+gl, gp, gd = f.svm_predict_probability(x, want_dec=True)
+print('max |prob - ref|', np.abs(gp - z['prob']).max(), 'max |dec - ref|', np.abs(gd[:8] - z['dec']).max(), 'labels equal', (gl == z['label']).all())
+rng = np.random.default_rng(0)
+for n in (256, 4096, 16384):
+    X = x[rng.integers(0, len(x), n)]
+    f.svm_predict_probability(X)
+    t0 = time.time(); f.svm_predict_probability(X); dt = time.time() - t0
+    print(f'n={n}: {dt*1e3:.2f} ms  -> {n/dt:.0f} vectors/s (incl. H2D of {X.nbytes/1e6:.0f} MB)')
