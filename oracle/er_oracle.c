@@ -791,3 +791,183 @@ void ero_classify(const uint8_t *plane, int stride, const int32_t *boxes, int n,
         if (s_weak) s_weak[i] = sw;
     }
 }
+
+/* ======================================================================== */
+/* OCR scorer, feature half (src/OCR.cpp:67-218), slope == 0 -- unpinned     */
+/* ======================================================================== */
+
+/* cv::threshold(..., THRESH_OTSU): getThreshVal_Otsu_8u of OpenCV 4.x (imgproc/thresh.cpp).
+ * `invert` applies 255 - p first (chain_run thresholds 255 - src, src/OCR.cpp:72). */
+int ero_otsu_threshold(const uint8_t *img, int stride, int w, int h, int invert)
+{
+    int hist[256] = {0};
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) hist[invert ? 255 - img[(size_t)y * stride + x] : img[(size_t)y * stride + x]]++;
+    double mu = 0, scale = 1. / ((double)w * h);
+    for (int i = 0; i < 256; ++i) mu += i * (double)hist[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; ++i) {
+        double p_i = hist[i] * scale, q2, mu2, sigma;
+        mu1 *= q1;
+        q1 += p_i;
+        q2 = 1. - q1;
+        const double mn = q1 < q2 ? q1 : q2, mx = q1 > q2 ? q1 : q2;
+        if (mn < FLT_EPSILON || mx > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        mu2 = (mu - q1 * mu1) / q2;
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    return (int)max_val;
+}
+
+/* chain_run lines 72 + 79: Otsu-binarise 255-roi (dst = v > thresh ? 255 : 0), then ARAN(img_L = 30) */
+void ero_ocr_normalise(const uint8_t *roi, int stride, int w, int h, uint8_t img30[30 * 30])
+{
+    const int L = 30;
+    const int th = ero_otsu_threshold(roi, stride, w, h, 1);
+    uint8_t *bin = (uint8_t *)malloc((size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) bin[(size_t)y * w + x] = (255 - roi[(size_t)y * stride + x]) > th ? 255 : 0;
+    const double R1 = (w > h) ? (double)h / w : (double)w / h;
+    int dw, dh;
+    if (w > h) { dw = L; dh = (int)(L * pow(R1, 0.5)); }
+    else       { dw = (int)(L * pow(R1, 0.5)); dh = L; }
+    memset(img30, 0, (size_t)L * L);
+    if (dw > 0 && dh > 0) {
+        uint8_t tmp[30 * 30];
+        ero_resize_linear_u8(bin, w, w, h, tmp, dw, dw, dh);
+        if (dw > dh) {
+            const int off = (L - dh) / 2;
+            for (int i = 0; i < dh; ++i) memcpy(img30 + (size_t)(i + off) * L, tmp + (size_t)i * dw, (size_t)dw);
+        } else {
+            const int off = (L - dw) / 2;
+            for (int i = 0; i < dh; ++i) memcpy(img30 + (size_t)i * L + off, tmp + (size_t)i * dw, (size_t)dw);
+        }
+    }
+    free(bin);
+}
+
+/* OCR::chain_code_direction(p1 = next point, p2 = current point), src/OCR.cpp:602-622 */
+static int chain_dir(int nx, int ny, int cx, int cy)
+{
+    if (nx < cx && ny == cy) return 0;
+    if (nx < cx && ny < cy) return 1;
+    if (nx == cx && ny < cy) return 2;
+    if (nx > cx && ny < cy) return 3;
+    if (nx > cx && ny == cy) return 4;
+    if (nx > cx && ny > cy) return 5;
+    if (nx == cx && ny > cy) return 6;
+    if (nx < cx && ny > cy) return 7;
+    return -1;
+}
+
+/* cv::findContours(RETR_LIST, CHAIN_APPROX_NONE) restated from OpenCV's contours.cpp (Suzuki-Abe border
+ * following, cvFindNextContour + icvFetchContour) fused with the loop of extract_feature
+ * (src/OCR.cpp:155-168): every border is closed, single-point borders are skipped, and for each
+ * consecutive pair (p_j, p_j+1) the bitmap of direction(p_j+1 relative to p_j) gets 255 at p_j. */
+void ero_chain_bitmaps(const uint8_t img30[30 * 30], uint8_t maps[8 * 30 * 30])
+{
+    enum { L = 30, W = L + 2 };
+    signed char f[W * W];                       /* 0/1 image with a one-pixel zero frame */
+    memset(f, 0, sizeof(f));
+    for (int y = 0; y < L; ++y)
+        for (int x = 0; x < L; ++x) f[(y + 1) * W + x + 1] = img30[y * L + x] ? 1 : 0;
+    memset(maps, 0, 8 * L * L);
+    /* 8 neighbours, counter-clockwise on screen starting east (CV_INIT_3X3_DELTAS) */
+    const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int delta[8];
+    for (int k = 0; k < 8; ++k) delta[k] = dy[k] * W + dx[k];
+    static int px[4 * W * W], py[4 * W * W];
+    for (int y = 1; y <= L; ++y) {
+        int prev = 0;
+        for (int x = 1; x <= L + 1; ++x) {
+            int p = f[y * W + x];
+            if (p == prev) continue;
+            int is_hole = 0;
+            if (!(prev == 0 && p == 1)) {
+                if (p != 0 || prev < 1) { prev = p; continue; }
+                is_hole = 1;
+            }
+            /* ---- icvFetchContour from (x - is_hole, y) ---- */
+            const int i0 = y * W + x - is_hole;
+            const int nbd = 2;
+            int s_end = is_hole ? 0 : 4, s = s_end, i1 = i0, n = 0;
+            do { s = (s - 1) & 7; i1 = i0 + delta[s]; } while (f[i1] == 0 && s != s_end);
+            int cx = x - is_hole, cy = y;
+            if (s == s_end) {                   /* isolated pixel */
+                f[i0] = (signed char)(nbd | -128);
+                px[n] = cx; py[n] = cy; ++n;
+            } else {
+                int i3 = i0;
+                for (;;) {
+                    int i4;
+                    s_end = s;
+                    for (;;) { i4 = i3 + delta[++s & 7]; if (f[i4] != 0) break; }
+                    s &= 7;
+                    if ((unsigned)(s - 1) < (unsigned)s_end) f[i3] = (signed char)(nbd | -128);
+                    else if (f[i3] == 1) f[i3] = (signed char)nbd;
+                    px[n] = cx; py[n] = cy; ++n;
+                    cx += dx[s]; cy += dy[s];
+                    if (i4 == i0 && i3 == i1) break;
+                    i3 = i4;
+                    s = (s + 4) & 7;
+                }
+            }
+            if (n > 1)
+                for (int j = 0; j < n; ++j) {
+                    const int jn = (j + 1) % n;          /* contour closed with its first point (:163) */
+                    const int d = chain_dir(px[jn] - 1, py[jn] - 1, px[j] - 1, py[j] - 1);
+                    if (d >= 0) maps[d * L * L + (py[j] - 1) * L + (px[j] - 1)] = 255;
+                }
+            p = f[y * W + x];
+            prev = p;
+        }
+    }
+}
+
+static int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
+
+void ero_chain_features(const uint8_t *roi, int stride, int w, int h, uint8_t q[1800])
+{
+    enum { L = 30, F = 15 };
+    uint8_t img[L * L], maps[8 * L * L];
+    ero_ocr_normalise(roi, stride, w, h, img);
+    ero_chain_bitmaps(img, maps);
+    static const int kg[7] = {8, 28, 56, 72, 56, 28, 8};   /* getGaussianKernel(7, sigma<=0) in 8.8 fixed point */
+    for (int c = 0; c < 8; ++c) {
+        const uint8_t *m = maps + c * L * L;
+        int hrow[L * L];
+        for (int y = 0; y < L; ++y)
+            for (int x = 0; x < L; ++x) {
+                int s = 0;
+                for (int k = -3; k <= 3; ++k) s += m[y * L + reflect101(x + k, L)] * kg[k + 3];
+                hrow[y * L + x] = s;                         /* ufixedpoint16, 8 fractional bits */
+            }
+        uint8_t blur[L * L];
+        int mn = 255, mx = 0;
+        for (int y = 0; y < L; ++y)
+            for (int x = 0; x < L; ++x) {
+                int s = 0;
+                for (int k = -3; k <= 3; ++k) s += hrow[reflect101(y + k, L) * L + x] * kg[k + 3];
+                const int v = (s + (1 << 15)) >> 16;         /* round to nearest, 16 fractional bits */
+                blur[y * L + x] = (uint8_t)(v > 255 ? 255 : v);
+                if (blur[y * L + x] < mn) mn = blur[y * L + x];
+                if (blur[y * L + x] > mx) mx = blur[y * L + x];
+            }
+        /* cv::normalize(NORM_MINMAX, 0..255) = convertTo(CV_8U, scale, shift) in float */
+        const double scale = (mx - mn) > DBL_EPSILON ? 255.0 / (mx - mn) : 0.0, shift = 0.0 - mn * scale;
+        const float a = (float)scale, b = (float)shift;
+        uint8_t nrm[L * L];
+        for (int i = 0; i < L * L; ++i) {
+            const float v = (float)blur[i] * a + b;
+            int r = (int)lrintf(v);
+            nrm[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+        for (int y = 0; y < F; ++y)                          /* resize 30 -> 15: exact 2x, INTER_AREA path */
+            for (int x = 0; x < F; ++x)
+                q[c * F * F + y * F + x] = (uint8_t)((nrm[(2 * y) * L + 2 * x] + nrm[(2 * y) * L + 2 * x + 1] +
+                                                      nrm[(2 * y + 1) * L + 2 * x] + nrm[(2 * y + 1) * L + 2 * x + 1] + 2) >> 2);
+    }
+}

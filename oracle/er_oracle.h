@@ -126,6 +126,22 @@ void ero_classify(const uint8_t *plane, int stride,
                   const ero_cascade *strong, const ero_cascade *weak,
                   uint8_t *cls, double *s_strong, double *s_weak);
 
+/* ---- OCR scorer, feature half (config 3) -- "parity unpinned" ------------
+ * OCR::chain_run up to the svm call (src/OCR.cpp:67-91) for slope == 0 (no rotation):
+ *   threshold(255 - roi, THRESH_OTSU)  ->  ARAN(30)  ->  extract_feature (src/OCR.cpp:144-218):
+ *   findContours(RETR_LIST, CHAIN_APPROX_NONE) -> 8 direction bitmaps -> GaussianBlur 7x7 ->
+ *   normalize(0,255,MINMAX) -> resize 15x15 -> q[1800] (feature value = q/255.0).
+ * cv::threshold/Otsu, cv::findContours (Suzuki-Abe border following), cv::GaussianBlur (8-bit
+ * fixed-point kernel 8,28,56,72,56,28,8 / 256, BORDER_REFLECT_101) and cv::normalize are restated
+ * from OpenCV 4.x; none of it can be pinned here.                                            */
+int  ero_otsu_threshold(const uint8_t *img, int stride, int w, int h, int invert);
+/* binary 0/255 image of the inverted ROI, ARAN-normalised to 30x30 (zero padded) */
+void ero_ocr_normalise(const uint8_t *roi, int stride, int w, int h, uint8_t img30[30 * 30]);
+/* the eight 30x30 direction bitmaps (0/255) of extract_feature, before blurring */
+void ero_chain_bitmaps(const uint8_t img30[30 * 30], uint8_t maps[8 * 30 * 30]);
+/* the complete feature vector: q[8*15*15] */
+void ero_chain_features(const uint8_t *roi, int stride, int w, int h, uint8_t q[1800]);
+
 /* ---- build-defined pyramid (no reference counterpart) -- */
 /* Level k plane size: (lround(w0*2^(-k/2)), lround(h0*2^(-k/2))), min 1.
  * Level k (k>=1) is DEFINED as ero_resize_linear_u8(level k-1 -> dims k).    */

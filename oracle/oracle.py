@@ -94,6 +94,10 @@ class Oracle:
         L.ero_classify.argtypes = [u8p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p,
                                    u8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ero_pyr_dims.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ero_chain_features.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.ero_ocr_normalise.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.ero_chain_bitmaps.argtypes = [u8p, u8p]
+        L.ero_otsu_threshold.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
 
@@ -196,6 +200,24 @@ class Oracle:
         self.lib.ero_lbp_hist(roi.ctypes.data_as(C.POINTER(C.c_uint8)), roi.shape[1], roi.shape[1], roi.shape[0],
                               out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
+
+    def chain_features(self, roi: np.ndarray) -> np.ndarray:
+        roi = _u8(roi)
+        q = np.zeros(1800, np.uint8)
+        p = C.POINTER(C.c_uint8)
+        self.lib.ero_chain_features(roi.ctypes.data_as(p), roi.shape[1], roi.shape[1], roi.shape[0], q.ctypes.data_as(p))
+        return q
+
+    def otsu(self, img: np.ndarray, invert: bool = False) -> int:
+        img = _u8(img)
+        return int(self.lib.ero_otsu_threshold(img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[1], img.shape[0], int(invert)))
+
+    def chain_bitmaps(self, img30: np.ndarray) -> np.ndarray:
+        img30 = _u8(img30)
+        m = np.zeros((8, 30, 30), np.uint8)
+        p = C.POINTER(C.c_uint8)
+        self.lib.ero_chain_bitmaps(img30.ctypes.data_as(p), m.ctypes.data_as(p))
+        return m
 
     def cascade_load(self, path: str) -> "OracleCascade":
         h = self.lib.ero_cascade_load(path.encode())

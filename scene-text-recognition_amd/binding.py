@@ -118,6 +118,7 @@ def load_library():
     L.str_er_load_svm_model_mem.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int32]
     L.str_er_svm_info.argtypes = [vp, i32p, i32p, i32p]
     L.str_er_svm_predict_probability.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.str_er_ocr_chain_run.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
@@ -410,6 +411,18 @@ class ERFilter:
         self._check(self.L.str_er_svm_predict_probability(self.h, _np_ptr(a), n, dim, _np_ptr(label), _np_ptr(prob),
                                                           _np_ptr(dec) if want_dec else None))
         return (label, prob, dec) if want_dec else (label, prob)
+
+    def chain_run(self, plane: np.ndarray, boxes_xywh: np.ndarray, classify: bool = True):
+        """OCR::chain_run (src/OCR.cpp:67-140) with slope 0 for every box: (q[n,1800] uint8, label, prob) or q only."""
+        a = np.ascontiguousarray(plane, dtype=np.uint8)
+        b = np.ascontiguousarray(boxes_xywh, dtype=np.int32).reshape(-1, 4)
+        n = len(b)
+        q = np.zeros((n, 1800), np.uint8)
+        label = np.zeros(n, np.int32)
+        prob = np.zeros(n, np.float64)
+        self._check(self.L.str_er_ocr_chain_run(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), n,
+                                                _np_ptr(label) if classify else None, _np_ptr(prob) if classify else None, _np_ptr(q)))
+        return (q, label, prob) if classify else q
 
     def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):
         """ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816).  With no boxes the whole

@@ -69,4 +69,8 @@ void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int str
 // CascadeBoost::predict on explicit feature vectors (n x 1024 doubles).
 void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, CascadeDev c);
 
+// OCR::chain_run feature extraction (slope 0) for n boxes of one device plane: q_out [n x 1800] u8 and/or x_out [n x xdim] f64 (= q/255).
+void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
+                           double *x_out, int xdim);
+
 } // namespace str_er

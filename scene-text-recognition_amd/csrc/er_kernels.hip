@@ -1837,4 +1837,208 @@ void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, Casc
     hipLaunchKernelGGL(k_cascade_fv, dim3(n < 2048 ? n : 2048), dim3(CLS_THREADS), 0, s, fv, n, out, c);
 }
 
+// ------------------------------------------------------------------------------------
+// OCR scorer, feature half (config 3): OCR::chain_run up to the svm call
+// (src/OCR.cpp:67-91) with slope == 0, one workgroup per ER:
+//   Otsu threshold of 255 - roi  ->  ARAN(30) of the binarised image  ->  extract_feature
+//   (src/OCR.cpp:144-218): border following, 8 direction bitmaps, 7x7 Gaussian (8-bit fixed point),
+//   min-max normalisation, 2x2 area decimation  ->  q[1800] (feature = q / 255.0).
+// Follows oracle/er_oracle.c (ero_chain_features), which restates the OpenCV primitives involved.
+// ------------------------------------------------------------------------------------
+struct ChainShared {
+    uint32_t    hist[256];
+    int         thresh;
+    uint8_t     img[30 * 30 + 4];
+    signed char f[32 * 32];
+    uint8_t     maps[8 * 900];
+    uint16_t    hrow[8 * 900];
+    uint32_t    mn[8], mx[8];
+};
+
+// resize_px with a per-tap transform: tap = (255 - (p ^ inv)) > thresh ? 255 : 0
+__device__ __forceinline__ int bin_tap(const uint8_t *p, int inv, int th) { return (255 - (*p ^ inv)) > th ? 255 : 0; }
+
+__device__ __forceinline__ int resize_px_bin(const ResizeGeom &g, const uint8_t *__restrict__ src, int sstride, int inv, int th,
+                                             int dx, int dy)
+{
+    if (g.mode == 0) return bin_tap(src + (size_t)dy * sstride + dx, inv, th);
+    if (g.mode == 1) {
+        const uint8_t *r0 = src + (size_t)(2 * dy) * sstride + 2 * dx, *r1 = r0 + sstride;
+        return (bin_tap(r0, inv, th) + bin_tap(r0 + 1, inv, th) + bin_tap(r1, inv, th) + bin_tap(r1 + 1, inv, th) + 2) >> 2;
+    }
+    float fx = (float)((dx + 0.5) * g.scale_x - 0.5);
+    int   sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= g.sw - 1) { fx = 0.f; sx = g.sw - 1; }
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+    int   sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+    const int y0 = min(max(sy, 0), g.sh - 1), y1 = min(max(sy + 1, 0), g.sh - 1);
+    const int sx1 = (sx + 1 < g.sw) ? sx + 1 : sx;
+    const uint8_t *p0 = src + (size_t)y0 * sstride, *p1 = src + (size_t)y1 * sstride;
+    const int r0 = bin_tap(p0 + sx, inv, th) * a0 + bin_tap(p0 + sx1, inv, th) * a1;
+    const int r1 = bin_tap(p1 + sx, inv, th) * a0 + bin_tap(p1 + sx1, inv, th) * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return min(max(v, 0), 255);
+}
+
+__device__ __forceinline__ int reflect101_30(int i) { return i < 0 ? -i : (i >= 30 ? 58 - i : i); }
+
+__global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restrict__ plane, int stride, int inv,
+                                                        const int32_t *__restrict__ boxes, int n, uint8_t *__restrict__ q_out,
+                                                        double *__restrict__ x_out, int xdim)
+{
+    __shared__ ChainShared sh;
+    const int tid = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+        const int bx = boxes[4 * bi], by = boxes[4 * bi + 1], bw = boxes[4 * bi + 2], bh = boxes[4 * bi + 3];
+        const uint8_t *roi = plane + (size_t)by * stride + bx;
+        // ---- Otsu (getThreshVal_Otsu_8u) on 255 - roi
+        sh.hist[tid] = 0;
+        for (int i = tid; i < 8; i += 256) { sh.mn[i] = 255; sh.mx[i] = 0; }
+        for (int i = tid; i < 900; i += 256) sh.img[i] = 0;
+        for (int i = tid; i < 32 * 32; i += 256) sh.f[i] = 0;
+        for (int i = tid; i < 8 * 900; i += 256) sh.maps[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < bw * bh; i += 256) {
+            const int y = i / bw, x = i - y * bw;
+            atomicAdd(&sh.hist[255 - (roi[(size_t)y * stride + x] ^ inv)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double mu = 0;
+            const double scale = 1. / ((double)bw * bh);
+            for (int i = 0; i < 256; ++i) mu += i * (double)sh.hist[i];
+            mu *= scale;
+            double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+            for (int i = 0; i < 256; ++i) {
+                const double p_i = sh.hist[i] * scale;
+                mu1 *= q1;
+                q1 += p_i;
+                const double q2 = 1. - q1;
+                if (fmin(q1, q2) < (double)FLT_EPSILON || fmax(q1, q2) > 1. - (double)FLT_EPSILON) continue;
+                mu1 = (mu1 + i * p_i) / q1;
+                const double mu2 = (mu - q1 * mu1) / q2;
+                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+            }
+            sh.thresh = (int)max_val;
+        }
+        __syncthreads();
+        // ---- ARAN(30) of the binarised ROI
+        {
+            const int    th = sh.thresh;
+            const double R1 = (bw > bh) ? (double)bh / bw : (double)bw / bh;
+            const int    k = (int)(30.0 * sqrt(R1));
+            const int    dw = (bw > bh) ? 30 : k, dh = (bw > bh) ? k : 30;
+            if (dw > 0 && dh > 0) {
+                const int offy = (dw > dh) ? (30 - dh) / 2 : 0, offx = (dw > dh) ? 0 : (30 - dw) / 2;
+                const ResizeGeom g = resize_geom(bw, bh, dw, dh);
+                for (int i = tid; i < dw * dh; i += 256) {
+                    const int dy = i / dw, dx = i - dy * dw;
+                    const int v = resize_px_bin(g, roi, stride, inv, th, dx, dy);
+                    sh.img[(dy + offy) * 30 + dx + offx] = (uint8_t)v;
+                    sh.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- border following (cv::findContours RETR_LIST / CHAIN_APPROX_NONE) + direction bitmaps: one lane
+        if (tid == 0) {
+            const int ddx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, ddy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+            for (int y = 1; y <= 30; ++y) {
+                int prev = 0;
+                for (int x = 1; x <= 31; ++x) {
+                    int p = sh.f[y * 32 + x];
+                    if (p == prev) continue;
+                    int is_hole = 0;
+                    if (!(prev == 0 && p == 1)) {
+                        if (p != 0 || prev < 1) { prev = p; continue; }
+                        is_hole = 1;
+                    }
+                    const int i0 = y * 32 + x - is_hole;
+                    int s_end = is_hole ? 0 : 4, s = s_end, i1 = i0;
+                    do { s = (s - 1) & 7; i1 = i0 + ddy[s] * 32 + ddx[s]; } while (sh.f[i1] == 0 && s != s_end);
+                    int cx = x - is_hole, cy = y;
+                    if (s == s_end) {
+                        sh.f[i0] = (signed char)(2 | -128);          // isolated pixel: a one-point contour, skipped (:160)
+                    } else {
+                        int i3 = i0;
+                        for (;;) {
+                            int i4;
+                            s_end = s;
+                            for (;;) { ++s; i4 = i3 + ddy[s & 7] * 32 + ddx[s & 7]; if (sh.f[i4] != 0) break; }
+                            s &= 7;
+                            if ((unsigned)(s - 1) < (unsigned)s_end) sh.f[i3] = (signed char)(2 | -128);
+                            else if (sh.f[i3] == 1) sh.f[i3] = 2;
+                            // next point relative to the current one (OCR::chain_code_direction, :602-622)
+                            const int sx = ddx[s], sy = ddy[s];
+                            int d;
+                            if (sx < 0 && sy == 0) d = 0; else if (sx < 0 && sy < 0) d = 1; else if (sx == 0 && sy < 0) d = 2;
+                            else if (sx > 0 && sy < 0) d = 3; else if (sx > 0 && sy == 0) d = 4; else if (sx > 0 && sy > 0) d = 5;
+                            else if (sx == 0 && sy > 0) d = 6; else d = 7;
+                            sh.maps[d * 900 + (cy - 1) * 30 + (cx - 1)] = 255;
+                            cx += sx; cy += sy;
+                            if (i4 == i0 && i3 == i1) break;
+                            i3 = i4;
+                            s = (s + 4) & 7;
+                        }
+                    }
+                    p = sh.f[y * 32 + x];
+                    prev = p;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- GaussianBlur 7x7 (kernel 8,28,56,72,56,28,8 / 256, BORDER_REFLECT_101), fixed point
+        for (int i = tid; i < 8 * 900; i += 256) {
+            const int c = i / 900, r = i - c * 900, y = r / 30, x = r - y * 30;
+            const uint8_t *m = sh.maps + c * 900 + y * 30;
+            const int s = 8 * (m[reflect101_30(x - 3)] + m[reflect101_30(x + 3)]) + 28 * (m[reflect101_30(x - 2)] + m[reflect101_30(x + 2)]) +
+                          56 * (m[reflect101_30(x - 1)] + m[reflect101_30(x + 1)]) + 72 * m[x];
+            sh.hrow[i] = (uint16_t)s;
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * 900; i += 256) {
+            const int c = i / 900, r = i - c * 900, y = r / 30, x = r - y * 30;
+            const uint16_t *hc = sh.hrow + c * 900 + x;
+            const int s = 8 * (hc[reflect101_30(y - 3) * 30] + hc[reflect101_30(y + 3) * 30]) +
+                          28 * (hc[reflect101_30(y - 2) * 30] + hc[reflect101_30(y + 2) * 30]) +
+                          56 * (hc[reflect101_30(y - 1) * 30] + hc[reflect101_30(y + 1) * 30]) + 72 * hc[y * 30];
+            const int v = min((s + (1 << 15)) >> 16, 255);
+            sh.maps[i] = (uint8_t)v;                     // each lane overwrites only its own element; hrow is the source
+            atomicMin(&sh.mn[c], (uint32_t)v);
+            atomicMax(&sh.mx[c], (uint32_t)v);
+        }
+        __syncthreads();
+        // ---- normalize(0, 255, NORM_MINMAX) in float, then resize 30 -> 15 (exact 2x: area)
+        for (int i = tid; i < 8 * 900; i += 256) {
+            const int    c = i / 900;
+            const int    mn = (int)sh.mn[c], mx = (int)sh.mx[c];
+            const double scale = (mx - mn) > 0 ? 255.0 / (mx - mn) : 0.0, shift = 0.0 - mn * scale;
+            const float  v = (float)sh.maps[i] * (float)scale + (float)shift;
+            sh.hrow[i] = (uint16_t)min(max(__float2int_rn(v), 0), 255);
+        }
+        __syncthreads();
+        for (int i = tid; i < 1800; i += 256) {
+            const int c = i / 225, r = i - c * 225, y = r / 15, x = r - y * 15;
+            const uint16_t *m = sh.hrow + c * 900 + (2 * y) * 30 + 2 * x;
+            const int v = (m[0] + m[1] + m[30] + m[31] + 2) >> 2;
+            if (q_out) q_out[(size_t)bi * 1800 + i] = (uint8_t)v;
+            if (x_out) x_out[(size_t)bi * xdim + i] = v / 255.0;       // fv.value = ptr[p] / 255.0 (src/OCR.cpp:211)
+        }
+        __syncthreads();
+    }
+}
+
+void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
+                           double *x_out, int xdim)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, plane, stride, inv, boxes, n, q_out, x_out, xdim);
+}
+
 } // namespace str_er

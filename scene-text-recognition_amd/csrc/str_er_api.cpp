@@ -1037,6 +1037,67 @@ int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, in
     return STR_ER_OK;
 }
 
+int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
+                         int32_t *label, double *prob, uint8_t *q_out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
+    const bool want_svm = label != nullptr || prob != nullptr;
+    if (want_svm && (!label || !prob)) return fail(c, STR_ER_EINVAL, "label and prob must be given together");
+    if (want_svm && !c->svm_loaded) return fail(c, STR_ER_ESTATE, "svm model not loaded");
+    if (want_svm && c->svm.dim != 1800) return fail(c, STR_ER_ESTATE, "chain_run needs a model loaded with dim = 1800 (8 x 15 x 15)");
+    for (int i = 0; i < n; ++i) {
+        const int32_t *b = boxes + 4 * (size_t)i;
+        if (b[2] < 1 || b[3] < 1 || b[0] < 0 || b[1] < 0 || (int64_t)b[0] + b[2] > w || (int64_t)b[1] + b[3] > h)
+            return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " outside the plane");
+    }
+    if (n == 0) return STR_ER_OK;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    if ((size_t)w * h > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
+    const SvmDev &m = c->svm;
+    const size_t n_pad = align_up((size_t)n, 64), np = want_svm ? (size_t)m.k * (m.k - 1) / 2 : 0;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_box = take(16 * (size_t)n), o_q = take(1800 * (size_t)n), o_x = take(want_svm ? (size_t)n * 1800 * 8 : 0),
+                 o_xf = take(want_svm ? n_pad * m.dpad * 4 + 256 : 0), o_xn = take(want_svm ? n_pad * 8 : 0),
+                 o_kv = take(want_svm ? n_pad * m.l_pad * 8 : 0), o_dec = take((size_t)n * np * 8),
+                 o_prob = take(want_svm ? (size_t)n * m.k * 8 : 0), o_lab = take((size_t)n * 4);
+    int rc = ensure_scratch(c, off);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    launch_chain_features(st, c->d_pix, w, 0, reinterpret_cast<const int32_t *>(s + o_box), n, s + o_q,
+                          want_svm ? reinterpret_cast<double *>(s + o_x) : nullptr, 1800);
+    std::vector<double> pall;
+    if (want_svm) {
+        HIP_TRY(c, hipMemsetAsync(s + o_xf, 0, n_pad * m.dpad * 4 + 256, st));
+        HIP_TRY(c, hipMemsetAsync(s + o_xn, 0, n_pad * 8, st));
+        launch_svm_predict(st, reinterpret_cast<const double *>(s + o_x), n, 1800, reinterpret_cast<float *>(s + o_xf),
+                           reinterpret_cast<double *>(s + o_xn), (int)n_pad, reinterpret_cast<double *>(s + o_kv),
+                           reinterpret_cast<double *>(s + o_dec), reinterpret_cast<double *>(s + o_prob),
+                           reinterpret_cast<int32_t *>(s + o_lab), m);
+        pall.resize((size_t)n * m.k);
+        HIP_TRY(c, hipMemcpyAsync(pall.data(), s + o_prob, pall.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(label, s + o_lab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, s + o_q, 1800 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (want_svm) {
+        // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. assumes model->label[i] == i
+        std::vector<int32_t> lab(m.k);
+        HIP_TRY(c, hipMemcpy(lab.data(), m.label, (size_t)m.k * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            int idx = -1;
+            for (int k = 0; k < m.k; ++k) if (lab[k] == label[i]) { idx = k; break; }
+            prob[i] = idx >= 0 ? pall[(size_t)i * m.k + idx] : 0.0;
+        }
+    }
+    return STR_ER_OK;
+}
+
 int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
                     int32_t cap, int32_t *n_pool, int32_t *ambiguous)
 {

@@ -246,4 +246,34 @@ private:
     }
 };
 
+// `class OCR` of the reference (inc/OCR.h:26-53), the part on the config-3 path: the constructor loads the
+// libsvm model (OCR::OCR, src/OCR.cpp:19-22) and chain_run scores one ER (src/OCR.cpp:67-140).  It shares the
+// ERFilter's context (the reference hangs the OCR object off ERFilter::ocr, inc/ER.h:119).
+class OCR {
+public:
+    OCR(ERFilter &filter, const char *svm_file_name, int _img_L = 30, int _feature_L = 15) : ctx_(filter.handle())
+    {
+        if (_img_L != 30 || _feature_L != 15) throw std::runtime_error("OCR: only img_L = 30, feature_L = 15 (src/main.cpp:25) are built");
+        if (str_er_load_svm_model(ctx_, svm_file_name, 8 * _feature_L * _feature_L) != STR_ER_OK)
+            throw std::runtime_error(std::string("svm_load_model: ") + str_er_last_error(ctx_));
+    }
+
+    // double OCR::chain_run(Mat src, int thresh, double slope): src = channel(bound).  Returns table[label] + prob.
+    // `thresh` is ignored exactly as in the reference (THRESH_OTSU overrides it); |slope| > 0.01 (rotation) is not built.
+    double chain_run(const Image8 &plane, const Rect &bound, int /*thresh*/, double slope)
+    {
+        if (slope > 0.01 || slope < -0.01) throw std::runtime_error("OCR::chain_run: rotation (|slope| > 0.01) is not built");
+        const int32_t box[4] = {bound.x, bound.y, bound.width, bound.height};
+        int32_t label = 0;
+        double  prob = 0;
+        const int rc = str_er_ocr_chain_run(ctx_, plane.data, plane.cols, plane.rows, plane.step, box, 1, &label, &prob, nullptr);
+        if (rc != STR_ER_OK) throw std::runtime_error(std::string("chain_run: ") + str_er_last_error(ctx_));
+        static const char *table = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz&()";   // src/OCR.cpp:10
+        return (label >= 0 && label < 65 ? table[label] : '?') + prob;
+    }
+
+private:
+    str_er_ctx *ctx_;
+};
+
 } // namespace str_er_host

@@ -104,3 +104,68 @@ def test_gpu_svm_errors(S, model_path):
         f.svm_predict_probability(np.zeros((1, 900)))
     assert e.value.code == -1
     f.close()
+
+
+# ---- feature half (row a13): chain-code features; oracle restates the OpenCV primitives ("parity unpinned") ----
+def test_oracle_chain_bitmaps_rectangle(oracle):
+    """cv::findContours traces an outer border starting at its top-left pixel and going DOWN first."""
+    img = np.zeros((30, 30), np.uint8)
+    img[5:12, 8:20] = 255
+    m = oracle.chain_bitmaps(img)
+    assert [int((m[d] > 0).sum()) for d in range(8)] == [11, 0, 6, 0, 11, 0, 6, 0]
+    assert (m[6][5:11, 8] == 255).all() and (m[4][11, 8:19] == 255).all()      # left edge: next point below; bottom: next to the right
+    assert (m[2][6:12, 19] == 255).all() and (m[0][5, 9:20] == 255).all()      # right edge: next above; top: next to the left
+    one = np.zeros((30, 30), np.uint8)
+    one[3, 3] = 255
+    assert oracle.chain_bitmaps(one).sum() == 0                                  # one-point contours are skipped (src/OCR.cpp:160)
+    ring = np.zeros((30, 30), np.uint8)
+    ring[4:20, 4:20] = 255
+    ring[8:16, 8:16] = 0
+    m = oracle.chain_bitmaps(ring)
+    assert (m > 0).sum() == 60 + 32          # outer border 60 px + hole border 32 px (8-connected: it cuts the hole's corners)
+    assert [int((m[d] > 0).sum()) for d in (1, 3, 5, 7)] == [1, 1, 1, 1]      # the four diagonal steps of the hole border
+
+
+def test_oracle_otsu(oracle):
+    img = np.concatenate([np.full(500, 40, np.uint8), np.full(300, 200, np.uint8)]).reshape(20, 40)
+    t = oracle.otsu(img)
+    assert 40 <= t < 200
+    assert oracle.otsu(img, invert=True) == 255 - 200 or 55 <= oracle.otsu(img, invert=True) < 215
+
+
+@pytest.mark.gpu
+def test_gpu_chain_features_match_oracle(erf, oracle, S):
+    img = S.synth.gray(S.synth.stext_bgr(S.synth.frame_seed(4), 640, 480))
+    res = erf.detect_planes(img)
+    boxes = np.stack([res.cands["x"], res.cands["y"], res.cands["w"], res.cands["h"]], axis=1).astype(np.int32)
+    rng = np.random.default_rng(3)
+    extra = []
+    for _ in range(60):
+        bw, bh = int(rng.integers(2, 200)), int(rng.integers(2, 200))
+        extra.append((int(rng.integers(0, 640 - bw)), int(rng.integers(0, 480 - bh)), bw, bh))
+    boxes = np.concatenate([boxes, np.array(extra + [(0, 0, 60, 60), (5, 5, 1, 1), (0, 0, 640, 480)], np.int32)])
+    q = erf.chain_run(img, boxes, classify=False)
+    for b, row in zip(boxes, q):
+        exp = oracle.chain_features(img[b[1]:b[1] + b[3], b[0]:b[0] + b[2]])
+        assert (row == exp).all(), b
+    assert (q > 0).any()
+
+
+@pytest.mark.gpu
+def test_gpu_chain_run_end_to_end(erf, oracle, S, model_path):
+    """chain_run = features + svm_predict_probability; compared with oracle features fed to the oracle SVM."""
+    from oracle.oracle import OracleSVM
+    erf.load_svm_model(model_path, 1800)
+    m = OracleSVM(oracle, model_path)
+    img = S.synth.gray(S.synth.stext_bgr(S.synth.frame_seed(6), 640, 480))
+    res = erf.detect_planes(img)
+    c = res.cands[res.cands["cls"] > 0]
+    boxes = np.stack([c["x"], c["y"], c["w"], c["h"]], axis=1).astype(np.int32)
+    assert len(boxes) > 0
+    q, label, prob = erf.chain_run(img, boxes)
+    for i, b in enumerate(boxes):
+        l, p, _ = m.predict_probability(q[i] / 255.0)
+        assert abs(prob[i] - p[np.argmax(p)]) < TOL
+        top2 = np.sort(p)[-2:]
+        if top2[1] - top2[0] > 10 * TOL:
+            assert label[i] == l
