@@ -1843,7 +1843,7 @@ void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, Casc
 //   Otsu threshold of 255 - roi  ->  ARAN(30) of the binarised image  ->  extract_feature
 //   (src/OCR.cpp:144-218): border following, 8 direction bitmaps, 7x7 Gaussian (8-bit fixed point),
 //   min-max normalisation, 2x2 area decimation  ->  q[1800] (feature = q / 255.0).
-// Follows oracle/er_oracle.c (ero_chain_features), which restates the OpenCV primitives involved.
+// The OpenCV primitives involved (Otsu, findContours, GaussianBlur, normalize) are restated from OpenCV 4.x.
 // ------------------------------------------------------------------------------------
 struct ChainShared {
     uint32_t    hist[256];
