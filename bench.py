@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
     ap.add_argument("--kind", choices=["text", "noise"], default="text")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ocr", action="store_true",
+                    help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
+                         "(synthetic stand-in for the missing classifier/OCR.model: tests/golden/ocr_synth.model.gz)")
     ap.add_argument("--pipelines", type=int, default=2,
                     help="independent batches in flight per GPU (each has its own context, stream and workspace)")
     args = ap.parse_args()
@@ -148,7 +151,11 @@ def main():
                                        channel_mask=cfg["channel_mask"], device=dev_index))
         f.load_cascade(0, cascades[0])
         f.load_cascade(1, cascades[1])
+        if args.ocr:
+            import gzip
+            f.load_svm_model_text(gzip.open(os.path.join(ROOT, "tests", "golden", "ocr_synth.model.gz")).read(), 1800)
         filters.append(f)
+    stages = S.STAGE_ALL | (S.STAGE_OCR if args.ocr else 0)
 
     # synthetic frames of this rank's shard: global frame index = rank*F + i
     n_distinct = min(F, 4)
@@ -170,7 +177,7 @@ def main():
         def worker(p):
             torch.cuda.set_device(dev_index)
             for i in range(p, n_batches, P):
-                results[i] = filters[p].detect_bgr_device(d_frames.data_ptr(), W, H, F)
+                results[i] = filters[p].detect_bgr_device(d_frames.data_ptr(), W, H, F, stages)
                 done[i].set()
 
         threads = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
@@ -211,7 +218,7 @@ def main():
     if P > 1:
         n_cal = 3
         for _ in range(n_cal):
-            rc = filters[0].detect_bgr_device(d_frames.data_ptr(), W, H, F)
+            rc = filters[0].detect_bgr_device(d_frames.data_ptr(), W, H, F, stages)
             for k, v in rc.profile.items():
                 serial_prof[k] = serial_prof.get(k, 0.0) + v / n_cal
     else:
@@ -244,7 +251,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg['label']}; S-{args.kind} frames", "frames_per_gpu_per_step": F,
+            "config": {"workload": f"{args.workload}: {cfg['label']}; S-{args.kind} frames" +
+                                   ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr else ""),
+                       "frames_per_gpu_per_step": F,
                        "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
                        "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P},

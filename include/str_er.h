@@ -51,6 +51,7 @@ extern "C" {
 #define STR_ER_STAGE_NMS      2u   /* non_maximum_supression   src/ER.cpp:416-505 */
 #define STR_ER_STAGE_CLASSIFY 4u   /* classify                 src/ER.cpp:507-528 */
 #define STR_ER_STAGE_ALL      7u
+#define STR_ER_STAGE_OCR      8u   /* config 3: OCR::chain_run (slope 0) on every strong/weak ER; needs an SVM model */
 /* output options */
 #define STR_ER_WANT_NODES     16u  /* also return the kept-node table of every plane */
 
@@ -238,6 +239,11 @@ const str_er_plane_info *str_er_result_plane_infos(const str_er_result *r, int32
 const str_er_cand *str_er_result_cands(const str_er_result *r, int32_t *n);
 /* Candidates of one plane (a slice of the array above). */
 const str_er_cand *str_er_result_plane_cands(const str_er_result *r, int32_t plane, int32_t *n);
+/* With STR_ER_STAGE_OCR: per candidate of str_er_result_cands(), the class label chosen by
+ * svm_predict_probability and its probability (what OCR::chain_run returns as table[label] + prob,
+ * src/OCR.cpp:139); label -1 / prob 0 for candidates that are neither strong nor weak.  NULL otherwise. */
+const int32_t *str_er_result_ocr_labels(const str_er_result *r, int32_t *n);
+const double  *str_er_result_ocr_probs(const str_er_result *r, int32_t *n);
 /* Kept-node table of one plane, ascending (key, level); NULL unless STR_ER_WANT_NODES. */
 const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n);
 /* times[7] = {extract, nms, classify, track, group, ocr, total} seconds, the contract of

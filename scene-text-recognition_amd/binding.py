@@ -17,7 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, WANT_NODES = 1, 2, 4, 7, 16
+STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES = 1, 2, 4, 7, 8, 16
 CLS_POOL, CLS_STRONG, CLS_WEAK = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -132,6 +132,10 @@ def load_library():
     L.str_er_result_plane_cands.restype = vp
     L.str_er_result_plane_nodes.argtypes = [vp, C.c_int32, i32p]
     L.str_er_result_plane_nodes.restype = vp
+    L.str_er_result_ocr_labels.argtypes = [vp, i32p]
+    L.str_er_result_ocr_labels.restype = vp
+    L.str_er_result_ocr_probs.argtypes = [vp, i32p]
+    L.str_er_result_ocr_probs.restype = vp
     L.str_er_result_times.argtypes = [vp]
     L.str_er_result_times.restype = f64p
     L.str_er_result_cands_to_device.argtypes = [vp, vp, vp, C.c_int32, i32p]
@@ -182,6 +186,8 @@ class Result:
 
     def __init__(self, info: np.ndarray, cands: np.ndarray, times: np.ndarray, profile: dict, nodes=None):
         self.info, self.cands, self.times, self.profile, self._nodes = info, cands, times, profile, nodes
+        self.ocr_label = None      # with STAGE_OCR: per candidate, -1 for cls == 0
+        self.ocr_prob = None
         self._planes = None
 
     @property
@@ -288,7 +294,14 @@ class ERFilter:
                                  if nn.value else np.zeros(0, NODE_DTYPE))
             t = L.str_er_result_times(rh)
             times = np.array([t[i] for i in range(7)])
-            return Result(info, cands, times, self.last_profile(), nodes)
+            res = Result(info, cands, times, self.last_profile(), nodes)
+            no = C.c_int32()
+            lp = L.str_er_result_ocr_labels(rh, C.byref(no))
+            if lp and no.value:
+                res.ocr_label = np.frombuffer((C.c_char * (4 * no.value)).from_address(lp), dtype=np.int32).copy()
+                pp = L.str_er_result_ocr_probs(rh, C.byref(no))
+                res.ocr_prob = np.frombuffer((C.c_char * (8 * no.value)).from_address(pp), dtype=np.float64).copy()
+            return res
         finally:
             L.str_er_result_free(rh)
 

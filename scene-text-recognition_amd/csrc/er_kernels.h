@@ -73,4 +73,8 @@ void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, Casc
 void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
                            double *x_out, int xdim);
 
+// Batch form: list the strong/weak candidates (n = their number, known on the host from the plane counters) and
+// extract their chain-code features straight from the device planes into x_out [n x xdim] (f64, q/255).
+void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out, int n, double *x_out, int xdim);
+
 } // namespace str_er

@@ -1887,14 +1887,25 @@ __device__ __forceinline__ int resize_px_bin(const ResizeGeom &g, const uint8_t 
 
 __device__ __forceinline__ int reflect101_30(int i) { return i < 0 ? -i : (i >= 30 ? 58 - i : i); }
 
+// Box source: either explicit boxes on one plane (single-stage API), or the batch's classified
+// candidates: ocr_list[i] = index into cands[], whose plane says which channel / pyramid level / polarity.
 __global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restrict__ plane, int stride, int inv,
                                                         const int32_t *__restrict__ boxes, int n, uint8_t *__restrict__ q_out,
-                                                        double *__restrict__ x_out, int xdim)
+                                                        double *__restrict__ x_out, int xdim, const CandRec *__restrict__ cands,
+                                                        const uint32_t *__restrict__ ocr_list, const PlaneDesc *__restrict__ planes)
 {
     __shared__ ChainShared sh;
     const int tid = threadIdx.x;
     for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-        const int bx = boxes[4 * bi], by = boxes[4 * bi + 1], bw = boxes[4 * bi + 2], bh = boxes[4 * bi + 3];
+        int bx, by, bw, bh;
+        if (cands) {
+            const CandRec   &cd = cands[ocr_list[bi]];
+            const PlaneDesc &pd = planes[cd.plane];
+            bx = cd.x; by = cd.y; bw = cd.w; bh = cd.h;
+            plane = pd.pix; stride = pd.stride; inv = pd.invert;
+        } else {
+            bx = boxes[4 * bi]; by = boxes[4 * bi + 1]; bw = boxes[4 * bi + 2]; bh = boxes[4 * bi + 3];
+        }
         const uint8_t *roi = plane + (size_t)by * stride + bx;
         // ---- Otsu (getThreshVal_Otsu_8u) on 255 - roi
         sh.hist[tid] = 0;
@@ -2038,7 +2049,41 @@ void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int 
                            double *x_out, int xdim)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, plane, stride, inv, boxes, n, q_out, x_out, xdim);
+    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, plane, stride, inv, boxes, n, q_out, x_out, xdim,
+                       (const CandRec *)nullptr, (const uint32_t *)nullptr, (const PlaneDesc *)nullptr);
+}
+
+// indices of the strong / weak candidates of the batch, in candidate order (deterministic)
+__global__ __launch_bounds__(1024) void k_ocr_list(BatchDev b, uint32_t *__restrict__ list, uint32_t *__restrict__ n_out)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    const uint32_t total = *b.total_cands;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = (i < total && b.cands[i].cls != 0) ? 1u : 0u;
+        const uint32_t incl = wave_incl_scan(v);
+        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+        if (v) list[off + incl - 1] = i;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = s_carry;
+}
+
+void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out, int n, double *x_out, int xdim)
+{
+    hipLaunchKernelGGL(k_ocr_list, dim3(1), dim3(1024), 0, s, b, list, n_out);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, (const uint8_t *)nullptr, 0, 0, (const int32_t *)nullptr, n,
+                       (uint8_t *)nullptr, x_out, xdim, (const CandRec *)b.cands, (const uint32_t *)list, b.planes);
 }
 
 } // namespace str_er

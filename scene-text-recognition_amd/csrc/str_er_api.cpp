@@ -54,6 +54,9 @@ struct str_er_result {
     std::vector<uint32_t> cand_off;          // n_planes + 1
     std::vector<std::vector<str_er_node>> nodes;
     bool have_nodes = false;
+    std::vector<int32_t> ocr_label;
+    std::vector<double> ocr_prob;
+    bool have_ocr = false;
     double times[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -349,6 +352,9 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if (!(stages & STR_ER_STAGE_EXTRACT)) return fail(c, STR_ER_EINVAL, "stages must include STR_ER_STAGE_EXTRACT");
     if ((stages & STR_ER_STAGE_CLASSIFY) && !(stages & STR_ER_STAGE_NMS))
         return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_CLASSIFY needs STR_ER_STAGE_NMS");
+    if ((stages & STR_ER_STAGE_OCR) && !(stages & STR_ER_STAGE_CLASSIFY)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_OCR needs STR_ER_STAGE_CLASSIFY");
+    if ((stages & STR_ER_STAGE_OCR) && !(c->svm_loaded && c->svm.dim == 1800))
+        return fail(c, STR_ER_ESTATE, "STR_ER_STAGE_OCR needs an SVM model loaded with dim = 1800 (str_er_load_svm_model)");
 
     const DetectParams dp = make_dp(c);
     hipStream_t s = c->stream;
@@ -431,6 +437,50 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         if (hipMemcpyAsync(r->cands.data(), c->d_cands, sizeof(CandRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
             delete r; return fail(c, STR_ER_EHIP, "candidate copy failed");
         }
+    if ((stages & STR_ER_STAGE_OCR) && total) {
+        // second phase: the host now knows how many strong/weak ERs there are
+        size_t n_ocr = 0;
+        for (int i = 0; i < np; ++i) n_ocr += c->h_ctr[i].n_strong + c->h_ctr[i].n_weak;
+        r->ocr_label.assign(total, -1);
+        r->ocr_prob.assign(total, 0.0);
+        r->have_ocr = true;
+        if (n_ocr) {
+            const SvmDev &m = c->svm;
+            const size_t n_pad = align_up(n_ocr, 64), npairs = (size_t)m.k * (m.k - 1) / 2;
+            size_t off = 0;
+            auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+            const size_t o_list = take(4 * (size_t)total + 64), o_x = take(n_ocr * 1800 * 8), o_xf = take(n_pad * m.dpad * 4 + 256), o_xn = take(n_pad * 8),
+                         o_kv = take(n_pad * m.l_pad * 8), o_dec = take(n_ocr * npairs * 8), o_prob = take(n_ocr * m.k * 8), o_lab = take(n_ocr * 4);
+            int rc2 = ensure_scratch(c, off);
+            if (rc2 != STR_ER_OK) { delete r; return rc2; }
+            uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+            uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
+            launch_ocr_features(s, bd, d_list + 16, d_list, (int)n_ocr, reinterpret_cast<double *>(sc + o_x), 1800);
+            hipError_t e = hipMemsetAsync(sc + o_xf, 0, n_pad * m.dpad * 4 + 256, s);
+            if (e == hipSuccess) e = hipMemsetAsync(sc + o_xn, 0, n_pad * 8, s);
+            launch_svm_predict(s, reinterpret_cast<const double *>(sc + o_x), (int)n_ocr, 1800, reinterpret_cast<float *>(sc + o_xf),
+                               reinterpret_cast<double *>(sc + o_xn), (int)n_pad, reinterpret_cast<double *>(sc + o_kv),
+                               reinterpret_cast<double *>(sc + o_dec), reinterpret_cast<double *>(sc + o_prob),
+                               reinterpret_cast<int32_t *>(sc + o_lab), m);
+            std::vector<uint32_t> list(n_ocr);
+            std::vector<int32_t> lab(n_ocr), mlab(m.k);
+            std::vector<double> pall(n_ocr * m.k);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(list.data(), d_list + 16, 4 * n_ocr, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), sc + o_lab, 4 * n_ocr, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(pall.data(), sc + o_prob, 8 * pall.size(), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(mlab.data(), m.label, 4 * (size_t)m.k, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, std::string("OCR stage: ") + hipGetErrorString(e)); }
+            for (size_t i = 0; i < n_ocr; ++i) {
+                if (list[i] >= total) continue;
+                int idx = -1;
+                for (int k = 0; k < m.k; ++k) if (mlab[k] == lab[i]) { idx = k; break; }
+                r->ocr_label[list[i]] = lab[i];
+                r->ocr_prob[list[i]] = idx >= 0 ? pall[i * m.k + idx] : 0.0;
+            }
+        }
+    }
     const bool want_nodes = (stages & STR_ER_WANT_NODES) != 0;
     if (want_nodes) {
         r->nodes.resize(np);
@@ -1207,6 +1257,20 @@ const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t pla
     if (!r || !r->have_nodes || plane < 0 || plane >= (int32_t)r->planes.size()) { if (n) *n = 0; return nullptr; }
     if (n) *n = (int32_t)r->nodes[plane].size();
     return r->nodes[plane].data();
+}
+
+const int32_t *str_er_result_ocr_labels(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_ocr) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->ocr_label.size();
+    return r->ocr_label.data();
+}
+
+const double *str_er_result_ocr_probs(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_ocr) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->ocr_prob.size();
+    return r->ocr_prob.data();
 }
 
 const double *str_er_result_times(const str_er_result *r) { return r ? r->times : nullptr; }

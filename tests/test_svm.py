@@ -169,3 +169,37 @@ def test_gpu_chain_run_end_to_end(erf, oracle, S, model_path):
         top2 = np.sort(p)[-2:]
         if top2[1] - top2[0] > 10 * TOL:
             assert label[i] == l
+
+
+@pytest.mark.gpu
+def test_gpu_config3_full_pipeline(S, cascade_paths, oracle, oracle_cascades, model_path):
+    """BASELINE configs[2]: frames -> ER extract -> 2-stage classify -> chain-code + SVM on every strong/weak ER,
+    all planes (inverted ones included) in one call; OCR outputs checked against the oracle per candidate."""
+    from oracle.oracle import OracleSVM
+    f = S.ERFilter(params=S.Params(max_width=640, max_height=480, max_frames=2))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    f.load_svm_model(model_path, 1800)
+    m = OracleSVM(oracle, model_path)
+    frames = S.synth.frames_bgr("text", 20, 2, 640, 480)
+    a = np.ascontiguousarray(frames)
+    import ctypes as C
+    rh = C.c_void_p()
+    f._check(f.L.str_er_detect_bgr(f.h, a.ctypes.data, 640, 480, 3 * 640, 3 * 640 * 480, 2, 0, S.STAGE_ALL | S.STAGE_OCR, C.byref(rh)))
+    res = f._collect(rh)
+    assert res.ocr_label is not None and len(res.ocr_label) == len(res.cands)
+    planes = [oracle.compute_channels(fr) for fr in frames]
+    n_checked = 0
+    for i, c in enumerate(res.cands):
+        if c["cls"] == 0:
+            assert res.ocr_label[i] == -1 and res.ocr_prob[i] == 0
+            continue
+        img = planes[int(c["frame"])][int(c["ch"])]
+        q = oracle.chain_features(img[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]])
+        l, p, _ = m.predict_probability(q / 255.0)
+        assert abs(res.ocr_prob[i] - p.max()) < TOL
+        top2 = np.sort(p)[-2:]
+        if top2[1] - top2[0] > 10 * TOL:
+            assert res.ocr_label[i] == l
+        n_checked += 1
+    assert n_checked > 10
+    f.close()
