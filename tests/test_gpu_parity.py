@@ -380,3 +380,18 @@ def test_random_small_planes_many(erf, oracle, oracle_cascades):
                 check_plane_against_oracle(oracle, p, img, oracle_cascades, min_area=10)
     finally:
         erf.set_min_area(120)
+
+
+def test_natural_image_crops(erf, oracle, oracle_cascades):
+    """Crops of the reference's sample photographs (tests/golden/icdar_crops.npz): all six planes of each."""
+    z = np.load(os.path.join(GOLDEN, "icdar_crops.npz"))
+    n_amb = 0
+    for name in sorted(z.files):
+        frame = np.ascontiguousarray(z[name])
+        res = erf.text_detect(frame, want_nodes=True)
+        planes = oracle.compute_channels(frame)
+        assert (erf.compute_channels(frame) == planes).all()
+        for p in res.planes:
+            check_plane_against_oracle(oracle, p, planes[p.ch], oracle_cascades)
+            n_amb += p.ambiguous
+    print("ambiguous NMS nodes on natural crops:", n_amb)
