@@ -203,26 +203,59 @@ __device__ __forceinline__ int resize_px(const ResizeGeom &g, const uint8_t *__r
     return min(max(v, 0), 255);
 }
 
-// Pyramid level: every lane produces 4 consecutive output pixels (one dword store); the
-// geometry (mode, scales) is computed once on the host with the same IEEE operations.
+// Pyramid level: every lane owns 4 consecutive output columns of RESIZE_ROWS consecutive rows: the
+// column coefficients (the expensive f64/f32 part of cv::resize's tables) are computed once per lane
+// and reused for all rows; one dword store per row.  The geometry is computed once on the host.
+constexpr int RESIZE_ROWS = 8;
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride, int64_t splane_pitch,
                                                 int64_t sframe_pitch, uint8_t *__restrict__ dst, int dstride,
                                                 int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame,
                                                 ResizeGeom g)
 {
     const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int dy = blockIdx.y;
+    const int dy0 = blockIdx.y * RESIZE_ROWS;
     if (dx0 >= g.dw) return;
     const int f = blockIdx.z / planes_per_frame, c = blockIdx.z % planes_per_frame;
     const uint8_t *s = src + (size_t)f * sframe_pitch + (size_t)c * splane_pitch;
-    uint8_t       *d = dst + (size_t)f * dframe_pitch + (size_t)c * dplane_pitch + (size_t)dy * dstride + dx0;
-    if (dx0 + 4 <= g.dw && (dstride & 3) == 0) {
+    uint8_t       *d = dst + (size_t)f * dframe_pitch + (size_t)c * dplane_pitch;
+    if (g.mode != 2) {      // copy / exact 2x2: no tables
+        for (int r = 0; r < RESIZE_ROWS && dy0 + r < g.dh; ++r)
+            for (int k = 0; k < 4 && dx0 + k < g.dw; ++k)
+                d[(size_t)(dy0 + r) * dstride + dx0 + k] = (uint8_t)resize_px(g, s, sstride, 0, dx0 + k, dy0 + r);
+        return;
+    }
+    int sx[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float fx = (float)((dx0 + k + 0.5) * g.scale_x - 0.5);
+        int   x = (int)floorf(fx);
+        fx -= (float)x;
+        if (x < 0) { fx = 0.f; x = 0; }
+        if (x >= g.sw - 1) { fx = 0.f; x = g.sw - 1; }
+        sx[k] = x; sx1[k] = (x + 1 < g.sw) ? x + 1 : x;
+        a0[k] = __float2int_rn((1.f - fx) * 2048.f); a1[k] = __float2int_rn(fx * 2048.f);
+    }
+    const bool full = dx0 + 4 <= g.dw && (dstride & 3) == 0;
+    for (int r = 0; r < RESIZE_ROWS; ++r) {
+        const int dy = dy0 + r;
+        if (dy >= g.dh) break;
+        float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+        int   sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+        const uint8_t *p0 = s + (size_t)min(max(sy, 0), g.sh - 1) * sstride, *p1 = s + (size_t)min(max(sy + 1, 0), g.sh - 1) * sstride;
         uint32_t v = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v |= (uint32_t)resize_px(g, s, sstride, 0, dx0 + k, dy) << (8 * k);
-        *reinterpret_cast<uint32_t *>(d) = v;
-    } else {
-        for (int k = 0; k < 4 && dx0 + k < g.dw; ++k) d[k] = (uint8_t)resize_px(g, s, sstride, 0, dx0 + k, dy);
+        for (int k = 0; k < 4; ++k) {
+            const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
+            const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
+            const int o = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+            v |= (uint32_t)o << (8 * k);
+        }
+        uint8_t *o = d + (size_t)dy * dstride + dx0;
+        if (full) *reinterpret_cast<uint32_t *>(o) = v;
+        else for (int k = 0; k < 4 && dx0 + k < g.dw; ++k) o[k] = (uint8_t)(v >> (8 * k));
     }
 }
 
@@ -244,7 +277,7 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                    int64_t dframe_pitch, int planes_per_frame, int n_frames)
 {
     const int quads = (dw + 3) / 4;
-    dim3 grid((quads + 255) / 256, dh, planes_per_frame * n_frames);
+    dim3 grid((quads + 255) / 256, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, planes_per_frame * n_frames);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, sstride, splane_pitch, sframe_pitch, dst, dstride,
                        dplane_pitch, dframe_pitch, planes_per_frame, host_resize_geom(sw, sh, dw, dh));
 }
