@@ -599,14 +599,22 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         // closed node adds its totals to its parent here in LDS and is exported only if the
         // reference would keep it (area > MIN_AREA); the thousands of small speckle nodes never
         // reach global memory, yet they are counted (ER::area includes the node count).
-        uint32_t           *s_w0 = s_work;                                   // [FOLD_CAP]
-        uint32_t           *s_row = s_work + FOLD_CAP;                       // [FOLD_CAP]
-        unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * FOLD_CAP); // [FOLD_CAP]
+        // The three arrays are packed for the tile's own node count n (not FOLD_CAP): what is left
+        // of s_work behind them holds the export list further down.
+        const uint32_t      n_even = (total_all + 1u) & ~1u;
+        uint32_t           *s_w0 = s_work;                                   // [n_even]
+        uint32_t           *s_row = s_work + n_even;                         // [n_even]
+        unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * n_even); // [n_even]
+        uint32_t           *s_exp = s_work + 4 * n_even;                     // [4 * (FOLD_CAP - n_even)]
         for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
         __syncthreads();
         {
-            uint32_t cur = NONE, cnt = 0;
+            // the lane's pixels form runs with a common node: one set of atomics per run.  The run
+            // that holds the node's level root also carries the node itself (+1 in bits 12..), a run
+            // with a pixel on a seam carries the open bit (OR-ed separately: an add could carry).
+            uint32_t cur = NONE, cnt = 0, open = 0;
             unsigned long long col = 0;
+            const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
 #pragma unroll
             for (int k = 0; k <= TILE_PPT; ++k) {
                 uint32_t id = NONE;
@@ -620,31 +628,20 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                         atomicAdd(&s_w0[cur], cnt);
                         atomicOr(&s_row[cur], 1u << ly);
                         atomicOr(&s_col[cur], col);
+                        if (open) atomicOr(&s_w0[cur], 0x80000000u);
                     }
-                    cur = id; cnt = 0; col = 0;
+                    cur = id; cnt = 0; col = 0; open = 0;
                 }
-                if (id != NONE) { ++cnt; col |= 1ull << (lx + k); }
+                if (id != NONE) {
+                    const int xx = lx + k;
+                    cnt += 1u + (((rootmask >> k) & 1u) << 12);
+                    col |= 1ull << xx;
+                    open |= (uint32_t)(top || bot || (xx == 0 && tx > 0) || (xx == TILE_W - 1 && tx + 1 < pd.tiles_x));
+                }
             }
         }
-        // (open bits are OR-ed separately: an add could carry)
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            if (lev[k] == WALL) continue;
-            const int  xx = lx + k;
-            const bool on_seam = (ly == 0 && ty > 0) || (ly == TILE_H - 1 && ty + 1 < pd.tiles_y) ||
-                                 (xx == 0 && tx > 0) || (xx == TILE_W - 1 && tx + 1 < pd.tiles_x);
-            if (!on_seam) continue;
-            const uint32_t p = p0 + k;
-            const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
-            atomicOr(&s_w0[s_nid[LX(r)]], 0x80000000u);
-        }
-        {
-            uint32_t id = aid0;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k)
-                if ((rootmask >> k) & 1) atomicAdd(&s_w0[id++], 1u << 12);     // the node itself
-        }
         __syncthreads();
+        PHASE_MARK(5);
         // bottom-up over the levels present in the tile: children are at lower levels than parents
         const uint32_t lmin = s_lmin, lmax = s_lmax;
         for (uint32_t t = lmin; t <= lmax && lmin != 0xFFFFFFFFu; ++t) {
@@ -667,6 +664,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             }
             __syncthreads();
         }
+        PHASE_MARK(7);
         // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
         // node of the flood's start pixel
         uint32_t expmask = 0, openmask = 0;
@@ -685,46 +683,64 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         }
         const uint32_t eid0 = block_excl_scan(__popc(expmask), s_wsum, &total);
         // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
+        // One exported node: everything it needs is in LDS except its own level and whether it is open.
+        auto export_node = [&](uint32_t p, uint32_t a, uint32_t l, bool open) {
+            const size_t id = nb + base + s_nid[LX(p)];
+            uint32_t     q = s_par[LX(p)], ql = 0;
+            if (q != NONE) { ql = (q >> 16) & 0xFFu; q &= 0xFFFFu; }
+            while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
+                const uint32_t w2 = s_par[LX(q)];
+                if (w2 == NONE) q = NONE;
+                else { ql = (w2 >> 16) & 0xFFu; q = w2 & 0xFFFFu; }
+            }
+            const uint32_t v = s_w0[a];
+            b.na.par[id] = (q == NONE) ? NONE : PAR_MAKE(ql, base + s_nid[LX(q)]);
+            b.na.lvl[id] = (uint8_t)l;
+            b.na.dead[id] = open ? 0 : 2;                    // 2 = closed: totals are final
+            b.na.cnt[id] = v & 0xFFFu;
+            b.na.nod[id] = (v >> 12) & 0xFFFu;
+            const unsigned long long cm = s_col[a];
+            const uint32_t           rm = s_row[a];
+            b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
+            b.na.x1[id] = ox + 63 - __clzll((long long)cm);
+            b.na.y0[id] = oy + __ffs((int)rm) - 1;
+            b.na.y1[id] = oy + 31 - __clz((int)rm);
+            b.na.key[id] = (uint32_t)((oy + (int)(p >> 6)) * pd.w + ox + (int)(p & 63u));
+        };
+        // The exported nodes are listed behind the statistics (p | a << 11 | level << 21 | open << 31)
+        // and written out one per lane; a tile too full for the list writes them from the owners.
+        const bool listed = 4u * n_even + total <= 4u * (uint32_t)FOLD_CAP;
         {
-            uint32_t id = eid0;
+            uint32_t id = eid0, aid = aid0, lo = 0xFFFFFFFFu, hi = 0;
 #pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k)
-                if ((rootmask >> k) & 1) s_nid[OWN(k)] = ((expmask >> k) & 1) ? (uint16_t)id++ : (uint16_t)0xFFFFu;
+            for (int k = 0; k < TILE_PPT; ++k) {
+                if (!((rootmask >> k) & 1)) continue;
+                const uint32_t a = aid++;
+                if ((expmask >> k) & 1) {
+                    const uint32_t open = (openmask >> k) & 1u;
+                    if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
+                    if (listed) s_exp[id] = (p0 + k) | (a << 11) | (lev[k] << 21) | (open << 31);
+                    s_nid[OWN(k)] = (uint16_t)id++;
+                } else {
+                    s_nid[OWN(k)] = (uint16_t)0xFFFFu;
+                }
+            }
+            if (lo != 0xFFFFFFFFu) { atomicMin(&s_lmin2, lo); atomicMax(&s_lmax2, hi); }
         }
         __syncthreads();
-        {
-            uint32_t aid = aid0, lo = 0xFFFFFFFFu, hi = 0;
+        if (listed) {
+            for (uint32_t e = tid; e < total; e += TILE_THREADS) {
+                const uint32_t w = s_exp[e];
+                export_node(w & 0x7FFu, (w >> 11) & 0x3FFu, (w >> 21) & 0x3FFu, (w >> 31) != 0);
+            }
+        } else {
+            uint32_t aid = aid0;
 #pragma unroll 1
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (!((rootmask >> k) & 1)) continue;
                 const uint32_t a = aid++;
-                if (!((expmask >> k) & 1)) continue;
-                const uint32_t p = p0 + k;
-                const size_t   id = nb + base + s_nid[LX(p)];
-                uint32_t       q = s_par[LX(p)], ql = 0;
-                if (q != NONE) { ql = (q >> 16) & 0xFFu; q &= 0xFFFFu; }
-                while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
-                    const uint32_t w2 = s_par[LX(q)];
-                    if (w2 == NONE) q = NONE;
-                    else { ql = (w2 >> 16) & 0xFFu; q = w2 & 0xFFFFu; }
-                }
-                const uint32_t v = s_w0[a];
-                const bool     open = (openmask >> k) & 1;
-                if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
-                b.na.par[id] = (q == NONE) ? NONE : PAR_MAKE(ql, base + s_nid[LX(q)]);
-                b.na.lvl[id] = (uint8_t)lev[k];
-                b.na.dead[id] = open ? 0 : 2;                    // 2 = closed: totals are final
-                b.na.cnt[id] = v & 0xFFFu;
-                b.na.nod[id] = (v >> 12) & 0xFFFu;
-                const unsigned long long cm = s_col[a];
-                const uint32_t           rm = s_row[a];
-                b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
-                b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-                b.na.y0[id] = oy + __ffs((int)rm) - 1;
-                b.na.y1[id] = oy + 31 - __clz((int)rm);
-                b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+                if ((expmask >> k) & 1) export_node(p0 + k, a, lev[k], (openmask >> k) & 1);
             }
-            if (lo != 0xFFFFFFFFu) { atomicMin(&s_lmin2, lo); atomicMax(&s_lmax2, hi); }
         }
     } else {
         // ---- dense tile (more than FOLD_CAP nodes): export every node with its own statistics,
