@@ -210,13 +210,20 @@ int str_er_svm_predict_probability(str_er_ctx *ctx, const double *x, int32_t n, 
                                    double *dec);
 
 /* OCR::chain_run(Mat src, int thresh, double slope) (src/OCR.cpp:67-140) for n boxes (ER::bound) of one host
- * plane (the channel the ER came from), with slope == 0 (the rotation of :73-78 for |slope| > 0.01 is not
- * built): Otsu-binarise 255-roi, ARAN(30), chain-code features (src/OCR.cpp:144-218), then
+ * plane (the channel the ER came from), with slope == 0: Otsu-binarise 255-roi, ARAN(30), chain-code
+ * features (src/OCR.cpp:144-218), then
  * svm_predict_probability.  label[i] = class label, prob[i] = pv[label] (chain_run returns
  * table[label] + prob); q_out (optional) receives the 1800 feature bytes of every box (value = q/255);
  * label/prob may be NULL to get the features only (no SVM model needed then).                        */
 int str_er_ocr_chain_run(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes_xywh,
                          int32_t n, int32_t *label, double *prob, uint8_t *q_out);
+
+/* The same with the text line's slope per box (Text::slope, src/ER.cpp:731): where |slope[i]| > 0.01 the
+ * binarised ROI goes through OCR::rotate_mat(atan2(slope, 1), crop = true) (src/OCR.cpp:73-78, 254-357)
+ * before ARAN.  slope == NULL means all zero.  A non-finite slope is STR_ER_EINVAL.                   */
+int str_er_ocr_chain_run_slope(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h, int64_t stride,
+                               const int32_t *boxes_xywh, const double *slope, int32_t n, int32_t *label, double *prob,
+                               uint8_t *q_out);
 
 /* ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a caller-supplied kept tree
  * (parent indices; root points to itself or -1).  pool_idx receives up to cap node

@@ -793,7 +793,7 @@ void ero_classify(const uint8_t *plane, int stride, const int32_t *boxes, int n,
 }
 
 /* ======================================================================== */
-/* OCR scorer, feature half (src/OCR.cpp:67-218), slope == 0 -- unpinned     */
+/* OCR scorer, feature half (src/OCR.cpp:67-218, 254-357) -- unpinned        */
 /* ======================================================================== */
 
 /* cv::threshold(..., THRESH_OTSU): getThreshVal_Otsu_8u of OpenCV 4.x (imgproc/thresh.cpp).
@@ -847,6 +847,87 @@ void ero_ocr_normalise(const uint8_t *roi, int stride, int w, int h, uint8_t img
         }
     }
     free(bin);
+}
+
+/* OCR::rotate_mat (src/OCR.cpp:254-357): rotate about ((cols-1)/2, (rows-1)/2) by rad with a
+ * hand-written bilinear tap; with `crop` the rows that would show the slanted top/bottom edges are
+ * cut (crop_height may be negative for rad < 0, which grows the canvas instead -- kept).  The last
+ * row/column of the canvas are never written (loops are exclusive), nor is the first row when
+ * cropping.  *dst is malloc'ed (dw x dh, tight); returns 0.                                      */
+int ero_rotate_mat(const uint8_t *src, int w, int h, double rad, int crop, uint8_t **dst, int *dw, int *dh)
+{
+    const int x0 = (int)((w - 1) / 2.0), y0 = (int)((h - 1) / 2.0);
+    const int cx[4] = {0 - x0, (w - 1) - x0, (w - 1) - x0, 0 - x0};
+    const int cy[4] = {0 - y0, 0 - y0, (h - 1) - y0, (h - 1) - y0};
+    int nx[4], ny[4];
+    for (int k = 0; k < 4; ++k) {
+        nx[k] = (int)round(cx[k] * cos(rad) - cy[k] * sin(rad));
+        ny[k] = (int)round(cx[k] * sin(rad) + cy[k] * cos(rad));
+    }
+    int max_x = nx[0], max_y = ny[0], min_x = nx[0], min_y = ny[0];
+    for (int k = 1; k < 4; ++k) {
+        if (nx[k] > max_x) max_x = nx[k];
+        if (ny[k] > max_y) max_y = ny[k];
+        if (nx[k] < min_x) min_x = nx[k];
+        if (ny[k] < min_y) min_y = ny[k];
+    }
+    int ch = 0;
+    if (crop) {
+        ch = (int)((nx[1] - nx[0]) * tan(rad) * 0.5);
+        if (max_y - min_y + 1 - 2 * ch <= 0) return ero_rotate_mat(src, w, h, rad, 0, dst, dw, dh);
+    }
+    const int rw = max_x - min_x + 1, rh = max_y - min_y + 1 - 2 * ch;
+    uint8_t  *tmp = (uint8_t *)calloc((size_t)rw * rh, 1);
+    for (int i = min_y + ch; i < max_y - ch; ++i) {
+        uint8_t *t = tmp + (size_t)(i - min_y - ch) * rw;
+        for (int j = min_x; j < max_x; ++j) {
+            const double new_j = cos(rad) * j - sin(rad) * (i - ch) + x0;
+            const double new_i = sin(rad) * j + cos(rad) * (i - ch) + y0;
+            if (!(new_i > 0 && new_j > 0 && new_i < h - 1 && new_j < w - 1)) continue;
+            if (crop && !(i > (min_y + ch) && i < (max_y - ch))) continue;
+            const uint8_t *sp = src + (size_t)(int)new_i * w + (int)new_j;
+            if (new_i == floor(new_i) && new_j == floor(new_j)) t[j - min_x] = sp[0];
+            else {
+                const double alpha = new_i - floor(new_i), beta = new_j - floor(new_j);
+                const uint8_t A = sp[0], B = sp[1], C = sp[w], D = sp[w + 1];
+                t[j - min_x] = (uint8_t)round((1 - alpha) * (1 - beta) * A + (1 - alpha) * beta * B + alpha * (1 - beta) * C + alpha * beta * D);
+            }
+        }
+    }
+    *dst = tmp; *dw = rw; *dh = rh;
+    return 0;
+}
+
+/* chain_run lines 72-79 with a text-line slope: Otsu-binarise 255-roi, rotate_mat(atan2(slope,1), crop)
+ * when |slope| > 0.01, then ARAN(30).                                                                */
+void ero_ocr_normalise_slope(const uint8_t *roi, int stride, int w, int h, double slope, uint8_t img30[30 * 30])
+{
+    const int L = 30;
+    if (!(fabs(slope) > 0.01)) { ero_ocr_normalise(roi, stride, w, h, img30); return; }
+    const int th = ero_otsu_threshold(roi, stride, w, h, 1);
+    uint8_t *bin = (uint8_t *)malloc((size_t)w * h), *rot = NULL;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) bin[(size_t)y * w + x] = (255 - roi[(size_t)y * stride + x]) > th ? 255 : 0;
+    int rw = 0, rh = 0;
+    ero_rotate_mat(bin, w, h, atan2(slope, 1), 1, &rot, &rw, &rh);
+    free(bin);
+    const double R1 = (rw > rh) ? (double)rh / rw : (double)rw / rh;
+    int dw, dh;
+    if (rw > rh) { dw = L; dh = (int)(L * pow(R1, 0.5)); }
+    else         { dw = (int)(L * pow(R1, 0.5)); dh = L; }
+    memset(img30, 0, (size_t)L * L);
+    if (dw > 0 && dh > 0) {
+        uint8_t tmp[30 * 30];
+        ero_resize_linear_u8(rot, rw, rw, rh, tmp, dw, dw, dh);
+        if (dw > dh) {
+            const int off = (L - dh) / 2;
+            for (int i = 0; i < dh; ++i) memcpy(img30 + (size_t)(i + off) * L, tmp + (size_t)i * dw, (size_t)dw);
+        } else {
+            const int off = (L - dw) / 2;
+            for (int i = 0; i < dh; ++i) memcpy(img30 + (size_t)i * L + off, tmp + (size_t)i * dw, (size_t)dw);
+        }
+    }
+    free(rot);
 }
 
 /* OCR::chain_code_direction(p1 = next point, p2 = current point), src/OCR.cpp:602-622 */
@@ -931,9 +1012,14 @@ static int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >=
 
 void ero_chain_features(const uint8_t *roi, int stride, int w, int h, uint8_t q[1800])
 {
+    ero_chain_features_slope(roi, stride, w, h, 0.0, q);
+}
+
+void ero_chain_features_slope(const uint8_t *roi, int stride, int w, int h, double slope, uint8_t q[1800])
+{
     enum { L = 30, F = 15 };
     uint8_t img[L * L], maps[8 * L * L];
-    ero_ocr_normalise(roi, stride, w, h, img);
+    ero_ocr_normalise_slope(roi, stride, w, h, slope, img);
     ero_chain_bitmaps(img, maps);
     static const int kg[7] = {8, 28, 56, 72, 56, 28, 8};   /* getGaussianKernel(7, sigma<=0) in 8.8 fixed point */
     for (int c = 0; c < 8; ++c) {

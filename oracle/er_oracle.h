@@ -127,7 +127,7 @@ void ero_classify(const uint8_t *plane, int stride,
                   uint8_t *cls, double *s_strong, double *s_weak);
 
 /* ---- OCR scorer, feature half (config 3) -- "parity unpinned" ------------
- * OCR::chain_run up to the svm call (src/OCR.cpp:67-91) for slope == 0 (no rotation):
+ * OCR::chain_run up to the svm call (src/OCR.cpp:67-91); the plain entry points are slope == 0 (no rotation):
  *   threshold(255 - roi, THRESH_OTSU)  ->  ARAN(30)  ->  extract_feature (src/OCR.cpp:144-218):
  *   findContours(RETR_LIST, CHAIN_APPROX_NONE) -> 8 direction bitmaps -> GaussianBlur 7x7 ->
  *   normalize(0,255,MINMAX) -> resize 15x15 -> q[1800] (feature value = q/255.0).
@@ -141,6 +141,10 @@ void ero_ocr_normalise(const uint8_t *roi, int stride, int w, int h, uint8_t img
 void ero_chain_bitmaps(const uint8_t img30[30 * 30], uint8_t maps[8 * 30 * 30]);
 /* the complete feature vector: q[8*15*15] */
 void ero_chain_features(const uint8_t *roi, int stride, int w, int h, uint8_t q[1800]);
+/* the same with the text line's slope (src/OCR.cpp:73-78, rotate_mat :254-357) */
+int  ero_rotate_mat(const uint8_t *src, int w, int h, double rad, int crop, uint8_t **dst, int *dw, int *dh);
+void ero_ocr_normalise_slope(const uint8_t *roi, int stride, int w, int h, double slope, uint8_t img30[30 * 30]);
+void ero_chain_features_slope(const uint8_t *roi, int stride, int w, int h, double slope, uint8_t q[1800]);
 
 /* ---- build-defined pyramid (no reference counterpart) -- */
 /* Level k plane size: (lround(w0*2^(-k/2)), lround(h0*2^(-k/2))), min 1.

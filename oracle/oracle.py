@@ -95,6 +95,9 @@ class Oracle:
                                    u8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ero_pyr_dims.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ero_chain_features.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.ero_chain_features_slope.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, u8p]
+        L.ero_ocr_normalise_slope.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, u8p]
+        L.ero_rotate_mat.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ero_ocr_normalise.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.ero_chain_bitmaps.argtypes = [u8p, u8p]
         L.ero_otsu_threshold.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -201,12 +204,30 @@ class Oracle:
                               out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
 
-    def chain_features(self, roi: np.ndarray) -> np.ndarray:
+    def chain_features(self, roi: np.ndarray, slope: float = 0.0) -> np.ndarray:
         roi = _u8(roi)
         q = np.zeros(1800, np.uint8)
         p = C.POINTER(C.c_uint8)
-        self.lib.ero_chain_features(roi.ctypes.data_as(p), roi.shape[1], roi.shape[1], roi.shape[0], q.ctypes.data_as(p))
+        self.lib.ero_chain_features_slope(roi.ctypes.data_as(p), roi.shape[1], roi.shape[1], roi.shape[0], float(slope), q.ctypes.data_as(p))
         return q
+
+    def rotate_mat(self, img: np.ndarray, rad: float, crop: bool = True) -> np.ndarray:
+        """OCR::rotate_mat (src/OCR.cpp:254-357)."""
+        img = _u8(img)
+        p = C.POINTER(C.c_uint8)
+        dst = p()
+        dw, dh = C.c_int(0), C.c_int(0)
+        self.lib.ero_rotate_mat(img.ctypes.data_as(p), img.shape[1], img.shape[0], float(rad), int(crop), C.byref(dst), C.byref(dw), C.byref(dh))
+        out = np.ctypeslib.as_array(dst, shape=(dh.value, dw.value)).copy()
+        self._libc.free(C.cast(dst, C.c_void_p))
+        return out
+
+    def ocr_normalise(self, roi: np.ndarray, slope: float = 0.0) -> np.ndarray:
+        roi = _u8(roi)
+        out = np.zeros((30, 30), np.uint8)
+        p = C.POINTER(C.c_uint8)
+        self.lib.ero_ocr_normalise_slope(roi.ctypes.data_as(p), roi.shape[1], roi.shape[1], roi.shape[0], float(slope), out.ctypes.data_as(p))
+        return out
 
     def otsu(self, img: np.ndarray, invert: bool = False) -> int:
         img = _u8(img)

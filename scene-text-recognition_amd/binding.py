@@ -119,6 +119,7 @@ def load_library():
     L.str_er_svm_info.argtypes = [vp, i32p, i32p, i32p]
     L.str_er_svm_predict_probability.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.str_er_ocr_chain_run.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
+    L.str_er_ocr_chain_run_slope.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int32, vp, vp, vp]
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
@@ -425,16 +426,21 @@ class ERFilter:
                                                           _np_ptr(dec) if want_dec else None))
         return (label, prob, dec) if want_dec else (label, prob)
 
-    def chain_run(self, plane: np.ndarray, boxes_xywh: np.ndarray, classify: bool = True):
-        """OCR::chain_run (src/OCR.cpp:67-140) with slope 0 for every box: (q[n,1800] uint8, label, prob) or q only."""
+    def chain_run(self, plane: np.ndarray, boxes_xywh: np.ndarray, classify: bool = True, slope=None):
+        """OCR::chain_run (src/OCR.cpp:67-140) for every box: (q[n,1800] uint8, label, prob) or q only.
+        slope: None (all 0), one number (the Text line's slope, src/ER.cpp:731) or one per box."""
         a = np.ascontiguousarray(plane, dtype=np.uint8)
         b = np.ascontiguousarray(boxes_xywh, dtype=np.int32).reshape(-1, 4)
         n = len(b)
         q = np.zeros((n, 1800), np.uint8)
         label = np.zeros(n, np.int32)
         prob = np.zeros(n, np.float64)
-        self._check(self.L.str_er_ocr_chain_run(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), n,
-                                                _np_ptr(label) if classify else None, _np_ptr(prob) if classify else None, _np_ptr(q)))
+        sl = None
+        if slope is not None:
+            sl = np.ascontiguousarray(np.broadcast_to(np.asarray(slope, np.float64), (n,)))
+        self._check(self.L.str_er_ocr_chain_run_slope(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b),
+                                                      _np_ptr(sl) if sl is not None else None, n,
+                                                      _np_ptr(label) if classify else None, _np_ptr(prob) if classify else None, _np_ptr(q)))
         return (q, label, prob) if classify else q
 
     def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):

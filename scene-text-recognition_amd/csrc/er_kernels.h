@@ -71,7 +71,7 @@ void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, Casc
 
 // OCR::chain_run feature extraction (slope 0) for n boxes of one device plane: q_out [n x 1800] u8 and/or x_out [n x xdim] f64 (= q/255).
 void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
-                           double *x_out, int xdim);
+                           double *x_out, int xdim, const RotGeom *rot);
 
 // Batch form: list the strong/weak candidates (n = their number, known on the host from the plane counters) and
 // extract their chain-code features straight from the device planes into x_out [n x xdim] (f64, q/255).

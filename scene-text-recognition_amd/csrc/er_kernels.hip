@@ -1904,17 +1904,41 @@ struct ChainShared {
     uint32_t    mn[8], mx[8];
 };
 
-// resize_px with a per-tap transform: tap = (255 - (p ^ inv)) > thresh ? 255 : 0
+// Source of ARAN(30): the Otsu-binarised ROI, tap = (255 - (p ^ inv)) > thresh ? 255 : 0 ...
 __device__ __forceinline__ int bin_tap(const uint8_t *p, int inv, int th) { return (255 - (*p ^ inv)) > th ? 255 : 0; }
 
-__device__ __forceinline__ int resize_px_bin(const ResizeGeom &g, const uint8_t *__restrict__ src, int sstride, int inv, int th,
-                                             int dx, int dy)
-{
-    if (g.mode == 0) return bin_tap(src + (size_t)dy * sstride + dx, inv, th);
-    if (g.mode == 1) {
-        const uint8_t *r0 = src + (size_t)(2 * dy) * sstride + 2 * dx, *r1 = r0 + sstride;
-        return (bin_tap(r0, inv, th) + bin_tap(r0 + 1, inv, th) + bin_tap(r1, inv, th) + bin_tap(r1 + 1, inv, th) + 2) >> 2;
+struct BinSrc {
+    const uint8_t *roi; int stride, inv, th;
+    __device__ __forceinline__ int operator()(int x, int y) const { return bin_tap(roi + (size_t)y * stride + x, inv, th); }
+};
+// ... or that image seen through OCR::rotate_mat (src/OCR.cpp:282-352): canvas pixel (x, y) is rebuilt
+// from its four binarised source taps with the reference's own f64 expression, in its order.
+struct RotSrc {
+    BinSrc b; int bw, bh; RotGeom r;
+    __device__ __forceinline__ int operator()(int x, int y) const
+    {
+        const int i = y + r.min_y + r.ch, j = x + r.min_x;
+        if (i >= r.max_y - r.ch || j >= r.max_x) return 0;                   // the loops are exclusive
+        const double new_j = r.c * (double)j - r.s * (double)(i - r.ch) + (double)r.x0;
+        const double new_i = r.s * (double)j + r.c * (double)(i - r.ch) + (double)r.y0;
+        if (!(new_i > 0 && new_j > 0 && new_i < (double)(bh - 1) && new_j < (double)(bw - 1))) return 0;
+        if (r.crop && !(i > r.min_y + r.ch && i < r.max_y - r.ch)) return 0;
+        const int    sy = (int)new_i, sx = (int)new_j;
+        const double fi = floor(new_i), fj = floor(new_j);
+        if (new_i == fi && new_j == fj) return b(sx, sy);
+        const double alpha = new_i - fi, beta = new_j - fj;
+        const double A = (double)b(sx, sy), B = (double)b(sx + 1, sy), C = (double)b(sx, sy + 1), D = (double)b(sx + 1, sy + 1);
+        const double v = (1 - alpha) * (1 - beta) * A + (1 - alpha) * beta * B + alpha * (1 - beta) * C + alpha * beta * D;
+        return (int)(uint8_t)round(v);
     }
+};
+
+// resize_px over an arbitrary source (same arithmetic as resize_px)
+template <class Src>
+__device__ __forceinline__ int resize_px_src(const ResizeGeom &g, const Src &src, int dx, int dy)
+{
+    if (g.mode == 0) return src(dx, dy);
+    if (g.mode == 1) return (src(2 * dx, 2 * dy) + src(2 * dx + 1, 2 * dy) + src(2 * dx, 2 * dy + 1) + src(2 * dx + 1, 2 * dy + 1) + 2) >> 2;
     float fx = (float)((dx + 0.5) * g.scale_x - 0.5);
     int   sx = (int)floorf(fx);
     fx -= (float)sx;
@@ -1927,9 +1951,8 @@ __device__ __forceinline__ int resize_px_bin(const ResizeGeom &g, const uint8_t 
     const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
     const int y0 = min(max(sy, 0), g.sh - 1), y1 = min(max(sy + 1, 0), g.sh - 1);
     const int sx1 = (sx + 1 < g.sw) ? sx + 1 : sx;
-    const uint8_t *p0 = src + (size_t)y0 * sstride, *p1 = src + (size_t)y1 * sstride;
-    const int r0 = bin_tap(p0 + sx, inv, th) * a0 + bin_tap(p0 + sx1, inv, th) * a1;
-    const int r1 = bin_tap(p1 + sx, inv, th) * a0 + bin_tap(p1 + sx1, inv, th) * a1;
+    const int r0 = src(sx, y0) * a0 + src(sx1, y0) * a1;
+    const int r1 = src(sx, y1) * a0 + src(sx1, y1) * a1;
     const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
     return min(max(v, 0), 255);
 }
@@ -1941,7 +1964,8 @@ __device__ __forceinline__ int reflect101_30(int i) { return i < 0 ? -i : (i >= 
 __global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restrict__ plane, int stride, int inv,
                                                         const int32_t *__restrict__ boxes, int n, uint8_t *__restrict__ q_out,
                                                         double *__restrict__ x_out, int xdim, const CandRec *__restrict__ cands,
-                                                        const uint32_t *__restrict__ ocr_list, const PlaneDesc *__restrict__ planes)
+                                                        const uint32_t *__restrict__ ocr_list, const PlaneDesc *__restrict__ planes,
+                                                        const RotGeom *__restrict__ rot)
 {
     __shared__ ChainShared sh;
     const int tid = threadIdx.x;
@@ -1988,20 +2012,32 @@ __global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restric
             sh.thresh = (int)max_val;
         }
         __syncthreads();
-        // ---- ARAN(30) of the binarised ROI
+        // ---- ARAN(30) of the binarised (and, for a slanted text line, rotated) ROI
         {
-            const int    th = sh.thresh;
-            const double R1 = (bw > bh) ? (double)bh / bw : (double)bw / bh;
+            const BinSrc bsrc{roi, stride, inv, sh.thresh};
+            const bool   ron = rot != nullptr && rot[bi].on != 0;
+            const int    sw = ron ? rot[bi].rw : bw, shh = ron ? rot[bi].rh : bh;
+            const double R1 = (sw > shh) ? (double)shh / sw : (double)sw / shh;
             const int    k = (int)(30.0 * sqrt(R1));
-            const int    dw = (bw > bh) ? 30 : k, dh = (bw > bh) ? k : 30;
+            const int    dw = (sw > shh) ? 30 : k, dh = (sw > shh) ? k : 30;
             if (dw > 0 && dh > 0) {
                 const int offy = (dw > dh) ? (30 - dh) / 2 : 0, offx = (dw > dh) ? 0 : (30 - dw) / 2;
-                const ResizeGeom g = resize_geom(bw, bh, dw, dh);
-                for (int i = tid; i < dw * dh; i += 256) {
-                    const int dy = i / dw, dx = i - dy * dw;
-                    const int v = resize_px_bin(g, roi, stride, inv, th, dx, dy);
-                    sh.img[(dy + offy) * 30 + dx + offx] = (uint8_t)v;
-                    sh.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
+                const ResizeGeom g = resize_geom(sw, shh, dw, dh);
+                if (ron) {
+                    const RotSrc rsrc{bsrc, bw, bh, rot[bi]};
+                    for (int i = tid; i < dw * dh; i += 256) {
+                        const int dy = i / dw, dx = i - dy * dw;
+                        const int v = resize_px_src(g, rsrc, dx, dy);
+                        sh.img[(dy + offy) * 30 + dx + offx] = (uint8_t)v;
+                        sh.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
+                    }
+                } else {
+                    for (int i = tid; i < dw * dh; i += 256) {
+                        const int dy = i / dw, dx = i - dy * dw;
+                        const int v = resize_px_src(g, bsrc, dx, dy);
+                        sh.img[(dy + offy) * 30 + dx + offx] = (uint8_t)v;
+                        sh.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
+                    }
                 }
             }
         }
@@ -2095,11 +2131,11 @@ __global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restric
 }
 
 void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
-                           double *x_out, int xdim)
+                           double *x_out, int xdim, const RotGeom *rot)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, plane, stride, inv, boxes, n, q_out, x_out, xdim,
-                       (const CandRec *)nullptr, (const uint32_t *)nullptr, (const PlaneDesc *)nullptr);
+                       (const CandRec *)nullptr, (const uint32_t *)nullptr, (const PlaneDesc *)nullptr, rot);
 }
 
 // indices of the strong / weak candidates of the batch, in candidate order (deterministic)
@@ -2132,7 +2168,7 @@ void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint3
     hipLaunchKernelGGL(k_ocr_list, dim3(1), dim3(1024), 0, s, b, list, n_out);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, (const uint8_t *)nullptr, 0, 0, (const int32_t *)nullptr, n,
-                       (uint8_t *)nullptr, x_out, xdim, (const CandRec *)b.cands, (const uint32_t *)list, b.planes);
+                       (uint8_t *)nullptr, x_out, xdim, (const CandRec *)b.cands, (const uint32_t *)list, b.planes, (const RotGeom *)nullptr);
 }
 
 } // namespace str_er

@@ -115,6 +115,16 @@ struct DetectParams {
 };
 
 // Matches str_er_cand in include/str_er.h (48 bytes).
+// OCR::rotate_mat (src/OCR.cpp:254-357) for one box: canvas size and mapping, computed on the host
+// (libm cos/sin/tan/round, exactly as the reference evaluates them); on == 0 means "not rotated".
+struct RotGeom {
+    int32_t on, crop;
+    int32_t rw, rh;            // canvas (the image ARAN then sees)
+    int32_t min_x, min_y, max_x, max_y, ch, x0, y0;
+    int32_t pad_;
+    double  c, s;              // cos(rad), sin(rad)
+};
+
 struct CandRec {
     uint32_t frame;
     uint8_t  ch, pyr, level, cls;

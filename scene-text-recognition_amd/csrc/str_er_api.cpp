@@ -1087,8 +1087,44 @@ int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, in
     return STR_ER_OK;
 }
 
+// OCR::rotate_mat's canvas for a w x h box (src/OCR.cpp:256-290): corner rounding, crop height and the
+// fall-back to the uncropped canvas, evaluated with the host libm exactly as the reference does.
+static RotGeom make_rot_geom(int w, int h, double slope)
+{
+    RotGeom g;
+    std::memset(&g, 0, sizeof(g));
+    if (!(std::fabs(slope) > 0.01)) return g;
+    const double rad = std::atan2(slope, 1.0);
+    const int    x0 = (int)((w - 1) / 2.0), y0 = (int)((h - 1) / 2.0);
+    const int    cx[4] = {0 - x0, (w - 1) - x0, (w - 1) - x0, 0 - x0}, cy[4] = {0 - y0, 0 - y0, (h - 1) - y0, (h - 1) - y0};
+    int          nx[4], ny[4];
+    for (int k = 0; k < 4; ++k) {
+        nx[k] = (int)std::round(cx[k] * std::cos(rad) - cy[k] * std::sin(rad));
+        ny[k] = (int)std::round(cx[k] * std::sin(rad) + cy[k] * std::cos(rad));
+    }
+    g.max_x = std::max(std::max(nx[0], nx[1]), std::max(nx[2], nx[3]));
+    g.max_y = std::max(std::max(ny[0], ny[1]), std::max(ny[2], ny[3]));
+    g.min_x = std::min(std::min(nx[0], nx[1]), std::min(nx[2], nx[3]));
+    g.min_y = std::min(std::min(ny[0], ny[1]), std::min(ny[2], ny[3]));
+    g.on = 1;
+    g.crop = 1;
+    g.ch = (int)((nx[1] - nx[0]) * std::tan(rad) * 0.5);
+    if (g.max_y - g.min_y + 1 - 2 * g.ch <= 0) { g.crop = 0; g.ch = 0; }
+    g.rw = g.max_x - g.min_x + 1;
+    g.rh = g.max_y - g.min_y + 1 - 2 * g.ch;
+    g.x0 = x0; g.y0 = y0;
+    g.c = std::cos(rad); g.s = std::sin(rad);
+    return g;
+}
+
 int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
                          int32_t *label, double *prob, uint8_t *q_out)
+{
+    return str_er_ocr_chain_run_slope(c, plane, w, h, stride, boxes, nullptr, n, label, prob, q_out);
+}
+
+int str_er_ocr_chain_run_slope(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes,
+                               const double *slope, int32_t n, int32_t *label, double *prob, uint8_t *q_out)
 {
     if (!c) return STR_ER_EINVAL;
     if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
@@ -1110,6 +1146,7 @@ int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t
     const size_t n_pad = align_up((size_t)n, 64), np = want_svm ? (size_t)m.k * (m.k - 1) / 2 : 0;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_rot = take(slope ? sizeof(RotGeom) * (size_t)n : 0);
     const size_t o_box = take(16 * (size_t)n), o_q = take(1800 * (size_t)n), o_x = take(want_svm ? (size_t)n * 1800 * 8 : 0),
                  o_xf = take(want_svm ? n_pad * m.dpad * 4 + 256 : 0), o_xn = take(want_svm ? n_pad * 8 : 0),
                  o_kv = take(want_svm ? n_pad * m.l_pad * 8 : 0), o_dec = take((size_t)n * np * 8),
@@ -1118,8 +1155,18 @@ int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t
     if (rc != STR_ER_OK) return rc;
     uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    std::vector<RotGeom> rot;
+    if (slope) {
+        rot.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            if (!std::isfinite(slope[i])) return fail(c, STR_ER_EINVAL, "slope " + std::to_string(i) + " is not finite");
+            rot[(size_t)i] = make_rot_geom(boxes[4 * (size_t)i + 2], boxes[4 * (size_t)i + 3], slope[i]);
+        }
+        HIP_TRY(c, hipMemcpyAsync(s + o_rot, rot.data(), sizeof(RotGeom) * (size_t)n, hipMemcpyHostToDevice, st));
+    }
     launch_chain_features(st, c->d_pix, w, 0, reinterpret_cast<const int32_t *>(s + o_box), n, s + o_q,
-                          want_svm ? reinterpret_cast<double *>(s + o_x) : nullptr, 1800);
+                          want_svm ? reinterpret_cast<double *>(s + o_x) : nullptr, 1800,
+                          slope ? reinterpret_cast<const RotGeom *>(s + o_rot) : nullptr);
     std::vector<double> pall;
     if (want_svm) {
         HIP_TRY(c, hipMemsetAsync(s + o_xf, 0, n_pad * m.dpad * 4 + 256, st));

@@ -259,14 +259,14 @@ public:
     }
 
     // double OCR::chain_run(Mat src, int thresh, double slope): src = channel(bound).  Returns table[label] + prob.
-    // `thresh` is ignored exactly as in the reference (THRESH_OTSU overrides it); |slope| > 0.01 (rotation) is not built.
+    // `thresh` is ignored exactly as in the reference (THRESH_OTSU overrides it); |slope| > 0.01 rotates the
+    // binarised ROI by atan2(slope, 1) first (rotate_mat, src/OCR.cpp:73-78).
     double chain_run(const Image8 &plane, const Rect &bound, int /*thresh*/, double slope)
     {
-        if (slope > 0.01 || slope < -0.01) throw std::runtime_error("OCR::chain_run: rotation (|slope| > 0.01) is not built");
         const int32_t box[4] = {bound.x, bound.y, bound.width, bound.height};
         int32_t label = 0;
         double  prob = 0;
-        const int rc = str_er_ocr_chain_run(ctx_, plane.data, plane.cols, plane.rows, plane.step, box, 1, &label, &prob, nullptr);
+        const int rc = str_er_ocr_chain_run_slope(ctx_, plane.data, plane.cols, plane.rows, plane.step, box, &slope, 1, &label, &prob, nullptr);
         if (rc != STR_ER_OK) throw std::runtime_error(std::string("chain_run: ") + str_er_last_error(ctx_));
         static const char *table = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz&()";   // src/OCR.cpp:10
         return (label >= 0 && label < 65 ? table[label] : '?') + prob;

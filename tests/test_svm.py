@@ -133,6 +133,72 @@ def test_oracle_otsu(oracle):
     assert oracle.otsu(img, invert=True) == 255 - 200 or 55 <= oracle.otsu(img, invert=True) < 215
 
 
+def test_oracle_rotate_mat(oracle):
+    """OCR::rotate_mat (src/OCR.cpp:254-357): canvas size from the rounded corners, cropped by
+    (int)((x2' - x1') * tan(rad) / 2) rows top and bottom; first row, last row and last column stay 0."""
+    img = np.full((21, 41), 255, np.uint8)
+    rad = float(np.arctan2(0.2, 1.0))
+    full = oracle.rotate_mat(img, rad, crop=False)
+    c, s = np.cos(rad), np.sin(rad)
+    xs = [round(x * c - y * s) for x, y in ((-20, -10), (20, -10), (20, 10), (-20, 10))]
+    ys = [round(x * s + y * c) for x, y in ((-20, -10), (20, -10), (20, 10), (-20, 10))]
+    assert full.shape == (max(ys) - min(ys) + 1, max(xs) - min(xs) + 1)
+    assert (full[-1] == 0).all() and (full[:, -1] == 0).all()                    # loops are exclusive (:292-295, :328-331)
+    assert full[full.shape[0] // 2, full.shape[1] // 2] == 255                  # the centre maps into the source
+    assert set(np.unique(full)) <= {0, 255}                                      # constant source: every bilinear tap is 255
+    ch = int((xs[1] - xs[0]) * np.tan(rad) * 0.5)
+    crop = oracle.rotate_mat(img, rad, crop=True)
+    assert crop.shape == (full.shape[0] - 2 * ch, full.shape[1]) and ch > 0
+    assert (crop[0] == 0).all()                                                  # i > min_y + crop_height (:301)
+    # quirk kept: the source row is taken at (i - crop_height), so the cropped canvas shows the TOP rows of the
+    # full canvas (rows 1 .. n-2), not its middle band
+    assert (crop[1:-1] == full[1:crop.shape[0] - 1]).all()
+    # negative angle: crop_height < 0 grows the canvas (kept as is)
+    neg = oracle.rotate_mat(img, -rad, crop=True)
+    assert neg.shape[0] > full.shape[0]
+    # degenerate boxes still give a canvas (the uncropped fall-back of :285-289 needs 2*crop_height >= canvas height,
+    # which the corner rounding never produces for rad > 0)
+    assert oracle.rotate_mat(np.full((1, 61), 255, np.uint8), float(np.arctan2(0.6, 1.0)), crop=True).shape[0] >= 1
+    assert oracle.rotate_mat(np.full((1, 1), 255, np.uint8), 0.5, crop=True).shape == (1, 1)
+    # interpolation: a half-plane edge produces intermediate grey levels
+    half = np.zeros((31, 31), np.uint8)
+    half[:, 16:] = 255
+    r = oracle.rotate_mat(half, rad, crop=False)
+    assert len(np.unique(r)) > 2
+    # |slope| <= 0.01 is not rotated at all (:73)
+    roi = np.random.default_rng(0).integers(0, 256, (40, 50), dtype=np.uint8)
+    assert (oracle.ocr_normalise(roi, 0.01) == oracle.ocr_normalise(roi, 0.0)).all()
+    assert (oracle.ocr_normalise(roi, 0.3) != oracle.ocr_normalise(roi, 0.0)).any()
+
+
+@pytest.mark.gpu
+def test_gpu_chain_features_rotated_match_oracle(erf, oracle, S):
+    """chain_run with a text-line slope (src/OCR.cpp:73-78): rotate_mat sits between Otsu and ARAN."""
+    img = S.synth.gray(S.synth.stext_bgr(S.synth.frame_seed(4), 640, 480))
+    res = erf.detect_planes(img)
+    boxes = np.stack([res.cands["x"], res.cands["y"], res.cands["w"], res.cands["h"]], axis=1).astype(np.int32)
+    rng = np.random.default_rng(5)
+    extra = []
+    for _ in range(80):
+        bw, bh = int(rng.integers(2, 160)), int(rng.integers(2, 160))
+        extra.append((int(rng.integers(0, 640 - bw)), int(rng.integers(0, 480 - bh)), bw, bh))
+    boxes = np.concatenate([boxes, np.array(extra + [(0, 0, 60, 60), (5, 5, 1, 1), (7, 7, 2, 1), (3, 3, 61, 5), (0, 0, 640, 480)], np.int32)])
+    slopes = rng.uniform(-0.8, 0.8, len(boxes))
+    slopes[::7] = 0.0
+    slopes[1::7] = 0.01
+    slopes[2::7] = -0.0101
+    q = erf.chain_run(img, boxes, classify=False, slope=slopes)
+    for b, sl, row in zip(boxes, slopes, q):
+        exp = oracle.chain_features(img[b[1]:b[1] + b[3], b[0]:b[0] + b[2]], float(sl))
+        assert (row == exp).all(), (b, sl)
+    # one slope for the whole word, as er_ocr passes text.slope (src/ER.cpp:731)
+    q1 = erf.chain_run(img, boxes[:10], classify=False, slope=0.25)
+    for b, row in zip(boxes[:10], q1):
+        assert (row == oracle.chain_features(img[b[1]:b[1] + b[3], b[0]:b[0] + b[2]], 0.25)).all()
+    with pytest.raises(S.StrErError):
+        erf.chain_run(img, boxes[:2], classify=False, slope=float("nan"))
+
+
 @pytest.mark.gpu
 def test_gpu_chain_features_match_oracle(erf, oracle, S):
     img = S.synth.gray(S.synth.stext_bgr(S.synth.frame_seed(4), 640, 480))
