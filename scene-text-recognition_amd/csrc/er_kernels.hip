@@ -440,6 +440,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
 
     // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
     uint32_t lev[TILE_PPT];
+    uint32_t left_lev;          // level of the pixel left of the lane's first one (WALL at the tile edge)
     {
         uint8_t px[TILE_PPT];
         int     nvalid = 0;
@@ -468,11 +469,28 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; point every
         // pixel of a run at the run's first pixel
         uint32_t head = p0;
-        s_par[OWN(0)] = NONE;
 #pragma unroll
         for (int k = 1; k < TILE_PPT; ++k) {
             if (lev[k] != WALL && lev[k] == lev[k - 1]) s_par[OWN(k)] = (lev[k] << 16) | head;
             else { head = p0 + k; s_par[OWN(k)] = NONE; }
+        }
+        // ... and across the lane boundary: if the lane's first pixel continues the run of the pixel to
+        // its left, it points at the head of that run.  The 8 lanes of a tile row are neighbours in the
+        // wave; a lane that is one single run and itself continues leftwards forwards the head it got.
+        left_lev = __shfl_up(lev[TILE_PPT - 1], 1);
+        if (lx == 0) left_lev = WALL;
+        const bool joins = lev[0] != WALL && lev[0] == left_lev;
+        {
+            uint32_t val = head;                       // head of the lane's last run
+            bool     pass = joins && head == p0;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const uint32_t lv = __shfl_up(val, o);
+                const int      lp = __shfl_up((int)pass, o);
+                if (pass) { val = lv; pass = lp != 0; }
+            }
+            const uint32_t t = __shfl_up(val, 1);
+            s_par[OWN(0)] = joins ? ((lev[0] << 16) | t) : NONE;
         }
         __syncthreads();
         if (walls) atomicAdd(&s_walls, walls);
@@ -491,12 +509,16 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             if (lev[k] == WALL) continue;
             const uint32_t p = p0 + k;
             if (round == 0) {
-                if (k == 0) { if (lx > 0 && s_lev[LX(p - 1)] != WALL) emask |= 1u; }
-                else if (lev[k - 1] != WALL && lev[k - 1] != lev[k]) emask |= 1u << k;
+                // (an equal-level left neighbour is already linked: by the run pointers above)
+                const uint32_t ll = k == 0 ? left_lev : lev[k > 0 ? k - 1 : 0];
+                if (ll != WALL && ll != lev[k]) emask |= 1u << k;
             } else if (ly + 1 < TILE_H) {
                 const uint32_t lq = s_lev[LX(p + TILE_W)];
                 if (lq != WALL) {
-                    const bool covered = k > 0 && lev[k - 1] == lev[k] && s_lev[LX(p + TILE_W - 1)] == lq;
+                    // covered: the column to the left joins the same two nodes
+                    bool covered;
+                    if (k > 0) covered = lev[k - 1] == lev[k] && s_lev[LX(p + TILE_W - 1)] == lq;
+                    else       covered = left_lev == lev[0] && s_lev[LX(lx > 0 ? p + TILE_W - 1 : p + TILE_W)] == lq;
                     if (!covered) emask |= 1u << k;
                 }
             }
@@ -519,22 +541,29 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     }
 
     // ---- flatten: every pixel points straight at its level root ----------------------------
+    // (the pixels of one run share their node: only the run's first pixel walks)
     uint32_t rootmask = 0;
+    {
+        uint32_t r_run = NONE;
 #pragma unroll
-    for (int k = 0; k < TILE_PPT; ++k) {
-        if (lev[k] == WALL) continue;
-        const uint32_t p = p0 + k, l = lev[k];
-        uint32_t w = LD_WG(&s_par[LX(p)]);
-        if (w != NONE && (w >> 16) == l) {
-            uint32_t r = w & 0xFFFFu;
-            for (;;) {
-                const uint32_t w2 = LD_WG(&s_par[LX(r)]);
-                if (w2 == NONE || (w2 >> 16) != l) break;
-                r = w2 & 0xFFFFu;
+        for (int k = 0; k < TILE_PPT; ++k) {
+            if (lev[k] == WALL) continue;
+            const uint32_t p = p0 + k, l = lev[k];
+            if (k > 0 && lev[k > 0 ? k - 1 : 0] == l) { s_par[LX(p)] = (l << 16) | r_run; continue; }
+            uint32_t w = LD_WG(&s_par[LX(p)]);
+            if (w != NONE && (w >> 16) == l) {
+                uint32_t r = w & 0xFFFFu;
+                for (;;) {
+                    const uint32_t w2 = LD_WG(&s_par[LX(r)]);
+                    if (w2 == NONE || (w2 >> 16) != l) break;
+                    r = w2 & 0xFFFFu;
+                }
+                s_par[LX(p)] = (l << 16) | r;
+                r_run = r;
+            } else {
+                rootmask |= 1u << k;
+                r_run = p;
             }
-            s_par[LX(p)] = (l << 16) | r;
-        } else {
-            rootmask |= 1u << k;
         }
     }
     __syncthreads();
