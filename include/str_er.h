@@ -54,6 +54,7 @@ extern "C" {
 #define STR_ER_STAGE_OCR      8u   /* config 3: OCR::chain_run (slope 0) on every strong/weak ER; needs an SVM model */
 /* output options */
 #define STR_ER_WANT_NODES     16u  /* also return the kept-node table of every plane */
+#define STR_ER_STAGE_TRACK    32u  /* calc_color + ERFilter::er_track on the strong/weak ERs of every image (src/ER.cpp:530-590); BGR frames only */
 
 /* candidate class: which list of text_detect() the ER landed in (src/ER.cpp:516-526) */
 #define STR_ER_CLS_POOL   0   /* pooled by NMS, rejected by both cascades */
@@ -218,6 +219,19 @@ int str_er_svm_predict_probability(str_er_ctx *ctx, const double *x, int32_t n, 
 int str_er_ocr_chain_run(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes_xywh,
                          int32_t n, int32_t *label, double *prob, uint8_t *q_out);
 
+/* calc_color(ER*, Mat mask_channel, Mat color_img) (src/ER.cpp:1391-1419) for n boxes (ER::bound) of one host
+ * mask plane and one host 3-byte interleaved colour image (the Ycrcb Mat): colors[i][0..2] = ER::color1..3.
+ * The colour image is read from its own row 0 / column 0 for every box, as the reference does (:1404).
+ * It must be at least as large as the largest box.                                                    */
+int str_er_calc_color(str_er_ctx *ctx, const uint8_t *mask_plane, int32_t w, int32_t h, int64_t stride, const uint8_t *color_img,
+                      int32_t cw, int32_t ch, int64_t cstride, const int32_t *boxes_xywh, int32_t n, double *colors);
+
+/* ERFilter::er_track (src/ER.cpp:530-590) on caller-supplied ERs of ONE image: cands[i].{x,y,w,h,area,cls}
+ * (cls 1 = from strong[], 2 = from weak[], others ignored) and colors[i][3] (from str_er_calc_color);
+ * tracked[i] = 1 for the members of all_er, cx/cy (optional) receive ER::center.                     */
+int str_er_er_track(str_er_ctx *ctx, const str_er_cand *cands, const double *colors, int32_t n, uint8_t *tracked, int32_t *cx,
+                    int32_t *cy);
+
 /* The same with the text line's slope per box (Text::slope, src/ER.cpp:731): where |slope[i]| > 0.01 the
  * binarised ROI goes through OCR::rotate_mat(atan2(slope, 1), crop = true) (src/OCR.cpp:73-78, 254-357)
  * before ARAN.  slope == NULL means all zero.  A non-finite slope is STR_ER_EINVAL.                   */
@@ -251,10 +265,24 @@ const str_er_cand *str_er_result_plane_cands(const str_er_result *r, int32_t pla
  * src/OCR.cpp:139); label -1 / prob 0 for candidates that are neither strong nor weak.  NULL otherwise. */
 const int32_t *str_er_result_ocr_labels(const str_er_result *r, int32_t *n);
 const double  *str_er_result_ocr_probs(const str_er_result *r, int32_t *n);
+/* With STR_ER_STAGE_TRACK: per candidate of str_er_result_cands(), what er_track leaves on the ER
+ * (ER::color1-3, ER::center) and whether it is in `tracked` (all_er of src/ER.cpp:530).  An image is
+ * one frame at one pyramid level (the reference has only level 0): its strong ERs and every weak ER the
+ * rule at :575-587 ties, directly or through other tracked ERs, to one of them.  all_er's ORDER (strong
+ * lists, then weak ones as found) is not reproduced -- er_grouping sorts it first thing (:614).
+ * Records of pool-only candidates (cls 0) are all zero.  NULL without the stage.                   */
+typedef struct str_er_track {
+    double   color1, color2, color3;     /* NaN where the Otsu mask is empty (0.0 / 0 in calc_color) */
+    int32_t  cx, cy;
+    uint32_t tracked;
+    uint32_t reserved;
+} str_er_track;
+const str_er_track *str_er_result_tracks(const str_er_result *r, int32_t *n);
 /* Kept-node table of one plane, ascending (key, level); NULL unless STR_ER_WANT_NODES. */
 const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n);
 /* times[7] = {extract, nms, classify, track, group, ocr, total} seconds, the contract of
- * ERFilter::text_detect's return value (src/ER.cpp:99-110); track/group/ocr are 0 here.
+ * ERFilter::text_detect's return value (src/ER.cpp:99-110); track is filled by STR_ER_STAGE_TRACK, ocr by
+ * STR_ER_STAGE_OCR, group is 0.
  * extract/nms/classify are GPU stage times for the whole batch (HIP events).          */
 const double *str_er_result_times(const str_er_result *r);
 /* Device copy of the candidate array (for an RCCL gather without a host round trip):

@@ -51,7 +51,8 @@ class Tree:
 def build(force: bool = False) -> None:
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
     so = os.path.join(HERE, "liber_oracle.so")
-    src = [os.path.join(HERE, f) for f in ("er_oracle.c", "er_oracle.h", "svm_oracle.c", "svm_oracle.h", "Makefile")]
+    src = [os.path.join(HERE, f) for f in ("er_oracle.c", "er_oracle.h", "svm_oracle.c", "svm_oracle.h", "er_group_oracle.c",
+                                           "er_group_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
     ref_missing = os.path.exists("/root/reference/src/adaboost.cpp") and not all(
         os.path.exists(os.path.join(HERE, "_ref", f)) for f in ("libref_adaboost.so", "libref_svm.so", "svm-train"))
@@ -101,6 +102,8 @@ class Oracle:
         L.ero_ocr_normalise.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.ero_chain_bitmaps.argtypes = [u8p, u8p]
         L.ero_otsu_threshold.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ero_calc_color.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.POINTER(C.c_double)]
+        L.ero_er_track.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
 
@@ -228,6 +231,25 @@ class Oracle:
         p = C.POINTER(C.c_uint8)
         self.lib.ero_ocr_normalise_slope(roi.ctypes.data_as(p), roi.shape[1], roi.shape[1], roi.shape[0], float(slope), out.ctypes.data_as(p))
         return out
+
+    # -- er_group_oracle.c ---------------------------------
+    ER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("cx", "<i4"), ("cy", "<i4"), ("area", "<i4"),
+                         ("ch", "<i4"), ("cls", "<i4"), ("id", "<i4"), ("color1", "<f8"), ("color2", "<f8"), ("color3", "<f8")])
+
+    def calc_color(self, mask_plane: np.ndarray, color_img: np.ndarray, box) -> np.ndarray:
+        m, ci = _u8(mask_plane), _u8(color_img)
+        out = np.zeros(3, np.float64)
+        p = C.POINTER(C.c_uint8)
+        self.lib.ero_calc_color(m.ctypes.data_as(p), m.shape[1], int(box[0]), int(box[1]), int(box[2]), int(box[3]),
+                                ci.ctypes.data_as(p), ci.shape[1] * 3, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def er_track(self, ers: np.ndarray):
+        """ers: ER_DTYPE array (x,y,w,h,area,cls,color1-3 filled).  Returns (order of all_er, ers with cx/cy set)."""
+        e = np.ascontiguousarray(ers, dtype=self.ER_DTYPE).copy()
+        order = np.zeros(len(e) + 1, np.int32)
+        n = self.lib.ero_er_track(e.ctypes.data_as(C.c_void_p), len(e), order.ctypes.data_as(C.POINTER(C.c_int)))
+        return order[:n].copy(), e
 
     def otsu(self, img: np.ndarray, invert: bool = False) -> int:
         img = _u8(img)

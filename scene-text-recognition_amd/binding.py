@@ -17,7 +17,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES = 1, 2, 4, 7, 8, 16
+STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES, STAGE_TRACK = 1, 2, 4, 7, 8, 16, 32
+TRACK_DTYPE = np.dtype([("color1", "<f8"), ("color2", "<f8"), ("color3", "<f8"), ("cx", "<i4"), ("cy", "<i4"),
+                        ("tracked", "<u4"), ("reserved", "<u4")])
 CLS_POOL, CLS_STRONG, CLS_WEAK = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -133,6 +135,10 @@ def load_library():
     L.str_er_result_plane_cands.restype = vp
     L.str_er_result_plane_nodes.argtypes = [vp, C.c_int32, i32p]
     L.str_er_result_plane_nodes.restype = vp
+    L.str_er_result_tracks.argtypes = [vp, i32p]
+    L.str_er_result_tracks.restype = vp
+    L.str_er_calc_color.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp]
+    L.str_er_er_track.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
     L.str_er_result_ocr_labels.argtypes = [vp, i32p]
     L.str_er_result_ocr_labels.restype = vp
     L.str_er_result_ocr_probs.argtypes = [vp, i32p]
@@ -189,6 +195,7 @@ class Result:
         self.info, self.cands, self.times, self.profile, self._nodes = info, cands, times, profile, nodes
         self.ocr_label = None      # with STAGE_OCR: per candidate, -1 for cls == 0
         self.ocr_prob = None
+        self.tracks = None         # with STAGE_TRACK: TRACK_DTYPE per candidate (zeros for cls == 0)
         self._planes = None
 
     @property
@@ -302,6 +309,10 @@ class ERFilter:
                 res.ocr_label = np.frombuffer((C.c_char * (4 * no.value)).from_address(lp), dtype=np.int32).copy()
                 pp = L.str_er_result_ocr_probs(rh, C.byref(no))
                 res.ocr_prob = np.frombuffer((C.c_char * (8 * no.value)).from_address(pp), dtype=np.float64).copy()
+            tp = L.str_er_result_tracks(rh, C.byref(no))
+            if tp:
+                res.tracks = (np.frombuffer((C.c_char * (40 * no.value)).from_address(tp), dtype=TRACK_DTYPE).copy()
+                              if no.value else np.zeros(0, TRACK_DTYPE))
             return res
         finally:
             L.str_er_result_free(rh)
@@ -442,6 +453,33 @@ class ERFilter:
                                                       _np_ptr(sl) if sl is not None else None, n,
                                                       _np_ptr(label) if classify else None, _np_ptr(prob) if classify else None, _np_ptr(q)))
         return (q, label, prob) if classify else q
+
+    # ---- the first consumers of the classified ERs --------------------------------
+    def calc_color(self, mask_plane: np.ndarray, color_img: np.ndarray, boxes_xywh: np.ndarray) -> np.ndarray:
+        """calc_color (src/ER.cpp:1391-1419) for every box: [n,3] = ER::color1..3 (color_img: H x W x 3 uint8, the Ycrcb Mat)."""
+        a = np.ascontiguousarray(mask_plane, dtype=np.uint8)
+        ci = np.ascontiguousarray(color_img, dtype=np.uint8)
+        if ci.ndim != 3 or ci.shape[2] != 3:
+            raise ValueError("color_img must be H x W x 3")
+        b = np.ascontiguousarray(boxes_xywh, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((len(b), 3), np.float64)
+        self._check(self.L.str_er_calc_color(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(ci), ci.shape[1], ci.shape[0],
+                                             ci.shape[1] * 3, _np_ptr(b), len(b), _np_ptr(out)))
+        return out
+
+    def er_track(self, cands: np.ndarray, colors: np.ndarray):
+        """ERFilter::er_track (src/ER.cpp:530-590) on the ERs of one image: cands (CAND_DTYPE; cls 1 = strong[], 2 = weak[]) and
+        their colours [n,3] -> (tracked[n] bool, cx[n], cy[n])."""
+        cd = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        col = np.ascontiguousarray(colors, dtype=np.float64).reshape(-1, 3)
+        n = len(cd)
+        if len(col) != n:
+            raise ValueError("one colour triple per candidate")
+        tr = np.zeros(n, np.uint8)
+        cx = np.zeros(n, np.int32)
+        cy = np.zeros(n, np.int32)
+        self._check(self.L.str_er_er_track(self.h, _np_ptr(cd), _np_ptr(col), n, _np_ptr(tr), _np_ptr(cx), _np_ptr(cy)))
+        return tr.astype(bool), cx, cy
 
     def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):
         """ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816).  With no boxes the whole

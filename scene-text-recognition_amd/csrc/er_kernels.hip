@@ -27,6 +27,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "er_device.h"
 #include "er_kernels.h"
 
 namespace str_er {
@@ -2021,25 +2022,7 @@ __global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restric
             atomicAdd(&sh.hist[255 - (roi[(size_t)y * stride + x] ^ inv)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            double mu = 0;
-            const double scale = 1. / ((double)bw * bh);
-            for (int i = 0; i < 256; ++i) mu += i * (double)sh.hist[i];
-            mu *= scale;
-            double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-            for (int i = 0; i < 256; ++i) {
-                const double p_i = sh.hist[i] * scale;
-                mu1 *= q1;
-                q1 += p_i;
-                const double q2 = 1. - q1;
-                if (fmin(q1, q2) < (double)FLT_EPSILON || fmax(q1, q2) > 1. - (double)FLT_EPSILON) continue;
-                mu1 = (mu1 + i * p_i) / q1;
-                const double mu2 = (mu - q1 * mu1) / q2;
-                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
-            }
-            sh.thresh = (int)max_val;
-        }
+        if (tid == 0) sh.thresh = otsu_from_hist(sh.hist, (double)bw * bh);
         __syncthreads();
         // ---- ARAN(30) of the binarised (and, for a slanted text line, rotated) ROI
         {

@@ -33,6 +33,8 @@ struct PlaneDesc {
     uint32_t pool_base;     // offset in the pool arrays (capacity pool_cap)
     uint32_t frame;
     uint8_t  ch, pyr, pad0, pad1;
+    uint32_t color_pitch;   // BGR frames: bytes between the Y, Cr, Cb planes of this level (pix - (ch % 3) * color_pitch is Y); 0 = no colour image
+    uint32_t pad2;
 };
 
 // Per-plane device counters, zeroed before every batch.

@@ -21,6 +21,7 @@
 
 #include "er_kernels.h"
 #include "svm_kernels.h"
+#include "track_kernels.h"
 
 using namespace str_er;
 
@@ -57,6 +58,8 @@ struct str_er_result {
     std::vector<int32_t> ocr_label;
     std::vector<double> ocr_prob;
     bool have_ocr = false;
+    std::vector<str_er_track> tracks;
+    bool have_tracks = false;
     double times[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -88,6 +91,7 @@ struct str_er_ctx {
     uint32_t *d_tile_cnt = nullptr; uint8_t *d_tile_lo = nullptr, *d_tile_hi = nullptr; size_t tile_slots = 0;
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
+    TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
     uint32_t *d_total = nullptr;
     uint16_t *d_cand_plane = nullptr;
     NodeRec *d_nodes = nullptr;
@@ -293,6 +297,7 @@ struct Batch {
     std::vector<PlaneDesc> planes;
     uint32_t n_tiles = 0, n_pairs = 0, max_nodes_plane = 0;
     size_t slots = 0, seam = 0;
+    int planes_per_image = 0;       // BGR frames: planes of one (frame, pyramid level), consecutive in `planes`; 0 = no colour image
 };
 
 void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int invert, uint32_t frame, int ch, int pyr,
@@ -356,6 +361,10 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if ((stages & STR_ER_STAGE_OCR) && !(c->svm_loaded && c->svm.dim == 1800))
         return fail(c, STR_ER_ESTATE, "STR_ER_STAGE_OCR needs an SVM model loaded with dim = 1800 (str_er_load_svm_model)");
 
+    if ((stages & STR_ER_STAGE_TRACK) && !(stages & STR_ER_STAGE_CLASSIFY)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs STR_ER_STAGE_CLASSIFY");
+    if ((stages & STR_ER_STAGE_TRACK) && b.planes_per_image <= 0)
+        return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs BGR frames (calc_color reads the YCrCb image)");
+
     const DetectParams dp = make_dp(c);
     hipStream_t s = c->stream;
     std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
@@ -406,6 +415,14 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     }
     rec(c, "classify");
     const int i_cls = c->n_ev - 1;
+    if (stages & STR_ER_STAGE_TRACK) {
+        const int n_img = np / b.planes_per_image;
+        launch_calc_color_batch(s, bd, c->d_track);
+        launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
+        launch_er_track(s, c->d_cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
+        rec(c, "track");
+    }
+    const int i_trk = c->n_ev - 1;
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -437,6 +454,15 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         if (hipMemcpyAsync(r->cands.data(), c->d_cands, sizeof(CandRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
             delete r; return fail(c, STR_ER_EHIP, "candidate copy failed");
         }
+    if ((stages & STR_ER_STAGE_TRACK)) {
+        r->tracks.resize(total);
+        r->have_tracks = true;
+        static_assert(sizeof(str_er_track) == sizeof(TrackRec), "track record layout");
+        if (total && hipMemcpyAsync(r->tracks.data(), c->d_track, sizeof(TrackRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
+            delete r; return fail(c, STR_ER_EHIP, "track copy failed");
+        }
+    }
+    const auto t_ocr0 = std::chrono::steady_clock::now();
     if ((stages & STR_ER_STAGE_OCR) && total) {
         // second phase: the host now knows how many strong/weak ERs there are
         size_t n_ocr = 0;
@@ -481,6 +507,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
             }
         }
     }
+    const double t_ocr_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ocr0).count();
     const bool want_nodes = (stages & STR_ER_WANT_NODES) != 0;
     if (want_nodes) {
         r->nodes.resize(np);
@@ -557,6 +584,8 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     for (int i = 1; i < c->n_ev; ++i)
         if (hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) == hipSuccess) c->profile[i].second = ms;
     r->times[0] = stage_s[0]; r->times[1] = stage_s[1]; r->times[2] = stage_s[2];
+    if ((stages & STR_ER_STAGE_TRACK) && hipEventElapsedTime(&ms, c->ev[i_cls], c->ev[i_trk]) == hipSuccess) r->times[3] = ms * 1e-3;
+    if (stages & STR_ER_STAGE_OCR) r->times[5] = t_ocr_s;
     r->times[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     *out = r;
     return STR_ER_OK;
@@ -696,6 +725,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_cnt, c->tile_slots)); A(dev_alloc(c, c->d_tile_lo, c->tile_slots)); A(dev_alloc(c, c->d_tile_hi, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
+    A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
@@ -805,7 +835,9 @@ int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, i
             for (int ch : c->chans) {
                 const uint8_t *pix = c->d_pix + (size_t)f * frame_bytes + geo[l].off + (size_t)(ch % 3) * plane_sz(l);
                 add_plane(b, pix, geo[l].w, geo[l].h, geo[l].stride, ch >= 3, (uint32_t)f, ch, l, c->kept_cap, c->pool_cap);
+                b.planes.back().color_pitch = (uint32_t)plane_sz(l);
             }
+    b.planes_per_image = (int)c->chans.size();
     return run_batch(c, b, stages, out, t0, true);
 }
 
@@ -1320,7 +1352,83 @@ const double *str_er_result_ocr_probs(const str_er_result *r, int32_t *n)
     return r->ocr_prob.data();
 }
 
+const str_er_track *str_er_result_tracks(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_tracks) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->tracks.size();
+    return r->tracks.data();
+}
+
 const double *str_er_result_times(const str_er_result *r) { return r ? r->times : nullptr; }
+
+int str_er_calc_color(str_er_ctx *c, const uint8_t *mask_plane, int32_t w, int32_t h, int64_t stride, const uint8_t *color_img, int32_t cw,
+                      int32_t ch, int64_t cstride, const int32_t *boxes, int32_t n, double *colors)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!mask_plane || !color_img || w < 1 || h < 1 || stride < w || cw < 1 || ch < 1 || cstride < (int64_t)cw * 3 || n < 0 ||
+        (n > 0 && (!boxes || !colors)))
+        return fail(c, STR_ER_EINVAL, "bad arguments");
+    for (int i = 0; i < n; ++i) {
+        const int32_t *b = boxes + 4 * (size_t)i;
+        if (b[2] < 1 || b[3] < 1 || b[0] < 0 || b[1] < 0 || (int64_t)b[0] + b[2] > w || (int64_t)b[1] + b[3] > h)
+            return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " outside the plane");
+        if (b[2] > cw || b[3] > ch) return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " larger than the colour image");
+    }
+    if (n == 0) return STR_ER_OK;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    if ((size_t)w * h > c->pix_bytes || (size_t)cw * 3 * ch > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "image larger than the context capacity");
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, mask_plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)cw * 3, color_img, (size_t)cstride, (size_t)cw * 3, (size_t)ch, hipMemcpyHostToDevice, st));
+    const size_t o_box = 0, o_tr = align_up(16 * (size_t)n, 256);
+    int rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * (size_t)n);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(sc + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    ColorSrc col{c->d_in, c->d_in + 1, c->d_in + 2, 3, (int64_t)cw * 3};
+    launch_calc_color_boxes(st, c->d_pix, w, col, reinterpret_cast<const int32_t *>(sc + o_box), n, reinterpret_cast<TrackRec *>(sc + o_tr));
+    HIP_TRY(c, hipGetLastError());
+    std::vector<TrackRec> tr((size_t)n);
+    HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) { colors[3 * (size_t)i] = tr[(size_t)i].color1; colors[3 * (size_t)i + 1] = tr[(size_t)i].color2; colors[3 * (size_t)i + 2] = tr[(size_t)i].color3; }
+    return STR_ER_OK;
+}
+
+int str_er_er_track(str_er_ctx *c, const str_er_cand *cands, const double *colors, int32_t n, uint8_t *tracked, int32_t *cx, int32_t *cy)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (n < 0 || (n > 0 && (!cands || !colors || !tracked))) return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (n == 0) return STR_ER_OK;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    hipStream_t st = c->stream;
+    const size_t o_c = 0, o_tr = align_up(sizeof(CandRec) * (size_t)n, 256), o_list = align_up(o_tr + sizeof(TrackRec) * (size_t)n, 256),
+                 o_rng = align_up(o_list + 4 * (size_t)n, 256);
+    int rc = ensure_scratch(c, o_rng + 64);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+    std::vector<TrackRec> tr((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        TrackRec t{};
+        t.color1 = colors[3 * (size_t)i]; t.color2 = colors[3 * (size_t)i + 1]; t.color3 = colors[3 * (size_t)i + 2];
+        tr[(size_t)i] = t;
+    }
+    const uint32_t rng[2] = {0u, (uint32_t)n};
+    HIP_TRY(c, hipMemcpyAsync(sc + o_c, cands, sizeof(CandRec) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(sc + o_tr, tr.data(), sizeof(TrackRec) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(sc + o_rng, rng, sizeof(rng), hipMemcpyHostToDevice, st));
+    launch_er_track(st, reinterpret_cast<const CandRec *>(sc + o_c), reinterpret_cast<TrackRec *>(sc + o_tr),
+                    reinterpret_cast<uint32_t *>(sc + o_list), reinterpret_cast<const uint32_t *>(sc + o_rng), 1);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        tracked[i] = (uint8_t)tr[(size_t)i].tracked;
+        if (cx) cx[i] = tr[(size_t)i].cx;
+        if (cy) cy[i] = tr[(size_t)i].cy;
+    }
+    return STR_ER_OK;
+}
 
 int str_er_result_cands_to_device(str_er_ctx *c, const str_er_result *r, void *dst_dev, int32_t cap, int32_t *n)
 {
