@@ -54,6 +54,8 @@ extern "C" {
 #define STR_ER_STAGE_OCR      8u   /* config 3: OCR::chain_run (slope 0) on every strong/weak ER; needs an SVM model */
 /* output options */
 #define STR_ER_WANT_NODES     16u  /* also return the kept-node table of every plane */
+#define STR_ER_STAGE_GROUP    64u  /* ERFilter::er_grouping(tracked, text, false, false) (src/ER.cpp:612-692); needs STR_ER_STAGE_TRACK */
+#define STR_ER_GROUP_INNER_SUP 128u /* ... with inner_sup = true, as text_detect calls it when DO_OCR is defined (src/ER.cpp:69) */
 #define STR_ER_STAGE_TRACK    32u  /* calc_color + ERFilter::er_track on the strong/weak ERs of every image (src/ER.cpp:530-590); BGR frames only */
 
 /* candidate class: which list of text_detect() the ER landed in (src/ER.cpp:516-526) */
@@ -135,6 +137,24 @@ typedef struct str_er_plane_info {
                              there; 0 = result is order-independent   */
     int32_t  root;        /* index of the root in the kept-node table                 */
 } str_er_plane_info;
+
+/* STR_ER_STAGE_TRACK / STR_ER_STAGE_GROUP records (described at str_er_result_tracks / str_er_result_texts) */
+typedef struct str_er_track {
+    double   color1, color2, color3;     /* NaN where the Otsu mask is empty (0.0 / 0 in calc_color) */
+    int32_t  cx, cy;
+    uint32_t tracked;
+    uint32_t reserved;
+} str_er_track;
+typedef struct str_er_text {
+    uint32_t frame;
+    uint8_t  pyr, reserved0, reserved1, reserved2;
+    int32_t  first, count;
+    double   slope;
+    int32_t  x, y, w, h;
+} str_er_text;
+typedef struct str_er_gbound {
+    int32_t x, y, w, h, cx, cy;
+} str_er_gbound;
 
 /* ---- lifetime --------------------------------------------------------------------- */
 /* Fills the reference's own defaults (src/main.cpp:22): 8,120,900000,2,0.7; six
@@ -232,6 +252,14 @@ int str_er_calc_color(str_er_ctx *ctx, const uint8_t *mask_plane, int32_t w, int
 int str_er_er_track(str_er_ctx *ctx, const str_er_cand *cands, const double *colors, int32_t n, uint8_t *tracked, int32_t *cx,
                     int32_t *cy);
 
+/* ERFilter::er_grouping(all_er, text, false, inner_sup) (src/ER.cpp:612-692) on caller-supplied ERs of ONE image:
+ * cands[i].{x,y,w,h,area} and tracks[i].{color1-3, cx, cy, tracked} (all_er = the ones with tracked != 0).  The
+ * result holds copies of cands and tracks plus the lines (str_er_result_texts / _text_ers / _group_bounds);
+ * free it with str_er_result_free.  overlap_sup = true (only video_mode without DO_OCR asks for it,
+ * src/utils.cpp:196) is not built: STR_ER_EINVAL.                                                      */
+int str_er_er_grouping(str_er_ctx *ctx, const str_er_cand *cands, const str_er_track *tracks, int32_t n, int overlap_sup,
+                       int inner_sup, str_er_result **out);
+
 /* The same with the text line's slope per box (Text::slope, src/ER.cpp:731): where |slope[i]| > 0.01 the
  * binarised ROI goes through OCR::rotate_mat(atan2(slope, 1), crop = true) (src/OCR.cpp:73-78, 254-357)
  * before ARAN.  slope == NULL means all zero.  A non-finite slope is STR_ER_EINVAL.                   */
@@ -271,18 +299,25 @@ const double  *str_er_result_ocr_probs(const str_er_result *r, int32_t *n);
  * rule at :575-587 ties, directly or through other tracked ERs, to one of them.  all_er's ORDER (strong
  * lists, then weak ones as found) is not reproduced -- er_grouping sorts it first thing (:614).
  * Records of pool-only candidates (cls 0) are all zero.  NULL without the stage.                   */
-typedef struct str_er_track {
-    double   color1, color2, color3;     /* NaN where the Otsu mask is empty (0.0 / 0 in calc_color) */
-    int32_t  cx, cy;
-    uint32_t tracked;
-    uint32_t reserved;
-} str_er_track;
 const str_er_track *str_er_result_tracks(const str_er_result *r, int32_t *n);
+/* With STR_ER_STAGE_GROUP: the text lines (`vector<Text>` of src/ER.cpp:612) of every image, images in plane
+ * order.  A line's members are str_er_result_text_ers()[first .. first+count): indices into
+ * str_er_result_cands(), in the line's order (sorted by center.x); as in the reference an ER can sit in more
+ * than one line, and more than once in a line (:650-661 never merges two lines).  slope = fitline_avgslope of
+ * the members that survive overlap_ and inner_suppression; box = union of the members' bounds
+ * (the reference fills Text::box here only without DO_OCR, :684-690).
+ * Where the reference calls std::sort on center.x (:614, :668) this library sorts STABLY, ties in candidate
+ * order / current line order: the reference's order among equal center.x is unspecified (unstable sort over a
+ * traversal-dependent input order), so lines that hinge on such ties may legitimately differ from it.
+ * overlap_suppression rewrites bound and center of the ERs it merges into (:945-955, shared by all lines):
+ * str_er_result_group_bounds() has every candidate's bound and center as er_grouping leaves them.        */
+const str_er_text   *str_er_result_texts(const str_er_result *r, int32_t *n);
+const int32_t       *str_er_result_text_ers(const str_er_result *r, int32_t *n);
+const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n);
 /* Kept-node table of one plane, ascending (key, level); NULL unless STR_ER_WANT_NODES. */
 const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n);
 /* times[7] = {extract, nms, classify, track, group, ocr, total} seconds, the contract of
- * ERFilter::text_detect's return value (src/ER.cpp:99-110); track is filled by STR_ER_STAGE_TRACK, ocr by
- * STR_ER_STAGE_OCR, group is 0.
+ * ERFilter::text_detect's return value (src/ER.cpp:99-110); track, group and ocr are filled by their stages.
  * extract/nms/classify are GPU stage times for the whole batch (HIP events).          */
 const double *str_er_result_times(const str_er_result *r);
 /* Device copy of the candidate array (for an RCCL gather without a host round trip):

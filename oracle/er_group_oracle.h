@@ -38,6 +38,22 @@ void ero_calc_color(const uint8_t *mask_plane, int mstride, int bx, int by, int 
  * Sets cx, cy.  order[] receives the indices of all_er in the reference's order; returns its size. */
 int ero_er_track(ero_er *ers, int n, int *order);
 
+/* ERFilter::er_grouping(all_er, text, overlap_sup, inner_sup) (src/ER.cpp:612-692) with its helpers
+ * inner_suppression (:893-922), overlap_suppression (:925-964) and fitline_avgslope (:1361-1389).
+ * ers[0..n) is all_er (cx, cy, colours set); every std::sort by center.x of the reference is made
+ * STABLE here (ties keep their current order) -- the reference's sort is unstable, so its tie order is
+ * unspecified; this is the build's definition.  overlap_suppression rewrites bound/center of the ERs it
+ * merges into, in place (they are shared between lines), exactly as the reference does.
+ *
+ * Outputs: *n_all / all_idx = all_er after the sort (and suppressions), as indices into ers[];
+ * lines: line_first[k], line_count[k] slice member[] (indices into ers[], in the line's sorted order),
+ * slope[k], box[4k..] = union of the members' bounds at that moment (the !DO_OCR branch, :684-690).
+ * member_cap / line_cap bound the arrays; returns the number of lines or -1 on overflow.          */
+int ero_er_grouping(ero_er *ers, int n, int overlap_sup, int inner_sup, int *all_idx, int *n_all,
+                    int *line_first, int *line_count, double *slope, int *box, int line_cap, int *member, int member_cap);
+
+double ero_fitline_avgslope(const int *px, const int *py, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,10 @@ class Oracle:
         L.ero_otsu_threshold.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ero_calc_color.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.POINTER(C.c_double)]
         L.ero_er_track.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        ip, dp_ = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.ero_er_grouping.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, dp_, ip, C.c_int, ip, C.c_int]
+        L.ero_fitline_avgslope.argtypes = [ip, ip, C.c_int]
+        L.ero_fitline_avgslope.restype = C.c_double
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
 
@@ -250,6 +254,30 @@ class Oracle:
         order = np.zeros(len(e) + 1, np.int32)
         n = self.lib.ero_er_track(e.ctypes.data_as(C.c_void_p), len(e), order.ctypes.data_as(C.POINTER(C.c_int)))
         return order[:n].copy(), e
+
+    def er_grouping(self, ers: np.ndarray, overlap_sup: bool = False, inner_sup: bool = False):
+        """ers: all_er as an ER_DTYPE array (cx, cy, colours set).  Returns (all_idx after sort/suppression,
+        lines = [(member indices into ers, slope, box xywh)], ers as the call leaves them)."""
+        e = np.ascontiguousarray(ers, dtype=self.ER_DTYPE).copy()
+        n = len(e)
+        cap_l, cap_m = n + 1, n * n + 2 * n + 2
+        all_idx = np.zeros(n + 1, np.int32)
+        n_all = C.c_int(0)
+        first, count = np.zeros(cap_l, np.int32), np.zeros(cap_l, np.int32)
+        slope, box, member = np.zeros(cap_l, np.float64), np.zeros(4 * cap_l, np.int32), np.zeros(cap_m, np.int32)
+        ip, dp_ = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        nl = self.lib.ero_er_grouping(e.ctypes.data_as(C.c_void_p), n, int(overlap_sup), int(inner_sup), all_idx.ctypes.data_as(ip),
+                                      C.byref(n_all), first.ctypes.data_as(ip), count.ctypes.data_as(ip), slope.ctypes.data_as(dp_),
+                                      box.ctypes.data_as(ip), cap_l, member.ctypes.data_as(ip), cap_m)
+        assert nl >= 0, "oracle er_grouping overflow"
+        lines = [(member[first[k]:first[k] + count[k]].copy(), float(slope[k]), tuple(int(v) for v in box[4 * k:4 * k + 4])) for k in range(nl)]
+        return all_idx[:n_all.value].copy(), lines, e
+
+    def fitline_avgslope(self, pts) -> float:
+        px = np.ascontiguousarray([p[0] for p in pts], dtype=np.int32)
+        py = np.ascontiguousarray([p[1] for p in pts], dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        return float(self.lib.ero_fitline_avgslope(px.ctypes.data_as(ip), py.ctypes.data_as(ip), len(px)))
 
     def otsu(self, img: np.ndarray, invert: bool = False) -> int:
         img = _u8(img)

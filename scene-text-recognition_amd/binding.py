@@ -18,6 +18,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES, STAGE_TRACK = 1, 2, 4, 7, 8, 16, 32
+STAGE_GROUP, GROUP_INNER_SUP = 64, 128
+TEXT_DTYPE = np.dtype([("frame", "<u4"), ("pyr", "u1"), ("r0", "u1"), ("r1", "u1"), ("r2", "u1"), ("first", "<i4"), ("count", "<i4"),
+                       ("slope", "<f8"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4")])
+GBOUND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("cx", "<i4"), ("cy", "<i4")])
 TRACK_DTYPE = np.dtype([("color1", "<f8"), ("color2", "<f8"), ("color3", "<f8"), ("cx", "<i4"), ("cy", "<i4"),
                         ("tracked", "<u4"), ("reserved", "<u4")])
 CLS_POOL, CLS_STRONG, CLS_WEAK = 0, 1, 2
@@ -137,6 +141,10 @@ def load_library():
     L.str_er_result_plane_nodes.restype = vp
     L.str_er_result_tracks.argtypes = [vp, i32p]
     L.str_er_result_tracks.restype = vp
+    for fn in (L.str_er_result_texts, L.str_er_result_text_ers, L.str_er_result_group_bounds):
+        fn.argtypes = [vp, i32p]
+        fn.restype = vp
+    L.str_er_er_grouping.argtypes = [vp, vp, vp, C.c_int32, C.c_int, C.c_int, C.POINTER(vp)]
     L.str_er_calc_color.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp]
     L.str_er_er_track.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
     L.str_er_result_ocr_labels.argtypes = [vp, i32p]
@@ -196,6 +204,9 @@ class Result:
         self.ocr_label = None      # with STAGE_OCR: per candidate, -1 for cls == 0
         self.ocr_prob = None
         self.tracks = None         # with STAGE_TRACK: TRACK_DTYPE per candidate (zeros for cls == 0)
+        self.texts = None          # with STAGE_GROUP: TEXT_DTYPE per line; members = text_ers[first:first+count] (candidate indices)
+        self.text_ers = None
+        self.group_bounds = None   # GBOUND_DTYPE per candidate: bound / center as er_grouping leaves them
         self._planes = None
 
     @property
@@ -313,6 +324,16 @@ class ERFilter:
             if tp:
                 res.tracks = (np.frombuffer((C.c_char * (40 * no.value)).from_address(tp), dtype=TRACK_DTYPE).copy()
                               if no.value else np.zeros(0, TRACK_DTYPE))
+            xp = L.str_er_result_texts(rh, C.byref(no))
+            if xp:
+                res.texts = (np.frombuffer((C.c_char * (40 * no.value)).from_address(xp), dtype=TEXT_DTYPE).copy()
+                             if no.value else np.zeros(0, TEXT_DTYPE))
+                ep = L.str_er_result_text_ers(rh, C.byref(no))
+                res.text_ers = (np.frombuffer((C.c_char * (4 * no.value)).from_address(ep), dtype=np.int32).copy()
+                                if no.value else np.zeros(0, np.int32))
+                bp = L.str_er_result_group_bounds(rh, C.byref(no))
+                res.group_bounds = (np.frombuffer((C.c_char * (24 * no.value)).from_address(bp), dtype=GBOUND_DTYPE).copy()
+                                    if no.value else np.zeros(0, GBOUND_DTYPE))
             return res
         finally:
             L.str_er_result_free(rh)
@@ -480,6 +501,17 @@ class ERFilter:
         cy = np.zeros(n, np.int32)
         self._check(self.L.str_er_er_track(self.h, _np_ptr(cd), _np_ptr(col), n, _np_ptr(tr), _np_ptr(cx), _np_ptr(cy)))
         return tr.astype(bool), cx, cy
+
+    def er_grouping(self, cands: np.ndarray, tracks: np.ndarray, overlap_sup: bool = False, inner_sup: bool = False) -> Result:
+        """ERFilter::er_grouping(all_er, text, overlap_sup, inner_sup) (src/ER.cpp:612-692) on the ERs of one image
+        (cands CAND_DTYPE, tracks TRACK_DTYPE with color1-3 / cx / cy / tracked): Result with .texts / .text_ers / .group_bounds."""
+        cd = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        tr = np.ascontiguousarray(tracks, dtype=TRACK_DTYPE)
+        if len(cd) != len(tr):
+            raise ValueError("one track record per candidate")
+        rh = C.c_void_p()
+        self._check(self.L.str_er_er_grouping(self.h, _np_ptr(cd), _np_ptr(tr), len(cd), int(overlap_sup), int(inner_sup), C.byref(rh)))
+        return self._collect(rh)
 
     def make_LBP_hist(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None, return_tiles: bool = False):
         """ERFilter::make_LBP_hist(input, 2, 24) (src/ER.cpp:789-816).  With no boxes the whole

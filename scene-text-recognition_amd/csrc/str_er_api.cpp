@@ -22,6 +22,7 @@
 #include "er_kernels.h"
 #include "svm_kernels.h"
 #include "track_kernels.h"
+#include "er_group.h"
 
 using namespace str_er;
 
@@ -60,6 +61,10 @@ struct str_er_result {
     bool have_ocr = false;
     std::vector<str_er_track> tracks;
     bool have_tracks = false;
+    std::vector<str_er_text> texts;
+    std::vector<int32_t> text_ers;
+    std::vector<str_er_gbound> gbounds;
+    bool have_texts = false;
     double times[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -92,6 +97,7 @@ struct str_er_ctx {
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
     TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
+    uint32_t *d_group = nullptr, *d_group_pairs = nullptr; size_t group_words = 0, group_pair_cap = 0;   // STR_ER_STAGE_GROUP, grown on demand
     uint32_t *d_total = nullptr;
     uint16_t *d_cand_plane = nullptr;
     NodeRec *d_nodes = nullptr;
@@ -342,6 +348,95 @@ void rec(str_er_ctx *c, const char *name)
     }
 }
 
+// er_grouping for the images of a call.  img[g] = candidate range [lo, hi) of image g (on the device: d_cands / d_track
+// hold the same records the host has in r->cands / r->tracks).  GPU: sort ranks, inner_suppression flags, pair list;
+// host: the greedy line assignment and the per-line steps (er_group.cpp).
+int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, const std::vector<uint32_t> &img, bool inner_sup,
+                str_er_result *r)
+{
+    const int    G = (int)(img.size() / 2);
+    const size_t n_c = r->cands.size();
+    r->have_texts = true;
+    r->gbounds.resize(n_c);
+    for (size_t i = 0; i < n_c; ++i) {
+        const str_er_cand &cd = r->cands[i];
+        str_er_gbound &gb = r->gbounds[i];
+        gb.x = cd.x; gb.y = cd.y; gb.w = cd.w; gb.h = cd.h; gb.cx = r->tracks[i].cx; gb.cy = r->tracks[i].cy;
+    }
+    if (G == 0 || n_c == 0) return STR_ER_OK;
+    for (int g = 0; g < G; ++g)
+        if (img[2 * g + 1] - img[2 * g] > 65535u) return fail(c, STR_ER_ECAPACITY, "more than 65535 candidates in one image");
+    hipStream_t s = c->stream;
+    const size_t words = 4 * n_c + 4 * (size_t)G + 64;
+    if (words > c->group_words) {
+        if (c->d_group) { (void)hipFree(c->d_group); c->d_group = nullptr; c->group_words = 0; }
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_group), 4 * words) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (grouping workspace)");
+        c->group_words = words;
+    }
+    auto grow_pairs = [&](size_t cap) -> int {
+        if (cap <= c->group_pair_cap) return STR_ER_OK;
+        if (c->d_group_pairs) { (void)hipFree(c->d_group_pairs); c->d_group_pairs = nullptr; c->group_pair_cap = 0; }
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_group_pairs), 4 * cap) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (pair list)");
+        c->group_pair_cap = cap;
+        return STR_ER_OK;
+    };
+    int rc = grow_pairs(std::max<size_t>(8 * n_c, 4096));
+    if (rc != STR_ER_OK) return rc;
+    GroupBufs gb{};
+    gb.tmp_a = c->d_group; gb.tmp_b = gb.tmp_a + n_c; gb.sorted = gb.tmp_b + n_c; gb.row_cnt = gb.sorted + n_c;
+    gb.n_sorted = gb.row_cnt + n_c; gb.pair_off = gb.n_sorted + G;
+    uint32_t *d_rng = gb.pair_off + G + 1;
+    gb.pairs = c->d_group_pairs; gb.pair_cap = (uint32_t)std::min<size_t>(c->group_pair_cap, 0xFFFFFFFFu);
+    HIP_TRY(c, hipMemcpyAsync(d_rng, img.data(), 4 * img.size(), hipMemcpyHostToDevice, s));
+    launch_group_prepare(s, d_cands, d_track, d_rng, G, inner_sup ? 1 : 0, gb);
+    launch_group_pairs_count(s, d_cands, d_track, d_rng, G, gb);
+    launch_group_pairs_fill(s, d_cands, d_track, d_rng, G, gb);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<uint32_t> n_sorted((size_t)G), pair_off((size_t)G + 1), sorted(n_c);
+    HIP_TRY(c, hipMemcpyAsync(n_sorted.data(), gb.n_sorted, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pair_off.data(), gb.pair_off, 4 * ((size_t)G + 1), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(sorted.data(), gb.sorted, 4 * n_c, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const size_t n_pairs = pair_off[(size_t)G];
+    if (n_pairs > c->group_pair_cap) {               // the optimistic buffer was too small: the fill kernel did nothing
+        rc = grow_pairs(n_pairs + n_pairs / 4);
+        if (rc != STR_ER_OK) return rc;
+        gb.pairs = c->d_group_pairs; gb.pair_cap = (uint32_t)std::min<size_t>(c->group_pair_cap, 0xFFFFFFFFu);
+        launch_group_pairs_fill(s, d_cands, d_track, d_rng, G, gb);
+        HIP_TRY(c, hipGetLastError());
+    }
+    std::vector<uint32_t> pairs(n_pairs);
+    if (n_pairs) HIP_TRY(c, hipMemcpyAsync(pairs.data(), gb.pairs, 4 * n_pairs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    std::vector<GroupEr>  ers;
+    std::vector<TextLine> lines;
+    for (int g = 0; g < G; ++g) {
+        const uint32_t lo = img[2 * g], m = n_sorted[(size_t)g];
+        if (m == 0) continue;
+        ers.resize(m);
+        for (uint32_t k = 0; k < m; ++k) {
+            const str_er_gbound &b = r->gbounds[sorted[lo + k]];
+            ers[k] = GroupEr{b.x, b.y, b.w, b.h, b.cx, b.cy};
+        }
+        group_lines(ers, pairs.data() + pair_off[(size_t)g], pair_off[(size_t)g + 1] - pair_off[(size_t)g], lines);
+        for (uint32_t k = 0; k < m; ++k) {
+            str_er_gbound &b = r->gbounds[sorted[lo + k]];
+            b.x = ers[k].x; b.y = ers[k].y; b.w = ers[k].w; b.h = ers[k].h; b.cx = ers[k].cx; b.cy = ers[k].cy;
+        }
+        const str_er_cand &first = r->cands[lo];
+        for (const TextLine &t : lines) {
+            str_er_text tx{};
+            tx.frame = first.frame; tx.pyr = first.pyr;
+            tx.first = (int32_t)r->text_ers.size(); tx.count = (int32_t)t.ers.size();
+            tx.slope = t.slope; tx.x = t.box[0]; tx.y = t.box[1]; tx.w = t.box[2]; tx.h = t.box[3];
+            for (int32_t k : t.ers) r->text_ers.push_back((int32_t)sorted[lo + (uint32_t)k]);
+            r->texts.push_back(tx);
+        }
+    }
+    return STR_ER_OK;
+}
+
 // Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
 int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **out,
               std::chrono::steady_clock::time_point t_start, bool pre_recorded)
@@ -362,6 +457,8 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         return fail(c, STR_ER_ESTATE, "STR_ER_STAGE_OCR needs an SVM model loaded with dim = 1800 (str_er_load_svm_model)");
 
     if ((stages & STR_ER_STAGE_TRACK) && !(stages & STR_ER_STAGE_CLASSIFY)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs STR_ER_STAGE_CLASSIFY");
+    if ((stages & (STR_ER_STAGE_GROUP | STR_ER_GROUP_INNER_SUP)) && !(stages & STR_ER_STAGE_TRACK)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_GROUP needs STR_ER_STAGE_TRACK");
+    if ((stages & STR_ER_GROUP_INNER_SUP) && !(stages & STR_ER_STAGE_GROUP)) return fail(c, STR_ER_EINVAL, "STR_ER_GROUP_INNER_SUP modifies STR_ER_STAGE_GROUP");
     if ((stages & STR_ER_STAGE_TRACK) && b.planes_per_image <= 0)
         return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs BGR frames (calc_color reads the YCrCb image)");
 
@@ -461,6 +558,22 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         if (total && hipMemcpyAsync(r->tracks.data(), c->d_track, sizeof(TrackRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
             delete r; return fail(c, STR_ER_EHIP, "track copy failed");
         }
+    }
+    double t_group_s = 0;
+    if (stages & STR_ER_STAGE_GROUP) {
+        const auto tg0 = std::chrono::steady_clock::now();
+        if (hipStreamSynchronize(s) != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, "sync before grouping"); }
+        std::vector<uint32_t> img;
+        const int n_img = np / b.planes_per_image;
+        uint32_t off2 = 0;
+        for (int g = 0; g < n_img; ++g) {
+            img.push_back(off2);
+            for (int k = 0; k < b.planes_per_image; ++k) off2 += c->h_ctr[g * b.planes_per_image + k].n_pool;
+            img.push_back(off2);
+        }
+        const int rcg = group_phase(c, c->d_cands, c->d_track, img, (stages & STR_ER_GROUP_INNER_SUP) != 0, r);
+        if (rcg != STR_ER_OK) { delete r; return rcg; }
+        t_group_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     }
     const auto t_ocr0 = std::chrono::steady_clock::now();
     if ((stages & STR_ER_STAGE_OCR) && total) {
@@ -586,6 +699,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     r->times[0] = stage_s[0]; r->times[1] = stage_s[1]; r->times[2] = stage_s[2];
     if ((stages & STR_ER_STAGE_TRACK) && hipEventElapsedTime(&ms, c->ev[i_cls], c->ev[i_trk]) == hipSuccess) r->times[3] = ms * 1e-3;
     if (stages & STR_ER_STAGE_OCR) r->times[5] = t_ocr_s;
+    r->times[4] = t_group_s;
     r->times[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     *out = r;
     return STR_ER_OK;
@@ -643,6 +757,8 @@ void str_er_destroy(str_er_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_group) (void)hipFree(c->d_group);
+    if (c->d_group_pairs) (void)hipFree(c->d_group_pairs);
     for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
     if (c->d_svm_blob) (void)hipFree(c->d_svm_blob);
     if (c->h_planes) (void)hipHostFree(c->h_planes);
@@ -1357,6 +1473,67 @@ const str_er_track *str_er_result_tracks(const str_er_result *r, int32_t *n)
     if (!r || !r->have_tracks) { if (n) *n = 0; return nullptr; }
     if (n) *n = (int32_t)r->tracks.size();
     return r->tracks.data();
+}
+
+const str_er_text *str_er_result_texts(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_texts) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->texts.size();
+    static const str_er_text none{};
+    return r->texts.empty() ? &none : r->texts.data();
+}
+
+const int32_t *str_er_result_text_ers(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_texts) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->text_ers.size();
+    static const int32_t none = 0;
+    return r->text_ers.empty() ? &none : r->text_ers.data();
+}
+
+const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_texts) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->gbounds.size();
+    static const str_er_gbound none{};
+    return r->gbounds.empty() ? &none : r->gbounds.data();
+}
+
+int str_er_er_grouping(str_er_ctx *c, const str_er_cand *cands, const str_er_track *tracks, int32_t n, int overlap_sup, int inner_sup,
+                       str_er_result **out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!out || n < 0 || (n > 0 && (!cands || !tracks))) return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (overlap_sup) return fail(c, STR_ER_EINVAL, "er_grouping with overlap_sup = true is not built");
+    *out = nullptr;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    str_er_result *r = new (std::nothrow) str_er_result();
+    if (!r) return fail(c, STR_ER_ENOMEM, "result allocation");
+    r->cands.assign(cands, cands + n);
+    r->tracks.assign(tracks, tracks + n);
+    r->have_tracks = true;
+    r->cand_off.assign(2, 0); r->cand_off[1] = (uint32_t)n;
+    r->planes.resize(1);
+    std::memset(&r->planes[0], 0, sizeof(str_er_plane_info));
+    r->planes[0].n_pool = n; r->planes[0].root = -1;
+    int rc = STR_ER_OK;
+    if (n > 0) {
+        const size_t o_c = 0, o_tr = align_up(sizeof(CandRec) * (size_t)n, 256);
+        rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * (size_t)n);
+        if (rc == STR_ER_OK) {
+            uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+            hipError_t e = hipMemcpyAsync(sc + o_c, cands, sizeof(CandRec) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(sc + o_tr, tracks, sizeof(TrackRec) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) rc = fail(c, STR_ER_EHIP, hipGetErrorString(e));
+            else rc = group_phase(c, reinterpret_cast<const CandRec *>(sc + o_c), reinterpret_cast<const TrackRec *>(sc + o_tr),
+                                  std::vector<uint32_t>{0u, (uint32_t)n}, inner_sup != 0, r);
+        }
+    } else {
+        r->have_texts = true;
+    }
+    if (rc != STR_ER_OK) { delete r; return rc; }
+    *out = r;
+    return STR_ER_OK;
 }
 
 const double *str_er_result_times(const str_er_result *r) { return r ? r->times : nullptr; }

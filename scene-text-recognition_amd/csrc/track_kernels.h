@@ -33,4 +33,24 @@ void launch_group_ranges(hipStream_t s, const BatchDev &b, int planes_per_group,
 // er_track per image; list = scratch of as many words as there are candidates
 void launch_er_track(hipStream_t s, const CandRec *cands, TrackRec *tr, uint32_t *list, const uint32_t *ranges, int n_groups);
 
+// ---- er_grouping, the data-parallel half -------------------------------------
+// Per image g (candidate range ranges[2g..2g+1]); every array below is indexed from the image's `lo`:
+//   sorted[lo + k], k < n_sorted[g]   all_er after the stable sort by center.x (ties: candidate order) and,
+//                                     if inner_sup, ERFilter::inner_suppression -- candidate indices
+//   pairs[pair_off[g] ...]            (i << 16 | j), i < j positions in sorted[], for which the rule of
+//                                     src/ER.cpp:631-644 holds, in the order the reference's double loop meets them
+struct GroupBufs {
+    uint32_t *tmp_a, *tmp_b;       // scratch, one word per candidate each
+    uint32_t *sorted;              // one word per candidate
+    uint32_t *row_cnt;             // one word per candidate: pairs of row i, then their offset
+    uint32_t *n_sorted;            // per image
+    uint32_t *pair_off;            // per image + 1 (the last one is the total)
+    uint32_t *pairs;               // capacity pair_cap
+    uint32_t  pair_cap;
+};
+void launch_group_prepare(hipStream_t s, const CandRec *cands, const TrackRec *tr, const uint32_t *ranges, int n_groups, int inner_sup,
+                          const GroupBufs &g);
+void launch_group_pairs_count(hipStream_t s, const CandRec *cands, const TrackRec *tr, const uint32_t *ranges, int n_groups, const GroupBufs &g);
+void launch_group_pairs_fill(hipStream_t s, const CandRec *cands, const TrackRec *tr, const uint32_t *ranges, int n_groups, const GroupBufs &g);
+
 } // namespace str_er

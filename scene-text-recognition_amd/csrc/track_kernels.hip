@@ -173,4 +173,202 @@ void launch_er_track(hipStream_t s, const CandRec *cands, TrackRec *tr, uint32_t
     hipLaunchKernelGGL(k_er_track, dim3(n_groups), dim3(256), 0, s, cands, tr, list, ranges);
 }
 
+// ------------------------------------------------------------------------------------
+// er_grouping (src/ER.cpp:612-692), the parts that are independent per pair of ERs: the sort by
+// center.x (as a rank: position = number of ERs that come before), inner_suppression's flags
+// (:893-922) and the pairwise rule (:631-644) as a list of pairs in the reference's visiting order.
+// The greedy line assignment that consumes the pairs, and the per-line suppression / slope, are
+// sequential by definition and run on the host (er_group.cpp).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+// exclusive block scan of one value per lane (256 lanes); returns offset, *total = block sum
+__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *s_w, uint32_t *total)
+{
+    const int      tid = threadIdx.x;
+    const uint32_t incl = wave_incl_scan32(v);
+    __syncthreads();
+    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < (tid >> 6)) off += s_w[i]; tot += s_w[i]; }
+    *total = tot;
+    return off + incl - v;
+}
+
+struct GEr { int x, y, w, h, cx, cy, area; double c1, c2, c3; };
+__device__ __forceinline__ GEr load_ger(const CandRec *cands, const TrackRec *tr, uint32_t ci)
+{
+    const CandRec &c = cands[ci];
+    const TrackRec &t = tr[ci];
+    GEr e;
+    e.x = c.x; e.y = c.y; e.w = c.w; e.h = c.h; e.area = (int)c.area; e.cx = t.cx; e.cy = t.cy;
+    e.c1 = t.color1; e.c2 = t.color2; e.c3 = t.color3;
+    return e;
+}
+
+__global__ __launch_bounds__(256) void k_group_prepare(const CandRec *__restrict__ cands, const TrackRec *__restrict__ tr,
+                                                       const uint32_t *__restrict__ ranges, int inner_sup, GroupBufs g)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t lo = ranges[2 * blockIdx.x], hi = ranges[2 * blockIdx.x + 1];
+    const int      tid = threadIdx.x;
+    uint32_t *A = g.tmp_a + lo, *B = g.tmp_b + lo, *S = g.sorted + lo;
+    // 1. all_er in candidate order
+    uint32_t n_t = 0;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
+        const uint32_t i = i0 + tid;
+        const uint32_t f = (i < hi && tr[i].tracked) ? 1u : 0u;
+        uint32_t       tot;
+        const uint32_t off = block_scan256(f, s_w, &tot);
+        if (f) A[n_t + off] = i;
+        n_t += tot;
+    }
+    __syncthreads();
+    // 2. sort(all_er, center.x) (:614), stable: position = how many come before
+    for (uint32_t k = tid; k < n_t; k += 256) {
+        const int ck = tr[A[k]].cx;
+        uint32_t  rank = 0;
+        for (uint32_t j = 0; j < n_t; ++j) {
+            const int cj = tr[A[j]].cx;
+            rank += (cj < ck || (cj == ck && j < k)) ? 1u : 0u;
+        }
+        B[rank] = A[k];
+    }
+    __syncthreads();
+    // 3. inner_suppression (:893-922): j goes if some i contains it, shares its centre (within 0.2 of i's larger side) and
+    //    has more than twice its box area
+    uint32_t m = 0;
+    for (uint32_t j0 = 0; j0 < n_t; j0 += 256) {
+        const uint32_t j = j0 + tid;
+        uint32_t       keep = 0;
+        if (j < n_t) {
+            keep = 1;
+            if (inner_sup) {
+                const GEr b = load_ger(cands, tr, B[j]);
+                for (uint32_t i = 0; i < n_t && keep; ++i) {
+                    const GEr    a = load_ger(cands, tr, B[i]);
+                    const double dx = a.cx - b.cx, dy = a.cy - b.cy;
+                    if (sqrt(dx * dx + dy * dy) < 0.2 * max(a.w, a.h) && a.x <= b.x && a.y <= b.y && a.x + a.w >= b.x + b.w &&
+                        a.y + a.h >= b.y + b.h && (double)(a.w * a.h) / (double)(b.w * b.h) > 2.0)
+                        keep = 0;
+                }
+            }
+        }
+        uint32_t       tot;
+        const uint32_t off = block_scan256(keep, s_w, &tot);
+        if (keep) S[m + off] = B[j];
+        m += tot;
+    }
+    if (tid == 0) g.n_sorted[blockIdx.x] = m;
+}
+
+// the rule of src/ER.cpp:631-644, a before b in the sorted list
+__device__ __forceinline__ bool group_rule(const GEr &a, const GEr &b)
+{
+    return abs(a.cx - b.cx) < max(a.w, b.w) * 3.0 &&
+           abs(a.cy - b.cy) < (a.h + b.h) * 0.25 &&
+           abs(a.h - b.h) < min(a.h, b.h) &&
+           abs(a.w - b.w) < min(a.h, b.h * 2) &&
+           fabs(a.c1 - b.c1) < 25 && fabs(a.c2 - b.c2) < 25 && fabs(a.c3 - b.c3) < 25 &&
+           abs(a.area - b.area) < min(a.area, b.area) * 4;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_group_pairs(const CandRec *__restrict__ cands, const TrackRec *__restrict__ tr,
+                                                     const uint32_t *__restrict__ ranges, GroupBufs g, int n_groups)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t  lo = ranges[2 * blockIdx.x];
+    const uint32_t  m = g.n_sorted[blockIdx.x];
+    const uint32_t *S = g.sorted + lo;
+    uint32_t       *rc = g.row_cnt + lo;
+    const int       tid = threadIdx.x;
+    if (FILL) {
+        if (g.pair_off[n_groups] > g.pair_cap) return;            // the host grows the buffer and asks again
+        // row offsets: exclusive prefix of the row counts, from the image's base
+        uint32_t carry = g.pair_off[blockIdx.x];
+        for (uint32_t i0 = 0; i0 < m; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            const uint32_t v = i < m ? rc[i] : 0u;
+            uint32_t       tot;
+            const uint32_t off = block_scan256(v, s_w, &tot);
+            __syncthreads();
+            if (i < m) rc[i] = carry + off;
+            carry += tot;
+        }
+        __syncthreads();
+    }
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < m; i += 256) {
+        const GEr a = load_ger(cands, tr, S[i]);
+        uint32_t  n = 0, at = FILL ? rc[i] : 0u;
+        for (uint32_t j = i + 1; j < m; ++j)
+            if (group_rule(a, load_ger(cands, tr, S[j]))) {
+                if (FILL) g.pairs[at++] = (i << 16) | j;
+                ++n;
+            }
+        if (!FILL) rc[i] = n;
+        mine += n;
+    }
+    if (!FILL) {
+        uint32_t tot;
+        (void)block_scan256(mine, s_w, &tot);
+        if (tid == 0) g.pair_off[blockIdx.x] = tot;               // per-image count; k_pair_prefix turns it into offsets
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_pair_prefix(uint32_t *pair_off, int n_groups)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_groups; base += 1024) {
+        const int      i = base + tid;
+        const uint32_t v = i < n_groups ? pair_off[i] : 0u;
+        const uint32_t incl = wave_incl_scan32(v);
+        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+        if (i < n_groups) pair_off[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) pair_off[n_groups] = s_carry;
+}
+
+void launch_group_prepare(hipStream_t s, const CandRec *cands, const TrackRec *tr, const uint32_t *ranges, int n_groups, int inner_sup,
+                          const GroupBufs &g)
+{
+    if (n_groups <= 0) return;
+    hipLaunchKernelGGL(k_group_prepare, dim3(n_groups), dim3(256), 0, s, cands, tr, ranges, inner_sup, g);
+}
+
+void launch_group_pairs_count(hipStream_t s, const CandRec *cands, const TrackRec *tr, const uint32_t *ranges, int n_groups, const GroupBufs &g)
+{
+    if (n_groups <= 0) return;
+    hipLaunchKernelGGL(k_group_pairs<false>, dim3(n_groups), dim3(256), 0, s, cands, tr, ranges, g, n_groups);
+    hipLaunchKernelGGL(k_pair_prefix, dim3(1), dim3(1024), 0, s, g.pair_off, n_groups);
+}
+
+void launch_group_pairs_fill(hipStream_t s, const CandRec *cands, const TrackRec *tr, const uint32_t *ranges, int n_groups, const GroupBufs &g)
+{
+    if (n_groups <= 0) return;
+    hipLaunchKernelGGL(k_group_pairs<true>, dim3(n_groups), dim3(256), 0, s, cands, tr, ranges, g, n_groups);
+}
+
 } // namespace str_er

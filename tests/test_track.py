@@ -171,3 +171,134 @@ def test_gpu_track_stage_pyramid_and_errors(S, cascade_paths, oracle):
     with pytest.raises(S.StrErError):
         f.text_detect(frames, S.STAGE_EXTRACT | S.STAGE_NMS | S.STAGE_TRACK)
     f.close()
+
+
+# ---- er_grouping (src/ER.cpp:612-692) -------------------------------------------------
+def test_oracle_fitline_avgslope(oracle):
+    assert oracle.fitline_avgslope([(0, 0), (10, 1)]) == 0.0                               # <= 2 points (:1363)
+    assert oracle.fitline_avgslope([(0, 0), (10, 1), (20, 2), (30, 3)]) == pytest.approx(0.1)
+    # one outlier in a triple: the smallest |slope| of the three is taken (:1375-1380)
+    s = oracle.fitline_avgslope([(0, 0), (10, 0), (20, 9)])
+    assert s == 0.0
+    # a vertical pair gives +-inf, which never passes a `<` test against the finite ones but poisons nothing
+    assert oracle.fitline_avgslope([(0, 0), (0, 5), (10, 5)]) == 0.0
+
+
+def test_oracle_er_grouping_lines(oracle):
+    """Greedy line assignment in sorted order; a line never merges with another one (:650-661)."""
+    base = dict(y=100, w=20, h=30, area=400, color1=100.0, color2=120.0, color3=130.0, cls=1)
+    rows = [dict(base, x=300), dict(base, x=100), dict(base, x=130), dict(base, x=160, y=101), dict(base, x=330, y=140),
+            dict(base, x=600, color3=200.0)]
+    e = _ers(oracle, rows)
+    e["cx"], e["cy"] = e["x"] + e["w"] // 2, e["y"] + e["h"] // 2
+    all_idx, lines, after = oracle.er_grouping(e)
+    assert list(all_idx) == [1, 2, 3, 0, 4, 5]                                              # sorted by center.x
+    assert [list(l[0]) for l in lines] == [[1, 2, 3]]                                       # 0 and 4 differ by 40 in y: |dy| >= (30+30)/4
+    assert lines[0][2] == (100, 100, 80, 31)
+    assert lines[0][1] == pytest.approx((0.0 + 1 / 30 + 1 / 60) / 3)                        # slopes 0, 1/30, 1/60 are within epsilon: their mean
+    # equal center.x: the tie keeps the input order (stable sort)
+    rows = [dict(base, x=100, y=100), dict(base, x=100, y=104, w=20), dict(base, x=70)]
+    e = _ers(oracle, rows)
+    e["cx"], e["cy"] = e["x"] + e["w"] // 2, e["y"] + e["h"] // 2
+    all_idx, lines, after = oracle.er_grouping(e)
+    assert list(all_idx) == [2, 0, 1]
+    # members 0 and 1 overlap by > 0.5: overlap_suppression merges 1 into 0 (averaged bound) while computing the slope (:670-672)
+    assert (after[0]["y"], after[0]["h"], after[0]["cy"]) == (102, 30, 117) and after[1]["y"] == 104
+    # pair (0, 1) finds both already in the line and pushes 0 AGAIN (:650-654): members repeat, as in the reference
+    assert [list(l[0]) for l in lines] == [[2, 0, 1, 0]]
+    # inner_sup: an ER sitting concentrically inside a more than twice larger one goes before the pairing (:893-922)
+    rows = [dict(base, x=100, w=40, h=40, area=900), dict(base, x=110, y=110, w=20, h=20, area=300), dict(base, x=150, w=36, h=40, area=800)]
+    e = _ers(oracle, rows)
+    e["cx"], e["cy"] = e["x"] + e["w"] // 2, e["y"] + e["h"] // 2
+    assert list(oracle.er_grouping(e, inner_sup=True)[0]) == [0, 2]
+    assert list(oracle.er_grouping(e, inner_sup=False)[0]) == [0, 1, 2]
+
+
+def _expected_lines(oracle, res, sel, inner_sup):
+    """Oracle er_grouping on the tracked candidates `sel` (indices into res.cands, candidate order)."""
+    tr = res.tracks[sel]
+    keep = sel[tr["tracked"] != 0]
+    e = np.zeros(len(keep), oracle.ER_DTYPE)
+    for k, i in enumerate(keep):
+        c, t = res.cands[i], res.tracks[i]
+        e[k]["x"], e[k]["y"], e[k]["w"], e[k]["h"], e[k]["area"] = c["x"], c["y"], c["w"], c["h"], c["area"]
+        e[k]["cx"], e[k]["cy"] = t["cx"], t["cy"]
+        e[k]["color1"], e[k]["color2"], e[k]["color3"] = t["color1"], t["color2"], t["color3"]
+        e[k]["id"] = i
+    all_idx, lines, after = oracle.er_grouping(e, inner_sup=inner_sup)
+    return keep, lines, after
+
+
+def _check_lines(res, groups, oracle, inner_sup):
+    """groups: list of candidate-index arrays, one per image, in image order."""
+    li = 0
+    n_lines = 0
+    for sel in groups:
+        keep, lines, after = _expected_lines(oracle, res, sel, inner_sup)
+        for members, slope, box in lines:
+            t = res.texts[li]
+            got = res.text_ers[t["first"]:t["first"] + t["count"]]
+            assert list(got) == [int(keep[m]) for m in members], li
+            assert (t["slope"] == slope) or (np.isnan(t["slope"]) and np.isnan(slope)), (li, t["slope"], slope)
+            assert (int(t["x"]), int(t["y"]), int(t["w"]), int(t["h"])) == box
+            li += 1
+        n_lines += len(lines)
+        for k, i in enumerate(keep):
+            g = res.group_bounds[i]
+            assert (g["x"], g["y"], g["w"], g["h"], g["cx"], g["cy"]) == tuple(int(after[k][f]) for f in ("x", "y", "w", "h", "cx", "cy"))
+    assert li == len(res.texts)
+    return n_lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inner_sup", [False, True])
+def test_gpu_group_stage_matches_oracle(S, cascade_paths, oracle, inner_sup):
+    """text_detect through er_grouping (src/ER.cpp:33-69) on the reference's native 6 planes."""
+    W, H, F = 640, 480, 3
+    f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    frames = np.stack([S.synth.stext_bgr(S.synth.frame_seed(40 + i), W, H) for i in range(F)])
+    st = S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_GROUP | (S.GROUP_INNER_SUP if inner_sup else 0)
+    res = f.text_detect(frames, st)
+    assert res.texts is not None and res.times[4] > 0
+    groups = [np.nonzero(res.cands["frame"] == i)[0] for i in range(F)]
+    n_lines = _check_lines(res, groups, oracle, inner_sup)
+    assert n_lines > 0
+    assert (res.texts["frame"] == np.sort(res.texts["frame"])).all()
+    # single-stage entry point on image 0
+    sel = groups[0]
+    r1 = f.er_grouping(res.cands[sel], res.tracks[sel], inner_sup=inner_sup)
+    n0 = int((res.texts["frame"] == 0).sum())
+    assert len(r1.texts) == n0
+    for k in range(n0):
+        a, b = res.texts[k], r1.texts[k]
+        assert list(res.text_ers[a["first"]:a["first"] + a["count"]] - sel[0]) == list(r1.text_ers[b["first"]:b["first"] + b["count"]])
+        assert a["slope"] == b["slope"] or (np.isnan(a["slope"]) and np.isnan(b["slope"]))
+    with pytest.raises(S.StrErError):
+        f.er_grouping(res.cands[sel], res.tracks[sel], overlap_sup=True)
+    with pytest.raises(S.StrErError):
+        f.text_detect(frames, S.STAGE_ALL | S.STAGE_GROUP)
+    f.close()
+
+
+@pytest.mark.gpu
+def test_gpu_group_random_boxes(erf, oracle, S):
+    """er_grouping on made-up ERs: dense clusters with many equal centres, shared members, merges and NaN colours."""
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        n = int(rng.integers(1, 260))
+        cd = np.zeros(n, S.CAND_DTYPE)
+        tr = np.zeros(n, S.TRACK_DTYPE)
+        cd["x"] = rng.integers(0, 300, n); cd["y"] = rng.integers(0, 60 if trial % 2 else 200, n)
+        cd["w"] = rng.integers(4, 40, n); cd["h"] = rng.integers(6, 48, n)
+        cd["area"] = (cd["w"].astype(np.int64) * cd["h"] * rng.uniform(0.3, 1.0, n)).astype(np.uint32) + 1
+        cd["cls"] = rng.integers(0, 3, n)
+        tr["cx"] = cd["x"] + cd["w"] // 2; tr["cy"] = cd["y"] + cd["h"] // 2
+        for k in ("color1", "color2", "color3"):
+            tr[k] = rng.integers(90, 130, n)
+        tr["color2"][rng.random(n) < 0.03] = np.nan
+        tr["tracked"] = (rng.random(n) < 0.8) & (cd["cls"] != 0)
+        for inner in (False, True):
+            res = erf.er_grouping(cd, tr, inner_sup=inner)
+            res.cands, res.tracks = cd, tr
+            _check_lines(res, [np.arange(n)], oracle, inner)
