@@ -314,6 +314,8 @@ const str_er_track *str_er_result_tracks(const str_er_result *r, int32_t *n);
 const str_er_text   *str_er_result_texts(const str_er_result *r, int32_t *n);
 const int32_t       *str_er_result_text_ers(const str_er_result *r, int32_t *n);
 const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n);
+/* all_er as er_grouping leaves it (sorted by center.x, minus inner_suppression's victims): candidate indices, images concatenated */
+const int32_t       *str_er_result_group_all(const str_er_result *r, int32_t *n);
 /* Kept-node table of one plane, ascending (key, level); NULL unless STR_ER_WANT_NODES. */
 const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n);
 /* times[7] = {extract, nms, classify, track, group, ocr, total} seconds, the contract of

@@ -141,7 +141,7 @@ def load_library():
     L.str_er_result_plane_nodes.restype = vp
     L.str_er_result_tracks.argtypes = [vp, i32p]
     L.str_er_result_tracks.restype = vp
-    for fn in (L.str_er_result_texts, L.str_er_result_text_ers, L.str_er_result_group_bounds):
+    for fn in (L.str_er_result_texts, L.str_er_result_text_ers, L.str_er_result_group_bounds, L.str_er_result_group_all):
         fn.argtypes = [vp, i32p]
         fn.restype = vp
     L.str_er_er_grouping.argtypes = [vp, vp, vp, C.c_int32, C.c_int, C.c_int, C.POINTER(vp)]
@@ -207,6 +207,7 @@ class Result:
         self.texts = None          # with STAGE_GROUP: TEXT_DTYPE per line; members = text_ers[first:first+count] (candidate indices)
         self.text_ers = None
         self.group_bounds = None   # GBOUND_DTYPE per candidate: bound / center as er_grouping leaves them
+        self.group_all = None      # all_er after er_grouping's sort / inner_suppression (candidate indices, images concatenated)
         self._planes = None
 
     @property
@@ -331,6 +332,9 @@ class ERFilter:
                 ep = L.str_er_result_text_ers(rh, C.byref(no))
                 res.text_ers = (np.frombuffer((C.c_char * (4 * no.value)).from_address(ep), dtype=np.int32).copy()
                                 if no.value else np.zeros(0, np.int32))
+                ap = L.str_er_result_group_all(rh, C.byref(no))
+                res.group_all = (np.frombuffer((C.c_char * (4 * no.value)).from_address(ap), dtype=np.int32).copy()
+                                 if no.value else np.zeros(0, np.int32))
                 bp = L.str_er_result_group_bounds(rh, C.byref(no))
                 res.group_bounds = (np.frombuffer((C.c_char * (24 * no.value)).from_address(bp), dtype=GBOUND_DTYPE).copy()
                                     if no.value else np.zeros(0, GBOUND_DTYPE))

@@ -64,6 +64,7 @@ struct str_er_result {
     std::vector<str_er_text> texts;
     std::vector<int32_t> text_ers;
     std::vector<str_er_gbound> gbounds;
+    std::vector<int32_t> group_all;
     bool have_texts = false;
     double times[7] = {0, 0, 0, 0, 0, 0, 0};
 };
@@ -419,6 +420,7 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
             const str_er_gbound &b = r->gbounds[sorted[lo + k]];
             ers[k] = GroupEr{b.x, b.y, b.w, b.h, b.cx, b.cy};
         }
+        for (uint32_t k = 0; k < m; ++k) r->group_all.push_back((int32_t)sorted[lo + k]);
         group_lines(ers, pairs.data() + pair_off[(size_t)g], pair_off[(size_t)g + 1] - pair_off[(size_t)g], lines);
         for (uint32_t k = 0; k < m; ++k) {
             str_er_gbound &b = r->gbounds[sorted[lo + k]];
@@ -1489,6 +1491,14 @@ const int32_t *str_er_result_text_ers(const str_er_result *r, int32_t *n)
     if (n) *n = (int32_t)r->text_ers.size();
     static const int32_t none = 0;
     return r->text_ers.empty() ? &none : r->text_ers.data();
+}
+
+const int32_t *str_er_result_group_all(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_texts) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->group_all.size();
+    static const int32_t none = 0;
+    return r->group_all.empty() ? &none : r->group_all.data();
 }
 
 const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n)

@@ -16,6 +16,7 @@
 // CV_Assert (src/ER.cpp:242): by throwing (std::runtime_error instead of cv::Exception).
 #pragma once
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 #include <memory>
@@ -38,6 +39,7 @@ struct Image8 {
 };
 
 struct Rect { int x = 0, y = 0, width = 0, height = 0; int area() const { return width * height; } };
+struct Point { int x = 0, y = 0; };
 
 // Field-for-field the hot-path part of the reference's struct ER (inc/ER.h:42-80).
 struct ER {
@@ -47,12 +49,21 @@ struct ER {
     bool done = false;
     double stability = 0;
     ER *parent = nullptr, *child = nullptr, *next = nullptr;
+    Point center;                                  // set by er_track (src/ER.cpp:542)
+    double color1 = 0, color2 = 0, color3 = 0;     // set by er_track -> calc_color
     int ch = 0;
     // set by classify on pooled ERs (not in the reference, where strong/weak are separate lists)
     double score_strong = -DBL_MAX, score_weak = 0;
     uint32_t key = 0;
 };
 typedef std::vector<ER *> ERs;
+
+// struct Text (inc/ER.h:84-97), the part er_grouping fills
+struct Text {
+    ERs ers;
+    double slope = 0;
+    Rect box;
+};
 
 // Owns the nodes of one plane's tree (the reference leaks them in image_mode and frees them
 // with ERFilter::er_delete in video_mode, src/ER.cpp:194-233, src/utils.cpp:212-213).
@@ -189,6 +200,91 @@ public:
         std::vector<double> h(1024);
         check(str_er_lbp_hist(ctx_.get(), input.data, input.cols, input.rows, input.step, box, 1, h.data(), nullptr));
         return h;
+    }
+
+    // void ERFilter::er_track(vector<ERs> &strong, vector<ERs> &weak, ERs &all_er, vector<Mat> &channel, Mat Ycrcb)
+    // (src/ER.cpp:530-590).  channel[i] is the plane strong[i] / weak[i] came from, Ycrcb the 8UC3 image
+    // compute_channels made.  all_er = the strong ERs (channel order), then the tracked weak ones in channel / list
+    // order (the reference appends them in the order its nested loops find them; er_grouping sorts all_er anyway).
+    void er_track(std::vector<ERs> &strong, std::vector<ERs> &weak, ERs &all_er, const std::vector<Image8> &channel, const Image8 &Ycrcb)
+    {
+        if (Ycrcb.channels != 3) throw std::runtime_error("er_track: Ycrcb must be 8UC3");
+        std::vector<ER *> ers;
+        std::vector<str_er_cand> cands;
+        std::vector<double> colors;
+        for (size_t i = 0; i < strong.size(); ++i)
+            for (int pass = 0; pass < 2; ++pass) {
+                ERs &list = pass == 0 ? strong[i] : weak[i];
+                if (list.empty()) continue;
+                std::vector<int32_t> boxes;
+                for (ER *e : list) { boxes.push_back(e->bound.x); boxes.push_back(e->bound.y); boxes.push_back(e->bound.width); boxes.push_back(e->bound.height); }
+                std::vector<double> col(3 * list.size());
+                check(str_er_calc_color(ctx_.get(), channel[i].data, channel[i].cols, channel[i].rows, channel[i].step, Ycrcb.data, Ycrcb.cols,
+                                        Ycrcb.rows, Ycrcb.step, boxes.data(), (int32_t)list.size(), col.data()));
+                for (size_t k = 0; k < list.size(); ++k) {
+                    ER *e = list[k];
+                    e->color1 = col[3 * k]; e->color2 = col[3 * k + 1]; e->color3 = col[3 * k + 2];
+                    e->center.x = e->bound.x + e->bound.width / 2; e->center.y = e->bound.y + e->bound.height / 2;
+                    e->ch = (int)i;
+                    str_er_cand c{};
+                    c.ch = (uint8_t)i; c.cls = pass == 0 ? STR_ER_CLS_STRONG : STR_ER_CLS_WEAK;
+                    c.x = (uint16_t)e->bound.x; c.y = (uint16_t)e->bound.y; c.w = (uint16_t)e->bound.width; c.h = (uint16_t)e->bound.height;
+                    c.area = (uint32_t)e->area; c.key = e->key;
+                    ers.push_back(e); cands.push_back(c);
+                    colors.insert(colors.end(), col.begin() + 3 * k, col.begin() + 3 * k + 3);
+                }
+            }
+        std::vector<uint8_t> tracked(ers.size());
+        check(str_er_er_track(ctx_.get(), cands.data(), colors.data(), (int32_t)ers.size(), tracked.data(), nullptr, nullptr));
+        for (size_t k = 0; k < ers.size(); ++k) if (cands[k].cls == STR_ER_CLS_STRONG) all_er.push_back(ers[k]);
+        for (size_t k = 0; k < ers.size(); ++k) if (cands[k].cls == STR_ER_CLS_WEAK && tracked[k]) all_er.push_back(ers[k]);
+    }
+
+    // void ERFilter::er_grouping(ERs &all_er, vector<Text> &text, bool overlap_sup, bool inner_sup) (src/ER.cpp:612-692).
+    // all_er comes back sorted by center.x (and inner-suppressed); bound / center of ERs that overlap_suppression merged
+    // into are updated in place as in the reference.  overlap_sup = true is not built.
+    void er_grouping(ERs &all_er, std::vector<Text> &text, bool overlap_sup = false, bool inner_sup = false)
+    {
+        // ties in center.x are broken by candidate order = (channel, key), whatever order all_er arrives in
+        std::sort(all_er.begin(), all_er.end(), [](const ER *a, const ER *b) { return a->ch != b->ch ? a->ch < b->ch : a->key < b->key; });
+        const int32_t n = (int32_t)all_er.size();
+        std::vector<str_er_cand> cands((size_t)n);
+        std::vector<str_er_track> tr((size_t)n);
+        for (int32_t k = 0; k < n; ++k) {
+            const ER *e = all_er[(size_t)k];
+            str_er_cand c{};
+            c.x = (uint16_t)e->bound.x; c.y = (uint16_t)e->bound.y; c.w = (uint16_t)e->bound.width; c.h = (uint16_t)e->bound.height;
+            c.area = (uint32_t)e->area; c.ch = (uint8_t)e->ch; c.key = e->key;
+            cands[(size_t)k] = c;
+            str_er_track t{};
+            t.color1 = e->color1; t.color2 = e->color2; t.color3 = e->color3; t.cx = e->center.x; t.cy = e->center.y; t.tracked = 1;
+            tr[(size_t)k] = t;
+        }
+        str_er_result *r = nullptr;
+        check(str_er_er_grouping(ctx_.get(), cands.data(), tr.data(), n, overlap_sup ? 1 : 0, inner_sup ? 1 : 0, &r));
+        std::unique_ptr<str_er_result, void (*)(str_er_result *)> guard(r, str_er_result_free);
+        int32_t nt = 0, ne = 0, nb = 0;
+        const str_er_text   *tx = str_er_result_texts(r, &nt);
+        const int32_t       *te = str_er_result_text_ers(r, &ne);
+        const str_er_gbound *gb = str_er_result_group_bounds(r, &nb);
+        for (int32_t k = 0; k < nb; ++k) {
+            ER *e = all_er[(size_t)k];
+            e->bound.x = gb[k].x; e->bound.y = gb[k].y; e->bound.width = gb[k].w; e->bound.height = gb[k].h;
+            e->center.x = gb[k].cx; e->center.y = gb[k].cy;
+        }
+        (void)ne;
+        const ERs in(all_er);
+        for (int32_t i = 0; i < nt; ++i) {
+            Text t;
+            for (int32_t k = 0; k < tx[i].count; ++k) t.ers.push_back(in[(size_t)te[tx[i].first + k]]);
+            t.slope = tx[i].slope;
+            t.box.x = tx[i].x; t.box.y = tx[i].y; t.box.width = tx[i].w; t.box.height = tx[i].h;
+            text.push_back(t);
+        }
+        int32_t na = 0;
+        const int32_t *ga = str_er_result_group_all(r, &na);       // all_er: sorted, inner-suppressed
+        all_er.clear();
+        for (int32_t k = 0; k < na; ++k) all_er.push_back(in[(size_t)ga[k]]);
     }
 
     // void ERFilter::er_delete(ER *er) (src/ER.cpp:194-233): the table owns the nodes

@@ -5,8 +5,8 @@
 //   ./example_text_detect strong.classifier weak.classifier frame.bgr 640 480
 //
 // frame.bgr is a raw interleaved 8-bit BGR dump.  Prints one line per plane and one per strong/weak ER,
-// then exercises the staged calls (er_tree_extract -> non_maximum_supression -> classify) on plane 0
-// and checks that they give the same pool as the fused call.
+// then exercises the staged calls (er_tree_extract -> non_maximum_supression -> classify) on plane 0,
+// checks that they give the same pool as the fused call, and runs er_track + er_grouping on the result.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -56,6 +56,21 @@ int main(int argc, char **argv)
         er_filter.classify(pool0, strong0, weak0, plane);
         bool same = r0 && pool0.size() == pool[0].size() && strong0.size() == strong[0].size() && weak0.size() == weak[0].size();
         for (size_t i = 0; same && i < pool0.size(); ++i) same = pool0[i]->key == pool[0][i]->key && pool0[i]->area == pool[0][i]->area;
+        // the rest of text_detect (src/ER.cpp:62-69): er_track, then er_grouping(tracked, text, false, true)
+        std::vector<uint8_t> ycrcb((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; ++i) { ycrcb[3 * i] = channels[0][i]; ycrcb[3 * i + 1] = channels[1][i]; ycrcb[3 * i + 2] = channels[2][i]; }
+        std::vector<Image8> chan;
+        for (int i = 0; i < 6; ++i) chan.emplace_back(channels[i].data(), w, h, w, 1);
+        ERs tracked;
+        er_filter.er_track(strong, weak, tracked, chan, Image8(ycrcb.data(), w, h, (int64_t)w * 3, 3));
+        std::vector<Text> text;
+        er_filter.er_grouping(tracked, text, false, true);
+        std::printf("tracked %zu lines %zu\n", tracked.size(), text.size());
+        for (const Text &t : text) {
+            std::printf("T %.17g %d %d %d %d :", t.slope, t.box.x, t.box.y, t.box.width, t.box.height);
+            for (const ER *e : t.ers) std::printf(" %d/%u", e->ch, e->key);
+            std::printf("\n");
+        }
         std::printf("staged == fused on plane 0: %s\n", same ? "yes" : "NO");
         return same ? 0 : 1;
     } catch (const std::exception &e) {

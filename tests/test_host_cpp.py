@@ -25,7 +25,7 @@ def test_host_mirror_compiles(S, tmp_path):
 def test_host_mirror_has_the_reference_surface():
     txt = open(os.path.join(HOST, "er_filter_hip.hpp")).read()
     for name in ("text_detect", "compute_channels", "er_tree_extract", "non_maximum_supression", "classify", "er_delete",
-                 "make_LBP_hist", "set_thresh_step", "set_min_area", "stc", "wtc"):
+                 "make_LBP_hist", "set_thresh_step", "set_min_area", "stc", "wtc", "er_track", "er_grouping", "chain_run"):
         assert name in txt, name
 
 
@@ -48,4 +48,17 @@ def test_host_mirror_runs_and_matches_python(S, cascade_paths, tmp_path):
     exp = sorted([("S", int(c["ch"]), int(c["key"]), float(c["score_strong"])) for c in res.cands if c["cls"] == 1] +
                  [("W", int(c["ch"]), int(c["key"]), float(c["score_weak"])) for c in res.cands if c["cls"] == 2])
     assert got == exp and len(got) > 0
+    # er_track + er_grouping through the C++ mirror == the fused stages through Python
+    res2 = f.text_detect(frame, S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP)
+    head = [l for l in out if l.startswith("tracked ")][0].split()
+    assert int(head[1]) == int((res2.tracks["tracked"] != 0).sum()) and int(head[3]) == len(res2.texts)
+    lines = [l for l in out if l.startswith("T ")]
+    for l, t in zip(lines, res2.texts):
+        a, b = l.split(" :")
+        v = a.split()
+        assert float(v[1]) == t["slope"] or (np.isnan(float(v[1])) and np.isnan(t["slope"]))
+        assert [int(x) for x in v[2:6]] == [int(t["x"]), int(t["y"]), int(t["w"]), int(t["h"])]
+        members = res2.cands[res2.text_ers[t["first"]:t["first"] + t["count"]]]
+        assert b.split() == [f"{int(m['ch'])}/{int(m['key'])}" for m in members]
+    assert len(lines) == len(res2.texts) > 0
     f.close()

@@ -226,15 +226,17 @@ def _expected_lines(oracle, res, sel, inner_sup):
         e[k]["color1"], e[k]["color2"], e[k]["color3"] = t["color1"], t["color2"], t["color3"]
         e[k]["id"] = i
     all_idx, lines, after = oracle.er_grouping(e, inner_sup=inner_sup)
-    return keep, lines, after
+    return keep, lines, after, keep[all_idx]
 
 
 def _check_lines(res, groups, oracle, inner_sup):
     """groups: list of candidate-index arrays, one per image, in image order."""
     li = 0
     n_lines = 0
+    all_er = []
     for sel in groups:
-        keep, lines, after = _expected_lines(oracle, res, sel, inner_sup)
+        keep, lines, after, ga = _expected_lines(oracle, res, sel, inner_sup)
+        all_er += [int(v) for v in ga]
         for members, slope, box in lines:
             t = res.texts[li]
             got = res.text_ers[t["first"]:t["first"] + t["count"]]
@@ -247,6 +249,7 @@ def _check_lines(res, groups, oracle, inner_sup):
             g = res.group_bounds[i]
             assert (g["x"], g["y"], g["w"], g["h"], g["cx"], g["cy"]) == tuple(int(after[k][f]) for f in ("x", "y", "w", "h", "cx", "cy"))
     assert li == len(res.texts)
+    assert list(res.group_all) == all_er
     return n_lines
 
 
