@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
     ap.add_argument("--kind", choices=["text", "noise"], default="text")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--group", action="store_true",
+                    help="also run the rest of text_detect: calc_color + er_track + er_grouping(inner_sup) (SURVEY 8(f) rows 1-2)")
     ap.add_argument("--ocr", action="store_true",
                     help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
                          "(synthetic stand-in for the missing classifier/OCR.model: tests/golden/ocr_synth.model.gz)")
@@ -155,7 +157,7 @@ def main():
             import gzip
             f.load_svm_model_text(gzip.open(os.path.join(ROOT, "tests", "golden", "ocr_synth.model.gz")).read(), 1800)
         filters.append(f)
-    stages = S.STAGE_ALL | (S.STAGE_OCR if args.ocr else 0)
+    stages = S.STAGE_ALL | (S.STAGE_OCR if args.ocr else 0) | ((S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP) if args.group else 0)
 
     # synthetic frames of this rank's shard: global frame index = rank*F + i
     n_distinct = min(F, 4)
@@ -252,7 +254,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['label']}; S-{args.kind} frames" +
-                                   ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr else ""),
+                                   ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr else "") +
+                                   ("; + calc_color, er_track, er_grouping (text lines)" if args.group else ""),
                        "frames_per_gpu_per_step": F,
                        "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
