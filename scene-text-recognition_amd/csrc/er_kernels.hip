@@ -302,11 +302,17 @@ constexpr uint32_t WALL = 0xFFFFu;
 #define PAR_LVL(w) ((w) >> 24)
 #define PAR_MAKE(l, id) (((uint32_t)(l) << 24) | (uint32_t)(id))
 
-// LDS placement of pixel p: k-major ("transposed"), so that when every lane touches the k-th of
-// its 8 consecutive pixels (p = 8*lane + k) the wave hits 64 consecutive words -- no bank
-// conflicts.  Stored pointers stay logical pixel numbers; only the addressing goes through LX.
-#define LX(p)  ((((uint32_t)(p)) & 7u) << 8 | (((uint32_t)(p)) >> 3))
-#define OWN(k) ((uint32_t)((k) << 8) + (uint32_t)threadIdx.x)
+// LDS placement of pixel p: one unused word after every 32 pixels ("skewed"), slot = p + p / 32.  When every
+// lane touches the k-th of its 8 consecutive pixels (p = 8 * lane + k) a half-wave then hits 32 different
+// banks instead of 4, and -- unlike a transposed layout -- the map is monotonic: slots compare like pixels
+// (the canonical level root stays "the smallest one"), a lane's 8 pixels are 8 consecutive slots, the pixel
+// below is always +66.  So the whole kernel works in slot numbers (all stored pointers are slots) and only
+// converts back, SLOT_PIXEL, where a pixel position is needed.
+constexpr int TILE_SLOTS = TILE_PX + TILE_PX / 32;      // 2112
+constexpr int TILE_WS = TILE_W + TILE_W / 32;           // 66: slot distance of vertically adjacent pixels
+#define SLOT_PIXEL(q) ((q) - (q) / 33u)
+#define LX(q)  (q)
+#define OWN(k) (p0 + (uint32_t)(k))
 
 // Developer aid: build with -DSTR_ER_PHASE_PROF to accumulate per-phase cycle counts of
 // k_tile_tree (lane 0 of every block) into g_tile_phase[]; read with str_er_debug_phase_cycles().
@@ -414,14 +420,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wsum
 }
 
 constexpr int STAT_CHUNK = 512;   // dense tiles: nodes whose statistics are accumulated per pass
-constexpr int FOLD_CAP = 896;     // tiles with at most this many nodes fold their closed nodes in LDS
+constexpr int FOLD_CAP = 884;     // tiles with at most this many nodes fold their closed nodes in LDS
 
 __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectParams prm)
 {
-    // 26.6 KB of LDS -> 6 workgroups (24 waves) per CU
-    __shared__ uint32_t s_par[TILE_PX];
+    // 26.2 KB of LDS -> 6 workgroups (24 waves) per CU: LDS is handed out in 1280-byte granules, 21 of them (26880 B) is the most
+    // that still fits six times into 160 KB -- FOLD_CAP is sized for exactly that
+    __shared__ uint32_t s_par[TILE_SLOTS];
     __shared__ uint32_t s_work[4 * FOLD_CAP]; // edge worklist, later the per-node statistics
-    __shared__ uint16_t s_lev[TILE_PX];      // levels; once the connects are done the same array
+    __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
     __shared__ uint32_t s_walls, s_lmin, s_lmax, s_lmin2, s_lmax2, s_start;
@@ -433,7 +440,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     const int       tx = tl % pd.tiles_x, ty = tl / pd.tiles_x;
     const int       ox = tx * TILE_W, oy = ty * TILE_H;
     const int       ly = tid >> 3, lx = (tid & 7) * TILE_PPT;
-    const uint32_t  p0 = (uint32_t)tid * TILE_PPT;
+    const uint32_t  p0 = (uint32_t)tid * TILE_PPT + ((uint32_t)tid >> 2);   // slot of the lane's first pixel
+    const uint32_t  pl = p0 - 1u - ((tid & 3) == 0 ? 1u : 0u);             // slot of the pixel to its left (lx > 0)
     const int       gx = ox + lx, gy = oy + ly;
 
     if (tid == 0) { s_walls = 0; s_lmin = 0xFFFFFFFFu; s_lmax = 0; s_lmin2 = 0xFFFFFFFFu; s_lmax2 = 0; }
@@ -514,12 +522,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 const uint32_t ll = k == 0 ? left_lev : lev[k > 0 ? k - 1 : 0];
                 if (ll != WALL && ll != lev[k]) emask |= 1u << k;
             } else if (ly + 1 < TILE_H) {
-                const uint32_t lq = s_lev[LX(p + TILE_W)];
+                const uint32_t lq = s_lev[LX(p + TILE_WS)];
                 if (lq != WALL) {
                     // covered: the column to the left joins the same two nodes
                     bool covered;
-                    if (k > 0) covered = lev[k - 1] == lev[k] && s_lev[LX(p + TILE_W - 1)] == lq;
-                    else       covered = left_lev == lev[0] && s_lev[LX(lx > 0 ? p + TILE_W - 1 : p + TILE_W)] == lq;
+                    if (k > 0) covered = lev[k - 1] == lev[k] && s_lev[LX(p + TILE_WS - 1)] == lq;
+                    else       covered = left_lev == lev[0] && s_lev[LX(lx > 0 ? pl + TILE_WS : p + TILE_WS)] == lq;
                     if (!covered) emask |= 1u << k;
                 }
             }
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         for (int k = 0; k < TILE_PPT; ++k)
             if ((emask >> k) & 1) {
                 const uint32_t p = p0 + k;
-                s_work[off++] = round == 0 ? ((p - 1) | (p << 16)) : (p | ((p + TILE_W) << 16));
+                s_work[off++] = round == 0 ? ((k == 0 ? pl : p - 1) | (p << 16)) : (p | ((p + TILE_WS) << 16));
             }
         __syncthreads();
         for (uint32_t e = tid; e < n_edges; e += TILE_THREADS) {
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             int sp = -1;
             if (s_lev[LX(0)] != WALL) sp = 0;
             else if (pd.w > 1 && s_lev[LX(1)] != WALL) sp = 1;
-            else if (pd.h > 1 && s_lev[LX(TILE_W)] != WALL) sp = TILE_W;
+            else if (pd.h > 1 && s_lev[LX(TILE_WS)] != WALL) sp = TILE_WS;
             if (sp >= 0) {
                 const uint32_t l = s_lev[LX(sp)], w = s_par[LX(sp)];
                 sr = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : (uint32_t)sp;
@@ -735,9 +743,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             b.na.x1[id] = ox + 63 - __clzll((long long)cm);
             b.na.y0[id] = oy + __ffs((int)rm) - 1;
             b.na.y1[id] = oy + 31 - __clz((int)rm);
-            b.na.key[id] = (uint32_t)((oy + (int)(p >> 6)) * pd.w + ox + (int)(p & 63u));
+            const uint32_t px = SLOT_PIXEL(p);
+            b.na.key[id] = (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u));
         };
-        // The exported nodes are listed behind the statistics (p | a << 11 | level << 21 | open << 31)
+        // The exported nodes are listed behind the statistics (slot | a << 12 | level << 22 | open << 31)
         // and written out one per lane; a tile too full for the list writes them from the owners.
         const bool listed = 4u * n_even + total <= 4u * (uint32_t)FOLD_CAP;
         {
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 if ((expmask >> k) & 1) {
                     const uint32_t open = (openmask >> k) & 1u;
                     if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
-                    if (listed) s_exp[id] = (p0 + k) | (a << 11) | (lev[k] << 21) | (open << 31);
+                    if (listed) s_exp[id] = (p0 + k) | (a << 12) | (lev[k] << 22) | (open << 31);
                     s_nid[OWN(k)] = (uint16_t)id++;
                 } else {
                     s_nid[OWN(k)] = (uint16_t)0xFFFFu;
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         if (listed) {
             for (uint32_t e = tid; e < total; e += TILE_THREADS) {
                 const uint32_t w = s_exp[e];
-                export_node(w & 0x7FFu, (w >> 11) & 0x3FFu, (w >> 21) & 0x3FFu, (w >> 31) != 0);
+                export_node(w & 0xFFFu, (w >> 12) & 0x3FFu, (w >> 22) & 0xFFu, (w >> 31) != 0);
             }
         } else {
             uint32_t aid = aid0;
