@@ -334,7 +334,13 @@ __device__ unsigned long long g_tile_phase[16];
 #endif
 #else
 #define CNT(i, v) do { } while (0)
+#ifdef STR_ER_STOP_AFTER
+// Developer aid: -DSTR_ER_STOP_AFTER=n ends k_tile_tree after phase n (0 load .. 6 seam map) so that the cost of each
+// phase can be read off as a difference of kernel times; only meaningful with STR_ER_DEBUG_TILE_ONLY=1 (str_er_api.cpp).
+#define PHASE_MARK(i) do { if ((i) == STR_ER_STOP_AFTER) return; } while (0)
+#else
 #define PHASE_MARK(i) do { } while (0)
+#endif
 #define PHASE_INIT() do { } while (0)
 #endif
 
@@ -420,9 +426,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wsum
 }
 
 constexpr int STAT_CHUNK = 512;   // dense tiles: nodes whose statistics are accumulated per pass
-constexpr int FOLD_CAP = 884;     // tiles with at most this many nodes fold their closed nodes in LDS
+constexpr int FOLD_CAP = 880;     // tiles with at most this many nodes fold their closed nodes in LDS
 
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectParams prm)
+// (6 waves per SIMD = the 6 workgroups per CU the LDS allows: keeps the register allocation at or below 80 VGPRs)
+__global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, DetectParams prm)
 {
     // 26.2 KB of LDS -> 6 workgroups (24 waves) per CU: LDS is handed out in 1280-byte granules, 21 of them (26880 B) is the most
     // that still fits six times into 160 KB -- FOLD_CAP is sized for exactly that
@@ -432,6 +439,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
     __shared__ uint32_t s_walls, s_lmin, s_lmax, s_lmin2, s_lmax2, s_start;
+    __shared__ uint32_t s_present[8];        // which levels have a node in this tile
 
     const int       tid = threadIdx.x;
     const int       pi = b.tile_plane[blockIdx.x];
@@ -445,6 +453,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     const int       gx = ox + lx, gy = oy + ly;
 
     if (tid == 0) { s_walls = 0; s_lmin = 0xFFFFFFFFu; s_lmax = 0; s_lmin2 = 0xFFFFFFFFu; s_lmax2 = 0; }
+    if (tid < 8) s_present[tid] = 0;
     PHASE_INIT();
 
     // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
@@ -552,13 +561,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
     // ---- flatten: every pixel points straight at its level root ----------------------------
     // (the pixels of one run share their node: only the run's first pixel walks)
     uint32_t rootmask = 0;
+    uint32_t rk[TILE_PPT];          // slot of the level root of each of the lane's pixels
     {
         uint32_t r_run = NONE;
 #pragma unroll
         for (int k = 0; k < TILE_PPT; ++k) {
+            rk[k] = NONE;
             if (lev[k] == WALL) continue;
             const uint32_t p = p0 + k, l = lev[k];
-            if (k > 0 && lev[k > 0 ? k - 1 : 0] == l) { s_par[LX(p)] = (l << 16) | r_run; continue; }
+            if (k > 0 && lev[k > 0 ? k - 1 : 0] == l) { s_par[LX(p)] = (l << 16) | r_run; rk[k] = r_run; continue; }
             uint32_t w = LD_WG(&s_par[LX(p)]);
             if (w != NONE && (w >> 16) == l) {
                 uint32_t r = w & 0xFFFFu;
@@ -573,6 +584,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 rootmask |= 1u << k;
                 r_run = p;
             }
+            rk[k] = r_run;
         }
     }
     __syncthreads();
@@ -583,6 +595,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         for (int k = 0; k < TILE_PPT; ++k) {
             if (!((rootmask >> k) & 1)) continue;
             lmin = min(lmin, lev[k]); lmax = max(lmax, lev[k]);
+            if (!(k > 0 && ((rootmask >> (k > 0 ? k - 1 : 0)) & 1) && lev[k > 0 ? k - 1 : 0] == lev[k]))
+                atomicOr(&s_present[(lev[k] >> 5) & 7u], 1u << (lev[k] & 31u));
             const uint32_t p = p0 + k;
             const uint32_t w = s_par[LX(p)];
             if (w == NONE) continue;
@@ -656,11 +670,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
 #pragma unroll
             for (int k = 0; k <= TILE_PPT; ++k) {
                 uint32_t id = NONE;
-                if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL) {
-                    const uint32_t p = p0 + k;
-                    const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
-                    id = s_nid[LX(r)];
-                }
+                if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL)
+                    id = (k > 0 && lev[k > 0 ? k - 1 : 0] == lev[k < TILE_PPT ? k : 0]) ? cur : (uint32_t)s_nid[LX(rk[k < TILE_PPT ? k : 0])];
                 if (id != cur) {
                     if (cur != NONE) {
                         atomicAdd(&s_w0[cur], cnt);
@@ -681,8 +692,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         __syncthreads();
         PHASE_MARK(5);
         // bottom-up over the levels present in the tile: children are at lower levels than parents
-        const uint32_t lmin = s_lmin, lmax = s_lmax;
-        for (uint32_t t = lmin; t <= lmax && lmin != 0xFFFFFFFFu; ++t) {
+        // (only the levels that occur: one barrier per level)
+        for (int wd = 0; wd < 8; ++wd) {
+          uint32_t pm = s_present[wd];
+          while (pm) {
+            const uint32_t t = (uint32_t)wd * 32u + (uint32_t)__ffs((int)pm) - 1u;
+            pm &= pm - 1u;
             uint32_t id = aid0;
 #pragma unroll
             for (int k = 0; k < TILE_PPT; ++k) {
@@ -701,6 +716,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 }
             }
             __syncthreads();
+          }
         }
         PHASE_MARK(7);
         // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
@@ -798,9 +814,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
                 for (int k = 0; k <= TILE_PPT; ++k) {
                     uint32_t id = NONE;
                     if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL) {
-                        const uint32_t p = p0 + k;
-                        const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
-                        id = (uint32_t)s_nid[LX(r)] - c0;
+                        id = (uint32_t)s_nid[LX(rk[k < TILE_PPT ? k : 0])] - c0;
                         if (id >= (uint32_t)STAT_CHUNK) id = NONE;
                     }
                     if (id != cur) {
@@ -847,7 +861,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
         b.tile_hi[blockIdx.x] = (uint8_t)min(s_lmax2, 255u);
         if (tl == 0) b.ctr[pi].start_node = (s_start == NONE) ? NONE : base + s_nid[LX(s_start)];
     }
-    PHASE_MARK(5);
+    PHASE_MARK(13);
 
     // ---- node id of every tile-border pixel, for the seam pass ---------------------------
     // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
@@ -864,11 +878,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_tree(BatchDev b, DetectPa
             if (!(top || bot || lef || rig)) continue;
             if (gx + k >= pd.w || gy >= pd.h) continue;
             uint32_t id = NONE;
-            if (lev[k] != WALL) {
-                const uint32_t p = p0 + k;
-                const uint32_t r = ((rootmask >> k) & 1) ? p : (s_par[LX(p)] & 0xFFFFu);
-                id = base + s_nid[LX(r)];
-            }
+            if (lev[k] != WALL) id = base + s_nid[LX(rk[k])];
             if (top) seam[((size_t)(ty - 1) * 2 + 1) * pd.w + gx + k] = id;
             if (bot) seam[((size_t)ty * 2) * pd.w + gx + k] = id;
             if (lef) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = id;

@@ -496,6 +496,13 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
 
     launch_tile_tree(s, bd, dp);                      rec(c, "tile_tree");
+    if (std::getenv("STR_ER_DEBUG_TILE_ONLY")) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
+        float ms = 0;
+        (void)hipStreamSynchronize(s);
+        (void)hipEventElapsedTime(&ms, c->ev[c->n_ev - 2], c->ev[c->n_ev - 1]);
+        std::fprintf(stderr, "[str_er] tile_tree alone: %.4f ms\n", ms);
+        return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
+    }
     launch_seam(s, bd);                               rec(c, "seam");
     launch_level_prefix(s, bd);
     launch_resolve(s, bd);                            rec(c, "resolve");

@@ -19,7 +19,7 @@ f.detect_bgr_device(d.data_ptr(), W, H, F)
 L.str_er_debug_phase_cycles(out, 1)
 r = f.detect_bgr_device(d.data_ptr(), W, H, F)
 L.str_er_debug_phase_cycles(out, 1)
-names = ['load+prelink', 'h-edges', 'v-edges', 'flatten', 'ids', 'stats+export', 'seam-map', 'bottom-up']
+names = ['load+prelink', 'h-edges', 'v-edges', 'flatten', 'ids', 'run stats', 'seam-map', 'bottom-up']
 tot = sum(out[i] for i in range(8))
 ntiles = F * 6 * 30 * 34
 print(kind, 'tile_tree ms', r.profile['tile_tree'], 'tiles', ntiles)
