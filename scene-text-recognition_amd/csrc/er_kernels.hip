@@ -912,10 +912,27 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // are not coherent with each other, so every access to `par` that may race goes through
 // an agent-scope atomic).  Levels are immutable here and read with plain loads.
 // ------------------------------------------------------------------------------------
+#ifdef STR_ER_SEAM_PROF
+// Developer aid: -DSTR_ER_SEAM_PROF counts the work of k_seam; read with str_er_debug_seam_counts().
+__device__ unsigned long long g_seam_cnt[8];
+#define SCNT(i, v) atomicAdd(&g_seam_cnt[i], (unsigned long long)(v))
+extern "C" void str_er_debug_seam_counts(unsigned long long *out8, int reset)
+{
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_seam_cnt), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seam_cnt), z, sizeof(z));
+    }
+}
+#else
+#define SCNT(i, v) do { } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t node_find(uint32_t *par, uint32_t &a, uint32_t la)
 {
     uint32_t wa = LD_AGENT(&par[a]);
     while (wa != NONE && PAR_LVL(wa) == la) {
+        SCNT(2, 1);
         const uint32_t nx = PAR_ID(wa);
         const uint32_t w2 = LD_AGENT(&par[nx]);
         if (w2 != NONE && PAR_LVL(w2) == la) ST_AGENT(&par[a], w2);   // path halving, same node
@@ -928,7 +945,10 @@ __device__ __forceinline__ uint32_t node_find(uint32_t *par, uint32_t &a, uint32
 __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, uint32_t a, uint32_t b)
 {
     uint32_t la = lvl[a], lb = lvl[b];
+    SCNT(0, 1);
+    if (la == lb) SCNT(5, 1);
     for (;;) {
+        SCNT(1, 1);
         uint32_t wa = node_find(par, a, la);
         uint32_t wb = node_find(par, b, lb);
         if (a == b) return;
@@ -940,7 +960,8 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
         }
         if (la == lb || wa == NONE || PAR_LVL(wa) > lb) {
             const uint32_t old = atomicCAS(&par[a], wa, PAR_MAKE(lb, b));
-            if (old != wa) continue;
+            SCNT(3, 1);
+            if (old != wa) { SCNT(4, 1); continue; }
             if (wa == NONE) return;
             a = PAR_ID(wa);
             la = PAR_LVL(wa);
@@ -951,12 +972,21 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
     }
 }
 
+#ifndef SEAM_XCD_AFFINE
+#define SEAM_XCD_AFFINE 0   // measured: 1 helps S-noise (seam 1.7 -> 1.2 ms) and hurts S-text (1.0 -> 1.3 ms)
+#endif
 __global__ __launch_bounds__(256) void k_seam(BatchDev b)
 {
     // a block never straddles two planes: the host lists (plane, first pair) per block
-    const int        pi = b.seam_block_plane[blockIdx.x];
+    // Workgroups are dealt to the 8 XCDs round-robin; renumber them so that consecutive seam blocks (= one plane's
+    // seams) run on ONE XCD and the plane's parent words stay in that XCD's L2 (for speed only: every access that can
+    // race is agent-scope anyway).
+    const uint32_t per = (b.n_seam_blocks + 7u) / 8u;
+    const uint32_t vb = SEAM_XCD_AFFINE ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    if (vb >= b.n_seam_blocks) return;
+    const int        pi = b.seam_block_plane[vb];
     const PlaneDesc &pd = b.planes[pi];
-    const uint32_t   i = b.seam_block_first[blockIdx.x] + threadIdx.x;
+    const uint32_t   i = b.seam_block_first[vb] + threadIdx.x;
     uint32_t         na = NONE, nbn = NONE;
     if (i < pd.n_pairs) {
         const uint32_t *seam = b.seam + pd.seam_base;
@@ -976,7 +1006,23 @@ __global__ __launch_bounds__(256) void k_seam(BatchDev b)
     // only the first lane of a run does the work.
     const uint32_t pa = __shfl_up(na, 1), pb = __shfl_up(nbn, 1);
     const bool     dup = (threadIdx.x & 63) != 0 && pa == na && pb == nbn;
+    if (i < pd.n_pairs) SCNT(6, 1);
+    // ... and the same pair keeps coming back further along the seam (background | speckle | background ...): a connect is
+    // idempotent, so only the first lane of the block that brings a pair does it (open-addressing set in LDS).
+    __shared__ unsigned long long s_seen[512];
+    s_seen[threadIdx.x] = ~0ull; s_seen[threadIdx.x + 256] = ~0ull;
+    __syncthreads();
     if (na == NONE || nbn == NONE || dup) return;
+    {
+        const unsigned long long key = (unsigned long long)na | ((unsigned long long)nbn << 32);
+        uint32_t h = (na * 0x9E3779B1u ^ nbn * 0x85EBCA77u) >> 23;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&s_seen[h], ~0ull, key);
+            if (old == ~0ull) break;
+            if (old == key) return;
+            h = (h + 1u) & 511u;
+        }
+    }
     const size_t nb = pd.node_base;
     node_connect(b.na.par + nb, b.na.lvl + nb, na, nbn);
 }
@@ -984,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_seam(BatchDev b)
 void launch_seam(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_seam_blocks) return;
-    hipLaunchKernelGGL(k_seam, dim3(b.n_seam_blocks), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(256), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------
