@@ -8,12 +8,17 @@ reference performs implicitly when `er_track` reads every channel's strong/weak 
 
   all_gather(count per rank)  ->  all_gather(records padded to the max count)
 
+A single large frame (BASELINE configs[4]: one 3840x2160 frame, 3 channels x 12 levels) has no frames to deal out: there the
+(channel, level) planes are dealt out whole, longest first (`shard_planes_lpt`); the level-0 planes bound the speed-up at
+about total pixels / largest plane (~6x on 8 GPUs), which only spatial strips (8(f)-4) would lift.
+
 Over xGMI this is latency-bound (a few KB per rank).  Works with backend "nccl" (= RCCL on
 ROCm, device tensors) and "gloo" (CPU tensors, used by the world_size-2 tests).
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import math
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -53,3 +58,88 @@ def gather_candidates(cands: np.ndarray, device: torch.device, frame_offset: int
         raw = outs[r][: counts_h[r] * CAND_DTYPE.itemsize].cpu().numpy()
         parts.append(raw.view(CAND_DTYPE).copy())
     return np.concatenate(parts) if parts else np.zeros(0, CAND_DTYPE)
+
+
+def pyr_dims(w0: int, h0: int, level: int) -> Tuple[int, int]:
+    """Size of pyramid level `level` (include/str_er.h: round(W * 2^(-level/2)), at least 1)."""
+    s = math.pow(2.0, -0.5 * level)
+    return max(1, int(math.floor(w0 * s + 0.5))), max(1, int(math.floor(h0 * s + 0.5)))
+
+
+def frame_planes(w: int, h: int, n_levels: int, channel_mask: int) -> List[Tuple[int, int, int, int]]:
+    """(ch, pyr, width, height) of every logical plane of one frame, in the library's plane order (level-major)."""
+    out = []
+    for lvl in range(n_levels):
+        pw, ph = pyr_dims(w, h, lvl)
+        for ch in range(6):
+            if (channel_mask >> ch) & 1:
+                out.append((ch, lvl, pw, ph))
+    return out
+
+
+def shard_planes_lpt(costs: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of whole planes to `world` ranks: planes sorted by cost (descending, ties by
+    index) go one by one to the rank with the least load so far (ties: lowest rank).  Deterministic; every rank computes the
+    same table.  Returns the plane indices of each rank, ascending."""
+    order = sorted(range(len(costs)), key=lambda i: (-int(costs[i]), i))
+    load = [0] * world
+    mine: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        mine[r].append(i)
+        load[r] += int(costs[i])
+    return [sorted(m) for m in mine]
+
+
+def detect_plane_share(erf, bgr: np.ndarray, share: Sequence[int], n_levels: int, channel_mask: int = 0x3F, stages: int = 7) -> np.ndarray:
+    """Candidates of the planes `share` (indices into frame_planes()) of one frame, ordered by (plane, key); the `node`
+    field carries the global plane index.  Planes go through the plane entry point (`detect_planes`), the pyramid through
+    `resize_plane`: only the source-channel chains this share needs are built."""
+    a = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w = a.shape[:2]
+    planes = frame_planes(w, h, n_levels, channel_mask)
+    six = erf.compute_channels(a)
+    chain: Dict[Tuple[int, int], np.ndarray] = {}
+
+    def level_plane(src_ch: int, lvl: int) -> np.ndarray:       # level k = resize of level k-1 (include/str_er.h)
+        if (src_ch, lvl) not in chain:
+            if lvl == 0:
+                chain[(src_ch, 0)] = six[src_ch]
+            else:
+                pw, ph = pyr_dims(w, h, lvl)
+                chain[(src_ch, lvl)] = erf.resize_plane(level_plane(src_ch, lvl - 1), pw, ph)
+        return chain[(src_ch, lvl)]
+
+    by_size: Dict[Tuple[int, int], List[int]] = {}
+    for i in sorted(share):
+        by_size.setdefault((planes[i][2], planes[i][3]), []).append(i)
+    parts = []
+    for idx in by_size.values():
+        stack = []
+        for i in idx:
+            ch, lvl, _, _ = planes[i]
+            p = level_plane(ch % 3, lvl)
+            stack.append(255 - p if ch >= 3 else p)          # an inverted channel at level k = 255 - level k of its source
+        res = erf.detect_planes(np.stack(stack), stages)
+        for i, pr in zip(idx, res.planes):
+            c = pr.cands.copy()
+            c["ch"], c["pyr"], c["node"] = planes[i][0], planes[i][1], i
+            parts.append((i, c))
+    parts.sort(key=lambda t: t[0])
+    return np.concatenate([c for _, c in parts]) if parts else np.zeros(0, CAND_DTYPE)
+
+
+def detect_frame_plane_sharded(erf, bgr: np.ndarray, rank: int, world: int, n_levels: int, channel_mask: int = 0x3F,
+                               device: torch.device = None, stages: int = 7) -> np.ndarray:
+    """One frame, planes dealt out to the ranks (LPT by pixel count); every rank returns ALL candidates, ordered by
+    (plane, key) as a single-GPU `text_detect` with the same pyramid gives them.  `erf` needs capacity for the frame size
+    only (its own n_pyr_levels / channel_mask are not used).  Collective over the default process group when world > 1."""
+    h, w = bgr.shape[:2]
+    planes = frame_planes(w, h, n_levels, channel_mask)
+    share = shard_planes_lpt([pw * ph for (_, _, pw, ph) in planes], world)[rank]
+    mine = detect_plane_share(erf, bgr, share, n_levels, channel_mask, stages)
+    if world > 1:
+        mine = gather_candidates(mine, device or torch.device("cpu"))
+    out = mine[np.lexsort((mine["key"], mine["node"]))]
+    out["node"] = -1
+    return out

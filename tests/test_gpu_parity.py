@@ -395,3 +395,24 @@ def test_natural_image_crops(erf, oracle, oracle_cascades):
             check_plane_against_oracle(oracle, p, planes[p.ch], oracle_cascades)
             n_amb += p.ambiguous
     print("ambiguous NMS nodes on natural crops:", n_amb)
+
+
+def test_plane_sharded_frame_equals_fused_pyramid(S, cascade_paths):
+    """SURVEY 8(e), one large frame: the planes of a frame dealt out to ranks (LPT) and run through the plane entry
+    point give, put together, exactly the candidates of the fused pyramid call."""
+    W, H, L, MASK = 768, 432, 5, 0x2D
+    f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, n_pyr_levels=L, channel_mask=MASK))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    frame = S.synth.stext_bgr(S.synth.frame_seed(77), W, H)
+    fused = f.text_detect(frame).cands
+    planes = S.dist.frame_planes(W, H, L, MASK)
+    shares = S.dist.shard_planes_lpt([w * h for (_, _, w, h) in planes], 3)
+    parts = [S.dist.detect_plane_share(f, frame, sh, L, MASK) for sh in shares]
+    allc = np.concatenate(parts)
+    allc = allc[np.lexsort((allc["key"], allc["node"]))]
+    fields = ["frame", "ch", "pyr", "level", "cls", "x", "y", "w", "h", "area", "key", "score_strong", "score_weak"]
+    assert len(allc) == len(fused) > 0
+    assert allc[fields].tolist() == fused[fields].tolist()
+    one = S.dist.detect_frame_plane_sharded(f, frame, 0, 1, L, MASK)
+    assert one[fields].tolist() == fused[fields].tolist()
+    f.close()
