@@ -204,23 +204,41 @@ __device__ __forceinline__ int resize_px(const ResizeGeom &g, const uint8_t *__r
     return min(max(v, 0), 255);
 }
 
-// Pyramid level: every lane owns 4 consecutive output columns of RESIZE_ROWS consecutive rows: the
-// column coefficients (the expensive f64/f32 part of cv::resize's tables) are computed once per lane
-// and reused for all rows; one dword store per row.  The geometry is computed once on the host.
+// Pyramid level: one wave per workgroup produces a 256 x 8 tile of the output.  Every lane owns 4 consecutive
+// columns: their coefficients (the f64/f32 part of cv::resize's tables) are computed once and reused for the 8
+// rows; one dword store per row.  The source window of the tile is first copied into LDS with coalesced dword
+// loads -- byte gathers straight from global memory cost a texture-addresser pass per 4 lanes and bound the
+// kernel -- and the taps are byte reads from LDS.  Windows that do not fit (large reductions, unaligned rows:
+// only through str_er_resize_plane) take the taps from global memory.  The geometry is computed on the host.
 constexpr int RESIZE_ROWS = 8;
+constexpr int RS_WORDS = 96, RS_ROWS = 16;        // LDS window: 384 source bytes x 16 rows (a sqrt(2) step needs 364 x 14)
 
-__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride, int64_t splane_pitch,
-                                                int64_t sframe_pitch, uint8_t *__restrict__ dst, int dstride,
-                                                int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame,
-                                                ResizeGeom g)
+__device__ __forceinline__ int resize_sx(const ResizeGeom &g, int dx)
 {
-    const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const float fx = (float)((dx + 0.5) * g.scale_x - 0.5);
+    return min(max((int)floorf(fx), 0), g.sw - 1);
+}
+__device__ __forceinline__ int resize_sy(const ResizeGeom &g, int dy)
+{
+    const float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+    return (int)floorf(fy);
+}
+
+__global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, int sstride, int64_t splane_pitch,
+                                               int64_t sframe_pitch, uint8_t *__restrict__ dst, int dstride,
+                                               int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame,
+                                               ResizeGeom g)
+{
+    __shared__ uint32_t s_src[RS_ROWS * RS_WORDS];
+    const int tx0 = blockIdx.x * 256;
+    const int dx0 = tx0 + (int)threadIdx.x * 4;
     const int dy0 = blockIdx.y * RESIZE_ROWS;
-    if (dx0 >= g.dw) return;
+    const bool active = dx0 < g.dw;
     const int f = blockIdx.z / planes_per_frame, c = blockIdx.z % planes_per_frame;
     const uint8_t *s = src + (size_t)f * sframe_pitch + (size_t)c * splane_pitch;
     uint8_t       *d = dst + (size_t)f * dframe_pitch + (size_t)c * dplane_pitch;
     if (g.mode != 2) {      // copy / exact 2x2: no tables
+        if (!active) return;
         for (int r = 0; r < RESIZE_ROWS && dy0 + r < g.dh; ++r)
             for (int k = 0; k < 4 && dx0 + k < g.dw; ++k)
                 d[(size_t)(dy0 + r) * dstride + dx0 + k] = (uint8_t)resize_px(g, s, sstride, 0, dx0 + k, dy0 + r);
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float fx = (float)((dx0 + k + 0.5) * g.scale_x - 0.5);
+        float fx = (float)((min(dx0 + k, g.dw - 1) + 0.5) * g.scale_x - 0.5);
         int   x = (int)floorf(fx);
         fx -= (float)x;
         if (x < 0) { fx = 0.f; x = 0; }
@@ -237,24 +255,55 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
         sx[k] = x; sx1[k] = (x + 1 < g.sw) ? x + 1 : x;
         a0[k] = __float2int_rn((1.f - fx) * 2048.f); a1[k] = __float2int_rn(fx * 2048.f);
     }
+    // source window of the tile (uniform over the wave)
+    const int x_lo = resize_sx(g, tx0) & ~3;
+    const int x_last = resize_sx(g, min(tx0 + 255, g.dw - 1));
+    const int x_hi = (x_last + 1 < g.sw) ? x_last + 1 : x_last;
+    const int y_lo = min(max(resize_sy(g, dy0), 0), g.sh - 1);
+    const int y_hi = min(max(resize_sy(g, min(dy0 + RESIZE_ROWS - 1, g.dh - 1)) + 1, 0), g.sh - 1);
+    const int nwords = (x_hi - x_lo) / 4 + 1, nrows = y_hi - y_lo + 1;
+    const bool staged = nwords <= RS_WORDS && nrows <= RS_ROWS && (sstride & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 3) == 0;
+    if (staged) {
+        for (int i = threadIdx.x; i < nrows * nwords; i += 64) {
+            const int r = i / nwords, wd = i - r * nwords;
+            s_src[r * RS_WORDS + wd] = *reinterpret_cast<const uint32_t *>(s + (size_t)(y_lo + r) * sstride + x_lo + 4 * wd);
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_src);
     const bool full = dx0 + 4 <= g.dw && (dstride & 3) == 0;
+#pragma unroll 4
     for (int r = 0; r < RESIZE_ROWS; ++r) {
-        const int dy = dy0 + r;
-        if (dy >= g.dh) break;
+        const int dy = min(dy0 + r, g.dh - 1);
+        const bool live = dy0 + r < g.dh;
         float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
         int   sy = (int)floorf(fy);
         fy -= (float)sy;
         const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
-        const uint8_t *p0 = s + (size_t)min(max(sy, 0), g.sh - 1) * sstride, *p1 = s + (size_t)min(max(sy + 1, 0), g.sh - 1) * sstride;
+        const int ya = min(max(sy, 0), g.sh - 1), yb = min(max(sy + 1, 0), g.sh - 1);
         uint32_t v = 0;
+        if (staged) {
+            const uint8_t *p0 = lds + (ya - y_lo) * (RS_WORDS * 4) - x_lo, *p1 = lds + (yb - y_lo) * (RS_WORDS * 4) - x_lo;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
-            const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
-            const int o = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
-            v |= (uint32_t)o << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
+                const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
+                const int o = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+                v |= (uint32_t)o << (8 * k);
+            }
+        } else {
+            const uint8_t *p0 = s + (size_t)ya * sstride, *p1 = s + (size_t)yb * sstride;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
+                const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
+                const int o = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+                v |= (uint32_t)o << (8 * k);
+            }
         }
         uint8_t *o = d + (size_t)dy * dstride + dx0;
+        if (!live) continue;
         if (full) *reinterpret_cast<uint32_t *>(o) = v;
         else for (int k = 0; k < 4 && dx0 + k < g.dw; ++k) o[k] = (uint8_t)(v >> (8 * k));
     }
@@ -278,8 +327,8 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                    int64_t dframe_pitch, int planes_per_frame, int n_frames)
 {
     const int quads = (dw + 3) / 4;
-    dim3 grid((quads + 255) / 256, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, planes_per_frame * n_frames);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, sstride, splane_pitch, sframe_pitch, dst, dstride,
+    dim3 grid((quads + 63) / 64, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, planes_per_frame * n_frames);
+    hipLaunchKernelGGL(k_resize, grid, dim3(64), 0, s, src, sstride, splane_pitch, sframe_pitch, dst, dstride,
                        dplane_pitch, dframe_pitch, planes_per_frame, host_resize_geom(sw, sh, dw, dh));
 }
 
