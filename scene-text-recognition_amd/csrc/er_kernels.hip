@@ -1695,6 +1695,7 @@ struct Cls64Shared {
         Cls64Scratch p1;
         double       ab[sizeof(Cls64Scratch) / sizeof(double)];
     } u;
+    double stage_sum[CLS64_WAVES][64];   // phase 2: wave w leaves the sum of "its" stage for every ER here
 };
 constexpr int CLS_AB_CAP = (int)(sizeof(Cls64Scratch) / (2 * sizeof(double)));   // stumps that fit
 
@@ -1813,6 +1814,54 @@ __device__ __forceinline__ double lane_cascade_fast(const CascadeDev &c, const u
     return alive ? score : -DBL_MAX;
 }
 
+// The sum of ONE stage for the ER of every lane (same arithmetic as the stage loop above).  A cascade's stages do
+// not feed each other -- stage s is "sum of its stumps >= thresh[s]" -- so the stages of both cascades can run on
+// different waves at the same time; only the adds inside a stage are ordered.
+__device__ __forceinline__ double lane_stage_fast(const CascadeDev &c, int s, const uint8_t *row, const double *s_ab)
+{
+    const int lane = threadIdx.x & 63;
+    int       off = 0;
+    for (int i = 0; i < s; ++i) off += c.stage_n[i];
+    const int n = c.stage_n[s];
+    const int m = min(n, max(0, c.n_stumps - off));
+    double    acc = 0;
+    for (int base = 0; base < m; base += 64) {
+        const int pw = (base + lane < m) ? (int)c.w[off + base + lane] : 0;
+        const int cnt = min(64, m - base);
+        const double *ab = s_ab + 2 * (size_t)(off + base);
+        int j = 0;
+        for (; j + 8 <= cnt; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, j + u);
+                const uint32_t h = row[w & 1023u];
+                v[u] = ab[2 * (j + u) + (h < (w >> 10) ? 0 : 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; j < cnt; ++j) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, j);
+            const uint32_t h = row[w & 1023u];
+            acc += ab[2 * j + (h < (w >> 10) ? 0 : 1)];
+        }
+    }
+    return acc;
+}
+
+// CascadeBoost::predict's stage loop (src/adaboost.cpp:507-542) over stage sums that are already there
+__device__ __forceinline__ double cascade_from_stage_sums(const CascadeDev &c, const double *sums, int stride)
+{
+    double score = 0;
+    for (int s = 0; s < c.n_stages; ++s) {
+        const double acc = sums[(size_t)s * stride];
+        if (acc < (double)c.stage_thresh[s]) return -DBL_MAX;
+        score = acc;
+    }
+    return score;
+}
+
 __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectParams prm, CascadeDev strong,
                                                           CascadeDev weak, int run_cascades)
 {
@@ -1893,17 +1942,31 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
             for (int i = tid; i < 2 * weak.n_stumps; i += CLS64_THREADS) sh.u.ab[2 * strong.n_stumps + i] = weak.ab[i];
             __syncthreads();
         }
+        // stage-parallel form: wave w < S + W sums stage w of the strong cascade or stage w - S of the weak one
+        const bool par = fast && strong.n_stages + weak.n_stages <= CLS64_WAVES && strong.n_stages > 0 && weak.n_stages > 0;
+        if (par) {
+            if (wv < strong.n_stages + weak.n_stages) {
+                const uint8_t *row = sh.rows + (size_t)lane * CLS_ROW;
+                sh.stage_sum[wv][lane] = wv < strong.n_stages ? lane_stage_fast(strong, wv, row, sh.u.ab)
+                                                              : lane_stage_fast(weak, wv - strong.n_stages, row, sh.u.ab + 2 * strong.n_stumps);
+            }
+            __syncthreads();
+        }
         if (wv == 0) {
             const uint32_t cidx = c0 + lane;
             const bool     ok = cidx < total;
             int    cls = 0;
             double ss = -DBL_MAX, sw = 0;
-            if (run_cascades) {
+            if (run_cascades && par) {
+                ss = cascade_from_stage_sums(strong, &sh.stage_sum[0][lane], 64);
+                if (ss > -DBL_MAX) cls = 1;
+                else {                              // the weak cascade only speaks for what the strong one rejected (src/ER.cpp:521-526)
+                    sw = cascade_from_stage_sums(weak, &sh.stage_sum[strong.n_stages][lane], 64);
+                    if (sw > -DBL_MAX) cls = 2;
+                }
+            } else if (run_cascades) {
                 const uint8_t *row = sh.rows + (size_t)lane * CLS_ROW;
                 ss = fast ? lane_cascade_fast(strong, row, sh.u.ab, ok) : lane_cascade_generic(strong, row, ok);
-#ifdef STR_ER_PHASE_PROF
-                if (tid == 0) { const unsigned long long t2 = wall_clock64(); atomicAdd(&g_tile_phase[13], t2 - tp1); tp1 = t2; atomicAdd(&g_tile_phase[15], 1ull); }
-#endif
                 const bool need_weak = ok && !(ss > -DBL_MAX);
                 if (ss > -DBL_MAX) cls = 1;
                 if (__any(need_weak)) {
@@ -1911,9 +1974,6 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                                           : lane_cascade_generic(weak, row, need_weak);
                     if (need_weak) { sw = w; if (sw > -DBL_MAX) cls = 2; }
                 }
-#ifdef STR_ER_PHASE_PROF
-                if (tid == 0) { const unsigned long long t2 = wall_clock64(); atomicAdd(&g_tile_phase[14], t2 - tp1); }
-#endif
             }
             if (ok) {
                 const int        pi = b.cand_plane[cidx];
