@@ -18,9 +18,9 @@ Workloads (BASELINE.json `configs`):
 
 Extra objects on the JSON line:
   roofline     : HBM roofline of the dominant kernel (k_tile_tree), from HIP events recorded
-                 by the library on the stream the kernels run on.  With --pipelines 2 (default) two
+                 by the library on the stream the kernels run on.  With --pipelines 3 (default) three
                  batches share the GPU, so a kernel's event-to-event time in the timed region is
-                 roughly doubled; `serial_*` repeats the measurement with one batch in flight.
+                 stretched by its neighbours; `serial_*` repeats the measurement with one batch in flight.
   cpu_baseline : the oracle (a plain-C port of the reference's CPU algorithm) timed on this
                  box's host cores on a bounded sample, threads over planes like the
                  reference's `#pragma omp parallel for` (src/ER.cpp:50).
@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--ocr", action="store_true",
                     help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
                          "(synthetic stand-in for the missing classifier/OCR.model: tests/golden/ocr_synth.model.gz)")
-    ap.add_argument("--pipelines", type=int, default=2,
+    ap.add_argument("--pipelines", type=int, default=3,
                     help="independent batches in flight per GPU (each has its own context, stream and workspace)")
     args = ap.parse_args()
 
