@@ -28,6 +28,8 @@ struct BatchDev {
     uint32_t        *node_list; // exported nodes (global slot index), tile after tile
     uint16_t        *list_key;  // per list entry: level, or level | 0x100 for nodes that never push
     uint32_t         node_list_cap;
+    uint32_t        *acc_list; // the nodes that push to a parent, grouped by level (global slot index)
+    uint32_t        *lvl_tab;  // [0..256] count -> base per level, [260..515] scatter cursors
     uint32_t        *seam;     // node id of every tile-border pixel
     uint32_t        *pool;     // kept slots chosen by NMS, ascending key
     uint32_t        *pool_tmp;
@@ -51,6 +53,8 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_seam(hipStream_t s, const BatchDev &b);
 void launch_level_prefix(hipStream_t s, const BatchDev &b);
 void launch_resolve(hipStream_t s, const BatchDev &b);
+// group the pushing nodes by level (counting sort of the exported-node list), then one launch per level
+void launch_accumulate_prepare(hipStream_t s, const BatchDev &b);
 void launch_accumulate(hipStream_t s, const BatchDev &b, int level);
 void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p);

@@ -1247,11 +1247,79 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // er_merge's accumulation (src/ER.cpp:153-165), one level per launch: every live open node of
 // level t adds its (now final) totals to its parent.  Children are always at lower levels than
 // their parent, so launching t = 0,1,2,... in order is a topological order.
-constexpr int ACC_BLOCKS = 1024;
+// The nodes that push (open, alive, with a parent) are first grouped by level -- a counting sort of the exported-node
+// list in three small launches -- so that the launch of level t touches its own nodes only instead of scanning the list.
+constexpr int ACC_BLOCKS = 256;
+constexpr int ACC_CHUNK = 4096;          // list entries per workgroup pass of the counting sort
+constexpr int LVL_CURSOR = 260;          // lvl_tab: [0..256] counts -> bases, [260..515] cursors
+
+__global__ __launch_bounds__(256) void k_acc_hist(BatchDev b)
+{
+    __shared__ uint32_t s_h[256];
+    const uint32_t end = min(*b.n_listed, b.node_list_cap);
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const uint32_t k = b.list_key[i];
+        if (k < 0x100u) atomicAdd(&s_h[k], 1u);
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&b.lvl_tab[threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_acc_prefix(BatchDev b)
+{
+    __shared__ uint32_t s_w[4];
+    const int      tid = threadIdx.x;
+    const uint32_t v = b.lvl_tab[tid];
+    const uint32_t incl = wave_incl_scan(v);
+    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int k = 0; k < 4; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+    const uint32_t base = off + incl - v;
+    b.lvl_tab[tid] = base;
+    b.lvl_tab[LVL_CURSOR + tid] = base;
+    if (tid == 0) b.lvl_tab[256] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_acc_scatter(BatchDev b)
+{
+    __shared__ uint32_t s_h[256], s_base[256];
+    const uint32_t end = min(*b.n_listed, b.node_list_cap);
+    for (uint32_t c0 = blockIdx.x * ACC_CHUNK; c0 < end; c0 += gridDim.x * ACC_CHUNK) {
+        s_h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t c1 = min(c0 + (uint32_t)ACC_CHUNK, end);
+        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
+            const uint32_t k = b.list_key[i];
+            if (k < 0x100u) atomicAdd(&s_h[k], 1u);
+        }
+        __syncthreads();
+        const uint32_t n = s_h[threadIdx.x];
+        s_base[threadIdx.x] = n ? atomicAdd(&b.lvl_tab[LVL_CURSOR + threadIdx.x], n) : 0u;
+        s_h[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
+            const uint32_t k = b.list_key[i];
+            if (k < 0x100u) b.acc_list[s_base[k] + atomicAdd(&s_h[k], 1u)] = b.node_list[i];
+        }
+        __syncthreads();
+    }
+}
+
+void launch_accumulate_prepare(hipStream_t s, const BatchDev &b)
+{
+    if (!b.n_tiles) return;
+    (void)hipMemsetAsync(b.lvl_tab, 0, 257 * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_acc_hist, dim3(512), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_acc_prefix, dim3(1), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_acc_scatter, dim3(1024), dim3(256), 0, s, b);
+}
 
 __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
 {
-    const uint32_t beg = 0, end = min(*b.n_listed, b.node_list_cap);
+    const uint32_t beg = b.lvl_tab[level], end = b.lvl_tab[level + 1];
     const int      lane = threadIdx.x & 63;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i0 = beg + blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < end; i0 += stride) {
@@ -1259,11 +1327,9 @@ __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
         size_t   g = 0;
         size_t   gp = (size_t)-1;          // global slot of the parent; all-ones = inactive lane
         if (i < end) {
-            if (b.list_key[i] == (uint16_t)level) {
-                g = b.node_list[i];
-                const uint32_t w = b.na.par[g];
-                if (w != NONE) gp = (size_t)b.planes[b.tile_plane[g >> 11]].node_base + PAR_ID(w);
-            }
+            g = b.acc_list[i];
+            const uint32_t w = b.na.par[g];
+            if (w != NONE) gp = (size_t)b.planes[b.tile_plane[g >> 11]].node_base + PAR_ID(w);
         }
         const bool act = gp != (size_t)-1;
         unsigned long long todo = __ballot(act);
