@@ -337,6 +337,36 @@ int str_er_set_profiling(str_er_ctx *ctx, int enable);
 /* Bytes of device workspace held by the context. */
 int64_t str_er_workspace_bytes(const str_er_ctx *ctx);
 
+/* ---- frame ingest ------------------------------------------------------------------
+ * The reference takes its frames from the host (cv::imread / `cap >> frame`, src/utils.cpp:31, 59-82, 109) and calls
+ * text_detect on each.  A str_er_stream keeps `depth` batches in flight: it owns `depth` contexts (same parameters,
+ * each with its own HIP stream and workspace), one page-locked staging buffer per context and a worker thread per
+ * context, so the upload of one batch overlaps the kernels of the others.  Producer loop:
+ *
+ *     str_er_stream_acquire(s, &slot, &buf, &cap);     // a pinned buffer of max_frames * max_width * max_height * 3 bytes
+ *     ... decode / copy up to max_frames BGR frames into buf ...
+ *     str_er_stream_submit(s, slot, w, h, stride, frame_pitch, n_frames, stages, &ticket);
+ *     if (str_er_stream_pending(s) == depth) str_er_stream_next(s, &result, &ticket);   // oldest first; blocks until it is done
+ *
+ * acquire never blocks: with every buffer in flight it returns STR_ER_ESTATE (collect a result first).  Results come
+ * back in submission order and are freed with str_er_result_free.  Models are loaded into every context with
+ * str_er_stream_load_cascade (other per-context calls: str_er_stream_context).  One producer/consumer thread at a time. */
+typedef struct str_er_stream str_er_stream;
+int         str_er_stream_create(const str_er_params *p, int32_t depth, str_er_stream **out);
+void        str_er_stream_destroy(str_er_stream *s);
+int32_t     str_er_stream_depth(const str_er_stream *s);
+str_er_ctx *str_er_stream_context(str_er_stream *s, int32_t i);
+const char *str_er_stream_last_error(const str_er_stream *s);
+int         str_er_stream_load_cascade(str_er_stream *s, int which, const char *path);
+int         str_er_stream_acquire(str_er_stream *s, int32_t *slot, uint8_t **buffer, int64_t *capacity);
+int         str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                                 int32_t n_frames, uint32_t stages, uint64_t *ticket);
+/* convenience: acquire + copy the frames in (one extra host copy) + submit */
+int         str_er_stream_submit_copy(str_er_stream *s, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                                      int32_t n_frames, uint32_t stages, uint64_t *ticket);
+int         str_er_stream_next(str_er_stream *s, str_er_result **out, uint64_t *ticket);
+int32_t     str_er_stream_pending(str_er_stream *s);
+
 #ifdef __cplusplus
 }
 #endif

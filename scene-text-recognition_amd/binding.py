@@ -145,6 +145,20 @@ def load_library():
         fn.argtypes = [vp, i32p]
         fn.restype = vp
     L.str_er_er_grouping.argtypes = [vp, vp, vp, C.c_int32, C.c_int, C.c_int, C.POINTER(vp)]
+    L.str_er_stream_create.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.str_er_stream_destroy.argtypes = [vp]
+    L.str_er_stream_destroy.restype = None
+    L.str_er_stream_depth.argtypes = [vp]
+    L.str_er_stream_context.argtypes = [vp, C.c_int32]
+    L.str_er_stream_context.restype = vp
+    L.str_er_stream_last_error.argtypes = [vp]
+    L.str_er_stream_last_error.restype = C.c_char_p
+    L.str_er_stream_load_cascade.argtypes = [vp, C.c_int, C.c_char_p]
+    L.str_er_stream_acquire.argtypes = [vp, i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.str_er_stream_submit.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.str_er_stream_submit_copy.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.str_er_stream_next.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.str_er_stream_pending.argtypes = [vp]
     L.str_er_calc_color.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp]
     L.str_er_er_track.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
     L.str_er_result_ocr_labels.argtypes = [vp, i32p]
@@ -293,7 +307,7 @@ class ERFilter:
         self.params.min_area = m
 
     # ---- results ------------------------------------------------------------------------------
-    def _collect(self, rh: C.c_void_p) -> Result:
+    def _collect(self, rh: C.c_void_p, profile: Optional[dict] = None) -> Result:
         L = self.L
         try:
             n = C.c_int32()
@@ -314,7 +328,7 @@ class ERFilter:
                                  if nn.value else np.zeros(0, NODE_DTYPE))
             t = L.str_er_result_times(rh)
             times = np.array([t[i] for i in range(7)])
-            res = Result(info, cands, times, self.last_profile(), nodes)
+            res = Result(info, cands, times, self.last_profile() if profile is None else profile, nodes)
             no = C.c_int32()
             lp = L.str_er_result_ocr_labels(rh, C.byref(no))
             if lp and no.value:
@@ -539,3 +553,77 @@ class ERFilter:
 
     def workspace_bytes(self) -> int:
         return int(self.L.str_er_workspace_bytes(self.h))
+
+
+class FrameStream:
+    """Frame ingest (include/str_er.h, str_er_stream_*): `depth` batches of host frames in flight, uploads overlapping
+    compute.  acquire() hands out a page-locked numpy buffer to decode into; results come back in submission order."""
+
+    def __init__(self, params: Params, depth: int = 3):
+        self.L = load_library()
+        p = params
+        cp = _Params(p.thresh_step, p.min_area, p.max_area, p.stability_t, p.overlap_coef, p.n_pyr_levels,
+                     p.channel_mask, p.device, p.max_width, p.max_height, p.max_frames, p.kept_cap, p.pool_cap,
+                     p.sibling_order, p.stream)
+        h = C.c_void_p()
+        rc = self.L.str_er_stream_create(C.byref(cp), depth, C.byref(h))
+        if rc != 0:
+            raise StrErError(rc, (self.L.str_er_last_error(None) or b"").decode())
+        self.h = h
+        self.params = p
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.str_er_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise StrErError(rc, (self.L.str_er_stream_last_error(self.h) or b"").decode())
+
+    @property
+    def depth(self) -> int:
+        return int(self.L.str_er_stream_depth(self.h))
+
+    def load_cascade(self, which: int, path: str) -> None:
+        self._check(self.L.str_er_stream_load_cascade(self.h, which, path.encode()))
+
+    def acquire(self):
+        """(slot, uint8 view of the pinned staging buffer)."""
+        slot, buf, cap = C.c_int32(), C.c_void_p(), C.c_int64()
+        self._check(self.L.str_er_stream_acquire(self.h, C.byref(slot), C.byref(buf), C.byref(cap)))
+        arr = np.frombuffer((C.c_uint8 * cap.value).from_address(buf.value), dtype=np.uint8)
+        return slot.value, arr
+
+    def submit(self, slot: int, w: int, h: int, n_frames: int, stages: int = STAGE_ALL) -> int:
+        t = C.c_uint64()
+        self._check(self.L.str_er_stream_submit(self.h, slot, w, h, 3 * w, 3 * w * h, n_frames, stages, C.byref(t)))
+        return int(t.value)
+
+    def submit_copy(self, frames: np.ndarray, stages: int = STAGE_ALL) -> int:
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        if a.ndim == 3:
+            a = a[None]
+        n, h, w, _ = a.shape
+        t = C.c_uint64()
+        self._check(self.L.str_er_stream_submit_copy(self.h, _np_ptr(a), w, h, 3 * w, 3 * w * h, n, stages, C.byref(t)))
+        return int(t.value)
+
+    def pending(self) -> int:
+        return int(self.L.str_er_stream_pending(self.h))
+
+    def next(self):
+        """(ticket, Result) of the oldest submitted batch; blocks until it is done."""
+        rh, t = C.c_void_p(), C.c_uint64()
+        rc = self.L.str_er_stream_next(self.h, C.byref(rh), C.byref(t))
+        self._check(rc)
+        shim = object.__new__(ERFilter)
+        shim.L = self.L
+        shim.h = None
+        return int(t.value), ERFilter._collect(shim, rh, profile={})

@@ -928,9 +928,12 @@ int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, i
         // pack rows tightly while staging
         dstride = (int64_t)w * 3; dpitch = dstride * h;
         if ((size_t)dpitch * n_frames > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "staging buffer too small");
-        for (int f = 0; f < n_frames; ++f)
-            HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)f * dpitch, (size_t)dstride, bgr + (size_t)f * frame_pitch, (size_t)stride,
-                                        (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        if (stride == dstride && (n_frames == 1 || frame_pitch == dpitch))      // already tight: one linear copy
+            HIP_TRY(c, hipMemcpyAsync(c->d_in, bgr, (size_t)dpitch * n_frames, hipMemcpyHostToDevice, c->stream));
+        else
+            for (int f = 0; f < n_frames; ++f)
+                HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)f * dpitch, (size_t)dstride, bgr + (size_t)f * frame_pitch, (size_t)stride,
+                                            (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
         dbgr = c->d_in;
     } else if (mem_kind == STR_ER_MEM_DEVICE) dbgr = bgr;
     else return fail(c, STR_ER_EINVAL, "bad mem_kind");

@@ -1,0 +1,233 @@
+// stream_api.cpp -- frame ingest: host frames in, results out, with the uploads of one batch
+// overlapping the kernels of the others.
+//
+// The reference reads frames on the host (cv::imread, `cap >> frame`, src/utils.cpp:31, 59-82, 109) and hands each one to
+// text_detect.  Here a *stream* owns `depth` detector contexts (each with its own HIP stream and workspace), one
+// page-locked staging buffer per context and one worker thread per context: the producer acquires a staging buffer,
+// decodes / copies its frames straight into it, submits; the worker issues the H2D copy (true DMA, the buffer is pinned)
+// and the kernels on its context's stream while the other contexts compute; results come back in submission order.
+// Built on the public C ABI only (str_er_create / str_er_detect_bgr / ...).
+#include "../../include/str_er.h"
+
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct str_er_stream {
+    struct Slot {
+        str_er_ctx *ctx = nullptr;
+        uint8_t    *pinned = nullptr;
+        // job
+        bool     busy = false, has_job = false, done = false;
+        int32_t  w = 0, h = 0, n_frames = 0;
+        int64_t  stride = 0, pitch = 0;
+        uint32_t stages = 0;
+        uint64_t ticket = 0;
+        int      rc = STR_ER_OK;
+        str_er_result *result = nullptr;
+        std::string err;
+        std::thread worker;
+    };
+    std::vector<Slot> slots;
+    size_t   slot_bytes = 0;
+    int      device = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> order;       // slots in submission order, oldest first
+    uint64_t next_ticket = 1;
+    bool     stop = false;
+    std::string err;
+};
+
+namespace {
+
+void worker_main(str_er_stream *s, int idx)
+{
+    str_er_stream::Slot &sl = s->slots[(size_t)idx];
+    (void)hipSetDevice(s->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv.wait(lk, [&] { return s->stop || sl.has_job; });
+            if (s->stop && !sl.has_job) return;
+        }
+        str_er_result *r = nullptr;
+        const int rc = str_er_detect_bgr(sl.ctx, sl.pinned, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_HOST, sl.stages, &r);
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            sl.rc = rc;
+            sl.result = r;
+            if (rc != STR_ER_OK) sl.err = str_er_last_error(sl.ctx);
+            sl.has_job = false;
+            sl.done = true;
+        }
+        s->cv.notify_all();
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int str_er_stream_create(const str_er_params *p, int32_t depth, str_er_stream **out)
+{
+    if (!p || !out || depth < 1 || depth > 16) return STR_ER_EINVAL;
+    *out = nullptr;
+    str_er_stream *s = new (std::nothrow) str_er_stream();
+    if (!s) return STR_ER_ENOMEM;
+    s->device = p->device;
+    s->slot_bytes = (size_t)p->max_frames * (size_t)p->max_width * (size_t)p->max_height * 3;
+    s->slots.resize((size_t)depth);
+    int rc = STR_ER_OK;
+    for (int i = 0; i < depth && rc == STR_ER_OK; ++i) {
+        str_er_params q = *p;
+        q.stream = nullptr;                                   // every context gets its own stream
+        rc = str_er_create(&q, &s->slots[(size_t)i].ctx);
+        if (rc == STR_ER_OK && hipHostMalloc(reinterpret_cast<void **>(&s->slots[(size_t)i].pinned), s->slot_bytes, hipHostMallocDefault) != hipSuccess)
+            rc = STR_ER_ENOMEM;
+    }
+    if (rc != STR_ER_OK) {
+        for (auto &sl : s->slots) {
+            if (sl.pinned) (void)hipHostFree(sl.pinned);
+            if (sl.ctx) str_er_destroy(sl.ctx);
+        }
+        delete s;
+        return rc;
+    }
+    for (int i = 0; i < depth; ++i) s->slots[(size_t)i].worker = std::thread(worker_main, s, i);
+    *out = s;
+    return STR_ER_OK;
+}
+
+void str_er_stream_destroy(str_er_stream *s)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->stop = true;
+    }
+    s->cv.notify_all();
+    for (auto &sl : s->slots) if (sl.worker.joinable()) sl.worker.join();
+    for (auto &sl : s->slots) {
+        if (sl.result) str_er_result_free(sl.result);
+        if (sl.pinned) (void)hipHostFree(sl.pinned);
+        if (sl.ctx) str_er_destroy(sl.ctx);
+    }
+    delete s;
+}
+
+int32_t str_er_stream_depth(const str_er_stream *s) { return s ? (int32_t)s->slots.size() : 0; }
+
+str_er_ctx *str_er_stream_context(str_er_stream *s, int32_t i)
+{
+    return (s && i >= 0 && (size_t)i < s->slots.size()) ? s->slots[(size_t)i].ctx : nullptr;
+}
+
+const char *str_er_stream_last_error(const str_er_stream *s) { return s ? s->err.c_str() : "null stream"; }
+
+int str_er_stream_load_cascade(str_er_stream *s, int which, const char *path)
+{
+    if (!s) return STR_ER_EINVAL;
+    for (auto &sl : s->slots) {
+        const int rc = str_er_load_cascade(sl.ctx, which, path);
+        if (rc != STR_ER_OK) { s->err = str_er_last_error(sl.ctx); return rc; }
+    }
+    return STR_ER_OK;
+}
+
+int str_er_stream_acquire(str_er_stream *s, int32_t *slot, uint8_t **buffer, int64_t *capacity)
+{
+    if (!s || !slot || !buffer) return STR_ER_EINVAL;
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (size_t i = 0; i < s->slots.size(); ++i)
+        if (!s->slots[i].busy) {
+            s->slots[i].busy = true;
+            *slot = (int32_t)i;
+            *buffer = s->slots[i].pinned;
+            if (capacity) *capacity = (int64_t)s->slot_bytes;
+            return STR_ER_OK;
+        }
+    s->err = s->order.empty() ? "all staging buffers are acquired and none is submitted"
+                              : "all staging buffers are in flight: collect a result with str_er_stream_next first";
+    return STR_ER_ESTATE;
+}
+
+int str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                         uint32_t stages, uint64_t *ticket)
+{
+    if (!s || slot < 0 || (size_t)slot >= s->slots.size()) return STR_ER_EINVAL;
+    str_er_stream::Slot &sl = s->slots[(size_t)slot];
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!sl.busy || sl.has_job || sl.done) { s->err = "slot was not acquired (or is already submitted)"; return STR_ER_ESTATE; }
+        if (w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3 || (n_frames > 1 && frame_pitch < stride * (int64_t)h) ||
+            (uint64_t)(n_frames - 1) * (uint64_t)frame_pitch + (uint64_t)stride * (uint64_t)h > (uint64_t)s->slot_bytes) {
+            s->err = "frames do not fit the staging buffer";
+            return STR_ER_EINVAL;
+        }
+        sl.w = w; sl.h = h; sl.stride = stride; sl.pitch = frame_pitch; sl.n_frames = n_frames; sl.stages = stages;
+        sl.ticket = s->next_ticket++;
+        sl.has_job = true;
+        s->order.push_back(slot);
+        if (ticket) *ticket = sl.ticket;
+    }
+    s->cv.notify_all();
+    return STR_ER_OK;
+}
+
+int str_er_stream_submit_copy(str_er_stream *s, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                              int32_t n_frames, uint32_t stages, uint64_t *ticket)
+{
+    if (!s || !bgr || w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3) return STR_ER_EINVAL;
+    int32_t  slot = -1;
+    uint8_t *buf = nullptr;
+    int rc = str_er_stream_acquire(s, &slot, &buf, nullptr);
+    if (rc != STR_ER_OK) return rc;
+    const size_t row = (size_t)w * 3, fb = row * (size_t)h;
+    if (fb * (size_t)n_frames > s->slot_bytes) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->slots[(size_t)slot].busy = false;
+        s->err = "frames do not fit the staging buffer";
+        return STR_ER_ECAPACITY;
+    }
+    for (int f = 0; f < n_frames; ++f)
+        for (int y = 0; y < h; ++y)
+            std::memcpy(buf + (size_t)f * fb + (size_t)y * row, bgr + (size_t)f * (size_t)frame_pitch + (size_t)y * (size_t)stride, row);
+    return str_er_stream_submit(s, slot, w, h, (int64_t)row, (int64_t)fb, n_frames, stages, ticket);
+}
+
+int str_er_stream_next(str_er_stream *s, str_er_result **out, uint64_t *ticket)
+{
+    if (!s || !out) return STR_ER_EINVAL;
+    *out = nullptr;
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->order.empty()) { s->err = "nothing submitted"; return STR_ER_ESTATE; }
+    const int idx = s->order.front();
+    str_er_stream::Slot &sl = s->slots[(size_t)idx];
+    s->cv.wait(lk, [&] { return sl.done; });
+    s->order.pop_front();
+    const int rc = sl.rc;
+    *out = sl.result;
+    if (ticket) *ticket = sl.ticket;
+    if (rc != STR_ER_OK) s->err = sl.err;
+    sl.result = nullptr; sl.done = false; sl.busy = false;
+    lk.unlock();
+    s->cv.notify_all();
+    return rc;
+}
+
+int32_t str_er_stream_pending(str_er_stream *s)
+{
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lk(s->mu);
+    return (int32_t)s->order.size();
+}
+
+} // extern "C"
