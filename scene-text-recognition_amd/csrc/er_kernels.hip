@@ -444,6 +444,66 @@ __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_
     }
 }
 
+// All edges of a worklist, with the lanes kept busy: a connect takes anything from one to a dozen passes of its loop,
+// so "lane i does edge i, then everybody waits for the slowest lane" leaves most lanes idle most of the time.  Here a
+// lane that finishes its edge takes the next one from a workgroup-wide cursor straight away (one LDS atomic per wave and
+// pass for all its idle lanes); a wave leaves when the list is empty and its lanes are done.
+__device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint32_t *s_work, uint32_t n_edges,
+                                                 uint32_t *s_cursor)
+{
+    const int lane = threadIdx.x & 63;
+    bool      active = false, more = true;
+    uint32_t  a = 0, b = 0, la = 0, lb = 0;
+    for (;;) {
+        if (more) {
+            const unsigned long long idle = __ballot(!active);
+            if (idle) {
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t  base = 0;
+                if (lane == leader) base = atomicAdd(s_cursor, (uint32_t)__popcll(idle));
+                base = __shfl(base, leader);
+                if (base >= n_edges) more = false;
+                else if (!active) {
+                    const uint32_t e = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (e < n_edges) {
+                        const uint32_t w = s_work[e];
+                        a = w & 0xFFFFu; b = w >> 16;
+                        la = s_lev[LX(a)]; lb = s_lev[LX(b)];
+                        active = true;
+                        CNT(0, 1);
+                    }
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (active) {      // one pass of tile_connect's loop
+            CNT(1, 1);
+            uint32_t wa = tile_find(s_par, a, la);
+            uint32_t wb = tile_find(s_par, b, lb);
+            if (a == b) active = false;
+            else {
+                if (la > lb || (la == lb && a < b)) {
+                    uint32_t t;
+                    t = a; a = b; b = t;
+                    t = la; la = lb; lb = t;
+                    t = wa; wa = wb; wb = t;
+                }
+                if (la == lb || wa == NONE || (wa >> 16) > lb) {
+                    const uint32_t old = atomicCAS(&s_par[LX(a)], wa, (lb << 16) | b);
+                    CNT(3, 1);
+                    if (old == wa) {
+                        if (wa == NONE) active = false;     // a was a tree root: nothing left to merge
+                        else { a = wa & 0xFFFFu; la = wa >> 16; }
+                    } else CNT(4, 1);                       // somebody else moved a: same edge again
+                } else {
+                    a = wa & 0xFFFFu;                       // climb
+                    la = wa >> 16;
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
     const int lane = threadIdx.x & 63;
@@ -487,7 +547,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_walls, s_lmin, s_lmax, s_lmin2, s_lmax2, s_start;
+    __shared__ uint32_t s_walls, s_lmin, s_lmax, s_lmin2, s_lmax2, s_start, s_cursor;
     __shared__ uint32_t s_present[8];        // which levels have a node in this tile
 
     const int       tid = threadIdx.x;
@@ -598,11 +658,9 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                 const uint32_t p = p0 + k;
                 s_work[off++] = round == 0 ? ((k == 0 ? pl : p - 1) | (p << 16)) : (p | ((p + TILE_WS) << 16));
             }
+        if (tid == 0) s_cursor = 0;
         __syncthreads();
-        for (uint32_t e = tid; e < n_edges; e += TILE_THREADS) {
-            const uint32_t w = s_work[e];
-            tile_connect(s_par, s_lev, w & 0xFFFFu, w >> 16);
-        }
+        tile_connect_all(s_par, s_lev, s_work, n_edges, &s_cursor);
         __syncthreads();
         PHASE_MARK(1 + round);
     }
