@@ -1561,7 +1561,7 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // pass, the reference's answer depends on its flood's sibling order; here
 // the child with the extreme key wins and the plane is flagged (n_amb).
 // ------------------------------------------------------------------------------------
-constexpr int NMS_THREADS = 512;
+constexpr int NMS_THREADS = 1024;
 
 __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm)
 {
