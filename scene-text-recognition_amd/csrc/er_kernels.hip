@@ -1562,6 +1562,7 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // the child with the extreme key wins and the plane is flagged (n_amb).
 // ------------------------------------------------------------------------------------
 constexpr int NMS_THREADS = 1024;
+constexpr int NMS_SORT_CAP = 4096;       // pooled ERs of a plane whose keys are ranked out of LDS
 
 __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm)
 {
@@ -1656,12 +1657,25 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         if (tid == 0) atomicOr(&c.overflow, 2u);
         np = prm.pool_cap;
     }
-    // order the pool by key (keys are unique inside a plane)
-    for (uint32_t i = tid; i < np; i += NMS_THREADS) {
-        const uint32_t me = b.pool_tmp[pb + i], mk = kkey[me];
-        uint32_t       rank = 0;
-        for (uint32_t j = 0; j < np; ++j) rank += kkey[b.pool_tmp[pb + j]] < mk;
-        b.pool[pb + rank] = me;
+    // order the pool by key (keys are unique inside a plane): rank = number of smaller keys.  The keys are staged in LDS
+    // first -- ranking straight from the tables is two dependent global loads per comparison, the longest part of the kernel
+    __shared__ uint32_t s_keys[NMS_SORT_CAP];
+    if (np <= (uint32_t)NMS_SORT_CAP) {
+        for (uint32_t i = tid; i < np; i += NMS_THREADS) s_keys[i] = kkey[b.pool_tmp[pb + i]];
+        __syncthreads();
+        for (uint32_t i = tid; i < np; i += NMS_THREADS) {
+            const uint32_t mk = s_keys[i];
+            uint32_t       rank = 0;
+            for (uint32_t j = 0; j < np; ++j) rank += s_keys[j] < mk;
+            b.pool[pb + rank] = b.pool_tmp[pb + i];
+        }
+    } else {
+        for (uint32_t i = tid; i < np; i += NMS_THREADS) {
+            const uint32_t me = b.pool_tmp[pb + i], mk = kkey[me];
+            uint32_t       rank = 0;
+            for (uint32_t j = 0; j < np; ++j) rank += kkey[b.pool_tmp[pb + j]] < mk;
+            b.pool[pb + rank] = me;
+        }
     }
     if (tid == 0) c.n_pool = np;
 }
