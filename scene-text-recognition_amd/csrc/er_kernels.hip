@@ -27,6 +27,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "er_device.h"
 #include "er_kernels.h"
 
@@ -535,15 +537,27 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wsum
 }
 
 constexpr int STAT_CHUNK = 512;   // dense tiles: nodes whose statistics are accumulated per pass
-constexpr int FOLD_CAP = 880;     // tiles with at most this many nodes fold their closed nodes in LDS
+// per-node statistics in LDS: w0 (pixels | nodes | open), the set of tile rows, the set of tile columns
+typedef std::conditional<(TILE_H > 32), unsigned long long, uint32_t>::type rowmask_t;
+constexpr int      ROW_WORDS = (int)sizeof(rowmask_t) / 4;
+constexpr int      NODE_WORDS = 3 + ROW_WORDS;                   // s_work words per node
+constexpr int      CNT_BITS = TILE_PX > 2048 ? 13 : 12;          // a tile has up to TILE_PX pixels / nodes
+constexpr uint32_t CNT_MASK = (1u << CNT_BITS) - 1u;
+constexpr int      SLOT_BITS = TILE_PX > 2048 ? 13 : 12;         // export list entry: slot | node << SLOT_BITS | level << (SLOT_BITS + A_BITS)
+constexpr int      A_BITS = TILE_H > 32 ? 11 : 10;
+__device__ __forceinline__ int row_lo(uint32_t m) { return __ffs((int)m) - 1; }
+__device__ __forceinline__ int row_hi(uint32_t m) { return 31 - __clz((int)m); }
+__device__ __forceinline__ int row_lo(unsigned long long m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ int row_hi(unsigned long long m) { return 63 - __clzll((long long)m); }
+constexpr int FOLD_CAP = TILE_H > 32 ? 1408 : 880;     // tiles with at most this many nodes fold their closed nodes in LDS
 
-// (6 waves per SIMD = the 6 workgroups per CU the LDS allows: keeps the register allocation at or below 80 VGPRs)
+// (6 waves per SIMD = the 6 (3 with 64-row tiles) workgroups per CU the LDS allows: keeps the register allocation at or below 80 VGPRs)
 __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, DetectParams prm)
 {
     // 26.2 KB of LDS -> 6 workgroups (24 waves) per CU: LDS is handed out in 1280-byte granules, 21 of them (26880 B) is the most
-    // that still fits six times into 160 KB -- FOLD_CAP is sized for exactly that
+    // that still fits six times into 160 KB -- FOLD_CAP is sized for exactly that (64-row tiles: 42 granules, three times)
     __shared__ uint32_t s_par[TILE_SLOTS];
-    __shared__ uint32_t s_work[4 * FOLD_CAP]; // edge worklist, later the per-node statistics
+    __shared__ __attribute__((aligned(8))) uint32_t s_work[NODE_WORDS * FOLD_CAP]; // edge worklist, later the per-node statistics
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
@@ -751,7 +765,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
 
     if (total_all <= (uint32_t)FOLD_CAP) {
         // ---- fold path.  Statistics of every node of the tile live in LDS:
-        //   s_w0[a]  = pixels (bits 0-11) | nodes (bits 12-23) | open (bit 31)
+        //   s_w0[a]  = pixels (CNT_BITS bits) | nodes (CNT_BITS bits) | open (bit 31)
         //   s_row[a] = set of tile rows, s_col[a] = set of tile columns the component touches.
         // "open" = the component reaches a pixel that has a neighbour in another tile, so seam
         // merging may still change it.  Everything else ("closed") is final inside this tile: a
@@ -762,9 +776,9 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
         // of s_work behind them holds the export list further down.
         const uint32_t      n_even = (total_all + 1u) & ~1u;
         uint32_t           *s_w0 = s_work;                                   // [n_even]
-        uint32_t           *s_row = s_work + n_even;                         // [n_even]
-        unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * n_even); // [n_even]
-        uint32_t           *s_exp = s_work + 4 * n_even;                     // [4 * (FOLD_CAP - n_even)]
+        rowmask_t          *s_row = reinterpret_cast<rowmask_t *>(s_work + n_even);                  // [n_even]
+        unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * n_even); // [n_even]
+        uint32_t           *s_exp = s_work + NODE_WORDS * n_even;            // [NODE_WORDS * (FOLD_CAP - n_even)]
         for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
         __syncthreads();
         {
@@ -782,7 +796,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                 if (id != cur) {
                     if (cur != NONE) {
                         atomicAdd(&s_w0[cur], cnt);
-                        atomicOr(&s_row[cur], 1u << ly);
+                        atomicOr(&s_row[cur], (rowmask_t)1 << ly);
                         atomicOr(&s_col[cur], col);
                         if (open) atomicOr(&s_w0[cur], 0x80000000u);
                     }
@@ -790,7 +804,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                 }
                 if (id != NONE) {
                     const int xx = lx + k;
-                    cnt += 1u + (((rootmask >> k) & 1u) << 12);
+                    cnt += 1u + (((rootmask >> k) & 1u) << CNT_BITS);
                     col |= 1ull << xx;
                     open |= (uint32_t)(top || bot || (xx == 0 && tx > 0) || (xx == TILE_W - 1 && tx + 1 < pd.tiles_x));
                 }
@@ -817,7 +831,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                 const uint32_t v = s_w0[a];
                 if (v >> 31) atomicOr(&s_w0[pa], 0x80000000u);
                 else {
-                    atomicAdd(&s_w0[pa], v & 0xFFFFFFu);
+                    atomicAdd(&s_w0[pa], v & ((1u << (2 * CNT_BITS)) - 1u));
                     atomicOr(&s_row[pa], s_row[a]);
                     atomicOr(&s_col[pa], s_col[a]);
                 }
@@ -836,7 +850,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (!((rootmask >> k) & 1)) continue;
                 const uint32_t v = s_w0[id++];
-                const uint32_t area = (v & 0xFFFu) + ((v >> 12) & 0xFFFu);
+                const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
                 const bool     open = (v >> 31) != 0;
                 if (open) openmask |= 1u << k;
                 if (open || (int64_t)area > (int64_t)prm.min_area || s_par[OWN(k)] == NONE || p0 + k == sroot) expmask |= 1u << k;
@@ -858,20 +872,20 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
             b.na.par[id] = (q == NONE) ? NONE : PAR_MAKE(ql, base + s_nid[LX(q)]);
             b.na.lvl[id] = (uint8_t)l;
             b.na.dead[id] = open ? 0 : 2;                    // 2 = closed: totals are final
-            b.na.cnt[id] = v & 0xFFFu;
-            b.na.nod[id] = (v >> 12) & 0xFFFu;
+            b.na.cnt[id] = v & CNT_MASK;
+            b.na.nod[id] = (v >> CNT_BITS) & CNT_MASK;
             const unsigned long long cm = s_col[a];
-            const uint32_t           rm = s_row[a];
+            const rowmask_t          rm = s_row[a];
             b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
             b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-            b.na.y0[id] = oy + __ffs((int)rm) - 1;
-            b.na.y1[id] = oy + 31 - __clz((int)rm);
+            b.na.y0[id] = oy + row_lo(rm);
+            b.na.y1[id] = oy + row_hi(rm);
             const uint32_t px = SLOT_PIXEL(p);
             b.na.key[id] = (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u));
         };
-        // The exported nodes are listed behind the statistics (slot | a << 12 | level << 22 | open << 31)
+        // The exported nodes are listed behind the statistics (slot | a << SLOT_BITS | level << (SLOT_BITS + A_BITS))
         // and written out one per lane; a tile too full for the list writes them from the owners.
-        const bool listed = 4u * n_even + total <= 4u * (uint32_t)FOLD_CAP;
+        const bool listed = (uint32_t)NODE_WORDS * n_even + total <= (uint32_t)NODE_WORDS * (uint32_t)FOLD_CAP;
         {
             uint32_t id = eid0, aid = aid0, lo = 0xFFFFFFFFu, hi = 0;
 #pragma unroll
@@ -881,7 +895,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                 if ((expmask >> k) & 1) {
                     const uint32_t open = (openmask >> k) & 1u;
                     if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
-                    if (listed) s_exp[id] = (p0 + k) | (a << 12) | (lev[k] << 22) | (open << 31);
+                    if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (lev[k] << (SLOT_BITS + A_BITS));
                     s_nid[OWN(k)] = (uint16_t)id++;
                 } else {
                     s_nid[OWN(k)] = (uint16_t)0xFFFFu;
@@ -893,7 +907,8 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
         if (listed) {
             for (uint32_t e = tid; e < total; e += TILE_THREADS) {
                 const uint32_t w = s_exp[e];
-                export_node(w & 0xFFFu, (w >> 12) & 0x3FFu, (w >> 22) & 0xFFu, (w >> 31) != 0);
+                export_node(w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu,
+                            (s_w0[(w >> SLOT_BITS) & ((1u << A_BITS) - 1u)] >> 31) != 0);
             }
         } else {
             uint32_t aid = aid0;
@@ -909,10 +924,10 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
         // STAT_CHUNK nodes per pass; the global passes do all the accumulation.
         total = total_all;
         uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
-        uint32_t            *s_row = s_work + STAT_CHUNK;          // [STAT_CHUNK]
-        unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + 2 * STAT_CHUNK); // [STAT_CHUNK]
+        rowmask_t           *s_row = reinterpret_cast<rowmask_t *>(s_work + STAT_CHUNK);          // [STAT_CHUNK]
+        unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * STAT_CHUNK); // [STAT_CHUNK]
         for (uint32_t c0 = 0; c0 < total; c0 += STAT_CHUNK) {
-            for (int i = tid; i < 4 * STAT_CHUNK; i += TILE_THREADS) s_work[i] = 0;
+            for (int i = tid; i < NODE_WORDS * STAT_CHUNK; i += TILE_THREADS) s_work[i] = 0;
             __syncthreads();
             {   // the lane's pixels form runs with a common root: one set of atomics per run
                 uint32_t cur = NONE, cnt = 0;
@@ -927,7 +942,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                     if (id != cur) {
                         if (cur != NONE) {
                             atomicAdd(&s_cnt[cur], cnt);
-                            atomicOr(&s_row[cur], 1u << ly);
+                            atomicOr(&s_row[cur], (rowmask_t)1 << ly);
                             atomicOr(&s_col[cur], col);
                         }
                         cur = id; cnt = 0; col = 0;
@@ -950,11 +965,11 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
                 b.na.cnt[id] = s_cnt[li];
                 b.na.nod[id] = 1;
                 const unsigned long long cm = s_col[li];
-                const uint32_t           rm = s_row[li];
+                const rowmask_t          rm = s_row[li];
                 b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
                 b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-                b.na.y0[id] = oy + __ffs((int)rm) - 1;
-                b.na.y1[id] = oy + 31 - __clz((int)rm);
+                b.na.y0[id] = oy + row_lo(rm);
+                b.na.y1[id] = oy + row_hi(rm);
                 b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
             }
             __syncthreads();
@@ -1387,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
         if (i < end) {
             g = b.acc_list[i];
             const uint32_t w = b.na.par[g];
-            if (w != NONE) gp = (size_t)b.planes[b.tile_plane[g >> 11]].node_base + PAR_ID(w);
+            if (w != NONE) gp = (size_t)b.planes[b.tile_plane[g / (size_t)TILE_PX]].node_base + PAR_ID(w);
         }
         const bool act = gp != (size_t)-1;
         unsigned long long todo = __ballot(act);
@@ -1483,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
         const size_t g = b.node_list[i];
         if (b.na.dead[g] == 1) continue;
-        const int       pi = b.tile_plane[g >> 11];
+        const int       pi = b.tile_plane[g / (size_t)TILE_PX];
         PlaneCtr       &c = b.ctr[pi];
         const uint32_t  root = c.root_node;
         if (root == NONE) continue;

@@ -7,12 +7,17 @@ namespace str_er {
 
 // Tile of the in-LDS component-tree kernel.  64 pixels wide so a tile row is one
 // 64-byte scanline segment and the per-node column set fits one 64-bit mask;
-// 32 rows so the row set fits one 32-bit mask.
+// 32 rows (row set = one 32-bit mask, 256 lanes) or, with -DSTR_ER_TILE_H=64, 64 rows
+// (64-bit row mask, 512 lanes: a third fewer seam pixels, half as many tiles).
+#ifndef STR_ER_TILE_H
+#define STR_ER_TILE_H 32
+#endif
+static_assert(STR_ER_TILE_H == 32 || STR_ER_TILE_H == 64, "tile height is 32 or 64");
 constexpr int      TILE_W   = 64;
-constexpr int      TILE_H   = 32;
-constexpr int      TILE_PX  = TILE_W * TILE_H;   // 2048
-constexpr int      TILE_THREADS = 256;           // 4 wavefronts of 64
-constexpr int      TILE_PPT = TILE_PX / TILE_THREADS; // 8 consecutive pixels per lane
+constexpr int      TILE_H   = STR_ER_TILE_H;
+constexpr int      TILE_PX  = TILE_W * TILE_H;   // 2048 / 4096
+constexpr int      TILE_PPT = 8;                 // consecutive pixels per lane
+constexpr int      TILE_THREADS = TILE_PX / TILE_PPT; // 256 / 512: 4 / 8 wavefronts of 64
 constexpr uint32_t NONE     = 0xFFFFFFFFu;
 
 // One logical plane = one (frame, channel, pyramid level): the unit the reference
