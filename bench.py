@@ -160,7 +160,10 @@ def main():
             import gzip
             f.load_svm_model_text(gzip.open(os.path.join(ROOT, "tests", "golden", "ocr_synth.model.gz")).read(), 1800)
         filters.append(f)
-    stages = S.STAGE_ALL | (S.STAGE_OCR if args.ocr else 0) | ((S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP) if args.group else 0)
+    # --ocr alone scores every strong/weak ER (slope 0); with --group the scorer runs where er_ocr runs it: on the members of the text lines
+    stages = S.STAGE_ALL | ((S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP) if args.group else 0)
+    if args.ocr:
+        stages |= S.STAGE_OCR_LINES if args.group else S.STAGE_OCR
 
     # synthetic frames of this rank's shard: global frame index = rank*F + i
     n_distinct = min(F, 4)
@@ -289,8 +292,9 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['label']}; S-{args.kind} frames" +
-                                   ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr else "") +
-                                   ("; + calc_color, er_track, er_grouping (text lines)" if args.group else ""),
+                                   ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr and not args.group else "") +
+                                   ("; + calc_color, er_track, er_grouping (text lines)" if args.group else "") +
+                                   ("; + chain-code/SVM OCR scorer on the line members with the line slope (er_ocr, configs[2])" if args.ocr and args.group else ""),
                        "frames_per_gpu_per_step": F,
                        "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",

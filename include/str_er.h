@@ -56,6 +56,7 @@ extern "C" {
 #define STR_ER_WANT_NODES     16u  /* also return the kept-node table of every plane */
 #define STR_ER_STAGE_GROUP    64u  /* ERFilter::er_grouping(tracked, text, false, false) (src/ER.cpp:612-692); needs STR_ER_STAGE_TRACK */
 #define STR_ER_GROUP_INNER_SUP 128u /* ... with inner_sup = true, as text_detect calls it when DO_OCR is defined (src/ER.cpp:69) */
+#define STR_ER_STAGE_OCR_LINES 256u /* er_ocr's per-line scoring (src/ER.cpp:695-747): chain_run with the line's slope on every member; needs STR_ER_STAGE_GROUP + an SVM model */
 #define STR_ER_STAGE_TRACK    32u  /* calc_color + ERFilter::er_track on the strong/weak ERs of every image (src/ER.cpp:530-590); BGR frames only */
 
 /* candidate class: which list of text_detect() the ER landed in (src/ER.cpp:516-526) */
@@ -169,6 +170,8 @@ int  str_er_abi_version(void);
 
 /* ERFilter::set_thresh_step / set_min_area (src/ER.cpp:21-30) */
 int str_er_set_thresh_step(str_er_ctx *ctx, int32_t t);
+/* MIN_OCR_PROB, the last constructor argument of ERFilter (inc/ER.h:113; src/main.cpp:22 passes 0.15, the default here) */
+int str_er_set_min_ocr_prob(str_er_ctx *ctx, double min_ocr_prob);
 int str_er_set_min_area(str_er_ctx *ctx, int32_t m);
 
 /* ---- models: CascadeBoost::load_classifier (src/adaboost.cpp:873-951) --------------- */
@@ -316,6 +319,15 @@ const int32_t       *str_er_result_text_ers(const str_er_result *r, int32_t *n);
 const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n);
 /* all_er as er_grouping leaves it (sorted by center.x, minus inner_suppression's victims): candidate indices, images concatenated */
 const int32_t       *str_er_result_group_all(const str_er_result *r, int32_t *n);
+/* With STR_ER_STAGE_OCR_LINES: the first half of ERFilter::er_ocr (src/ER.cpp:695-747) on the lines of
+ * str_er_result_texts().  Parallel to str_er_result_text_ers(): label / prob = what OCR::chain_run(channel[er->ch](er->bound),
+ * level * THRESH_STEP, text.slope) returns for that member (bound as er_grouping left it), kept = 1 if the member survives the
+ * 0.95-overlap deletion (:700-721) and prob >= MIN_OCR_PROB (:737-741).  Per line: alive = at least 2 members kept (:743-747).
+ * The word graph, feedback verification and spelling correction that follow in er_ocr are not part of this library.        */
+const int32_t *str_er_result_line_labels(const str_er_result *r, int32_t *n);
+const double  *str_er_result_line_probs(const str_er_result *r, int32_t *n);
+const uint8_t *str_er_result_line_kept(const str_er_result *r, int32_t *n);
+const uint8_t *str_er_result_text_alive(const str_er_result *r, int32_t *n);
 /* Kept-node table of one plane, ascending (key, level); NULL unless STR_ER_WANT_NODES. */
 const str_er_node *str_er_result_plane_nodes(const str_er_result *r, int32_t plane, int32_t *n);
 /* times[7] = {extract, nms, classify, track, group, ocr, total} seconds, the contract of

@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES, STAGE_TRACK = 1, 2, 4, 7, 8, 16, 32
-STAGE_GROUP, GROUP_INNER_SUP = 64, 128
+STAGE_GROUP, GROUP_INNER_SUP, STAGE_OCR_LINES = 64, 128, 256
 TEXT_DTYPE = np.dtype([("frame", "<u4"), ("pyr", "u1"), ("r0", "u1"), ("r1", "u1"), ("r2", "u1"), ("first", "<i4"), ("count", "<i4"),
                        ("slope", "<f8"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4")])
 GBOUND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("cx", "<i4"), ("cy", "<i4")])
@@ -141,7 +141,9 @@ def load_library():
     L.str_er_result_plane_nodes.restype = vp
     L.str_er_result_tracks.argtypes = [vp, i32p]
     L.str_er_result_tracks.restype = vp
-    for fn in (L.str_er_result_texts, L.str_er_result_text_ers, L.str_er_result_group_bounds, L.str_er_result_group_all):
+    L.str_er_set_min_ocr_prob.argtypes = [vp, C.c_double]
+    for fn in (L.str_er_result_texts, L.str_er_result_text_ers, L.str_er_result_group_bounds, L.str_er_result_group_all,
+               L.str_er_result_line_labels, L.str_er_result_line_probs, L.str_er_result_line_kept, L.str_er_result_text_alive):
         fn.argtypes = [vp, i32p]
         fn.restype = vp
     L.str_er_er_grouping.argtypes = [vp, vp, vp, C.c_int32, C.c_int, C.c_int, C.POINTER(vp)]
@@ -222,6 +224,10 @@ class Result:
         self.text_ers = None
         self.group_bounds = None   # GBOUND_DTYPE per candidate: bound / center as er_grouping leaves them
         self.group_all = None      # all_er after er_grouping's sort / inner_suppression (candidate indices, images concatenated)
+        self.line_label = None     # with STAGE_OCR_LINES: per entry of text_ers, chain_run's label / prob with the line's slope,
+        self.line_prob = None      # whether the member survives er_ocr's two deletions, and per line whether >= 2 members do
+        self.line_kept = None
+        self.text_alive = None
         self._planes = None
 
     @property
@@ -352,6 +358,17 @@ class ERFilter:
                 bp = L.str_er_result_group_bounds(rh, C.byref(no))
                 res.group_bounds = (np.frombuffer((C.c_char * (24 * no.value)).from_address(bp), dtype=GBOUND_DTYPE).copy()
                                     if no.value else np.zeros(0, GBOUND_DTYPE))
+            lp2 = L.str_er_result_line_labels(rh, C.byref(no))
+            if lp2:
+                k = no.value
+                res.line_label = np.frombuffer((C.c_char * (4 * k)).from_address(lp2), dtype=np.int32).copy() if k else np.zeros(0, np.int32)
+                pp2 = L.str_er_result_line_probs(rh, C.byref(no))
+                res.line_prob = np.frombuffer((C.c_char * (8 * k)).from_address(pp2), dtype=np.float64).copy() if k else np.zeros(0, np.float64)
+                kp2 = L.str_er_result_line_kept(rh, C.byref(no))
+                res.line_kept = np.frombuffer((C.c_char * k).from_address(kp2), dtype=np.uint8).copy().astype(bool) if k else np.zeros(0, bool)
+                ap2 = L.str_er_result_text_alive(rh, C.byref(no))
+                res.text_alive = (np.frombuffer((C.c_char * no.value).from_address(ap2), dtype=np.uint8).copy().astype(bool)
+                                  if no.value else np.zeros(0, bool))
             return res
         finally:
             L.str_er_result_free(rh)
@@ -492,6 +509,11 @@ class ERFilter:
                                                       _np_ptr(sl) if sl is not None else None, n,
                                                       _np_ptr(label) if classify else None, _np_ptr(prob) if classify else None, _np_ptr(q)))
         return (q, label, prob) if classify else q
+
+    def set_min_ocr_prob(self, p: float) -> None:
+        """MIN_OCR_PROB, ERFilter's last constructor argument (inc/ER.h:113)."""
+        self._check(self.L.str_er_set_min_ocr_prob(self.h, float(p)))
+        self.min_ocr_prob = float(p)
 
     # ---- SURVEY 8(f) row 1: the first consumers of the classified ERs --------------------------------
     def calc_color(self, mask_plane: np.ndarray, color_img: np.ndarray, boxes_xywh: np.ndarray) -> np.ndarray:

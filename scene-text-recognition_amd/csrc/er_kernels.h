@@ -80,5 +80,8 @@ void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int 
 // Batch form: list the strong/weak candidates (n = their number, known on the host from the plane counters) and
 // extract their chain-code features straight from the device planes into x_out [n x xdim] (f64, q/255).
 void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out, int n, double *x_out, int xdim);
+// chain-code features of n records (plane = recs[list[i]].plane, box = its x,y,w,h), optionally rotated per record
+void launch_chain_features_members(hipStream_t s, const CandRec *recs, const uint32_t *list, const PlaneDesc *planes, int n, double *x_out, int xdim,
+                                   const RotGeom *rot);
 
 } // namespace str_er

@@ -2510,4 +2510,12 @@ void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint3
                        (uint8_t *)nullptr, x_out, xdim, (const CandRec *)b.cands, (const uint32_t *)list, b.planes, (const RotGeom *)nullptr);
 }
 
+void launch_chain_features_members(hipStream_t s, const CandRec *recs, const uint32_t *list, const PlaneDesc *planes, int n, double *x_out, int xdim,
+                                   const RotGeom *rot)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, (const uint8_t *)nullptr, 0, 0, (const int32_t *)nullptr, n,
+                       (uint8_t *)nullptr, x_out, xdim, recs, list, planes, rot);
+}
+
 } // namespace str_er

@@ -65,6 +65,10 @@ struct str_er_result {
     std::vector<int32_t> text_ers;
     std::vector<str_er_gbound> gbounds;
     std::vector<int32_t> group_all;
+    std::vector<int32_t> line_label;
+    std::vector<double> line_prob;
+    std::vector<uint8_t> line_kept, text_alive;
+    bool have_line_ocr = false;
     bool have_texts = false;
     double times[7] = {0, 0, 0, 0, 0, 0, 0};
 };
@@ -79,6 +83,7 @@ struct str_er_ctx {
     size_t slots = 0;                // node slots (== plane pixels) the workspace can hold
     int max_planes = 0;
     int kept_cap = 0, pool_cap = 0;
+    double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
     int64_t ws_bytes = 0;
 
     // device workspace
@@ -351,6 +356,130 @@ void rec(str_er_ctx *c, const char *name)
     }
 }
 
+// OCR::rotate_mat's canvas for a w x h box (src/OCR.cpp:256-290): corner rounding, crop height and the
+// fall-back to the uncropped canvas, evaluated with the host libm exactly as the reference does.
+RotGeom make_rot_geom(int w, int h, double slope)
+{
+    RotGeom g;
+    std::memset(&g, 0, sizeof(g));
+    if (!(std::fabs(slope) > 0.01)) return g;
+    const double rad = std::atan2(slope, 1.0);
+    const int    x0 = (int)((w - 1) / 2.0), y0 = (int)((h - 1) / 2.0);
+    const int    cx[4] = {0 - x0, (w - 1) - x0, (w - 1) - x0, 0 - x0}, cy[4] = {0 - y0, 0 - y0, (h - 1) - y0, (h - 1) - y0};
+    int          nx[4], ny[4];
+    for (int k = 0; k < 4; ++k) {
+        nx[k] = (int)std::round(cx[k] * std::cos(rad) - cy[k] * std::sin(rad));
+        ny[k] = (int)std::round(cx[k] * std::sin(rad) + cy[k] * std::cos(rad));
+    }
+    g.max_x = std::max(std::max(nx[0], nx[1]), std::max(nx[2], nx[3]));
+    g.max_y = std::max(std::max(ny[0], ny[1]), std::max(ny[2], ny[3]));
+    g.min_x = std::min(std::min(nx[0], nx[1]), std::min(nx[2], nx[3]));
+    g.min_y = std::min(std::min(ny[0], ny[1]), std::min(ny[2], ny[3]));
+    g.on = 1;
+    g.crop = 1;
+    g.ch = (int)((nx[1] - nx[0]) * std::tan(rad) * 0.5);
+    if (g.max_y - g.min_y + 1 - 2 * g.ch <= 0) { g.crop = 0; g.ch = 0; }
+    g.rw = g.max_x - g.min_x + 1;
+    g.rh = g.max_y - g.min_y + 1 - 2 * g.ch;
+    g.x0 = x0; g.y0 = y0;
+    g.c = std::cos(rad); g.s = std::sin(rad);
+    return g;
+}
+
+
+// er_ocr's per-line scoring (src/ER.cpp:695-747) on the lines group_phase left in r: every member is scored by
+// OCR::chain_run on its (possibly merged) bound with the line's slope -- one batched launch for all members of all lines --
+// then per line, last line first as the reference iterates: members whose boxes overlap by more than 0.95 lose the smaller one
+// (:700-721), members below MIN_OCR_PROB go (:737-741), a line with fewer than 2 members left is dropped (:743-747).
+int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
+{
+    const size_t n_m = r->text_ers.size();
+    r->have_line_ocr = true;
+    r->line_label.assign(n_m, -1);
+    r->line_prob.assign(n_m, 0.0);
+    r->line_kept.assign(n_m, 0);
+    r->text_alive.assign(r->texts.size(), 0);
+    if (n_m == 0) return STR_ER_OK;
+    const SvmDev &m = c->svm;
+    std::vector<CandRec> recs(n_m);
+    std::vector<RotGeom> rot(n_m);
+    std::vector<uint32_t> ident(n_m);
+    for (size_t t = 0; t < r->texts.size(); ++t) {
+        const str_er_text &tx = r->texts[t];
+        for (int32_t k = 0; k < tx.count; ++k) {
+            const size_t  j = (size_t)tx.first + (size_t)k;
+            const int32_t ci = r->text_ers[j];
+            CandRec       rc;
+            std::memcpy(&rc, &r->cands[(size_t)ci], sizeof(CandRec));
+            const str_er_gbound &g = r->gbounds[(size_t)ci];
+            rc.x = (uint16_t)g.x; rc.y = (uint16_t)g.y; rc.w = (uint16_t)g.w; rc.h = (uint16_t)g.h;
+            recs[j] = rc;
+            rot[j] = make_rot_geom(g.w, g.h, tx.slope);
+            ident[j] = (uint32_t)j;
+        }
+    }
+    hipStream_t s = c->stream;
+    const size_t n_pad = align_up(n_m, 64), npairs = (size_t)m.k * (m.k - 1) / 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_rec = take(sizeof(CandRec) * n_m), o_rot = take(sizeof(RotGeom) * n_m), o_list = take(4 * n_m), o_x = take(n_m * 1800 * 8),
+                 o_xf = take(n_pad * m.dpad * 4 + 256), o_xn = take(n_pad * 8), o_kv = take(n_pad * m.l_pad * 8), o_dec = take(n_m * npairs * 8),
+                 o_prob = take(n_m * m.k * 8), o_lab = take(n_m * 4);
+    int rc2 = ensure_scratch(c, off);
+    if (rc2 != STR_ER_OK) return rc2;
+    uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(sc + o_rec, recs.data(), sizeof(CandRec) * n_m, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(sc + o_rot, rot.data(), sizeof(RotGeom) * n_m, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(sc + o_list, ident.data(), 4 * n_m, hipMemcpyHostToDevice, s));
+    launch_chain_features_members(s, reinterpret_cast<const CandRec *>(sc + o_rec), reinterpret_cast<const uint32_t *>(sc + o_list), d_planes, (int)n_m,
+                                  reinterpret_cast<double *>(sc + o_x), 1800, reinterpret_cast<const RotGeom *>(sc + o_rot));
+    HIP_TRY(c, hipMemsetAsync(sc + o_xf, 0, n_pad * m.dpad * 4 + 256, s));
+    HIP_TRY(c, hipMemsetAsync(sc + o_xn, 0, n_pad * 8, s));
+    launch_svm_predict(s, reinterpret_cast<const double *>(sc + o_x), (int)n_m, 1800, reinterpret_cast<float *>(sc + o_xf),
+                       reinterpret_cast<double *>(sc + o_xn), (int)n_pad, reinterpret_cast<double *>(sc + o_kv),
+                       reinterpret_cast<double *>(sc + o_dec), reinterpret_cast<double *>(sc + o_prob), reinterpret_cast<int32_t *>(sc + o_lab), m);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<int32_t> lab(n_m), mlab((size_t)m.k);
+    std::vector<double>  pall(n_m * (size_t)m.k);
+    HIP_TRY(c, hipMemcpyAsync(lab.data(), sc + o_lab, 4 * n_m, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pall.data(), sc + o_prob, 8 * pall.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(mlab.data(), m.label, 4 * (size_t)m.k, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (size_t j = 0; j < n_m; ++j) {
+        int idx = -1;
+        for (int k = 0; k < m.k; ++k) if (mlab[(size_t)k] == lab[j]) { idx = k; break; }
+        r->line_label[j] = lab[j];
+        r->line_prob[j] = idx >= 0 ? pall[j * (size_t)m.k + (size_t)idx] : 0.0;
+    }
+    for (size_t t = r->texts.size(); t-- > 0;) {
+        const str_er_text &tx = r->texts[t];
+        const size_t       f = (size_t)tx.first, n = (size_t)tx.count;
+        std::vector<char>  del(n, 0);
+        for (size_t a = 0; a < n; ++a)
+            for (size_t bq = a + 1; bq < n; ++bq) {
+                const str_er_gbound &A = r->gbounds[(size_t)r->text_ers[f + a]], &B = r->gbounds[(size_t)r->text_ers[f + bq]];
+                const int ix = std::max(A.x, B.x), iy = std::max(A.y, B.y);
+                int       iw = std::min(A.x + A.w, B.x + B.w) - ix, ih = std::min(A.y + A.h, B.y + B.h) - iy;
+                if (iw <= 0 || ih <= 0) iw = ih = 0;
+                const int    ux = std::min(A.x, B.x), uy = std::min(A.y, B.y);
+                const double overlap_area = (double)(iw * ih);
+                const double union_area = (double)((std::max(A.x + A.w, B.x + B.w) - ux) * (std::max(A.y + A.h, B.y + B.h) - uy));
+                if (overlap_area / union_area > 0.95) {
+                    if (A.w * A.h > B.w * B.h) del[bq] = 1;
+                    else del[a] = 1;
+                }
+            }
+        size_t left = 0;
+        for (size_t a = 0; a < n; ++a) {
+            const bool keep = !del[a] && !(r->line_prob[f + a] < c->min_ocr_prob);
+            r->line_kept[f + a] = keep ? 1 : 0;
+            left += keep ? 1 : 0;
+        }
+        r->text_alive[t] = left >= 2 ? 1 : 0;      // min_pass_ocr (:698)
+    }
+    return STR_ER_OK;
+}
+
 // er_grouping for the images of a call.  img[g] = candidate range [lo, hi) of image g (on the device: d_cands / d_track
 // hold the same records the host has in r->cands / r->tracks).  GPU: sort ranks, inner_suppression flags, pair list;
 // host: the greedy line assignment and the per-line steps (er_group.cpp).
@@ -463,6 +592,9 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if ((stages & STR_ER_STAGE_TRACK) && !(stages & STR_ER_STAGE_CLASSIFY)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs STR_ER_STAGE_CLASSIFY");
     if ((stages & (STR_ER_STAGE_GROUP | STR_ER_GROUP_INNER_SUP)) && !(stages & STR_ER_STAGE_TRACK)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_GROUP needs STR_ER_STAGE_TRACK");
     if ((stages & STR_ER_GROUP_INNER_SUP) && !(stages & STR_ER_STAGE_GROUP)) return fail(c, STR_ER_EINVAL, "STR_ER_GROUP_INNER_SUP modifies STR_ER_STAGE_GROUP");
+    if ((stages & STR_ER_STAGE_OCR_LINES) && !(stages & STR_ER_STAGE_GROUP)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_OCR_LINES needs STR_ER_STAGE_GROUP");
+    if ((stages & STR_ER_STAGE_OCR_LINES) && !(c->svm_loaded && c->svm.dim == 1800))
+        return fail(c, STR_ER_ESTATE, "STR_ER_STAGE_OCR_LINES needs an SVM model loaded with dim = 1800 (str_er_load_svm_model)");
     if ((stages & STR_ER_STAGE_TRACK) && b.planes_per_image <= 0)
         return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs BGR frames (calc_color reads the YCrCb image)");
 
@@ -588,6 +720,10 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         t_group_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     }
     const auto t_ocr0 = std::chrono::steady_clock::now();
+    if (stages & STR_ER_STAGE_OCR_LINES) {
+        const int rcl = line_ocr_phase(c, c->d_planes, r);
+        if (rcl != STR_ER_OK) { delete r; return rcl; }
+    }
     if ((stages & STR_ER_STAGE_OCR) && total) {
         // second phase: the host now knows how many strong/weak ERs there are
         size_t n_ocr = 0;
@@ -710,7 +846,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         if (hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) == hipSuccess) c->profile[i].second = ms;
     r->times[0] = stage_s[0]; r->times[1] = stage_s[1]; r->times[2] = stage_s[2];
     if ((stages & STR_ER_STAGE_TRACK) && hipEventElapsedTime(&ms, c->ev[i_cls], c->ev[i_trk]) == hipSuccess) r->times[3] = ms * 1e-3;
-    if (stages & STR_ER_STAGE_OCR) r->times[5] = t_ocr_s;
+    if (stages & (STR_ER_STAGE_OCR | STR_ER_STAGE_OCR_LINES)) r->times[5] = t_ocr_s;
     r->times[4] = t_group_s;
     r->times[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     *out = r;
@@ -1250,36 +1386,6 @@ int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, in
     return STR_ER_OK;
 }
 
-// OCR::rotate_mat's canvas for a w x h box (src/OCR.cpp:256-290): corner rounding, crop height and the
-// fall-back to the uncropped canvas, evaluated with the host libm exactly as the reference does.
-static RotGeom make_rot_geom(int w, int h, double slope)
-{
-    RotGeom g;
-    std::memset(&g, 0, sizeof(g));
-    if (!(std::fabs(slope) > 0.01)) return g;
-    const double rad = std::atan2(slope, 1.0);
-    const int    x0 = (int)((w - 1) / 2.0), y0 = (int)((h - 1) / 2.0);
-    const int    cx[4] = {0 - x0, (w - 1) - x0, (w - 1) - x0, 0 - x0}, cy[4] = {0 - y0, 0 - y0, (h - 1) - y0, (h - 1) - y0};
-    int          nx[4], ny[4];
-    for (int k = 0; k < 4; ++k) {
-        nx[k] = (int)std::round(cx[k] * std::cos(rad) - cy[k] * std::sin(rad));
-        ny[k] = (int)std::round(cx[k] * std::sin(rad) + cy[k] * std::cos(rad));
-    }
-    g.max_x = std::max(std::max(nx[0], nx[1]), std::max(nx[2], nx[3]));
-    g.max_y = std::max(std::max(ny[0], ny[1]), std::max(ny[2], ny[3]));
-    g.min_x = std::min(std::min(nx[0], nx[1]), std::min(nx[2], nx[3]));
-    g.min_y = std::min(std::min(ny[0], ny[1]), std::min(ny[2], ny[3]));
-    g.on = 1;
-    g.crop = 1;
-    g.ch = (int)((nx[1] - nx[0]) * std::tan(rad) * 0.5);
-    if (g.max_y - g.min_y + 1 - 2 * g.ch <= 0) { g.crop = 0; g.ch = 0; }
-    g.rw = g.max_x - g.min_x + 1;
-    g.rh = g.max_y - g.min_y + 1 - 2 * g.ch;
-    g.x0 = x0; g.y0 = y0;
-    g.c = std::cos(rad); g.s = std::sin(rad);
-    return g;
-}
-
 int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
                          int32_t *label, double *prob, uint8_t *q_out)
 {
@@ -1512,6 +1618,46 @@ const int32_t *str_er_result_group_all(const str_er_result *r, int32_t *n)
     if (n) *n = (int32_t)r->group_all.size();
     static const int32_t none = 0;
     return r->group_all.empty() ? &none : r->group_all.data();
+}
+
+const int32_t *str_er_result_line_labels(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_line_ocr) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->line_label.size();
+    static const int32_t none = 0;
+    return r->line_label.empty() ? &none : r->line_label.data();
+}
+
+const double *str_er_result_line_probs(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_line_ocr) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->line_prob.size();
+    static const double none = 0;
+    return r->line_prob.empty() ? &none : r->line_prob.data();
+}
+
+const uint8_t *str_er_result_line_kept(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_line_ocr) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->line_kept.size();
+    static const uint8_t none = 0;
+    return r->line_kept.empty() ? &none : r->line_kept.data();
+}
+
+const uint8_t *str_er_result_text_alive(const str_er_result *r, int32_t *n)
+{
+    if (!r || !r->have_line_ocr) { if (n) *n = 0; return nullptr; }
+    if (n) *n = (int32_t)r->text_alive.size();
+    static const uint8_t none = 0;
+    return r->text_alive.empty() ? &none : r->text_alive.data();
+}
+
+int str_er_set_min_ocr_prob(str_er_ctx *c, double p)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!(p >= 0.0 && p <= 1.0)) return fail(c, STR_ER_EINVAL, "min_ocr_prob must be in [0, 1]");
+    c->min_ocr_prob = p;
+    return STR_ER_OK;
 }
 
 const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n)

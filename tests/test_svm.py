@@ -269,3 +269,61 @@ def test_gpu_config3_full_pipeline(S, cascade_paths, oracle, oracle_cascades, mo
         n_checked += 1
     assert n_checked > 10
     f.close()
+
+
+@pytest.mark.gpu
+def test_gpu_line_ocr_stage(S, cascade_paths, oracle, model_path):
+    """er_ocr's first half (src/ER.cpp:695-747) on the lines of er_grouping: chain_run with the line's slope on every member's
+    (merged) bound, the 0.95-overlap deletion, MIN_OCR_PROB, min_pass_ocr -- restated here over the oracle's pieces."""
+    from oracle.oracle import OracleSVM
+    W, H, F = 640, 480, 2
+    f = S.ERFilter(8, 120, 900000, 2, 0.7, 0.15, max_width=W, max_height=H, max_frames=F)
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    f.load_svm_model(model_path, 1800)
+    f.set_min_ocr_prob(0.05)
+    m = OracleSVM(oracle, model_path)
+    frames = np.stack([S.synth.stext_bgr(S.synth.frame_seed(40 + i), W, H) for i in range(F)])
+    st = S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP | S.STAGE_OCR_LINES
+    res = f.text_detect(frames, st)
+    assert res.line_label is not None and len(res.line_label) == len(res.text_ers) > 0 and res.times[5] > 0
+    planes = [oracle.compute_channels(fr) for fr in frames]
+    n_rot = 0
+    for t, tx in enumerate(res.texts):
+        mem = res.text_ers[tx["first"]:tx["first"] + tx["count"]]
+        boxes = res.group_bounds[mem]
+        probs = []
+        for j, (ci, g) in enumerate(zip(mem, boxes)):
+            c = res.cands[ci]
+            roi = planes[c["frame"]][c["ch"]][g["y"]:g["y"] + g["h"], g["x"]:g["x"] + g["w"]]
+            q = oracle.chain_features(roi, float(tx["slope"]))
+            n_rot += abs(tx["slope"]) > 0.01
+            l, p, _ = m.predict_probability(q / 255.0)
+            pmax = p[np.argmax(p)]
+            k = tx["first"] + j
+            assert abs(res.line_prob[k] - pmax) < TOL
+            top2 = np.sort(p)[-2:]
+            if top2[1] - top2[0] > 10 * TOL:
+                assert res.line_label[k] == l
+            probs.append(res.line_prob[k])
+        # the two deletions and min_pass_ocr, as the reference does them
+        n = len(mem)
+        dele = [False] * n
+        for a in range(n):
+            for b in range(a + 1, n):
+                A, B = boxes[a], boxes[b]
+                iw = min(A["x"] + A["w"], B["x"] + B["w"]) - max(A["x"], B["x"])
+                ih = min(A["y"] + A["h"], B["y"] + B["h"]) - max(A["y"], B["y"])
+                inter = float(iw * ih) if iw > 0 and ih > 0 else 0.0
+                uni = float((max(A["x"] + A["w"], B["x"] + B["w"]) - min(A["x"], B["x"])) * (max(A["y"] + A["h"], B["y"] + B["h"]) - min(A["y"], B["y"])))
+                if inter / uni > 0.95:
+                    if int(A["w"]) * int(A["h"]) > int(B["w"]) * int(B["h"]):
+                        dele[b] = True
+                    else:
+                        dele[a] = True
+        keep = [not dele[a] and not (probs[a] < 0.05) for a in range(n)]
+        assert list(res.line_kept[tx["first"]:tx["first"] + tx["count"]]) == keep
+        assert bool(res.text_alive[t]) == (sum(keep) >= 2)
+    assert n_rot > 0            # some line is slanted enough to go through rotate_mat
+    with pytest.raises(S.StrErError):
+        f.text_detect(frames, S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_OCR_LINES)
+    f.close()
