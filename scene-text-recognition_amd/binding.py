@@ -337,7 +337,7 @@ class ERFilter:
             res = Result(info, cands, times, self.last_profile() if profile is None else profile, nodes)
             no = C.c_int32()
             lp = L.str_er_result_ocr_labels(rh, C.byref(no))
-            if lp and no.value:
+            if lp:
                 res.ocr_label = np.frombuffer((C.c_char * (4 * no.value)).from_address(lp), dtype=np.int32).copy()
                 pp = L.str_er_result_ocr_probs(rh, C.byref(no))
                 res.ocr_prob = np.frombuffer((C.c_char * (8 * no.value)).from_address(pp), dtype=np.float64).copy()

@@ -724,6 +724,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         const int rcl = line_ocr_phase(c, c->d_planes, r);
         if (rcl != STR_ER_OK) { delete r; return rcl; }
     }
+    if (stages & STR_ER_STAGE_OCR) r->have_ocr = true;      // (an empty table, not a missing one, when there are no candidates)
     if ((stages & STR_ER_STAGE_OCR) && total) {
         // second phase: the host now knows how many strong/weak ERs there are
         size_t n_ocr = 0;
@@ -1579,21 +1580,24 @@ const int32_t *str_er_result_ocr_labels(const str_er_result *r, int32_t *n)
 {
     if (!r || !r->have_ocr) { if (n) *n = 0; return nullptr; }
     if (n) *n = (int32_t)r->ocr_label.size();
-    return r->ocr_label.data();
+    static const int32_t none = 0;
+    return r->ocr_label.empty() ? &none : r->ocr_label.data();
 }
 
 const double *str_er_result_ocr_probs(const str_er_result *r, int32_t *n)
 {
     if (!r || !r->have_ocr) { if (n) *n = 0; return nullptr; }
     if (n) *n = (int32_t)r->ocr_prob.size();
-    return r->ocr_prob.data();
+    static const double none = 0;
+    return r->ocr_prob.empty() ? &none : r->ocr_prob.data();
 }
 
 const str_er_track *str_er_result_tracks(const str_er_result *r, int32_t *n)
 {
     if (!r || !r->have_tracks) { if (n) *n = 0; return nullptr; }
     if (n) *n = (int32_t)r->tracks.size();
-    return r->tracks.data();
+    static const str_er_track none{};
+    return r->tracks.empty() ? &none : r->tracks.data();     // never NULL once the stage has run
 }
 
 const str_er_text *str_er_result_texts(const str_er_result *r, int32_t *n)

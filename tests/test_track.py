@@ -305,3 +305,23 @@ def test_gpu_group_random_boxes(erf, oracle, S):
             res = erf.er_grouping(cd, tr, inner_sup=inner)
             res.cands, res.tracks = cd, tr
             _check_lines(res, [np.arange(n)], oracle, inner)
+
+
+@pytest.mark.gpu
+def test_gpu_late_stages_on_empty_and_tiny_frames(S, cascade_paths):
+    """No candidates at all (flat frames), frames smaller than a tile, one frame of pure noise: the late stages return empty
+    tables, never garbage."""
+    st = S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP
+    for (w, h) in ((64, 48), (8, 8), (1, 1), (200, 3)):
+        f = S.ERFilter(params=S.Params(max_width=w, max_height=h, max_frames=2))
+        f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+        flat = np.full((2, h, w, 3), 128, np.uint8)
+        res = f.text_detect(flat, st)
+        assert len(res.tracks) == len(res.cands) and len(res.texts) == 0 and len(res.text_ers) == 0
+        assert len(res.group_bounds) == len(res.cands) and len(res.group_all) == 0
+        rng = np.random.default_rng(w * 1000 + h)
+        noise = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        res = f.text_detect(noise, st)
+        assert len(res.tracks) == len(res.cands)
+        assert (res.tracks["tracked"][res.cands["cls"] == 0] == 0).all()
+        f.close()
