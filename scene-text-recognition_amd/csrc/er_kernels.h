@@ -49,7 +49,8 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                    int64_t sframe_pitch, uint8_t *dst, int dw, int dh, int dstride, int64_t dplane_pitch,
                    int64_t dframe_pitch, int planes_per_frame, int n_frames);
 
-void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p);
+// sparse: the small-LDS / high-occupancy size of the kernel (text-like frames); dense: the big one (noise-like frames)
+void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
 void launch_seam(hipStream_t s, const BatchDev &b);
 void launch_level_prefix(hipStream_t s, const BatchDev &b);
 void launch_resolve(hipStream_t s, const BatchDev &b);

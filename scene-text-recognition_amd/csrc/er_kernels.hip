@@ -450,8 +450,8 @@ __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_
 // so "lane i does edge i, then everybody waits for the slowest lane" leaves most lanes idle most of the time.  Here a
 // lane that finishes its edge takes the next one from a workgroup-wide cursor straight away (one LDS atomic per wave and
 // pass for all its idle lanes); a wave leaves when the list is empty and its lanes are done.
-__device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint32_t *s_work, uint32_t n_edges,
-                                                 uint32_t *s_cursor)
+__device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges,
+                                                 uint32_t *s_cursor, int round)
 {
     const int lane = threadIdx.x & 63;
     bool      active = false, more = true;
@@ -468,8 +468,11 @@ __device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t
                 else if (!active) {
                     const uint32_t e = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     if (e < n_edges) {
-                        const uint32_t w = s_work[e];
-                        a = w & 0xFFFFu; b = w >> 16;
+                        // an entry is the slot p of the edge's second (round 0) or first (round 1) pixel: the edge is (left of p, p) --
+                        // one slot back, two across the unused word after every 32 pixels -- or (p, pixel below p)
+                        const uint32_t p = s_elist[e];
+                        if (round == 0) { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
+                        else { a = p; b = p + (uint32_t)TILE_WS; }
                         la = s_lev[LX(a)]; lb = s_lev[LX(b)];
                         active = true;
                         CNT(0, 1);
@@ -536,7 +539,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wsum
     return off + incl - v;
 }
 
-constexpr int STAT_CHUNK = 512;   // dense tiles: nodes whose statistics are accumulated per pass
 // per-node statistics in LDS: w0 (pixels | nodes | open), the set of tile rows, the set of tile columns
 typedef std::conditional<(TILE_H > 32), unsigned long long, uint32_t>::type rowmask_t;
 constexpr int      ROW_WORDS = (int)sizeof(rowmask_t) / 4;
@@ -549,13 +551,23 @@ __device__ __forceinline__ int row_lo(uint32_t m) { return __ffs((int)m) - 1; }
 __device__ __forceinline__ int row_hi(uint32_t m) { return 31 - __clz((int)m); }
 __device__ __forceinline__ int row_lo(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int row_hi(unsigned long long m) { return 63 - __clzll((long long)m); }
-constexpr int FOLD_CAP = TILE_H > 32 ? 1408 : 880;     // tiles with at most this many nodes fold their closed nodes in LDS
+// The tile kernel exists in two sizes.  FOLD_CAP = how many nodes a tile may have and still fold its closed nodes in LDS
+// (more: every node is exported and the global passes do the folding); it sets the size of s_work and with it how many
+// workgroups fit a CU.  The kernel waits on LDS round trips most of the time, so occupancy pays: measured on text-like frames
+// 4.50 ms (880 nodes, 6 workgroups per CU) -> 4.0 ms (480 nodes, 8 per CU, a few spilled registers).  Frames that are mostly
+// noise have ~860 nodes per tile and need the big one (with 480 the global accumulate pass quadruples).  The host picks per
+// batch from the node density of the previous batch (str_er_api.cpp).
+constexpr int FOLD_CAP_DENSE = TILE_H > 32 ? 1408 : 880;    // 21 (42) LDS granules of 1280 B: 6 (3) workgroups per CU
+constexpr int FOLD_CAP_SPARSE = TILE_H > 32 ? 1024 : 480;   // 16 (32) granules: 8 (4) workgroups per CU
 
-// (6 waves per SIMD = the 6 (3 with 64-row tiles) workgroups per CU the LDS allows: keeps the register allocation at or below 80 VGPRs)
-__global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, DetectParams prm)
+// (waves per SIMD = what the LDS allows: 6 with 80 VGPRs for the dense size, 8 with 64 VGPRs for the sparse one)
+template <int FOLD_CAP>
+__global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)) void k_tile_tree(BatchDev b, DetectParams prm)
 {
-    // 26.2 KB of LDS -> 6 workgroups (24 waves) per CU: LDS is handed out in 1280-byte granules, 21 of them (26880 B) is the most
-    // that still fits six times into 160 KB -- FOLD_CAP is sized for exactly that (64-row tiles: 42 granules, three times)
+    // dense size: 26.2 KB of LDS -> 6 workgroups (24 waves) per CU: LDS is handed out in 1280-byte granules, 21 of them (26880 B) is the
+    // most that still fits six times into 160 KB; sparse size: 19.9 KB = 16 granules, eight times
+    constexpr int STAT_CHUNK = FOLD_CAP < 512 ? FOLD_CAP : 512;   // dense tiles: nodes whose statistics are accumulated per pass
+    static_assert(2 * NODE_WORDS * FOLD_CAP >= TILE_PX, "the 16-bit edge list of a round (one entry per pixel at most) must fit s_work");
     __shared__ uint32_t s_par[TILE_SLOTS];
     __shared__ __attribute__((aligned(8))) uint32_t s_work[NODE_WORDS * FOLD_CAP]; // edge worklist, later the per-node statistics
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
@@ -643,6 +655,7 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
     // boundaries; vertical: the first column of a pair of runs -- the other columns join the same
     // two nodes); the list is compacted into LDS and dealt out evenly, so a lane whose pixels
     // happen to need many connects does not hold its whole wave back.
+    uint16_t *const s_elist = reinterpret_cast<uint16_t *>(s_work);     // one 16-bit slot per edge
     for (int round = 0; round < 2; ++round) {
         uint32_t emask = 0;
 #pragma unroll
@@ -670,11 +683,11 @@ __global__ __launch_bounds__(TILE_THREADS, 6) void k_tile_tree(BatchDev b, Detec
         for (int k = 0; k < TILE_PPT; ++k)
             if ((emask >> k) & 1) {
                 const uint32_t p = p0 + k;
-                s_work[off++] = round == 0 ? ((k == 0 ? pl : p - 1) | (p << 16)) : (p | ((p + TILE_WS) << 16));
+                s_elist[off++] = (uint16_t)p;          // the other end follows from the round: left neighbour / pixel below
             }
         if (tid == 0) s_cursor = 0;
         __syncthreads();
-        tile_connect_all(s_par, s_lev, s_work, n_edges, &s_cursor);
+        tile_connect_all(s_par, s_lev, s_elist, n_edges, &s_cursor, round);
         __syncthreads();
         PHASE_MARK(1 + round);
     }
@@ -1022,10 +1035,11 @@ extern "C" void str_er_debug_phase_cycles(unsigned long long *out16, int reset)
 }
 #endif
 
-void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p)
+void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse)
 {
     if (!b.n_tiles) return;
-    hipLaunchKernelGGL(k_tile_tree, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
+    if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
+    else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
 }
 
 // ------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ struct str_er_ctx {
     int max_planes = 0;
     int kept_cap = 0, pool_cap = 0;
     double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
+    bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
+    int    tile_mode = 0;             // 0 auto (from the node density of the previous batch), 1 sparse, 2 dense (STR_ER_TILE_KERNEL)
     int64_t ws_bytes = 0;
 
     // device workspace
@@ -629,7 +631,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     const BatchDev bd = make_batchdev(c, b);
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
 
-    launch_tile_tree(s, bd, dp);                      rec(c, "tile_tree");
+    launch_tile_tree(s, bd, dp, c->tile_sparse);      rec(c, "tile_tree");
     if (std::getenv("STR_ER_DEBUG_TILE_ONLY")) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
         (void)hipStreamSynchronize(s);
@@ -684,6 +686,13 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
                         std::to_string(c->h_ctr[i].n_kept) + " kept nodes, kept_cap = " + std::to_string(c->kept_cap));
         if (c->h_ctr[i].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
         if (c->h_ctr[i].overflow & 4u) return fail(c, STR_ER_ECAPACITY, "exported-node list overflow (more than half of the pixels are open tree nodes)");
+    }
+    if (c->tile_mode == 0 && b.n_tiles) {      // text-like frames make a few dozen nodes per tile, noise several hundred
+        unsigned long long created = 0;
+        for (int i = 0; i < np; ++i) created += c->h_ctr[i].n_created;
+        const double per_tile = (double)created / (double)b.n_tiles;
+        if (per_tile > 320.0) c->tile_sparse = false;
+        else if (per_tile < 240.0) c->tile_sparse = true;
     }
     str_er_result *r = new (std::nothrow) str_er_result();
     if (!r) return fail(c, STR_ER_ENOMEM, "result allocation");
@@ -941,6 +950,10 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     str_er_ctx *c = new (std::nothrow) str_er_ctx();
     if (!c) return fail(nullptr, STR_ER_ENOMEM, "context allocation");
     c->prm = *p;
+    if (const char *tk = std::getenv("STR_ER_TILE_KERNEL")) {      // developer switch: force one size of the tile kernel
+        if (!std::strcmp(tk, "sparse")) { c->tile_mode = 1; c->tile_sparse = true; }
+        else if (!std::strcmp(tk, "dense")) { c->tile_mode = 2; c->tile_sparse = false; }
+    }
     for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
     c->ppf = (int)c->chans.size() * p->n_pyr_levels;
     c->max_planes = c->ppf * p->max_frames;

@@ -416,3 +416,27 @@ def test_plane_sharded_frame_equals_fused_pyramid(S, cascade_paths):
     one = S.dist.detect_frame_plane_sharded(f, frame, 0, 1, L, MASK)
     assert one[fields].tolist() == fused[fields].tolist()
     f.close()
+
+
+def test_both_tile_kernel_sizes_give_the_same_answer(S, cascade_paths, monkeypatch):
+    """The tile kernel exists in a small-LDS / high-occupancy size and a big one (picked per batch from the node density of the
+    previous batch); both, and the automatic choice across a text -> noise -> text sequence, give identical results."""
+    W, H = 448, 320
+    text = np.stack([S.synth.stext_bgr(S.synth.frame_seed(5 + i), W, H) for i in range(2)])
+    noise = np.random.default_rng(3).integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    out = {}
+    for mode in ("sparse", "dense", ""):
+        if mode:
+            monkeypatch.setenv("STR_ER_TILE_KERNEL", mode)
+        else:
+            monkeypatch.delenv("STR_ER_TILE_KERNEL", raising=False)
+        f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=2))
+        f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+        out[mode] = [f.text_detect(x, want_nodes=True) for x in (text, noise, noise, text, text)]
+        f.close()
+    for mode in ("dense", ""):
+        for a, b in zip(out["sparse"], out[mode]):
+            assert a.cands.tobytes() == b.cands.tobytes() and a.info.tobytes() == b.info.tobytes()
+            for pa, pb in zip(a.planes, b.planes):
+                assert pa.nodes.tobytes() == pb.nodes.tobytes()
+    assert len(out[""][0].cands) > 0
