@@ -10,7 +10,7 @@ os.makedirs(DST, exist_ok=True)
 
 
 def short(n):
-    m = re.match(r"(?:str_er::)?([A-Za-z_0-9]+)", n)
+    m = re.match(r"(?:void )?(?:str_er::)?([A-Za-z_0-9]+)", n)     # "void str_er::k_tile_tree<480>(...)" -> k_tile_tree
     return m.group(1) if m else n
 
 

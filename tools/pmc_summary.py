@@ -2,7 +2,8 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs: mean counter value per kernel name."""
 import csv, sys, collections, re
 def short(n):
-    m = re.match(r"(?:str_er::)?([A-Za-z_0-9]+)", n); return m.group(1) if m else n
+    m = re.match(r"(?:void )?(?:str_er::)?([A-Za-z_0-9]+)", n)     # "void str_er::k_tile_tree<480>(...)" -> k_tile_tree
+    return m.group(1) if m else n
 for path in sys.argv[1:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
