@@ -325,3 +325,34 @@ def test_gpu_late_stages_on_empty_and_tiny_frames(S, cascade_paths):
         assert len(res.tracks) == len(res.cands)
         assert (res.tracks["tracked"][res.cands["cls"] == 0] == 0).all()
         f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,levels,mask,step", [(333, 201, 1, 0x3F, 8), (512, 300, 3, 0x07, 8), (257, 190, 2, 0x15, 4), (640, 360, 1, 0x38, 16)])
+def test_gpu_track_and_group_on_odd_sizes(S, cascade_paths, oracle, W, H, levels, mask, step):
+    """calc_color, er_track and er_grouping against the oracle on ragged frame sizes, channel subsets, pyramid levels, thresh steps."""
+    F = 2
+    f = S.ERFilter(params=S.Params(thresh_step=step, max_width=W, max_height=H, max_frames=F, n_pyr_levels=levels, channel_mask=mask))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    frames = np.stack([S.synth.stext_bgr(S.synth.frame_seed(70 + i), W, H) for i in range(F)])
+    res = f.text_detect(frames, S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP)
+    planes = {}
+    for i in range(F):
+        lvl = _ycrcb(oracle, frames[i])[:3]
+        for l in range(levels):
+            if l > 0:
+                dw, dh = oracle.pyr_dims(W, H, l)
+                lvl = np.stack([oracle.resize(p, dw, dh) for p in lvl])
+            planes[(i, l)] = np.concatenate([lvl, 255 - lvl])
+    groups = []
+    for sel, order, e in _expected_tracks(oracle, res, planes):
+        t = res.tracks[sel]
+        live = e["cls"] != 0
+        for k in ("color1", "color2", "color3"):
+            assert np.array_equal(t[k][live], e[k][live], equal_nan=True)
+        want = np.zeros(len(sel), bool)
+        want[order] = True
+        assert (t["tracked"].astype(bool) == want).all()
+        groups.append(sel)
+    _check_lines(res, groups, oracle, True)
+    f.close()
