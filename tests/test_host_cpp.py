@@ -62,3 +62,29 @@ def test_host_mirror_runs_and_matches_python(S, cascade_paths, tmp_path):
         assert b.split() == [f"{int(m['ch'])}/{int(m['key'])}" for m in members]
     assert len(lines) == len(res2.texts) > 0
     f.close()
+
+
+def _build_stream(S, tmp_path):
+    exe = str(tmp_path / "example_video_stream")
+    libdir = os.path.dirname(S.lib_path())
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", os.path.join(HOST, "example_video_stream.cpp"),
+                    "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lstr_er_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    return exe
+
+
+def test_stream_example_compiles(S, tmp_path):
+    assert os.path.exists(_build_stream(S, tmp_path))
+
+
+@pytest.mark.gpu
+def test_stream_example_runs(S, cascade_paths, tmp_path):
+    """video_mode's loop on the ingest stream: 7 frames in batches of 2, three batches in flight, equal to direct calls."""
+    exe = _build_stream(S, tmp_path)
+    frames = np.stack([S.synth.stext_bgr(S.synth.frame_seed(40 + i), 640, 480) for i in range(7)])
+    raw = tmp_path / "frames.bgr"
+    raw.write_bytes(frames.tobytes())
+    out = subprocess.run([exe, cascade_paths[0], cascade_paths[1], str(raw), "640", "480", "7", "2"], check=True, capture_output=True,
+                         text=True).stdout.splitlines()
+    assert out[-1] == "stream == direct calls: yes"
+    assert len([l for l in out if l.startswith("frame ")]) == 7
+    assert sum(int(l.split()[11]) for l in out if l.startswith("frame ")) > 0        # some text lines were found
