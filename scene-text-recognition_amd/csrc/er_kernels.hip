@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
 #ifndef SEAM_XCD_AFFINE
 #define SEAM_XCD_AFFINE 0   // measured: 1 helps S-noise (seam 1.7 -> 1.2 ms) and hurts S-text (1.0 -> 1.3 ms)
 #endif
-__global__ __launch_bounds__(256) void k_seam(BatchDev b)
+__global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b)
 {
     // a block never straddles two planes: the host lists (plane, first pair) per block
     // Workgroups are dealt to the 8 XCDs round-robin; renumber them so that consecutive seam blocks (= one plane's
@@ -1145,18 +1145,19 @@ __global__ __launch_bounds__(256) void k_seam(BatchDev b)
     if (i < pd.n_pairs) SCNT(6, 1);
     // ... and the same pair keeps coming back further along the seam (background | speckle | background ...): a connect is
     // idempotent, so only the first lane of the block that brings a pair does it (open-addressing set in LDS).
-    __shared__ unsigned long long s_seen[512];
-    s_seen[threadIdx.x] = ~0ull; s_seen[threadIdx.x + 256] = ~0ull;
+    __shared__ unsigned long long s_seen[2 * SEAM_BLOCK];
+    s_seen[threadIdx.x] = ~0ull; s_seen[threadIdx.x + SEAM_BLOCK] = ~0ull;
     __syncthreads();
     if (na == NONE || nbn == NONE || dup) return;
     {
         const unsigned long long key = (unsigned long long)na | ((unsigned long long)nbn << 32);
-        uint32_t h = (na * 0x9E3779B1u ^ nbn * 0x85EBCA77u) >> 23;
+        constexpr uint32_t HMASK = 2u * (uint32_t)SEAM_BLOCK - 1u;      // table of 2 * SEAM_BLOCK slots (a power of two)
+        uint32_t h = ((na * 0x9E3779B1u ^ nbn * 0x85EBCA77u) >> 16) & HMASK;
         for (;;) {
             const unsigned long long old = atomicCAS(&s_seen[h], ~0ull, key);
             if (old == ~0ull) break;
             if (old == key) return;
-            h = (h + 1u) & 511u;
+            h = (h + 1u) & HMASK;
         }
     }
     const size_t nb = pd.node_base;
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_seam(BatchDev b)
 void launch_seam(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_seam_blocks) return;
-    hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(SEAM_BLOCK), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------

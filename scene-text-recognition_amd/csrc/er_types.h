@@ -19,6 +19,7 @@ constexpr int      TILE_PX  = TILE_W * TILE_H;   // 2048 / 4096
 constexpr int      TILE_PPT = 8;                 // consecutive pixels per lane
 constexpr int      TILE_THREADS = TILE_PX / TILE_PPT; // 256 / 512: 4 / 8 wavefronts of 64
 constexpr uint32_t NONE     = 0xFFFFFFFFu;
+constexpr int      SEAM_BLOCK = 1024;          // seam pixel pairs (= lanes) per k_seam workgroup; the host lists (plane, first pair) per workgroup
 
 // One logical plane = one (frame, channel, pyramid level): the unit the reference
 // loops over at src/ER.cpp:50-60.  Inverted channels (255-x, src/ER.cpp:125-127) share

@@ -616,7 +616,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
             for (int i = 0; i < np; ++i) {
                 const PlaneDesc &pd = b.planes[i];
                 c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
-                for (uint32_t f0 = 0; f0 < pd.n_pairs; f0 += 256) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
+                for (uint32_t f0 = 0; f0 < pd.n_pairs; f0 += (uint32_t)SEAM_BLOCK) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
             }
             if (c->h_sb_plane.size() > c->sb_slots) return fail(c, STR_ER_ECAPACITY, "seam block table capacity exceeded");
             HIP_TRY(c, hipMemcpyAsync(c->d_tile_plane, c->h_tile_plane.data(), 2 * c->h_tile_plane.size(), hipMemcpyHostToDevice, s));
@@ -995,7 +995,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->ka.start, KP)); A(dev_alloc(c, c->ka.ncand, KP)); A(dev_alloc(c, c->ka.best, KP));
     A(dev_alloc(c, c->d_seam, c->seam_slots));
     c->tile_slots = c->slots / TILE_PX + 16;
-    c->sb_slots = c->seam_slots / 512 + (size_t)c->max_planes + 16;
+    c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     c->node_list_cap = c->slots / 2 + 4096;
     A(dev_alloc(c, c->d_lvl, 8192 + 64)); A(dev_alloc(c, c->d_node_list, c->node_list_cap)); A(dev_alloc(c, c->d_list_key, c->node_list_cap)); A(dev_alloc(c, c->d_acc_list, c->node_list_cap)); A(dev_alloc(c, c->d_lvl_tab, 520));   // chunk sums of the offset scan + total
