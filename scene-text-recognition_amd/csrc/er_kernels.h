@@ -29,6 +29,7 @@ struct BatchDev {
     uint16_t        *list_key;  // per list entry: level, or level | 0x100 for nodes that never push
     uint32_t         node_list_cap;
     uint32_t        *acc_list; // the nodes that push to a parent, grouped by level (global slot index)
+    uint32_t        *acc_parent; // ... and the global slot of each one's parent
     uint32_t        *lvl_tab;  // [0..256] count -> base per level, [260..515] scatter cursors
     uint32_t        *seam;     // node id of every tile-border pixel
     uint32_t        *pool;     // kept slots chosen by NMS, ascending key

@@ -1390,7 +1390,14 @@ __global__ __launch_bounds__(256) void k_acc_scatter(BatchDev b)
         __syncthreads();
         for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
             const uint32_t k = b.list_key[i];
-            if (k < 0x100u) b.acc_list[s_base[k] + atomicAdd(&s_h[k], 1u)] = b.node_list[i];
+            if (k < 0x100u) {
+                // the node and -- so that the per-level launches do not have to chase it -- the global slot of its parent
+                const uint32_t g = b.node_list[i];
+                const uint32_t w = b.na.par[g];
+                const uint32_t at = s_base[k] + atomicAdd(&s_h[k], 1u);
+                b.acc_list[at] = g;
+                b.acc_parent[at] = (w == NONE) ? NONE : b.planes[b.tile_plane[g / (uint32_t)TILE_PX]].node_base + PAR_ID(w);
+            }
         }
         __syncthreads();
     }
@@ -1416,8 +1423,8 @@ __global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
         size_t   gp = (size_t)-1;          // global slot of the parent; all-ones = inactive lane
         if (i < end) {
             g = b.acc_list[i];
-            const uint32_t w = b.na.par[g];
-            if (w != NONE) gp = (size_t)b.planes[b.tile_plane[g / (size_t)TILE_PX]].node_base + PAR_ID(w);
+            const uint32_t pg = b.acc_parent[i];
+            if (pg != NONE) gp = (size_t)pg;
         }
         const bool act = gp != (size_t)-1;
         unsigned long long todo = __ballot(act);

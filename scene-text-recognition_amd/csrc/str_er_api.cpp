@@ -101,7 +101,7 @@ struct str_er_ctx {
     std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
     uint32_t *d_lvl = nullptr, *d_node_list = nullptr, *d_tile_off = nullptr; size_t node_list_cap = 0;
     uint16_t *d_list_key = nullptr;
-    uint32_t *d_acc_list = nullptr, *d_lvl_tab = nullptr;
+    uint32_t *d_acc_list = nullptr, *d_acc_parent = nullptr, *d_lvl_tab = nullptr;
     uint32_t *d_tile_cnt = nullptr; uint8_t *d_tile_lo = nullptr, *d_tile_hi = nullptr; size_t tile_slots = 0;
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
@@ -343,7 +343,7 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
     d.tile_off = c->d_tile_off; d.chunk_sum = c->d_lvl; d.n_listed = c->d_lvl + 8192; d.node_list = c->d_node_list; d.list_key = c->d_list_key;
     d.node_list_cap = (uint32_t)c->node_list_cap;
-    d.acc_list = c->d_acc_list; d.lvl_tab = c->d_lvl_tab;
+    d.acc_list = c->d_acc_list; d.acc_parent = c->d_acc_parent; d.lvl_tab = c->d_lvl_tab;
     d.na = c->na; d.ka = c->ka; d.tile_cnt = c->d_tile_cnt; d.tile_lo = c->d_tile_lo; d.tile_hi = c->d_tile_hi; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane;
     return d;
@@ -998,7 +998,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     c->node_list_cap = c->slots / 2 + 4096;
-    A(dev_alloc(c, c->d_lvl, 8192 + 64)); A(dev_alloc(c, c->d_node_list, c->node_list_cap)); A(dev_alloc(c, c->d_list_key, c->node_list_cap)); A(dev_alloc(c, c->d_acc_list, c->node_list_cap)); A(dev_alloc(c, c->d_lvl_tab, 520));   // chunk sums of the offset scan + total
+    A(dev_alloc(c, c->d_lvl, 8192 + 64)); A(dev_alloc(c, c->d_node_list, c->node_list_cap)); A(dev_alloc(c, c->d_list_key, c->node_list_cap)); A(dev_alloc(c, c->d_acc_list, c->node_list_cap)); A(dev_alloc(c, c->d_acc_parent, c->node_list_cap)); A(dev_alloc(c, c->d_lvl_tab, 520));   // chunk sums of the offset scan + total
     A(dev_alloc(c, c->d_tile_off, c->tile_slots));
     A(dev_alloc(c, c->d_tile_cnt, c->tile_slots)); A(dev_alloc(c, c->d_tile_lo, c->tile_slots)); A(dev_alloc(c, c->d_tile_hi, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
