@@ -1146,22 +1146,31 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b)
     // ... and the same pair keeps coming back further along the seam (background | speckle | background ...): a connect is
     // idempotent, so only the first lane of the block that brings a pair does it (open-addressing set in LDS).
     __shared__ unsigned long long s_seen[2 * SEAM_BLOCK];
+    __shared__ uint32_t s_n;
     s_seen[threadIdx.x] = ~0ull; s_seen[threadIdx.x + SEAM_BLOCK] = ~0ull;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    if (na == NONE || nbn == NONE || dup) return;
-    {
+    bool mine = !(na == NONE || nbn == NONE || dup);
+    if (mine) {
         const unsigned long long key = (unsigned long long)na | ((unsigned long long)nbn << 32);
         constexpr uint32_t HMASK = 2u * (uint32_t)SEAM_BLOCK - 1u;      // table of 2 * SEAM_BLOCK slots (a power of two)
         uint32_t h = ((na * 0x9E3779B1u ^ nbn * 0x85EBCA77u) >> 16) & HMASK;
         for (;;) {
             const unsigned long long old = atomicCAS(&s_seen[h], ~0ull, key);
             if (old == ~0ull) break;
-            if (old == key) return;
+            if (old == key) { mine = false; break; }
             h = (h + 1u) & HMASK;
         }
     }
+    // The survivors (typically a tenth of the lanes, scattered over all 16 waves) are packed into the first waves: the other
+    // waves retire at once and make room for the next workgroups, so more connects -- chains of dependent fabric round
+    // trips -- are in flight per CU.
+    __shared__ uint32_t s_pa[SEAM_BLOCK], s_pb[SEAM_BLOCK];
+    if (mine) { const uint32_t at = atomicAdd(&s_n, 1u); s_pa[at] = na; s_pb[at] = nbn; }
+    __syncthreads();
+    if (threadIdx.x >= s_n) return;
     const size_t nb = pd.node_base;
-    node_connect(b.na.par + nb, b.na.lvl + nb, na, nbn);
+    node_connect(b.na.par + nb, b.na.lvl + nb, s_pa[threadIdx.x], s_pb[threadIdx.x]);
 }
 
 void launch_seam(hipStream_t s, const BatchDev &b)
