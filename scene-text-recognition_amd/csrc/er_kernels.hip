@@ -1258,7 +1258,9 @@ void launch_level_prefix(hipStream_t s, const BatchDev &b)
 // Nodes that were unified into another node of the same level hand their own
 // statistics to the surviving level root; surviving nodes get a canonical parent.
 // Every exported node is also entered into the level-sorted list (global slot index).
-__global__ __launch_bounds__(256) void k_resolve(BatchDev b)
+// the exported nodes as one dense list (global slot index), tile after tile: a wave per tile only copies numbers here, so
+// that the passes that chase pointers (k_resolve, k_select) run with one lane per node and every lane busy
+__global__ __launch_bounds__(256) void k_node_list(BatchDev b)
 {
     const int lane = threadIdx.x & 63;
     for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
@@ -1266,52 +1268,56 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
         if (!n) continue;
         const int       pi = b.tile_plane[t];
         const PlaneDesc &pd = b.planes[pi];
-        const size_t    nb = pd.node_base;
-        const uint32_t  base = (t - pd.tile_base) * (uint32_t)TILE_PX;
-        uint32_t       *par = b.na.par + nb;
-        const uint8_t  *lvl = b.na.lvl + nb;
-        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const bool     have = i < n;
-            const uint32_t x = base + (have ? i : 0);
-            const uint32_t l = have ? lvl[x] : 0xFFFFFFFFu;
-            if (!have) continue;
-            const uint32_t at = b.tile_off[t] + i;
-            const uint32_t w = LD_AGENT(&par[x]);
-            uint32_t       skip = b.na.dead[nb + x] ? 0x100u : 0u;      // closed nodes never push (totals final)
-            if (w != NONE && PAR_LVL(w) == l) {
-                uint32_t r = PAR_ID(w);
-                for (;;) {
-                    const uint32_t w2 = LD_AGENT(&par[r]);
-                    if (w2 == NONE || PAR_LVL(w2) != l) break;
-                    r = PAR_ID(w2);
-                }
-                b.na.dead[nb + x] = 1;
-                skip = 0x100u;
-                atomicAdd(&b.na.cnt[nb + r], b.na.cnt[nb + x]);
-                if (b.na.nod[nb + x] > 1) atomicAdd(&b.na.nod[nb + r], b.na.nod[nb + x] - 1);   // folded descendants
-                atomicMin(&b.na.x0[nb + r], b.na.x0[nb + x]);
-                atomicMin(&b.na.y0[nb + r], b.na.y0[nb + x]);
-                atomicMax(&b.na.x1[nb + r], b.na.x1[nb + x]);
-                atomicMax(&b.na.y1[nb + r], b.na.y1[nb + x]);
-                atomicMin(&b.na.key[nb + r], b.na.key[nb + x]);
-            } else if (w != NONE) {
-                uint32_t       q = PAR_ID(w);
-                const uint32_t lq = PAR_LVL(w);
-                for (;;) {
-                    const uint32_t w2 = LD_AGENT(&par[q]);
-                    if (w2 == NONE || PAR_LVL(w2) != lq) break;
-                    q = PAR_ID(w2);
-                }
-                if (q != PAR_ID(w)) ST_AGENT(&par[x], PAR_MAKE(lq, q));
-            } else {
-                skip = 0x100u;                                           // a tree root has nobody to push to
-            }
-            if (at < b.node_list_cap) {
-                b.node_list[at] = (uint32_t)(nb + x);
-                b.list_key[at] = (uint16_t)(l | skip);                  // what k_accumulate tests: level, or "never"
-            } else atomicOr(&b.ctr[pi].overflow, 4u);
+        const uint32_t  g0 = pd.node_base + (t - pd.tile_base) * (uint32_t)TILE_PX;
+        const uint32_t  off = b.tile_off[t];
+        for (uint32_t i = lane; i < n; i += 64) {
+            if (off + i < b.node_list_cap) b.node_list[off + i] = g0 + i;
+            else atomicOr(&b.ctr[pi].overflow, 4u);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resolve(BatchDev b)
+{
+    const uint32_t end = min(*b.n_listed, b.node_list_cap);
+    for (uint32_t at = blockIdx.x * blockDim.x + threadIdx.x; at < end; at += gridDim.x * blockDim.x) {
+        const uint32_t  g = b.node_list[at];
+        const int       pi = b.tile_plane[g / (uint32_t)TILE_PX];
+        const size_t    nb = b.planes[pi].node_base;
+        const uint32_t  x = g - (uint32_t)nb;
+        uint32_t       *par = b.na.par + nb;
+        const uint32_t  l = b.na.lvl[g];
+        const uint32_t  w = LD_AGENT(&par[x]);
+        uint32_t        skip = b.na.dead[g] ? 0x100u : 0u;      // closed nodes never push (totals final)
+        if (w != NONE && PAR_LVL(w) == l) {
+            uint32_t r = PAR_ID(w);
+            for (;;) {
+                const uint32_t w2 = LD_AGENT(&par[r]);
+                if (w2 == NONE || PAR_LVL(w2) != l) break;
+                r = PAR_ID(w2);
+            }
+            b.na.dead[g] = 1;
+            skip = 0x100u;
+            atomicAdd(&b.na.cnt[nb + r], b.na.cnt[g]);
+            if (b.na.nod[g] > 1) atomicAdd(&b.na.nod[nb + r], b.na.nod[g] - 1);   // folded descendants
+            atomicMin(&b.na.x0[nb + r], b.na.x0[g]);
+            atomicMin(&b.na.y0[nb + r], b.na.y0[g]);
+            atomicMax(&b.na.x1[nb + r], b.na.x1[g]);
+            atomicMax(&b.na.y1[nb + r], b.na.y1[g]);
+            atomicMin(&b.na.key[nb + r], b.na.key[g]);
+        } else if (w != NONE) {
+            uint32_t       q = PAR_ID(w);
+            const uint32_t lq = PAR_LVL(w);
+            for (;;) {
+                const uint32_t w2 = LD_AGENT(&par[q]);
+                if (w2 == NONE || PAR_LVL(w2) != lq) break;
+                q = PAR_ID(w2);
+            }
+            if (q != PAR_ID(w)) ST_AGENT(&par[x], PAR_MAKE(lq, q));
+        } else {
+            skip = 0x100u;                                           // a tree root has nobody to push to
+        }
+        b.list_key[at] = (uint16_t)(l | skip);                      // what the accumulate sort tests: level, or "never"
     }
 }
 
@@ -1319,7 +1325,8 @@ void launch_resolve(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_tiles) return;
     const uint32_t blocks = (b.n_tiles + 3) / 4;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_node_list, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_resolve, dim3(4096), dim3(256), 0, s, b);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
