@@ -8,6 +8,9 @@
  *
  *     compute_channels -> er_tree_extract -> non_maximum_supression -> classify
  *
+ * and, behind further stage flags, what text_detect does with the classified ERs (src/ER.cpp:62-72): calc_color + er_track,
+ * er_grouping, the chain-code / SVM scoring of er_ocr; plus a frame-ingest stream (str_er_stream_*).
+ *
  * Plain pointers and sizes only; no C++/torch types cross this header.  Every entry
  * point returns 0 (STR_ER_OK) or a negative STR_ER_E* code and never throws.  All
  * per-pixel work runs in hand-written HIP kernels; there is no CPU fallback -- if no
@@ -52,12 +55,14 @@ extern "C" {
 #define STR_ER_STAGE_CLASSIFY 4u   /* classify                 src/ER.cpp:507-528 */
 #define STR_ER_STAGE_ALL      7u
 #define STR_ER_STAGE_OCR      8u   /* config 3: OCR::chain_run (slope 0) on every strong/weak ER; needs an SVM model */
-/* output options */
+/* output option */
 #define STR_ER_WANT_NODES     16u  /* also return the kept-node table of every plane */
+/* the rest of text_detect (src/ER.cpp:62-72), BGR frames only */
+#define STR_ER_STAGE_TRACK    32u  /* calc_color + ERFilter::er_track on the strong/weak ERs of every image (src/ER.cpp:530-590) */
 #define STR_ER_STAGE_GROUP    64u  /* ERFilter::er_grouping(tracked, text, false, false) (src/ER.cpp:612-692); needs STR_ER_STAGE_TRACK */
 #define STR_ER_GROUP_INNER_SUP 128u /* ... with inner_sup = true, as text_detect calls it when DO_OCR is defined (src/ER.cpp:69) */
-#define STR_ER_STAGE_OCR_LINES 256u /* er_ocr's per-line scoring (src/ER.cpp:695-747): chain_run with the line's slope on every member; needs STR_ER_STAGE_GROUP + an SVM model */
-#define STR_ER_STAGE_TRACK    32u  /* calc_color + ERFilter::er_track on the strong/weak ERs of every image (src/ER.cpp:530-590); BGR frames only */
+#define STR_ER_STAGE_OCR_LINES 256u /* er_ocr's per-line scoring (src/ER.cpp:695-747): chain_run with the line's slope on every member;
+                                      needs STR_ER_STAGE_GROUP + an SVM model */
 
 /* candidate class: which list of text_detect() the ER landed in (src/ER.cpp:516-526) */
 #define STR_ER_CLS_POOL   0   /* pooled by NMS, rejected by both cascades */
