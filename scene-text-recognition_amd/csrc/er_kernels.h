@@ -52,7 +52,7 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 
 // sparse: the small-LDS / high-occupancy size of the kernel (text-like frames); dense: the big one (noise-like frames)
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
-void launch_seam(hipStream_t s, const BatchDev &b);
+void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);
 void launch_level_prefix(hipStream_t s, const BatchDev &b);
 void launch_resolve(hipStream_t s, const BatchDev &b);
 // group the pushing nodes by level (counting sort of the exported-node list), then one launch per level

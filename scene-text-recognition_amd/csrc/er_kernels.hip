@@ -1108,17 +1108,16 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
     }
 }
 
-#ifndef SEAM_XCD_AFFINE
-#define SEAM_XCD_AFFINE 0   // measured: 1 helps S-noise (seam 1.7 -> 1.2 ms) and hurts S-text (1.0 -> 1.3 ms)
-#endif
-__global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b)
+__global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
 {
     // a block never straddles two planes: the host lists (plane, first pair) per block
     // Workgroups are dealt to the 8 XCDs round-robin; renumber them so that consecutive seam blocks (= one plane's
     // seams) run on ONE XCD and the plane's parent words stay in that XCD's L2 (for speed only: every access that can
-    // race is agent-scope anyway).
+    // race is agent-scope anyway).  Measured: this helps noise-like frames (seam 1.56 -> 1.17 ms per 8 frames), where every
+    // node is touched by few connects, and hurts text-like ones (0.58 -> 0.86 ms per 32), where the connects of a plane pile up
+    // on a few hot background nodes -- so the host asks for it together with the big size of the tile kernel.
     const uint32_t per = (b.n_seam_blocks + 7u) / 8u;
-    const uint32_t vb = SEAM_XCD_AFFINE ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t vb = xcd_affine ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     if (vb >= b.n_seam_blocks) return;
     const int        pi = b.seam_block_plane[vb];
     const PlaneDesc &pd = b.planes[pi];
@@ -1173,10 +1172,10 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b)
     node_connect(b.na.par + nb, b.na.lvl + nb, s_pa[threadIdx.x], s_pb[threadIdx.x]);
 }
 
-void launch_seam(hipStream_t s, const BatchDev &b)
+void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 {
     if (!b.n_seam_blocks) return;
-    hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(SEAM_BLOCK), 0, s, b);
+    hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(SEAM_BLOCK), 0, s, b, xcd_affine ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------

@@ -639,7 +639,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         std::fprintf(stderr, "[str_er] tile_tree alone: %.4f ms\n", ms);
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
-    launch_seam(s, bd);                               rec(c, "seam");
+    launch_seam(s, bd, !c->tile_sparse);                                        rec(c, "seam");
     launch_level_prefix(s, bd);
     launch_resolve(s, bd);                            rec(c, "resolve");
     launch_accumulate_prepare(s, bd);
