@@ -3,7 +3,8 @@
 `write_classifier_text` produces what CascadeBoost::write_classifier writes
 (src/adaboost.cpp:954-993): header lines, then one `weight dim thresh cp cn ` row per
 stump (each row ends with a space).  Numbers are printed with repr()-precision so that
-strtod() gives back exactly the doubles stored in tests/golden/cascades.npz.
+strtod() gives back exactly the doubles stored in data/cascades.npz (the reference's trained
+strong / weak cascades as arrays; minted by tests/golden/make_cascades.py).
 """
 from __future__ import annotations
 
@@ -11,7 +12,7 @@ import os
 
 import numpy as np
 
-GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cascades.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cascades.npz")
 
 
 def _num(v: float) -> str:

@@ -61,16 +61,6 @@ __device__ __forceinline__ int find_plane_by_pair(const PlaneDesc *pl, int n, ui
     return lo;
 }
 
-__device__ __forceinline__ int find_plane_by_cand_unused(const PlaneCtr *ctr, int n, uint32_t c)
-{
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (ctr[mid].cand_base <= c) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
 // ------------------------------------------------------------------------------------
 // compute_channels (src/ER.cpp:114-128): OpenCV 8-bit BGR2YCrCb, yuv_shift = 14.
 // One lane converts 4 pixels: 12 bytes in (three dwords), three dwords out.

@@ -85,6 +85,7 @@ struct str_er_ctx {
     int kept_cap = 0, pool_cap = 0;
     double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
     bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
+    bool   dbg_tile_only = false, dbg_stats = false;   // developer aids (STR_ER_DEBUG_TILE_ONLY / _STATS), read once at create
     int    tile_mode = 0;             // 0 auto (from the node density of the previous batch), 1 sparse, 2 dense (STR_ER_TILE_KERNEL)
     int64_t ws_bytes = 0;
 
@@ -612,6 +613,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         key.push_back((uint32_t)np);
         for (const PlaneDesc &pd : b.planes) { key.push_back((uint32_t)pd.w); key.push_back((uint32_t)pd.h); }
         if (key != c->layout_key) {
+            c->layout_key.clear();          // the tables are being rebuilt: a failure below must not leave the old key naming them
             c->h_tile_plane.clear(); c->h_sb_plane.clear(); c->h_sb_first.clear();
             for (int i = 0; i < np; ++i) {
                 const PlaneDesc &pd = b.planes[i];
@@ -632,7 +634,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
 
     launch_tile_tree(s, bd, dp, c->tile_sparse);      rec(c, "tile_tree");
-    if (std::getenv("STR_ER_DEBUG_TILE_ONLY")) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
+    if (c->dbg_tile_only) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
         (void)hipStreamSynchronize(s);
         (void)hipEventElapsedTime(&ms, c->ev[c->n_ev - 2], c->ev[c->n_ev - 1]);
@@ -671,7 +673,7 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
 
-    if (std::getenv("STR_ER_DEBUG_STATS")) {     // developer aid: how many nodes left the tiles
+    if (c->dbg_stats) {     // developer aid: how many nodes left the tiles
         std::vector<uint32_t> tc(b.n_tiles);
         if (hipMemcpy(tc.data(), c->d_tile_cnt, 4 * (size_t)b.n_tiles, hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long tot = 0, mx = 0, created = 0;
@@ -954,6 +956,8 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         if (!std::strcmp(tk, "sparse")) { c->tile_mode = 1; c->tile_sparse = true; }
         else if (!std::strcmp(tk, "dense")) { c->tile_mode = 2; c->tile_sparse = false; }
     }
+    c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
+    c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
     for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
     c->ppf = (int)c->chans.size() * p->n_pyr_levels;
     c->max_planes = c->ppf * p->max_frames;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mint tests/golden/cascades.npz from the reference's trained model files.
+"""Mint scene-text-recognition_amd/data/cascades.npz (the model tables the package ships) from the reference's trained model files.
 
 Run in the development container only (needs /root/reference):
     python tests/golden/make_cascades.py
@@ -18,7 +18,7 @@ import sys
 import numpy as np
 
 REF = "/root/reference/classifier"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cascades.npz")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scene-text-recognition_amd", "data", "cascades.npz")
 
 
 def parse(path):

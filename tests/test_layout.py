@@ -46,5 +46,5 @@ def test_no_compat_layers():
 
 def test_repo_layout():
     for rel in ("bench.py", "__graft_entry__.py", "include/str_er.h", "oracle/er_oracle.c", "oracle/Makefile",
-                "tests/golden/cascades.npz", "tests/golden/make_cascades.py", "tests/golden/cascade_vectors.npz"):
+                "scene-text-recognition_amd/data/cascades.npz", "tests/golden/make_cascades.py", "tests/golden/cascade_vectors.npz"):
         assert os.path.exists(os.path.join(ROOT, rel)), rel

@@ -214,7 +214,7 @@ def test_cascade_matches_reference_library(oracle_cascades, cascade_paths):
 
 def test_golden_text_round_trip(S):
     """cascade_io rebuilds the reference's text format from the fixture without losing a bit."""
-    z = np.load(os.path.join(GOLDEN, "cascades.npz"))
+    z = np.load(S.cascade_io.GOLDEN)
     txt = S.cascade_io.golden_text("strong")
     rows = [l.split() for l in txt.split("\n")[4:] if l.strip()]
     assert len(rows) == 2660
