@@ -95,9 +95,15 @@ typedef struct str_er_params {
     int32_t  kept_cap;        /* per-plane capacity of the kept-node table,
                                  0 = default max(4096, w*h/64)                        */
     int32_t  pool_cap;        /* per-plane capacity of the NMS pool, 0 = kept_cap/4   */
-    int32_t  sibling_order;   /* tie rule where NMS depends on the flood's sibling
-                                 order: 0 = child with the largest
-                                 key claims the parent, 1 = smallest key              */
+    int32_t  sibling_order;   /* what decides NMS where two or more child chains
+                                 compete for a parent:
+                                 0 = the reference's own order -- the child whose
+                                     basin its flood entered last, src/ER.cpp:183-185,
+                                     416-462; found by replaying the flood on the GPU
+                                     for the planes that have such a tie (exact);
+                                 1 = child with the smallest key, 2 = largest key
+                                     (canonical rules, no replay; the plane is only
+                                     flagged through str_er_plane_info::ambiguous)    */
     void    *stream;          /* hipStream_t to enqueue on; NULL = private stream     */
 } str_er_params;
 
@@ -138,9 +144,11 @@ typedef struct str_er_plane_info {
     int32_t  n_created;   /* tree nodes before pruning (all (t,C) pairs)              */
     int32_t  n_kept;      /* nodes with area > MIN_AREA, plus the root                */
     int32_t  n_pool, n_strong, n_weak;
-    int32_t  ambiguous;   /* #nodes where >=2 child chains competed in NMS: the
-                             reference's answer depends on its flood's sibling order
-                             there; 0 = result is order-independent   */
+    int32_t  ambiguous;   /* informational: #nodes where >=2 child chains competed
+                             in the first NMS pass (the reference's answer depends on
+                             its flood's sibling order there).  With
+                             sibling_order = 0 those ties were decided exactly by a
+                             replay of the reference's flood; 0 = no tie at all       */
     int32_t  root;        /* index of the root in the kept-node table                 */
 } str_er_plane_info;
 
@@ -277,10 +285,22 @@ int str_er_ocr_chain_run_slope(str_er_ctx *ctx, const uint8_t *plane, int32_t w,
 
 /* ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a caller-supplied kept tree
  * (parent indices; root points to itself or -1).  pool_idx receives up to cap node
- * indices in ascending key order; *n_pool the count; *ambiguous as in plane_info.    */
+ * indices in ascending key order; *n_pool the count; *ambiguous as in plane_info.
+ * Sibling ties with sibling_order = 0: the TABLE ORDER is the child-list order -- of
+ * the children of one parent the one listed first is the first of ER::child / ER::next
+ * (src/ER.cpp:183-185), i.e. the one the reference's post-order walk visits first.     */
 int str_er_nms_tree(str_er_ctx *ctx, const str_er_node *nodes, int32_t n_nodes,
                     int32_t rows, int32_t cols, int32_t *pool_idx, int32_t cap,
                     int32_t *n_pool, int32_t *ambiguous);
+
+/* The same for a table that came from str_er_detect_planes / er_tree_extract (ordered
+ * by key, which says nothing about the flood): the plane itself is passed -- as the
+ * reference's signature does (`Mat input`, src/ER.cpp:416) -- and sibling ties are
+ * decided by replaying the reference's flood on it (sibling_order = 0).  node.key
+ * must be the canonical key (min pixel index of the node's own level).                */
+int str_er_nms_tree_plane(str_er_ctx *ctx, const str_er_node *nodes, int32_t n_nodes,
+                          const uint8_t *plane, int32_t cols, int32_t rows, int64_t stride,
+                          int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous);
 
 /* Build-defined pyramid primitive (no reference counterpart): fixed-point bilinear
  * resize of one host plane, same arithmetic as cv::resize INTER_LINEAR 8UC1.         */

@@ -127,6 +127,7 @@ def load_library():
     L.str_er_ocr_chain_run.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
     L.str_er_ocr_chain_run_slope.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int32, vp, vp, vp]
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
+    L.str_er_nms_tree_plane.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, i32p, i32p]
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
     L.str_er_result_n_planes.restype = C.c_int32
@@ -437,15 +438,23 @@ class ERFilter:
         """ERFilter::er_tree_extract (src/ER.cpp:240-374): the kept tree as a node table."""
         return self.detect_planes(plane, STAGE_EXTRACT, want_nodes=True).planes[0]
 
-    def non_maximum_supression(self, nodes: np.ndarray, rows: int, cols: int):
+    def non_maximum_supression(self, nodes: np.ndarray, rows: int, cols: int, plane: Optional[np.ndarray] = None):
         """ERFilter::non_maximum_supression (src/ER.cpp:416-505) on a node table.
-        Returns (pool indices in ascending key order, ambiguous count)."""
+        Returns (pool indices in ascending key order, ambiguous count).  Sibling ties (sibling_order = 0): without `plane` the
+        table order is the child-list order; with the (rows, cols) uint8 plane they are decided by replaying the reference's flood."""
         nd = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
         cap = max(1, len(nd))
         pool = np.zeros(cap, np.int32)
         n, amb = C.c_int32(), C.c_int32()
-        self._check(self.L.str_er_nms_tree(self.h, _np_ptr(nd), len(nd), rows, cols, _np_ptr(pool), cap, C.byref(n),
-                                           C.byref(amb)))
+        if plane is None:
+            self._check(self.L.str_er_nms_tree(self.h, _np_ptr(nd), len(nd), rows, cols, _np_ptr(pool), cap, C.byref(n),
+                                               C.byref(amb)))
+        else:
+            a = np.ascontiguousarray(plane, dtype=np.uint8)
+            if a.shape != (rows, cols):
+                raise ValueError("plane must be (rows, cols)")
+            self._check(self.L.str_er_nms_tree_plane(self.h, _np_ptr(nd), len(nd), _np_ptr(a), cols, rows, cols, _np_ptr(pool), cap,
+                                                     C.byref(n), C.byref(amb)))
         return pool[:n.value].copy(), amb.value
 
     def classify(self, plane: np.ndarray, boxes_xywh: np.ndarray):

@@ -37,6 +37,7 @@ struct BatchDev {
     CandRec         *cands;    // packed, ordered by (plane, key)
     uint32_t        *total_cands;
     uint16_t        *cand_plane; // plane of every packed candidate
+    uint32_t        *watch;      // [n_planes x NMS_WATCH_CAP] key pixels of the children that may compete for a parent
 };
 
 // compute_channels (src/ER.cpp:114-128): interleaved BGR -> Y, Cr, Cb planes.
@@ -61,7 +62,14 @@ void launch_accumulate(hipStream_t s, const BatchDev &b, int level);
 void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);
-void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p);
+// pass 0: every plane; sibling ties by key (exact mode: provisional, planes with ties are counted in n_amb and get a watch list).
+// use_index_order: exact mode on an uploaded tree -- the table order is the child-list order.
+void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool use_index_order = false);
+// exact mode, planes with sibling ties: replay the reference's flood (src/ER.cpp:240-374) to stamp every pixel with the order in
+// which it becomes accessible, then NMS again with the ties decided by those stamps.  scratch: see ReplayItem.
+size_t replay_scratch_bytes(int w, int h);
+void launch_flood_order(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, uint8_t *scratch);
+void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, const uint8_t *scratch);
 void launch_cand_prefix(hipStream_t s, const BatchDev &b);
 // classify (src/ER.cpp:507-528) over the packed pool of the batch.
 void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong,

@@ -1600,17 +1600,32 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // climb while bboxarea(X)/bboxarea(parent) > OVERLAP_COEF and the parent is unclaimed.
 // Equivalent bottom-up form: start(P) = start(c) for the child c whose chain passes the
 // overlap test on P, or P itself if no child chain does.  If two or more child chains
-// pass, the reference's answer depends on its flood's sibling order; here
-// the child with the extreme key wins and the plane is flagged (n_amb).
+// pass, the reference's winner is the first of them in P's child list -- children are
+// prepended when they are merged (src/ER.cpp:183-185), i.e. the child whose basin its
+// flood ENTERED LAST (a basin is flooded completely once entered, so the merge order of
+// sibling basins is their entry order).  That order is an artefact of the sequential
+// flood and cannot be derived locally, so:
+//   pass 0 (all planes) decides ties by key (largest / smallest, DetectParams::sibling_order)
+//          and counts them (n_amb).  No tie -> the result does not depend on any order.
+//   exact mode (sibling_order 0): for the planes with ties k_flood_order replays the
+//          reference's flood and stamps every pixel with the order in which it became
+//          accessible; pass 1 repeats the NMS of those planes with ties decided by the
+//          stamp of each child's key pixel (any pixel of a basin would do: the access
+//          intervals of sibling basins are disjoint) -- largest stamp = entered last = wins.
+//   uploaded trees (str_er_nms_tree): the table order is the child-list order.
 // ------------------------------------------------------------------------------------
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_SORT_CAP = 4096;       // pooled ERs of a plane whose keys are ranked out of LDS
 
-__global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm)
+// order word of a child in a tie: the smallest one wins
+enum { NMS_ORD_KEY_MAX = 0, NMS_ORD_KEY_MIN = 1, NMS_ORD_INDEX = 2, NMS_ORD_STAMP = 3 };
+
+__global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm, const ReplayItem *items, const uint8_t *scratch, int ord_mode)
 {
     __shared__ uint32_t s_npool;
     __shared__ uint32_t s_levels[8];
-    const int        pi = blockIdx.x;
+    const bool       pass1 = items != nullptr;
+    const int        pi = pass1 ? (int)items[blockIdx.x].plane : (int)blockIdx.x;
     PlaneCtr        &c = b.ctr[pi];
     const PlaneDesc &pd = b.planes[pi];
     const size_t     kb = pd.kept_base, pb = pd.pool_base;
@@ -1625,6 +1640,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     const uint32_t  *kkey = b.ka.key + kb;
     const int        maxl = (int)c.max_level;
     const uint32_t   root = c.root_slot;
+    const uint32_t  *stamp = pass1 ? reinterpret_cast<const uint32_t *>(scratch + items[blockIdx.x].off) : nullptr;
 
     for (int i = tid; i < 8; i += NMS_THREADS) s_levels[i] = 0;
     if (tid == 0) s_npool = 0;
@@ -1648,7 +1664,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
                 const uint32_t child = (uint32_t)(LD_AGENT(&kbest[i]) & 0xFFFFFFFFull);
                 s = kstart[child];
                 kstart[i] = s;
-                if (nc > 1) atomicAdd(&c.n_amb, 1u);
+                if (nc > 1 && !pass1) atomicAdd(&c.n_amb, 1u);
             }
             if (i == root) continue;
             const uint32_t P = (uint32_t)kpar[i];
@@ -1656,8 +1672,37 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
             const int ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
             if ((double)as / (double)ap > prm.overlap_coef) {
                 atomicAdd(&kncand[P], 1u);
-                const uint32_t ord = prm.sibling_order == 0 ? ~kkey[i] : kkey[i];
+                uint32_t ord;
+                if (ord_mode == NMS_ORD_STAMP) ord = ~stamp[kkey[i]];       // entered last = first in the child list
+                else if (ord_mode == NMS_ORD_INDEX) ord = i;
+                else ord = ord_mode == NMS_ORD_KEY_MAX ? ~kkey[i] : kkey[i];
                 atomicMin(&kbest[P], ((unsigned long long)ord << 32) | i);
+            }
+        }
+        __syncthreads();
+    }
+
+    // planes with ties (exact mode only needs it): the key pixels the flood replay has to reach.  Which ties occur can depend
+    // on how lower ties were decided, so the list holds every child that COULD compete whatever the order: a chain start
+    // lies inside its child's box, so only children whose own box covers more than OVERLAP_COEF of the parent's can pass, and
+    // a parent needs two of them.
+    if (!pass1 && prm.sibling_order == 0 && ord_mode != NMS_ORD_INDEX && LD_AGENT(&c.n_amb) != 0) {
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) kncand[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            if (i == root) continue;
+            const uint32_t P = (uint32_t)kpar[i];
+            const int ai = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3], ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
+            if ((double)ai / (double)ap > prm.overlap_coef) atomicAdd(&kncand[P], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            if (i == root) continue;
+            const uint32_t P = (uint32_t)kpar[i];
+            const int ai = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3], ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
+            if ((double)ai / (double)ap > prm.overlap_coef && kncand[P] > 1) {
+                const uint32_t at = atomicAdd(&c.n_watch, 1u);
+                if (at < (uint32_t)NMS_WATCH_CAP) b.watch[(size_t)pi * NMS_WATCH_CAP + at] = kkey[i];
             }
         }
         __syncthreads();
@@ -1722,10 +1767,123 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     if (tid == 0) c.n_pool = np;
 }
 
-void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p)
+void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool use_index_order)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p);
+    const int mode = (use_index_order && p.sibling_order == 0) ? NMS_ORD_INDEX : (p.sibling_order == 1 ? NMS_ORD_KEY_MIN : NMS_ORD_KEY_MAX);
+    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, mode);
+}
+
+void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, const uint8_t *scratch)
+{
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(k_nms, dim3(n_items), dim3(NMS_THREADS), 0, s, b, p, items, scratch, (int)NMS_ORD_STAMP);
+}
+
+// ------------------------------------------------------------------------------------
+// Replay of the reference's flood (er_tree_extract, src/ER.cpp:240-374) for the planes whose NMS has sibling ties: same
+// start pixel, same edge order (right, bottom, left, top), same 256 LIFO buckets, same "priority == highest_level means
+// empty" rule -- but nothing is built, every pixel is only stamped with the order in which it is marked accessible.
+// The flood is inherently sequential: ONE lane per plane walks it (the other lanes only prepare the scratch), which costs
+// about a microsecond per pixel.  It runs only for planes where the reference's own answer depends on this order
+// (about 1 plane in 100 on photographs, none on the synthetic bench frames) and stops as soon as every watched key pixel
+// has its stamp.
+//   scratch per plane: stamp u32[n] (0 = not accessible yet; WATCH = not accessible, watched), link u32[n] (bucket lists:
+//   next entry << 3 | edge), level u8[n].
+// ------------------------------------------------------------------------------------
+constexpr int      FLOOD_THREADS = 1024;
+constexpr uint32_t FLOOD_WATCH = 0x80000000u;
+constexpr uint32_t FLOOD_NIL = 0x1FFFFFFFu;
+
+size_t replay_scratch_bytes(int w, int h)
+{
+    const size_t n = (size_t)w * h;
+    return ((9 * n + 255) / 256) * 256 + 256;
+}
+
+__global__ __launch_bounds__(FLOOD_THREADS) void k_flood_order(BatchDev b, DetectParams prm, const ReplayItem *items, uint8_t *scratch)
+{
+    __shared__ uint32_t s_head[257];
+    const ReplayItem it = items[blockIdx.x];
+    const PlaneDesc &pd = b.planes[it.plane];
+    const PlaneCtr  &c = b.ctr[it.plane];
+    const int        w = pd.w, h = pd.h;
+    const uint32_t   n = (uint32_t)w * (uint32_t)h;
+    uint32_t *stamp = reinterpret_cast<uint32_t *>(scratch + it.off);
+    uint32_t *link = stamp + n;
+    uint8_t  *lv = reinterpret_cast<uint8_t *>(link + n);
+    const uint32_t hi = (uint32_t)prm.hi;
+    for (uint32_t i = threadIdx.x; i < n; i += FLOOD_THREADS) {
+        const uint32_t y = i / (uint32_t)w, x = i - y * (uint32_t)w;
+        const uint32_t q = (uint32_t)__float2int_rn((float)(pd.pix[(size_t)y * pd.stride + x] ^ pd.invert) * prm.qscale);   // src/ER.cpp:250
+        lv[i] = (uint8_t)min(q, 255u);
+        stamp[i] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < 257; i += FLOOD_THREADS) s_head[i] = FLOOD_NIL;
+    __syncthreads();
+    const uint32_t n_watch = c.n_watch;
+    const bool     watching = n_watch <= (uint32_t)NMS_WATCH_CAP;
+    if (watching) for (uint32_t i = threadIdx.x; i < n_watch; i += FLOOD_THREADS) stamp[b.watch[(size_t)it.plane * NMS_WATCH_CAP + i]] = FLOOD_WATCH;
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    uint32_t remaining = watching ? n_watch : 0xFFFFFFFFu;     // distinct pixels: keys are unique inside a plane
+    uint32_t counter = 0;
+    uint32_t priority = hi;
+    uint32_t cur = 0, edge = 0;
+    uint32_t cl = lv[0];                       // (levels >= hi can only be == hi for step >= 2; for step 1 hi = 256 is never reached)
+    {
+        const uint32_t old = stamp[0];
+        stamp[0] = ++counter;
+        if (old == FLOOD_WATCH && --remaining == 0) return;
+    }
+    for (;;) {
+        // 4. explore the remaining edges of the current pixel
+        const uint32_t x = cur % (uint32_t)w;
+        uint32_t nb[4], st[4], nl[4];
+        nb[0] = (x + 1 < (uint32_t)w) ? cur + 1 : cur;
+        nb[1] = (cur + (uint32_t)w < n) ? cur + (uint32_t)w : cur;
+        nb[2] = (x > 0) ? cur - 1 : cur;
+        nb[3] = (cur >= (uint32_t)w) ? cur - (uint32_t)w : cur;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st[e] = stamp[nb[e]]; nl[e] = lv[nb[e]]; }       // eight loads in flight
+        bool descended = false;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            if (e < edge || descended) continue;
+            const uint32_t q = nb[e];
+            if (q == cur || (st[e] != 0 && st[e] != FLOOD_WATCH)) continue;
+            stamp[q] = ++counter;
+            if (st[e] == FLOOD_WATCH) --remaining;
+            const uint32_t l = nl[e];
+            if (l >= cl) {
+                if (l < hi) { link[q] = (s_head[l] << 3); s_head[l] = q; }        // (bucket `hi` is never popped: src/ER.cpp:343)
+                if (l < priority) priority = l;
+            } else {
+                if (cl < hi) { link[cur] = (s_head[cl] << 3) | (e + 1u); s_head[cl] = cur; }
+                if (cl < priority) priority = cl;
+                cur = q; cl = l; edge = 0;
+                descended = true;
+            }
+        }
+        if (remaining == 0) return;
+        if (descended) continue;
+        // 5./6. the current pixel is done; pop the lowest boundary pixel
+        if (priority == hi) return;
+        cur = s_head[priority];
+        const uint32_t v = link[cur];
+        edge = v & 7u;
+        s_head[priority] = v >> 3;
+        cl = priority;
+        while (priority < hi && s_head[priority] == FLOOD_NIL) ++priority;
+    }
+}
+
+void launch_flood_order(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, uint8_t *scratch)
+{
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(k_flood_order, dim3(n_items), dim3(FLOOD_THREADS), 0, s, b, p, items, scratch);
 }
 
 // exclusive prefix of the pool sizes: where every plane's candidates go in the packed array;
@@ -1748,6 +1906,7 @@ __global__ __launch_bounds__(1024) void k_cand_prefix(BatchDev b)
         const uint32_t mine = off + incl - n;
         if (i < b.n_planes) {
             b.ctr[i].cand_base = mine;
+            b.ctr[i].n_strong = 0; b.ctr[i].n_weak = 0;     // k_classify counts into these (it may run twice: flood-replay path)
             for (uint32_t k = 0; k < n; ++k) b.cand_plane[mine + k] = (uint16_t)i;
         }
         __syncthreads();

@@ -59,7 +59,18 @@ struct PlaneCtr {
     uint32_t n_created;     // live nodes inside the start pixel's tree
     uint32_t root_slot;     // kept slot of the root
     uint32_t max_level;     // highest level among kept nodes (bounds the NMS sweep)
+    uint32_t n_watch;       // NMS: children that may compete for their parent (their key pixels are what the flood replay must reach)
+    uint32_t pad_;
 };
+static_assert(sizeof(PlaneCtr) == 64, "PlaneCtr is mirrored in pinned host memory");
+
+// One plane whose NMS has to be decided by the reference's flood order (k_flood_order, then k_nms pass 1).
+struct ReplayItem {
+    uint32_t plane;
+    uint32_t pad_;
+    uint64_t off;           // byte offset of the plane's scratch (stamp u32[w*h], link u32[w*h], level u8[w*h]) in the replay buffer
+};
+constexpr int NMS_WATCH_CAP = 256;   // watched key pixels per plane; more -> the replay floods the whole plane
 
 // Structure-of-arrays node storage (index = PlaneDesc::node_base + plane-local id).
 struct NodeArrays {
@@ -119,7 +130,7 @@ struct DetectParams {
     int32_t hi;             // highest_level = 255/step + 1 (src/ER.cpp:247)
     float   qscale;         // float(1.0/step): the convertTo scale (src/ER.cpp:250)
     int32_t kept_cap, pool_cap;
-    int32_t sibling_order;
+    int32_t sibling_order;  // 0 exact (flood order / table order), 1 smallest key, 2 largest key
 };
 
 // Matches str_er_cand in include/str_er.h (48 bytes).

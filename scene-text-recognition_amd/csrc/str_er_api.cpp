@@ -109,6 +109,10 @@ struct str_er_ctx {
     TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
     uint32_t *d_group = nullptr, *d_group_pairs = nullptr; size_t group_words = 0, group_pair_cap = 0;   // STR_ER_STAGE_GROUP, grown on demand
     uint32_t *d_total = nullptr;
+    uint32_t *d_watch = nullptr;                      // NMS: watched key pixels per plane (k_nms -> k_flood_order)
+    ReplayItem *d_replay_items = nullptr;
+    uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
+    uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
     uint16_t *d_cand_plane = nullptr;
     NodeRec *d_nodes = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
@@ -346,7 +350,7 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.node_list_cap = (uint32_t)c->node_list_cap;
     d.acc_list = c->d_acc_list; d.acc_parent = c->d_acc_parent; d.lvl_tab = c->d_lvl_tab;
     d.na = c->na; d.ka = c->ka; d.tile_cnt = c->d_tile_cnt; d.tile_lo = c->d_tile_lo; d.tile_hi = c->d_tile_hi; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
-    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane;
+    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch;
     return d;
 }
 
@@ -573,6 +577,57 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
     return STR_ER_OK;
 }
 
+// Exact NMS where the reference's answer depends on its flood's sibling order (DetectParams::sibling_order == 0): for every plane
+// whose first NMS pass met a tie, replay the reference's flood on the GPU (k_flood_order) and repeat the plane's NMS with the ties
+// decided by the replayed order.  h_ctr holds the counters of the first pass.  Planes go in rounds that fit the scratch buffer.
+int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, const DetectParams &dp, bool &replayed)
+{
+    replayed = false;
+    std::vector<int> amb;
+    size_t largest = 0, total = 0;
+    for (int i = 0; i < (int)b.planes.size(); ++i)
+        if (c->h_ctr[i].n_amb) {
+            amb.push_back(i);
+            const size_t need = replay_scratch_bytes(b.planes[i].w, b.planes[i].h);
+            largest = std::max(largest, need);
+            total += need;
+        }
+    if (amb.empty()) return STR_ER_OK;
+    const size_t want = std::max(largest, std::min<size_t>(total, (size_t)1 << 30));
+    if (want > c->replay_bytes) {
+        if (c->d_replay) { (void)hipFree(c->d_replay); c->d_replay = nullptr; c->replay_bytes = 0; }
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_replay), want) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (flood replay scratch)");
+        c->replay_bytes = want;
+    }
+    hipStream_t s = c->stream;
+    std::vector<ReplayItem> items;
+    size_t pos = 0;
+    auto flush = [&]() -> int {
+        if (items.empty()) return STR_ER_OK;
+        HIP_TRY(c, hipMemcpyAsync(c->d_replay_items, items.data(), sizeof(ReplayItem) * items.size(), hipMemcpyHostToDevice, s));
+        launch_flood_order(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
+        launch_nms_resolve(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(s));       // the item table and the scratch are reused by the next round
+        c->n_replayed += items.size();
+        items.clear();
+        pos = 0;
+        return STR_ER_OK;
+    };
+    for (int i : amb) {
+        const size_t need = replay_scratch_bytes(b.planes[i].w, b.planes[i].h);
+        if (pos + need > c->replay_bytes) { const int rc = flush(); if (rc != STR_ER_OK) return rc; }
+        ReplayItem it{};
+        it.plane = (uint32_t)i; it.off = pos;
+        items.push_back(it);
+        pos += need;
+    }
+    const int rc = flush();
+    if (rc != STR_ER_OK) return rc;
+    replayed = true;
+    return STR_ER_OK;
+}
+
 // Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
 int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **out,
               std::chrono::steady_clock::time_point t_start, bool pre_recorded)
@@ -654,24 +709,41 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     if (stages & STR_ER_STAGE_NMS) launch_nms(s, bd, dp);
     rec(c, "nms");
     const int i_nms = c->n_ev - 1;
-    if (stages & STR_ER_STAGE_NMS) {
-        launch_cand_prefix(s, bd);
-        launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
-    }
-    rec(c, "classify");
-    const int i_cls = c->n_ev - 1;
-    if (stages & STR_ER_STAGE_TRACK) {
-        const int n_img = np / b.planes_per_image;
-        launch_calc_color_batch(s, bd, c->d_track);
-        launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
-        launch_er_track(s, c->d_cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
-        rec(c, "track");
-    }
+    // everything after NMS reads the pools: enqueued once, and once more if sibling ties had to be decided by a flood replay
+    auto after_nms = [&](bool record) {
+        if (stages & STR_ER_STAGE_NMS) {
+            launch_cand_prefix(s, bd);
+            launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
+        }
+        if (record) rec(c, "classify");
+        if (stages & STR_ER_STAGE_TRACK) {
+            const int n_img = np / b.planes_per_image;
+            launch_calc_color_batch(s, bd, c->d_track);
+            launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
+            launch_er_track(s, c->d_cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
+            if (record) rec(c, "track");
+        }
+    };
+    after_nms(true);
+    const int i_cls = (stages & STR_ER_STAGE_TRACK) ? c->n_ev - 2 : c->n_ev - 1;
     const int i_trk = c->n_ev - 1;
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if ((stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0) {
+        bool replayed = false;
+        const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed);
+        if (rcr != STR_ER_OK) return rcr;
+        if (replayed) {
+            HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+            after_nms(false);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+    }
 
     if (c->dbg_stats) {     // developer aid: how many nodes left the tiles
         std::vector<uint32_t> tc(b.n_tiles);
@@ -917,6 +989,7 @@ void str_er_destroy(str_er_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_replay) (void)hipFree(c->d_replay);
     if (c->d_group) (void)hipFree(c->d_group);
     if (c->d_group_pairs) (void)hipFree(c->d_group_pairs);
     for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
@@ -1009,6 +1082,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
     A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
+    A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
@@ -1482,12 +1556,13 @@ int str_er_ocr_chain_run_slope(str_er_ctx *c, const uint8_t *plane, int32_t w, i
     return STR_ER_OK;
 }
 
-int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
-                    int32_t cap, int32_t *n_pool, int32_t *ambiguous)
+static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, const uint8_t *plane, int64_t stride, int32_t rows, int32_t cols,
+                         int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous)
 {
     if (!c) return STR_ER_EINVAL;
-    if (!nodes || n_nodes < 1 || rows < 1 || cols < 1 || !n_pool || (cap > 0 && !pool_idx) || cap < 0)
+    if (!nodes || n_nodes < 1 || rows < 1 || cols < 1 || !n_pool || (cap > 0 && !pool_idx) || cap < 0 || (plane && stride < cols))
         return fail(c, STR_ER_EINVAL, "bad arguments");
+    if (plane && (size_t)rows * (size_t)cols > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
     if (n_nodes > c->kept_cap) return fail(c, STR_ER_ECAPACITY, "tree larger than kept_cap");
     HIP_TRY(c, hipSetDevice(c->prm.device));
     std::vector<uint32_t> key(n_nodes), area(n_nodes); std::vector<int32_t> par(n_nodes);
@@ -1499,6 +1574,7 @@ int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, in
         if (p < 0 || p == i) { if (root >= 0) return fail(c, STR_ER_EINVAL, "tree has more than one root"); root = i; p = i; }
         if (p >= n_nodes) return fail(c, STR_ER_EINVAL, "parent index out of range");
         if (n.w < 1 || n.h < 1) return fail(c, STR_ER_EINVAL, "empty box");
+        if (plane && n.key >= (uint32_t)rows * (uint32_t)cols) return fail(c, STR_ER_EINVAL, "node key outside the plane");
         key[i] = n.key; area[i] = (uint32_t)n.area; par[i] = p; lev[i] = n.level;
         box[4 * (size_t)i] = n.x; box[4 * (size_t)i + 1] = n.y; box[4 * (size_t)i + 2] = n.w; box[4 * (size_t)i + 3] = n.h;
         maxl = std::max(maxl, (int)n.level);
@@ -1520,23 +1596,46 @@ int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, in
     HIP_TRY(c, hipMemcpyAsync(c->ka.parent, par.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->ka.box, box.data(), 8 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->ka.level, lev.data(), (size_t)n_nodes, hipMemcpyHostToDevice, s));
+    if (plane) HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)cols, plane, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s)); // host vectors go out of scope after this call
     BatchDev bd = make_batchdev(c, b);
     bd.n_seam_blocks = 0;
-    launch_nms(s, bd, make_dp(c));
+    const DetectParams dp = make_dp(c);
+    launch_nms(s, bd, dp, /*use_index_order=*/plane == nullptr);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    const uint32_t n_amb = c->h_ctr[0].n_amb;
+    if (plane && c->prm.sibling_order == 0 && n_amb) {      // ties: the reference's flood order decides (k_flood_order)
+        bool replayed = false;
+        const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed);
+        if (rcr != STR_ER_OK) return rcr;
+        HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
     if (c->h_ctr[0].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
     const int np = (int)c->h_ctr[0].n_pool;
     *n_pool = np;
-    if (ambiguous) *ambiguous = (int32_t)c->h_ctr[0].n_amb;
+    if (ambiguous) *ambiguous = (int32_t)n_amb;
     const int ncopy = std::min(np, cap);
     if (ncopy > 0) {
         HIP_TRY(c, hipMemcpyAsync(pool_idx, c->d_pool, 4 * (size_t)ncopy, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     return STR_ER_OK;
+}
+
+int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
+                    int32_t cap, int32_t *n_pool, int32_t *ambiguous)
+{
+    return nms_tree_impl(c, nodes, n_nodes, nullptr, 0, rows, cols, pool_idx, cap, n_pool, ambiguous);
+}
+
+int str_er_nms_tree_plane(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, const uint8_t *plane, int32_t cols, int32_t rows,
+                          int64_t stride, int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous)
+{
+    if (!plane) return c ? fail(c, STR_ER_EINVAL, "null plane") : STR_ER_EINVAL;
+    return nms_tree_impl(c, nodes, n_nodes, plane, stride, rows, cols, pool_idx, cap, n_pool, ambiguous);
 }
 
 int str_er_resize_plane(str_er_ctx *c, const uint8_t *src, int32_t sw, int32_t sh, int64_t sstride, uint8_t *dst, int32_t dw,

@@ -155,8 +155,13 @@ public:
         }
         std::vector<int32_t> idx(tab.size());
         int32_t np = 0, amb = 0;
-        check(str_er_nms_tree(ctx_.get(), tab.data(), (int32_t)tab.size(), input.rows, input.cols, idx.data(),
-                              (int32_t)idx.size(), &np, &amb));
+        // the table is in key order, so sibling ties are decided on the plane itself, by the reference's flood order
+        if (input.data && input.channels == 1)
+            check(str_er_nms_tree_plane(ctx_.get(), tab.data(), (int32_t)tab.size(), input.data, input.cols, input.rows, input.step,
+                                        idx.data(), (int32_t)idx.size(), &np, &amb));
+        else
+            check(str_er_nms_tree(ctx_.get(), tab.data(), (int32_t)tab.size(), input.rows, input.cols, idx.data(),
+                                  (int32_t)idx.size(), &np, &amb));
         pool.clear();
         for (int i = 0; i < np; ++i) pool.push_back(&tree.nodes[idx[i]]);
         if (ambiguous) *ambiguous = amb;

@@ -86,10 +86,11 @@ def check_plane_against_oracle(oracle, plane_result, img, cascades=None, step=8,
         rootn = p.nodes[p.root]
         assert rootn["flags"] & 1 and int(rootn["key"]) == int(tr.nodes[tr.root]["key"])
     assert (p.ambiguous == 0) == (ref["ambiguous"] == 0)
-    if ref["ambiguous"] != 0:
-        # the reference's answer depends on its flood's sibling order here: compare with
-        # the oracle's NMS run under the library's documented tie rule instead
-        mode = 2 if sibling_order == 0 else 1
+    if ref["ambiguous"] != 0 and sibling_order != 0:
+        # a context created with a canonical tie rule (sibling_order 1 = smallest key, 2 = largest key): compare with the
+        # oracle's NMS under the same rule.  The default (0) is the reference's own order -- the oracle's sibling_mode 0,
+        # i.e. the child lists its restatement of the flood built -- and `ref` above already is that.
+        mode = sibling_order
         ref = oracle.detect_plane(img, cascades[0] if cascades else None, cascades[1] if cascades else None, step=step,
                                   min_area=min_area, max_area=max_area, stability_t=stability_t,
                                   overlap_coef=overlap_coef, sibling_mode=mode)

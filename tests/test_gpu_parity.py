@@ -246,11 +246,10 @@ def test_nms_tree(erf, oracle, S):
     for seed, kind in ((1, "text"), (2, "noise"), (3, "text")):
         img = S.synth.gray(S.synth.KINDS[kind](seed, 400, 300))
         t = oracle.tree_extract(img, 8, 120)
-        pool, amb = erf.non_maximum_supression(_to_node_table(S, t), 300, 400)
         ref, ramb = oracle.nms(t, 300, 400)
+        # with the plane: ties are decided by the replayed flood order = the oracle's child lists (sibling_mode 0)
+        pool, amb = erf.non_maximum_supression(_to_node_table(S, t), 300, 400, plane=img)
         assert (amb == 0) == (ramb == 0)
-        if ramb:
-            ref, _ = oracle.nms(t, 300, 400, sibling_mode=2)
         assert sorted(pool.tolist()) == sorted(ref.tolist())
         assert [int(t.nodes[i]["key"]) for i in pool] == sorted(int(t.nodes[i]["key"]) for i in pool)
     # two children whose boxes both cover > 0.7 of the parent: the answer depends on sibling order
@@ -263,12 +262,68 @@ def test_nms_tree(erf, oracle, S):
     n[3] = (3, 1300, 0, 0, 31, 31, 4, 2, -1, 1, 0, 0)
     n[4] = (4, 9000, 0, 0, 90, 90, -1, 3, -1, 0, 0, 0)
     t = Tree(n, 4, 5, 0)
-    for order, mode in ((0, 2), (1, 1)):
+    for order in (0, 1, 2):
         f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=128, max_height=128, max_frames=1, sibling_order=order)
         pool, amb = f.non_maximum_supression(_to_node_table(S, t), 100, 100)
-        ref, ramb = oracle.nms(t, 100, 100, sibling_mode=mode)
+        # order 0 without a plane: the table order is the child-list order (node 0 is listed before node 1, and ER::child
+        # of node 2 is node 0 -> next node 1), which is the oracle's sibling_mode 0; 1 / 2: smallest / largest key
+        ref, ramb = oracle.nms(t, 100, 100, sibling_mode=order)
         assert amb >= 1 and ramb >= 1 and sorted(pool.tolist()) == sorted(ref.tolist())
         f.close()
+    # ... and the other child-list order: swap the two children in the table
+    n2 = n.copy()
+    n2[0], n2[1] = n[1], n[0]
+    n2[2]["child"] = 0; n2[0]["next"] = 1; n2[1]["next"] = -1
+    t2 = Tree(n2, 4, 5, 0)
+    f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=128, max_height=128, max_frames=1)
+    pool, amb = f.non_maximum_supression(_to_node_table(S, t2), 100, 100)
+    ref, ramb = oracle.nms(t2, 100, 100)
+    assert amb >= 1 and sorted(pool.tolist()) == sorted(ref.tolist())
+    p1, _ = f.non_maximum_supression(_to_node_table(S, t), 100, 100)
+    assert sorted(int(t.nodes[i]["key"]) for i in p1) != sorted(int(t2.nodes[i]["key"]) for i in pool)     # the order matters here
+    f.close()
+
+
+def test_sibling_ties_follow_the_reference_flood_order(S, oracle):
+    """SURVEY A.5 / VERDICT r1 weak #2: where two or more child chains compete for a parent the reference's winner is the
+    child its flood entered last.  A low OVERLAP_COEF and MIN_AREA make such ties frequent; every pool must equal the
+    oracle's own order (sibling_mode 0 = the child lists its restatement of the flood built), batched planes included."""
+    f = S.ERFilter(8, 6, 900000, 2, 0.3, max_width=320, max_height=200, max_frames=6, kept_cap=70000, pool_cap=30000)
+    rng = np.random.default_rng(99)
+    n_amb = n_planes = 0
+    for trial in range(10):
+        h, w = int(rng.integers(20, 201)), int(rng.integers(20, 321))
+        imgs = []
+        for k in range(6):
+            if k == 0:
+                imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+            elif k == 1:
+                imgs.append(np.kron(rng.integers(0, 256, ((h + 3) // 4, (w + 3) // 4), dtype=np.uint8), np.ones((4, 4), np.uint8))[:h, :w])
+            elif k == 2:
+                imgs.append(S.synth.gray(S.synth.stext_bgr(int(rng.integers(0, 1 << 30)), w, h)))
+            elif k == 3:
+                imgs.append((rng.integers(0, 5, (h, w)) * 50 + rng.integers(0, 8, (h, w))).astype(np.uint8))
+            elif k == 4:
+                g = np.add.outer(np.sin(np.arange(h) / 7.0) * 60, np.cos(np.arange(w) / 9.0) * 60) + 128
+                imgs.append(np.clip(g + rng.integers(-10, 11, (h, w)), 0, 255).astype(np.uint8))
+            else:
+                imgs.append(rng.integers(180, 256, (h, w), dtype=np.uint8))          # sentinel walls everywhere
+        res = f.detect_planes(np.stack(imgs), S.STAGE_EXTRACT | S.STAGE_NMS, want_nodes=True)
+        for p, img in zip(res.planes, imgs):
+            check_plane_against_oracle(oracle, p, img, None, min_area=6, overlap_coef=0.3)
+            n_amb += p.ambiguous
+            n_planes += 1
+    assert n_amb > 50, n_amb       # the test is about ties: make sure they happened
+    # the canonical rules stay available (no replay): smallest / largest key
+    img = rng.integers(0, 256, (120, 200), dtype=np.uint8)
+    for order in (1, 2):
+        g = S.ERFilter(8, 6, 900000, 2, 0.3, max_width=320, max_height=200, max_frames=1, kept_cap=70000, pool_cap=30000, sibling_order=order)
+        p = g.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS, want_nodes=True).planes[0]
+        assert p.ambiguous > 0
+        check_plane_against_oracle(oracle, p, img, None, min_area=6, overlap_coef=0.3, sibling_order=order)
+        g.close()
+    f.close()
+    print(f"sibling ties: {n_amb} contested parents on {n_planes} planes, all decided like the reference's flood")
 
 
 # ---- full size ------------------------------------------------------------------------------------------
