@@ -12,26 +12,14 @@ struct BatchDev {
     int32_t          n_planes;
     uint32_t         n_tiles;  // batch-wide
     uint32_t         n_pairs;  // batch-wide seam pixel pairs
-    uint32_t         max_nodes_plane; // largest plane capacity (w*h)
     NodeArrays       na;
     KeptArrays       ka;
     const uint16_t  *tile_plane;        // plane of every tile
     const uint16_t  *seam_block_plane;  // plane of every k_seam workgroup
     const uint32_t  *seam_block_first;  // its first pair inside that plane
     uint32_t         n_seam_blocks;
-    uint32_t        *tile_cnt; // nodes per tile (batch-wide tile numbering)
-    uint8_t         *tile_lo;  // lowest / highest node level of the tile
-    uint8_t         *tile_hi;
-    uint32_t        *tile_off;  // exclusive prefix of tile_cnt
-    uint32_t        *chunk_sum; // scratch of the offset scan
-    uint32_t        *n_listed;  // total exported nodes of the batch
-    uint32_t        *node_list; // exported nodes (global slot index), tile after tile
-    uint16_t        *list_key;  // per list entry: level, or level | 0x100 for nodes that never push
-    uint32_t         node_list_cap;
-    uint32_t        *acc_list; // the nodes that push to a parent, grouped by level (global slot index)
-    uint32_t        *acc_parent; // ... and the global slot of each one's parent
-    uint32_t        *lvl_tab;  // [0..256] count -> base per level, [260..515] scatter cursors
-    uint32_t        *seam;     // node id of every tile-border pixel
+    uint32_t        *tile_nbase; // plane-local id of every tile's first node record (NONE: the plane ran out of records)
+    uint16_t        *seam;     // node of every tile-border pixel: index inside its tile's records (0xFFFF: wall)
     uint32_t        *pool;     // kept slots chosen by NMS, ascending key
     uint32_t        *pool_tmp;
     CandRec         *cands;    // packed, ordered by (plane, key)
@@ -54,11 +42,10 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 // sparse: the small-LDS / high-occupancy size of the kernel (text-like frames); dense: the big one (noise-like frames)
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);
-void launch_level_prefix(hipStream_t s, const BatchDev &b);
 void launch_resolve(hipStream_t s, const BatchDev &b);
-// group the pushing nodes by level (counting sort of the exported-node list), then one launch per level
-void launch_accumulate_prepare(hipStream_t s, const BatchDev &b);
-void launch_accumulate(hipStream_t s, const BatchDev &b, int level);
+// er_merge's accumulation (src/ER.cpp:153-165) for the whole batch in ONE launch: a node pushes its totals to its parent when its
+// last open child has pushed (dependency counters, agent-scope release/acquire)
+void launch_reduce(hipStream_t s, const BatchDev &b);
 void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_walls, s_lmin, s_lmax, s_lmin2, s_lmax2, s_start, s_cursor;
+    __shared__ uint32_t s_walls, s_start, s_cursor, s_nbase;
     __shared__ uint32_t s_present[8];        // which levels have a node in this tile
 
     const int       tid = threadIdx.x;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     const uint32_t  pl = p0 - 1u - ((tid & 3) == 0 ? 1u : 0u);             // slot of the pixel to its left (lx > 0)
     const int       gx = ox + lx, gy = oy + ly;
 
-    if (tid == 0) { s_walls = 0; s_lmin = 0xFFFFFFFFu; s_lmax = 0; s_lmin2 = 0xFFFFFFFFu; s_lmax2 = 0; }
+    if (tid == 0) s_walls = 0;
     if (tid < 8) s_present[tid] = 0;
     PHASE_INIT();
 
@@ -714,11 +714,9 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     __syncthreads();
     // level roots: make the parent word point at the parent node's level root
     {
-        uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
 #pragma unroll
         for (int k = 0; k < TILE_PPT; ++k) {
             if (!((rootmask >> k) & 1)) continue;
-            lmin = min(lmin, lev[k]); lmax = max(lmax, lev[k]);
             if (!(k > 0 && ((rootmask >> (k > 0 ? k - 1 : 0)) & 1) && lev[k > 0 ? k - 1 : 0] == lev[k]))
                 atomicOr(&s_present[(lev[k] >> 5) & 7u], 1u << (lev[k] & 31u));
             const uint32_t p = p0 + k;
@@ -729,7 +727,6 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             if (wq != NONE && (wq >> 16) == (w >> 16)) q = wq & 0xFFFFu;
             s_par[LX(p)] = (w & 0xFFFF0000u) | q;
         }
-        if (rootmask) { atomicMin(&s_lmin, lmin); atomicMax(&s_lmax, lmax); }
     }
     PHASE_MARK(3);
 
@@ -762,9 +759,23 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     __syncthreads();
     PHASE_MARK(4);
 
-    const uint32_t base = tl * (uint32_t)TILE_PX;
-    const size_t   nb = pd.node_base;
+    NodeRec *const nrec = b.na.rec + pd.node_base;
     uint32_t total = 0;     // nodes exported by this tile
+    // The exported nodes of a tile are consecutive records of the plane, handed out with one atomic per tile (the ids depend on
+    // the order in which tiles finish; nothing downstream does -- results are ordered by key).  A plane that runs out of records
+    // flags it and exports nothing from this tile: the host grows the share and repeats the batch.
+    auto take_records = [&](uint32_t n) {
+        uint32_t at = atomicAdd(&b.ctr[pi].n_nodes, n);
+        if (at + n > pd.node_cap) { atomicOr(&b.ctr[pi].overflow, 8u); at = NONE; }
+        s_nbase = at;
+    };
+    auto put_record = [&](uint32_t id, uint32_t par, uint32_t cnt, uint32_t nod_flags, uint32_t key_lvl, uint32_t x0, uint32_t y0,
+                          uint32_t x1, uint32_t y1) {
+        uint4 *dst = reinterpret_cast<uint4 *>(nrec + id);
+        dst[0] = make_uint4(par, cnt, nod_flags, key_lvl);
+        dst[1] = make_uint4(x0, y0, x1, y1);
+        b.na.aux[pd.node_base + id] = 0;           // dependency counter of k_resolve / k_reduce
+    };
 
     if (total_all <= (uint32_t)FOLD_CAP) {
         // ---- fold path.  Statistics of every node of the tile live in LDS:
@@ -860,11 +871,11 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             }
         }
         const uint32_t eid0 = block_excl_scan(__popc(expmask), s_wsum, &total);
+        if (tid == 0) take_records(total);
         // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
         // One exported node: everything it needs is in LDS except its own level and whether it is open.
-        auto export_node = [&](uint32_t p, uint32_t a, uint32_t l, bool open) {
-            const size_t id = nb + base + s_nid[LX(p)];
-            uint32_t     q = s_par[LX(p)], ql = 0;
+        auto export_node = [&](uint32_t nbase, uint32_t p, uint32_t a, uint32_t l, bool open) {
+            uint32_t q = s_par[LX(p)], ql = 0;
             if (q != NONE) { ql = (q >> 16) & 0xFFu; q &= 0xFFFFu; }
             while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
                 const uint32_t w2 = s_par[LX(q)];
@@ -872,45 +883,39 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 else { ql = (w2 >> 16) & 0xFFu; q = w2 & 0xFFFFu; }
             }
             const uint32_t v = s_w0[a];
-            b.na.par[id] = (q == NONE) ? NONE : PAR_MAKE(ql, base + s_nid[LX(q)]);
-            b.na.lvl[id] = (uint8_t)l;
-            b.na.dead[id] = open ? 0 : 2;                    // 2 = closed: totals are final
-            b.na.cnt[id] = v & CNT_MASK;
-            b.na.nod[id] = (v >> CNT_BITS) & CNT_MASK;
             const unsigned long long cm = s_col[a];
             const rowmask_t          rm = s_row[a];
-            b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
-            b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-            b.na.y0[id] = oy + row_lo(rm);
-            b.na.y1[id] = oy + row_hi(rm);
             const uint32_t px = SLOT_PIXEL(p);
-            b.na.key[id] = (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u));
+            put_record(nbase + s_nid[LX(p)], (q == NONE) ? NONE : PAR_MAKE(ql, nbase + s_nid[LX(q)]), v & CNT_MASK,
+                       ((v >> CNT_BITS) & CNT_MASK) | (open ? 0u : NODE_CLOSED),
+                       (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u)) | (l << 24),
+                       ox + __ffsll((long long)cm) - 1, oy + row_lo(rm), ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
         };
         // The exported nodes are listed behind the statistics (slot | a << SLOT_BITS | level << (SLOT_BITS + A_BITS))
         // and written out one per lane; a tile too full for the list writes them from the owners.
         const bool listed = (uint32_t)NODE_WORDS * n_even + total <= (uint32_t)NODE_WORDS * (uint32_t)FOLD_CAP;
         {
-            uint32_t id = eid0, aid = aid0, lo = 0xFFFFFFFFu, hi = 0;
+            uint32_t id = eid0, aid = aid0;
 #pragma unroll
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (!((rootmask >> k) & 1)) continue;
                 const uint32_t a = aid++;
                 if ((expmask >> k) & 1) {
-                    const uint32_t open = (openmask >> k) & 1u;
-                    if (open) { lo = min(lo, lev[k]); hi = max(hi, lev[k]); }
                     if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (lev[k] << (SLOT_BITS + A_BITS));
                     s_nid[OWN(k)] = (uint16_t)id++;
                 } else {
                     s_nid[OWN(k)] = (uint16_t)0xFFFFu;
                 }
             }
-            if (lo != 0xFFFFFFFFu) { atomicMin(&s_lmin2, lo); atomicMax(&s_lmax2, hi); }
         }
         __syncthreads();
-        if (listed) {
+        const uint32_t nbase = s_nbase;
+        if (nbase == NONE) {
+            // no records: nothing leaves this tile
+        } else if (listed) {
             for (uint32_t e = tid; e < total; e += TILE_THREADS) {
                 const uint32_t w = s_exp[e];
-                export_node(w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu,
+                export_node(nbase, w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu,
                             (s_w0[(w >> SLOT_BITS) & ((1u << A_BITS) - 1u)] >> 31) != 0);
             }
         } else {
@@ -919,13 +924,14 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (!((rootmask >> k) & 1)) continue;
                 const uint32_t a = aid++;
-                if ((expmask >> k) & 1) export_node(p0 + k, a, lev[k], (openmask >> k) & 1);
+                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev[k], (openmask >> k) & 1);
             }
         }
     } else {
         // ---- dense tile (more than FOLD_CAP nodes): export every node with its own statistics,
         // STAT_CHUNK nodes per pass; the global passes do all the accumulation.
         total = total_all;
+        if (tid == 0) take_records(total);
         uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
         rowmask_t           *s_row = reinterpret_cast<rowmask_t *>(s_work + STAT_CHUNK);          // [STAT_CHUNK]
         unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * STAT_CHUNK); // [STAT_CHUNK]
@@ -954,46 +960,38 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 }
             }
             __syncthreads();
+            const uint32_t nbase = s_nbase;
 #pragma unroll 1
             for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
+                if (!((rootmask >> k) & 1) || nbase == NONE) continue;
                 const uint32_t p = p0 + k;
                 const uint32_t li = (uint32_t)s_nid[LX(p)] - c0;
                 if (li >= (uint32_t)STAT_CHUNK) continue;
-                const size_t   id = nb + base + s_nid[LX(p)];
                 const uint32_t w = s_par[LX(p)];
-                b.na.par[id] = (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, base + s_nid[LX(w & 0xFFFFu)]);
-                b.na.lvl[id] = (uint8_t)lev[k];
-                b.na.dead[id] = 0;
-                b.na.cnt[id] = s_cnt[li];
-                b.na.nod[id] = 1;
                 const unsigned long long cm = s_col[li];
                 const rowmask_t          rm = s_row[li];
-                b.na.x0[id] = ox + __ffsll((long long)cm) - 1;
-                b.na.x1[id] = ox + 63 - __clzll((long long)cm);
-                b.na.y0[id] = oy + row_lo(rm);
-                b.na.y1[id] = oy + row_hi(rm);
-                b.na.key[id] = (uint32_t)(gy * pd.w + gx + k);
+                put_record(nbase + s_nid[LX(p)], (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, nbase + s_nid[LX(w & 0xFFFFu)]), s_cnt[li], 1u,
+                           (uint32_t)(gy * pd.w + gx + k) | (lev[k] << 24), ox + __ffsll((long long)cm) - 1, oy + row_lo(rm),
+                           ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
             }
             __syncthreads();
         }
-        if (tid == 0) { s_lmin2 = s_lmin; s_lmax2 = s_lmax; }
     }
     __syncthreads();
+    const uint32_t nbase = s_nbase;
     if (tid == 0) {
-        b.tile_cnt[blockIdx.x] = total;
-        b.tile_lo[blockIdx.x] = (uint8_t)min(s_lmin2, 255u);
-        b.tile_hi[blockIdx.x] = (uint8_t)min(s_lmax2, 255u);
-        if (tl == 0) b.ctr[pi].start_node = (s_start == NONE) ? NONE : base + s_nid[LX(s_start)];
+        b.tile_nbase[blockIdx.x] = nbase;
+        if (tl == 0) b.ctr[pi].start_node = (s_start == NONE || nbase == NONE) ? NONE : nbase + s_nid[LX(s_start)];
     }
     PHASE_MARK(13);
 
-    // ---- node id of every tile-border pixel, for the seam pass ---------------------------
+    // ---- node of every tile-border pixel, for the seam pass: its index inside this tile's records (16 bits; the seam
+    // kernel adds tile_nbase) ---------------------------------------------------------------
     // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
-    // of w ids (pixel row j*TH-1, then j*TH); then for every vertical boundary i two
-    // columns of h ids (pixel column i*TW-1, then i*TW).  Each lane writes its own pixels.
+    // of w entries (pixel row j*TH-1, then j*TH); then for every vertical boundary i two
+    // columns of h entries (pixel column i*TW-1, then i*TW).  Each lane writes its own pixels.
     {
-        uint32_t *seam = b.seam + pd.seam_base;
+        uint16_t *seam = b.seam + pd.seam_base;
         const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
         const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
 #pragma unroll
@@ -1002,8 +1000,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             const bool lef = xx == 0 && tx > 0, rig = xx == TILE_W - 1 && tx + 1 < pd.tiles_x;
             if (!(top || bot || lef || rig)) continue;
             if (gx + k >= pd.w || gy >= pd.h) continue;
-            uint32_t id = NONE;
-            if (lev[k] != WALL) id = base + s_nid[LX(rk[k])];
+            uint16_t id = 0xFFFFu;
+            if (lev[k] != WALL && nbase != NONE) id = s_nid[LX(rk[k])];
             if (top) seam[((size_t)(ty - 1) * 2 + 1) * pd.w + gx + k] = id;
             if (bot) seam[((size_t)ty * 2) * pd.w + gx + k] = id;
             if (lef) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = id;
@@ -1054,29 +1052,30 @@ extern "C" void str_er_debug_seam_counts(unsigned long long *out8, int reset)
 #define SCNT(i, v) do { } while (0)
 #endif
 
-__device__ __forceinline__ uint32_t node_find(uint32_t *par, uint32_t &a, uint32_t la)
+// (node records are 8 dwords: the parent word of node i is at rec[i].par; `nr` below is the plane's first record)
+__device__ __forceinline__ uint32_t node_find(NodeRec *nr, uint32_t &a, uint32_t la)
 {
-    uint32_t wa = LD_AGENT(&par[a]);
+    uint32_t wa = LD_AGENT(&nr[a].par);
     while (wa != NONE && PAR_LVL(wa) == la) {
         SCNT(2, 1);
         const uint32_t nx = PAR_ID(wa);
-        const uint32_t w2 = LD_AGENT(&par[nx]);
-        if (w2 != NONE && PAR_LVL(w2) == la) ST_AGENT(&par[a], w2);   // path halving, same node
+        const uint32_t w2 = LD_AGENT(&nr[nx].par);
+        if (w2 != NONE && PAR_LVL(w2) == la) ST_AGENT(&nr[a].par, w2);   // path halving, same node
         a = nx;
         wa = w2;
     }
     return wa;
 }
 
-__device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, uint32_t a, uint32_t b)
+__device__ __forceinline__ void node_connect(NodeRec *nr, uint32_t a, uint32_t b)
 {
-    uint32_t la = lvl[a], lb = lvl[b];
+    uint32_t la = nr[a].key >> 24, lb = nr[b].key >> 24;       // levels are immutable: plain loads
     SCNT(0, 1);
     if (la == lb) SCNT(5, 1);
     for (;;) {
         SCNT(1, 1);
-        uint32_t wa = node_find(par, a, la);
-        uint32_t wb = node_find(par, b, lb);
+        uint32_t wa = node_find(nr, a, la);
+        uint32_t wb = node_find(nr, b, lb);
         if (a == b) return;
         if (la > lb || (la == lb && a < b)) {
             uint32_t t;
@@ -1085,7 +1084,7 @@ __device__ __forceinline__ void node_connect(uint32_t *par, const uint8_t *lvl, 
             t = wa; wa = wb; wb = t;
         }
         if (la == lb || wa == NONE || PAR_LVL(wa) > lb) {
-            const uint32_t old = atomicCAS(&par[a], wa, PAR_MAKE(lb, b));
+            const uint32_t old = atomicCAS(&nr[a].par, wa, PAR_MAKE(lb, b));
             SCNT(3, 1);
             if (old != wa) { SCNT(4, 1); continue; }
             if (wa == NONE) return;
@@ -1114,17 +1113,26 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
     const uint32_t   i = b.seam_block_first[vb] + threadIdx.x;
     uint32_t         na = NONE, nbn = NONE;
     if (i < pd.n_pairs) {
-        const uint32_t *seam = b.seam + pd.seam_base;
+        // an entry of the seam map is the node's index inside its tile's records; the tile's first record is tile_nbase
+        const uint16_t *seam = b.seam + pd.seam_base;
+        const uint32_t *tnb = b.tile_nbase + pd.tile_base;
+        uint32_t la, lb, ta, tb;
         if (i < pd.n_hpairs) {
             const uint32_t j = i / pd.w, x = i - j * pd.w;
-            na = seam[((size_t)j * 2) * pd.w + x];
-            nbn = seam[((size_t)j * 2 + 1) * pd.w + x];
+            la = seam[((size_t)j * 2) * pd.w + x];
+            lb = seam[((size_t)j * 2 + 1) * pd.w + x];
+            ta = j * pd.tiles_x + x / (uint32_t)TILE_W; tb = ta + pd.tiles_x;
         } else {
             const uint32_t i2 = i - pd.n_hpairs;
             const uint32_t k = i2 / pd.h, y = i2 - k * pd.h;
             const size_t   voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
-            na = seam[voff + ((size_t)k * 2) * pd.h + y];
-            nbn = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
+            la = seam[voff + ((size_t)k * 2) * pd.h + y];
+            lb = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
+            ta = (y / (uint32_t)TILE_H) * pd.tiles_x + k; tb = ta + 1;
+        }
+        if (la != 0xFFFFu && lb != 0xFFFFu) {
+            const uint32_t ba = tnb[ta], bb = tnb[tb];
+            if (ba != NONE && bb != NONE) { na = ba + la; nbn = bb + lb; }
         }
     }
     // neighbouring lanes very often carry the same pair (a flat region crossing the seam):
@@ -1158,8 +1166,7 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
     if (mine) { const uint32_t at = atomicAdd(&s_n, 1u); s_pa[at] = na; s_pb[at] = nbn; }
     __syncthreads();
     if (threadIdx.x >= s_n) return;
-    const size_t nb = pd.node_base;
-    node_connect(b.na.par + nb, b.na.lvl + nb, s_pa[threadIdx.x], s_pb[threadIdx.x]);
+    node_connect(b.na.rec + pd.node_base, s_pa[threadIdx.x], s_pb[threadIdx.x]);
 }
 
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
@@ -1169,153 +1176,62 @@ void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 }
 
 // ------------------------------------------------------------------------------------
-// Part 3: per-node passes.  Grid = (blocks, planes); lanes stride over the plane's nodes.
+// Part 3: per-node passes over the plane's records.  Grid = (NODE_BLOCKS, planes); a block strides over its plane's nodes.
 // ------------------------------------------------------------------------------------
-// Exported nodes are listed densely (tile after tile; offsets = exclusive prefix of tile_cnt), so the
-// level-by-level accumulation and the selection run with one lane per node instead of one sparse
-// wave per tile (a tile exports only ~10-15 nodes on text-like frames).
-constexpr int NODE_GRID = 65536;
-constexpr int SCAN_CHUNK = 1024;     // tiles per block of the offset scan
+constexpr int NODE_BLOCKS = 12;       // x 256 lanes per plane: a 1920x1080 plane of text-like frames exports ~12 000 nodes
 
-__global__ __launch_bounds__(256) void k_tile_scan1(BatchDev b)          // per-chunk sums
+__device__ __forceinline__ uint32_t plane_nodes(const BatchDev &b, int pi)
 {
-    __shared__ uint32_t s_w[4];
-    const uint32_t t0 = blockIdx.x * SCAN_CHUNK;
-    uint32_t sum = 0;
-    for (uint32_t t = t0 + threadIdx.x; t < min(t0 + (uint32_t)SCAN_CHUNK, b.n_tiles); t += 256) sum += b.tile_cnt[t];
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) b.chunk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    // a plane that ran out of records has holes in them: nothing downstream touches it (the host repeats the batch with more)
+    return (b.ctr[pi].overflow & 8u) ? 0u : b.ctr[pi].n_nodes;
 }
 
-__global__ __launch_bounds__(1024) void k_tile_scan2(BatchDev b, uint32_t n_chunks)   // scan of the chunk sums
-{
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_chunks; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n_chunks ? b.chunk_sum[i] : 0;
-        const uint32_t incl = wave_incl_scan(v);
-        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t off = s_carry, tot = 0;
-        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-        if (i < n_chunks) b.chunk_sum[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
-    }
-    if (tid == 0) *b.n_listed = s_carry;
-}
-
-__global__ __launch_bounds__(256) void k_tile_scan3(BatchDev b)          // offsets of the tiles of a chunk
-{
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_carry;
-    const int      tid = threadIdx.x;
-    const uint32_t t0 = blockIdx.x * SCAN_CHUNK;
-    if (tid == 0) s_carry = b.chunk_sum[blockIdx.x];
-    __syncthreads();
-    for (uint32_t base = 0; base < (uint32_t)SCAN_CHUNK; base += 256) {
-        const uint32_t t = t0 + base + tid;
-        const uint32_t v = t < b.n_tiles ? b.tile_cnt[t] : 0;
-        const uint32_t incl = wave_incl_scan(v);
-        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t off = s_carry, tot = 0;
-        for (int k = 0; k < 4; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-        if (t < b.n_tiles) b.tile_off[t] = off + incl - v;
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
-    }
-}
-
-void launch_level_prefix(hipStream_t s, const BatchDev &b)
-{
-    if (!b.n_tiles) return;
-    const uint32_t n_chunks = (b.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(k_tile_scan1, dim3(n_chunks), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, s, b, n_chunks);
-    hipLaunchKernelGGL(k_tile_scan3, dim3(n_chunks), dim3(256), 0, s, b);
-}
-
-// Nodes that were unified into another node of the same level hand their own
-// statistics to the surviving level root; surviving nodes get a canonical parent.
-// Every exported node is also entered into the level-sorted list (global slot index).
-// the exported nodes as one dense list (global slot index), tile after tile: a wave per tile only copies numbers here, so
-// that the passes that chase pointers (k_resolve, k_select) run with one lane per node and every lane busy
-__global__ __launch_bounds__(256) void k_node_list(BatchDev b)
-{
-    const int lane = threadIdx.x & 63;
-    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < b.n_tiles; t += gridDim.x * 4) {
-        const uint32_t n = b.tile_cnt[t];
-        if (!n) continue;
-        const int       pi = b.tile_plane[t];
-        const PlaneDesc &pd = b.planes[pi];
-        const uint32_t  g0 = pd.node_base + (t - pd.tile_base) * (uint32_t)TILE_PX;
-        const uint32_t  off = b.tile_off[t];
-        for (uint32_t i = lane; i < n; i += 64) {
-            if (off + i < b.node_list_cap) b.node_list[off + i] = g0 + i;
-            else atomicOr(&b.ctr[pi].overflow, 4u);
-        }
-    }
-}
-
+// Nodes that were unified into another node of the same level hand their own statistics to the surviving level root;
+// surviving nodes get a canonical parent (the parent node's level root).  Every node that will push its totals to a parent
+// -- open, alive, not a tree root -- is counted in the parent's dependency counter (aux).
 __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 {
-    const uint32_t end = min(*b.n_listed, b.node_list_cap);
-    for (uint32_t at = blockIdx.x * blockDim.x + threadIdx.x; at < end; at += gridDim.x * blockDim.x) {
-        const uint32_t  g = b.node_list[at];
-        const int       pi = b.tile_plane[g / (uint32_t)TILE_PX];
-        const size_t    nb = b.planes[pi].node_base;
-        const uint32_t  x = g - (uint32_t)nb;
-        uint32_t       *par = b.na.par + nb;
-        const uint32_t  l = b.na.lvl[g];
-        const uint32_t  w = LD_AGENT(&par[x]);
-        uint32_t        skip = b.na.dead[g] ? 0x100u : 0u;      // closed nodes never push (totals final)
+    const int       pi = blockIdx.y;
+    const uint32_t  n = plane_nodes(b, pi);
+    NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
+    uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        const uint32_t  l = nr[x].key >> 24;
+        const uint32_t  w = LD_AGENT(&nr[x].par);
         if (w != NONE && PAR_LVL(w) == l) {
             uint32_t r = PAR_ID(w);
             for (;;) {
-                const uint32_t w2 = LD_AGENT(&par[r]);
+                const uint32_t w2 = LD_AGENT(&nr[r].par);
                 if (w2 == NONE || PAR_LVL(w2) != l) break;
                 r = PAR_ID(w2);
             }
-            b.na.dead[g] = 1;
-            skip = 0x100u;
-            atomicAdd(&b.na.cnt[nb + r], b.na.cnt[g]);
-            if (b.na.nod[g] > 1) atomicAdd(&b.na.nod[nb + r], b.na.nod[g] - 1);   // folded descendants
-            atomicMin(&b.na.x0[nb + r], b.na.x0[g]);
-            atomicMin(&b.na.y0[nb + r], b.na.y0[g]);
-            atomicMax(&b.na.x1[nb + r], b.na.x1[g]);
-            atomicMax(&b.na.y1[nb + r], b.na.y1[g]);
-            atomicMin(&b.na.key[nb + r], b.na.key[g]);
+            const uint32_t nodw = nr[x].nod;
+            atomicOr(&nr[x].nod, NODE_DEAD);
+            atomicAdd(&nr[r].cnt, nr[x].cnt);
+            if ((nodw & NODE_CNT) > 1) atomicAdd(&nr[r].nod, (nodw & NODE_CNT) - 1);   // folded descendants
+            atomicMin(&nr[r].x0, nr[x].x0);
+            atomicMin(&nr[r].y0, nr[x].y0);
+            atomicMax(&nr[r].x1, nr[x].x1);
+            atomicMax(&nr[r].y1, nr[x].y1);
+            atomicMin(&nr[r].key, nr[x].key);          // same level: the top byte is equal, the minimum is over the pixel index
         } else if (w != NONE) {
             uint32_t       q = PAR_ID(w);
             const uint32_t lq = PAR_LVL(w);
             for (;;) {
-                const uint32_t w2 = LD_AGENT(&par[q]);
+                const uint32_t w2 = LD_AGENT(&nr[q].par);
                 if (w2 == NONE || PAR_LVL(w2) != lq) break;
                 q = PAR_ID(w2);
             }
-            if (q != PAR_ID(w)) ST_AGENT(&par[x], PAR_MAKE(lq, q));
-        } else {
-            skip = 0x100u;                                           // a tree root has nobody to push to
+            if (q != PAR_ID(w)) ST_AGENT(&nr[x].par, PAR_MAKE(lq, q));
+            if (!(nr[x].nod & NODE_CLOSED)) atomicAdd(&aux[q], 1u);      // closed nodes never push (their totals are final)
         }
-        b.list_key[at] = (uint16_t)(l | skip);                      // what the accumulate sort tests: level, or "never"
     }
 }
 
 void launch_resolve(hipStream_t s, const BatchDev &b)
 {
-    if (!b.n_tiles) return;
-    const uint32_t blocks = (b.n_tiles + 3) / 4;
-    hipLaunchKernelGGL(k_node_list, dim3(blocks < (uint32_t)NODE_GRID ? blocks : NODE_GRID), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_resolve, dim3(4096), dim3(256), 0, s, b);
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_resolve, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -1337,142 +1253,96 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
-// er_merge's accumulation (src/ER.cpp:153-165), one level per launch: every live open node of
-// level t adds its (now final) totals to its parent.  Children are always at lower levels than
-// their parent, so launching t = 0,1,2,... in order is a topological order.
-// The nodes that push (open, alive, with a parent) are first grouped by level -- a counting sort of the exported-node
-// list in three small launches -- so that the launch of level t touches its own nodes only instead of scanning the list.
-constexpr int ACC_BLOCKS = 256;
-constexpr int ACC_CHUNK = 4096;          // list entries per workgroup pass of the counting sort
-constexpr int LVL_CURSOR = 260;          // lvl_tab: [0..256] counts -> bases, [260..515] cursors
+// er_merge's accumulation (src/ER.cpp:153-165): every live open node adds its (final) totals to its parent.  One launch for
+// the whole tree: aux[q] counts the children of q that still have to push (k_resolve).  A node may push once its counter is 0;
+// whoever CLAIMS it (CAS 0 -> CLAIMED) does: the lane that meets it in the node sweep, or the lane whose push just brought the
+// counter to 0 and that then carries on towards the root.  Counter and claim are agent-scope acquire/release and all totals are
+// read and written with agent-scope atomics, so the pushes of other CUs (other XCDs, whose L2s are not coherent with this one)
+// are visible to the lane that continues.  (Round 1 launched once per level: ~32 dependent launches per batch -- the whole
+// cost of the step on small batches and on noise.)
+#define RMW_AGENT(op, p, v) __hip_atomic_fetch_##op((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+constexpr uint32_t NODE_CLAIMED = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(256) void k_acc_hist(BatchDev b)
+__device__ __forceinline__ void node_push(NodeRec *dst, uint32_t c, uint32_t nd, uint32_t bx0, uint32_t by0, uint32_t bx1, uint32_t by1)
 {
-    __shared__ uint32_t s_h[256];
-    const uint32_t end = min(*b.n_listed, b.node_list_cap);
-    s_h[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
-        const uint32_t k = b.list_key[i];
-        if (k < 0x100u) atomicAdd(&s_h[k], 1u);
-    }
-    __syncthreads();
-    if (s_h[threadIdx.x]) atomicAdd(&b.lvl_tab[threadIdx.x], s_h[threadIdx.x]);
+    RMW_AGENT(add, &dst->cnt, c); RMW_AGENT(add, &dst->nod, nd);
+    RMW_AGENT(min, &dst->x0, bx0); RMW_AGENT(min, &dst->y0, by0);
+    RMW_AGENT(max, &dst->x1, bx1); RMW_AGENT(max, &dst->y1, by1);
+}
+__device__ __forceinline__ bool node_claim(uint32_t *ctr)
+{
+    uint32_t expect = 0;
+    return __hip_atomic_compare_exchange_strong(ctr, &expect, NODE_CLAIMED, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// children done: `k` of them just pushed into the node with counter `ctr`; true if the caller now owns the node
+__device__ __forceinline__ bool node_arrive(uint32_t *ctr, uint32_t k)
+{
+    if (__hip_atomic_fetch_sub(ctr, k, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != k) return false;
+    return node_claim(ctr);
 }
 
-__global__ __launch_bounds__(256) void k_acc_prefix(BatchDev b)
+__global__ __launch_bounds__(256) void k_reduce(BatchDev b)
 {
-    __shared__ uint32_t s_w[4];
-    const int      tid = threadIdx.x;
-    const uint32_t v = b.lvl_tab[tid];
-    const uint32_t incl = wave_incl_scan(v);
-    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
-    for (int k = 0; k < 4; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-    const uint32_t base = off + incl - v;
-    b.lvl_tab[tid] = base;
-    b.lvl_tab[LVL_CURSOR + tid] = base;
-    if (tid == 0) b.lvl_tab[256] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_acc_scatter(BatchDev b)
-{
-    __shared__ uint32_t s_h[256], s_base[256];
-    const uint32_t end = min(*b.n_listed, b.node_list_cap);
-    for (uint32_t c0 = blockIdx.x * ACC_CHUNK; c0 < end; c0 += gridDim.x * ACC_CHUNK) {
-        s_h[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t c1 = min(c0 + (uint32_t)ACC_CHUNK, end);
-        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
-            const uint32_t k = b.list_key[i];
-            if (k < 0x100u) atomicAdd(&s_h[k], 1u);
-        }
-        __syncthreads();
-        const uint32_t n = s_h[threadIdx.x];
-        s_base[threadIdx.x] = n ? atomicAdd(&b.lvl_tab[LVL_CURSOR + threadIdx.x], n) : 0u;
-        s_h[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
-            const uint32_t k = b.list_key[i];
-            if (k < 0x100u) {
-                // the node and -- so that the per-level launches do not have to chase it -- the global slot of its parent
-                const uint32_t g = b.node_list[i];
-                const uint32_t w = b.na.par[g];
-                const uint32_t at = s_base[k] + atomicAdd(&s_h[k], 1u);
-                b.acc_list[at] = g;
-                b.acc_parent[at] = (w == NONE) ? NONE : b.planes[b.tile_plane[g / (uint32_t)TILE_PX]].node_base + PAR_ID(w);
+    const int       pi = blockIdx.y;
+    const uint32_t  n = plane_nodes(b, pi);
+    NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
+    uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
+    const int       lane = threadIdx.x & 63;
+    for (uint32_t x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += gridDim.x * blockDim.x) {
+        const uint32_t x = x0 + lane;
+        bool     act = false;
+        uint32_t q = NONE, c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
+        if (x < n) {
+            const uint32_t w = nr[x].par, f = nr[x].nod;          // parent and flags are final since k_resolve
+            act = w != NONE && !(f & (NODE_DEAD | NODE_CLOSED)) && LD_AGENT(&aux[x]) == 0 && node_claim(&aux[x]);
+            if (act) {
+                q = PAR_ID(w); c = LD_AGENT(&nr[x].cnt); nd = LD_AGENT(&nr[x].nod) & NODE_CNT;
+                bx0 = LD_AGENT(&nr[x].x0); by0 = LD_AGENT(&nr[x].y0); bx1 = LD_AGENT(&nr[x].x1); by1 = LD_AGENT(&nr[x].y1);
             }
         }
-        __syncthreads();
-    }
-}
-
-void launch_accumulate_prepare(hipStream_t s, const BatchDev &b)
-{
-    if (!b.n_tiles) return;
-    (void)hipMemsetAsync(b.lvl_tab, 0, 257 * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_acc_hist, dim3(512), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_acc_prefix, dim3(1), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_acc_scatter, dim3(1024), dim3(256), 0, s, b);
-}
-
-__global__ __launch_bounds__(256) void k_accumulate(BatchDev b, int level)
-{
-    const uint32_t beg = b.lvl_tab[level], end = b.lvl_tab[level + 1];
-    const int      lane = threadIdx.x & 63;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i0 = beg + blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < end; i0 += stride) {
-        const uint32_t i = i0 + lane;
-        size_t   g = 0;
-        size_t   gp = (size_t)-1;          // global slot of the parent; all-ones = inactive lane
-        if (i < end) {
-            g = b.acc_list[i];
-            const uint32_t pg = b.acc_parent[i];
-            if (pg != NONE) gp = (size_t)pg;
-        }
-        const bool act = gp != (size_t)-1;
+        // first step: lanes of the wave that share a parent combine (ballot + butterfly): one set of atomics and one
+        // decrement per distinct parent and wave -- the background node of a tile has hundreds of such children
+        bool cont = false;
         unsigned long long todo = __ballot(act);
-        if (!todo) continue;
-        uint32_t c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
-        if (act) {
-            c = b.na.cnt[g]; nd = b.na.nod[g];
-            bx0 = b.na.x0[g]; by0 = b.na.y0[g]; bx1 = b.na.x1[g]; by1 = b.na.y1[g];
-        }
-        const uint32_t plo = (uint32_t)gp, phi = (uint32_t)((unsigned long long)gp >> 32);
-        // lanes that share a parent combine first (ballot + butterfly): ONE set of atomics per
-        // distinct parent and wave instead of one per child
         while (todo) {
             const int      leader = __ffsll((long long)todo) - 1;
-            const uint32_t llo = __shfl(plo, leader), lhi = __shfl(phi, leader);
-            const bool     mine = act && plo == llo && phi == lhi;
+            const uint32_t lq = __shfl(q, leader);
+            const bool     mine = act && q == lq;
             const unsigned long long m = __ballot(mine);
-            const size_t   tp = ((size_t)lhi << 32) | llo;
-            if (__popcll(m) == 1) {
+            const uint32_t k = (uint32_t)__popcll(m);
+            if (k == 1) {
                 if (mine) {
-                    atomicAdd(&b.na.cnt[tp], c); atomicAdd(&b.na.nod[tp], nd);
-                    atomicMin(&b.na.x0[tp], bx0); atomicMin(&b.na.y0[tp], by0);
-                    atomicMax(&b.na.x1[tp], bx1); atomicMax(&b.na.y1[tp], by1);
+                    node_push(nr + lq, c, nd, bx0, by0, bx1, by1);
+                    cont = node_arrive(&aux[lq], 1u);
                 }
             } else {
                 const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
                 const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
                 const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
                 if (lane == leader) {
-                    atomicAdd(&b.na.cnt[tp], sc); atomicAdd(&b.na.nod[tp], sn);
-                    atomicMin(&b.na.x0[tp], mx0); atomicMin(&b.na.y0[tp], my0);
-                    atomicMax(&b.na.x1[tp], mx1); atomicMax(&b.na.y1[tp], my1);
+                    node_push(nr + lq, sc, sn, mx0, my0, mx1, my1);
+                    cont = node_arrive(&aux[lq], k);
                 }
             }
             todo &= ~m;
         }
+        // the lanes that now own a parent carry it upward
+        uint32_t g = q;
+        while (cont) {
+            const uint32_t w = LD_AGENT(&nr[g].par), f = LD_AGENT(&nr[g].nod);
+            if (w == NONE || (f & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
+            const uint32_t p = PAR_ID(w);
+            node_push(nr + p, LD_AGENT(&nr[g].cnt), f & NODE_CNT, LD_AGENT(&nr[g].x0), LD_AGENT(&nr[g].y0), LD_AGENT(&nr[g].x1), LD_AGENT(&nr[g].y1));
+            cont = node_arrive(&aux[p], 1u);
+            g = p;
+        }
     }
 }
 
-void launch_accumulate(hipStream_t s, const BatchDev &b, int level)
+void launch_reduce(hipStream_t s, const BatchDev &b)
 {
-    if (!b.n_tiles) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(ACC_BLOCKS), dim3(256), 0, s, b, level);
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_reduce, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b);
 }
 
 // Root of the tree that holds the flood's start pixel (er_stack.back(), src/ER.cpp:346).
@@ -1484,9 +1354,7 @@ __global__ void k_root(BatchDev b, DetectParams prm)
     if (pi >= b.n_planes) return;
     PlaneCtr       &c = b.ctr[pi];
     const PlaneDesc &pd = b.planes[pi];
-    const size_t    nb = pd.node_base;
-    const uint32_t *par = b.na.par + nb;
-    const uint8_t  *lvl = b.na.lvl + nb;
+    const NodeRec  *nr = b.na.rec + pd.node_base;
     uint32_t        x = c.start_node;
     if (x == NONE) {
         const size_t kb = pd.kept_base;
@@ -1503,11 +1371,11 @@ __global__ void k_root(BatchDev b, DetectParams prm)
         c.max_level = prm.hi;
         return;
     }
-    for (;;) { const uint32_t w = par[x]; if (w == NONE || PAR_LVL(w) != lvl[x]) break; x = PAR_ID(w); }
-    for (;;) { const uint32_t w = par[x]; if (w == NONE) break; x = PAR_ID(w); }
+    for (;;) { const uint32_t w = nr[x].par; if (w == NONE || PAR_LVL(w) != (nr[x].key >> 24)) break; x = PAR_ID(w); }
+    for (;;) { const uint32_t w = nr[x].par; if (w == NONE) break; x = PAR_ID(w); }
     c.root_node = x;
-    c.n_created = b.na.nod[nb + x];
-    c.max_level = lvl[x];
+    c.n_created = nr[x].nod & NODE_CNT;
+    c.max_level = nr[x].key >> 24;
 }
 
 void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p)
@@ -1521,31 +1389,31 @@ void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // trees (regions sealed off by sentinel-level pixels) were never visited by the flood.
 __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 {
-    const uint32_t end = min(*b.n_listed, b.node_list_cap);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
-        const size_t g = b.node_list[i];
-        if (b.na.dead[g] == 1) continue;
-        const int       pi = b.tile_plane[g / (size_t)TILE_PX];
-        PlaneCtr       &c = b.ctr[pi];
-        const uint32_t  root = c.root_node;
-        if (root == NONE) continue;
-        const PlaneDesc &pd = b.planes[pi];
-        const size_t    nb = pd.node_base;
-        const uint32_t  x = (uint32_t)(g - nb);
+    const int       pi = blockIdx.y;
+    PlaneCtr       &c = b.ctr[pi];
+    const uint32_t  root = c.root_node;
+    if (root == NONE) return;
+    const PlaneDesc &pd = b.planes[pi];
+    const uint32_t  n = plane_nodes(b, pi);
+    const NodeRec  *nr = b.na.rec + pd.node_base;
+    uint32_t       *aux = b.na.aux + pd.node_base;
+    const bool      walls = c.n_walls != 0;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        const uint32_t f = nr[x].nod;
+        if (f & NODE_DEAD) continue;
         if (x != root) {
-            const uint32_t area = b.na.cnt[g] + b.na.nod[g];
+            const uint32_t area = nr[x].cnt + (f & NODE_CNT);
             if ((int64_t)area <= (int64_t)prm.min_area) continue;
-            if (c.n_walls != 0) {
-                const uint32_t *par = b.na.par + nb;
+            if (walls) {
                 uint32_t y = x;
-                for (;;) { const uint32_t w = par[y]; if (w == NONE) break; y = PAR_ID(w); }
+                for (;;) { const uint32_t w = nr[y].par; if (w == NONE) break; y = PAR_ID(w); }
                 if (y != root) continue;
             }
         }
         const uint32_t slot = atomicAdd(&c.n_kept, 1u);
         if (slot < (uint32_t)prm.kept_cap) {
             b.ka.node[pd.kept_base + slot] = x;
-            b.na.kmap[g] = slot;
+            aux[x] = slot;
         } else {
             atomicOr(&c.overflow, 1u);
         }
@@ -1554,8 +1422,8 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p)
 {
-    if (!b.n_tiles) return;
-    hipLaunchKernelGGL(k_select, dim3(2048), dim3(256), 0, s, b, p);
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_select, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b, p);
 }
 
 // Kept-node records (flat form of struct ER, inc/ER.h:42-80).
@@ -1566,23 +1434,24 @@ __global__ __launch_bounds__(256) void k_kept(BatchDev b, DetectParams prm)
     if (c.root_node == NONE) return;
     const uint32_t  n = min(c.n_kept, (uint32_t)prm.kept_cap);
     const PlaneDesc &pd = b.planes[pi];
-    const size_t    nb = pd.node_base, kb = pd.kept_base;
+    const size_t    kb = pd.kept_base;
+    const NodeRec  *nr = b.na.rec + pd.node_base;
+    const uint32_t *aux = b.na.aux + pd.node_base;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         const uint32_t x = b.ka.node[kb + s];
-        const uint32_t p = b.na.par[nb + x];
-        b.ka.key[kb + s] = b.na.key[nb + x];
-        b.ka.area[kb + s] = b.na.cnt[nb + x] + b.na.nod[nb + x];
-        b.ka.level[kb + s] = b.na.lvl[nb + x];
-        const uint32_t x0 = b.na.x0[nb + x], y0 = b.na.y0[nb + x];
-        b.ka.box[4 * (kb + s) + 0] = (uint16_t)x0;
-        b.ka.box[4 * (kb + s) + 1] = (uint16_t)y0;
-        b.ka.box[4 * (kb + s) + 2] = (uint16_t)(b.na.x1[nb + x] - x0 + 1);
-        b.ka.box[4 * (kb + s) + 3] = (uint16_t)(b.na.y1[nb + x] - y0 + 1);
+        const NodeRec  r = nr[x];
+        b.ka.key[kb + s] = r.key & 0xFFFFFFu;
+        b.ka.area[kb + s] = r.cnt + (r.nod & NODE_CNT);
+        b.ka.level[kb + s] = (uint8_t)(r.key >> 24);
+        b.ka.box[4 * (kb + s) + 0] = (uint16_t)r.x0;
+        b.ka.box[4 * (kb + s) + 1] = (uint16_t)r.y0;
+        b.ka.box[4 * (kb + s) + 2] = (uint16_t)(r.x1 - r.x0 + 1);
+        b.ka.box[4 * (kb + s) + 3] = (uint16_t)(r.y1 - r.y0 + 1);
         if (x == c.root_node) {
             b.ka.parent[kb + s] = (int32_t)s;
             c.root_slot = s;
         } else {
-            b.ka.parent[kb + s] = (int32_t)b.na.kmap[nb + PAR_ID(p)];
+            b.ka.parent[kb + s] = (int32_t)aux[PAR_ID(r.par)];
         }
     }
 }

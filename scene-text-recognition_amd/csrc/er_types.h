@@ -33,26 +33,26 @@ struct PlaneDesc {
     uint32_t pair_base;     // first seam pixel-pair of this plane (batch-wide numbering)
     uint32_t n_hpairs;      // w * (tiles_y - 1)
     uint32_t n_pairs;       // n_hpairs + h * (tiles_x - 1)
-    uint32_t node_base;     // offset of this plane in the node arrays (capacity tiles * 2048)
-    uint32_t seam_base;     // offset in the seam map (u32 units)
+    uint32_t node_base;     // first record of this plane in the node records (capacity node_cap)
+    uint32_t seam_base;     // offset in the seam map (u16 units)
     uint32_t kept_base;     // offset in the kept-node arrays (capacity kept_cap)
     uint32_t pool_base;     // offset in the pool arrays (capacity pool_cap)
     uint32_t frame;
     uint8_t  ch, pyr, pad0, pad1;
     uint32_t color_pitch;   // BGR frames: bytes between the Y, Cr, Cb planes of this level (pix - (ch % 3) * color_pitch is Y); 0 = no colour image
-    uint32_t pad2;
+    uint32_t node_cap;      // node records this plane may use (a share of its pixel count; overflow -> the host grows the share and repeats)
 };
 
 // Per-plane device counters, zeroed before every batch.
 struct PlaneCtr {
-    uint32_t n_nodes;       // (unused; nodes are counted per tile)
+    uint32_t n_nodes;       // node records handed out to the plane's tiles (may exceed node_cap: then overflow bit 3 is set)
     uint32_t n_walls;       // in-image pixels at the sentinel level
     uint32_t start_node;    // node of the flood's start pixel, NONE if none (A.2)
     uint32_t root_node;     // root of the start pixel's tree
     uint32_t n_kept;
     uint32_t n_pool;
     uint32_t n_amb;
-    uint32_t overflow;      // bit0 kept table, bit1 pool
+    uint32_t overflow;      // bit0 kept table, bit1 pool, bit3 node records
     uint32_t n_strong;
     uint32_t n_weak;
     uint32_t cand_base;     // exclusive prefix of n_pool over planes
@@ -72,16 +72,22 @@ struct ReplayItem {
 };
 constexpr int NMS_WATCH_CAP = 256;   // watched key pixels per plane; more -> the replay floods the whole plane
 
-// Structure-of-arrays node storage (index = PlaneDesc::node_base + plane-local id).
+// One tree node that left its tile ("exported"): 32 bytes, written by k_tile_tree with two 16-byte stores, index =
+// PlaneDesc::node_base + plane-local id.  Ids are handed out densely per plane (PlaneCtr::n_nodes), a tile at a time.
+struct NodeRec {
+    uint32_t par;           // NONE (tree root) or level of the parent << 24 | plane-local id of the parent; CAS-ed by k_seam
+    uint32_t cnt;           // pixels: own -> subtree total
+    uint32_t nod;           // bits 0..23 nodes: 1 -> subtree total (pruned ones included); bits 24.. NODE_* flags
+    uint32_t key;           // bits 0..23 min linear pixel index of the node's own-level pixels; bits 24..31 the node's level
+    uint32_t x0, y0, x1, y1; // bbox: own -> subtree (atomicMin / atomicMax)
+};
+static_assert(sizeof(NodeRec) == 32, "two dwordx4 stores");
+constexpr uint32_t NODE_DEAD = 1u << 24;     // unified into another node of the same level (k_resolve)
+constexpr uint32_t NODE_CLOSED = 2u << 24;   // never touches a seam: totals were final in the tile, never pushes
+constexpr uint32_t NODE_CNT = 0xFFFFFFu;
 struct NodeArrays {
-    uint32_t *par;          // parent node id (plane-local), NONE for a tree root
-    uint8_t  *lvl;          // quantised level (immutable after the tile kernel)
-    uint32_t *cnt;          // pixels:  own -> subtree total
-    uint32_t *nod;          // nodes:   1   -> subtree total (pruned ones included)
-    uint32_t *x0, *y0, *x1, *y1; // bbox: own -> subtree
-    uint32_t *key;          // min linear pixel index of the node's own-level pixels
-    uint32_t *kmap;         // node id -> kept slot
-    uint8_t  *dead;         // 1 = unified into another node of the same level
+    NodeRec  *rec;
+    uint32_t *aux;          // per node: open pushing children not yet accumulated (k_resolve -> k_reduce), then node id -> kept slot (k_select -> k_kept)
 };
 
 // Kept-node storage (index = PlaneDesc::kept_base + slot).

@@ -40,10 +40,7 @@ struct HostCascade {
     CascadeDev dev{};
 };
 
-struct NodeRec { // == str_er_node
-    uint32_t key; int32_t parent; int32_t area; uint16_t x, y, w, h; uint8_t level, flags; uint16_t reserved;
-};
-static_assert(sizeof(NodeRec) == sizeof(str_er_node), "node layout");
+static_assert(sizeof(str_er_node) == 24, "node layout");
 static_assert(sizeof(CandRec) == sizeof(str_er_cand), "cand layout");
 
 struct PlaneGeom { int w, h, stride; size_t off; }; // physical planes of one pyramid level
@@ -96,14 +93,13 @@ struct str_er_ctx {
     PlaneCtr *d_ctr = nullptr;
     NodeArrays na{};
     KeptArrays ka{};
-    uint32_t *d_seam = nullptr; size_t seam_slots = 0;
+    uint16_t *d_seam = nullptr; size_t seam_slots = 0;
+    size_t node_slots = 0;            // node records allocated (NodeArrays::rec / aux)
+    double node_share = 0.25;         // records per padded plane pixel; grown (and the batch repeated) when a plane runs out
     uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
     std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
     std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
-    uint32_t *d_lvl = nullptr, *d_node_list = nullptr, *d_tile_off = nullptr; size_t node_list_cap = 0;
-    uint16_t *d_list_key = nullptr;
-    uint32_t *d_acc_list = nullptr, *d_acc_parent = nullptr, *d_lvl_tab = nullptr;
-    uint32_t *d_tile_cnt = nullptr; uint8_t *d_tile_lo = nullptr, *d_tile_hi = nullptr; size_t tile_slots = 0;
+    uint32_t *d_tile_nbase = nullptr; size_t tile_slots = 0;
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr;
     TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
@@ -114,7 +110,6 @@ struct str_er_ctx {
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
     uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
     uint16_t *d_cand_plane = nullptr;
-    NodeRec *d_nodes = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
     std::vector<void *> allocs;
 
@@ -158,6 +153,21 @@ template <typename T> int dev_alloc(str_er_ctx *c, T *&p, size_t n)
     c->allocs.push_back(v);
     c->ws_bytes += (int64_t)bytes;
     p = static_cast<T *>(v);
+    return STR_ER_OK;
+}
+
+// The node records (32 B + 4 B per record) are the one part of the workspace whose need depends on the frames' content: they
+// are allocated for `node_share` records per pixel and re-allocated larger when a batch overflows them (run_batch).
+int alloc_node_records(str_er_ctx *c, size_t n)
+{
+    if (c->na.rec) { (void)hipFree(c->na.rec); c->ws_bytes -= (int64_t)(c->node_slots * sizeof(NodeRec)); c->na.rec = nullptr; }
+    if (c->na.aux) { (void)hipFree(c->na.aux); c->ws_bytes -= (int64_t)(c->node_slots * 4); c->na.aux = nullptr; }
+    c->node_slots = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&c->na.rec), n * sizeof(NodeRec)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->na.aux), n * 4) != hipSuccess)
+        return fail(c, STR_ER_ENOMEM, "hipMalloc (node records, " + std::to_string(n * 36) + " bytes)");
+    c->node_slots = n;
+    c->ws_bytes += (int64_t)(n * 36);
     return STR_ER_OK;
 }
 
@@ -315,8 +325,8 @@ int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
 // ---- batch layout -------------------------------------------------------------------------------
 struct Batch {
     std::vector<PlaneDesc> planes;
-    uint32_t n_tiles = 0, n_pairs = 0, max_nodes_plane = 0;
-    size_t slots = 0, seam = 0;
+    uint32_t n_tiles = 0, n_pairs = 0;
+    size_t slots = 0, seam = 0, nodes = 0;      // padded pixels, seam entries, node records
     int planes_per_image = 0;       // BGR frames: planes of one (frame, pyramid level), consecutive in `planes`; 0 = no colour image
 };
 
@@ -330,26 +340,38 @@ void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int inver
     d.n_hpairs = (uint32_t)w * (d.tiles_y - 1);
     d.n_pairs = d.n_hpairs + (uint32_t)h * (d.tiles_x - 1);
     d.pair_base = b.n_pairs; b.n_pairs += d.n_pairs;
-    d.node_base = (uint32_t)b.slots; b.slots += (size_t)d.tiles_x * d.tiles_y * TILE_PX;
+    b.slots += (size_t)d.tiles_x * d.tiles_y * TILE_PX;      // (node records are laid out by assign_node_records)
     d.seam_base = (uint32_t)b.seam; b.seam += 2 * (size_t)d.n_pairs;
     d.kept_base = (uint32_t)(b.planes.size() * (size_t)kept_cap);
     d.pool_base = (uint32_t)(b.planes.size() * (size_t)pool_cap);
     d.frame = frame; d.ch = (uint8_t)ch; d.pyr = (uint8_t)pyr;
-    b.max_nodes_plane = std::max<uint32_t>(b.max_nodes_plane, (uint32_t)d.tiles_x * d.tiles_y * TILE_PX);
     b.planes.push_back(d);
+}
+
+// Node records: every plane gets `share` records per padded pixel (+ a floor for tiny planes), never more than one per pixel.
+size_t plane_node_cap(int tiles, double share)
+{
+    const size_t px = (size_t)tiles * TILE_PX;
+    return std::min<size_t>(px, (size_t)std::ceil((double)px * share) + 256);
+}
+void assign_node_records(Batch &b, double share)
+{
+    b.nodes = 0;
+    for (PlaneDesc &d : b.planes) {
+        d.node_base = (uint32_t)b.nodes;
+        d.node_cap = (uint32_t)plane_node_cap(d.tiles_x * d.tiles_y, share);
+        b.nodes += d.node_cap;
+    }
 }
 
 BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
 {
     BatchDev d{};
     d.planes = c->d_planes; d.ctr = c->d_ctr; d.n_planes = (int32_t)b.planes.size();
-    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.max_nodes_plane = b.max_nodes_plane;
+    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs;
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
-    d.tile_off = c->d_tile_off; d.chunk_sum = c->d_lvl; d.n_listed = c->d_lvl + 8192; d.node_list = c->d_node_list; d.list_key = c->d_list_key;
-    d.node_list_cap = (uint32_t)c->node_list_cap;
-    d.acc_list = c->d_acc_list; d.acc_parent = c->d_acc_parent; d.lvl_tab = c->d_lvl_tab;
-    d.na = c->na; d.ka = c->ka; d.tile_cnt = c->d_tile_cnt; d.tile_lo = c->d_tile_lo; d.tile_hi = c->d_tile_hi; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
+    d.na = c->na; d.ka = c->ka; d.tile_nbase = c->d_tile_nbase; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch;
     return d;
 }
@@ -629,15 +651,22 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
 }
 
 // Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
-int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **out,
+int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result **out,
               std::chrono::steady_clock::time_point t_start, bool pre_recorded)
 {
+    Batch b = b_in;
+    assign_node_records(b, c->node_share);
+    const int ev_entry = pre_recorded ? c->n_ev : -1;
     const int np = (int)b.planes.size();
     if (np == 0) return fail(c, STR_ER_EINVAL, "no planes");
     if (np > c->max_planes) return fail(c, STR_ER_ECAPACITY, "more planes than the context was created for");
     if (b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "planes exceed the pixel capacity of the context");
     if (b.seam > c->seam_slots) return fail(c, STR_ER_ECAPACITY, "seam map capacity exceeded");
     if (b.n_tiles > c->tile_slots) return fail(c, STR_ER_ECAPACITY, "tile table capacity exceeded");
+    if (b.nodes > c->node_slots) {       // (a layout with many tiny planes: the per-plane floor adds up)
+        const int rcn = alloc_node_records(c, b.nodes + b.nodes / 8);
+        if (rcn != STR_ER_OK) return rcn;
+    }
     if ((stages & STR_ER_STAGE_CLASSIFY) && !(c->casc[0].loaded && c->casc[1].loaded))
         return fail(c, STR_ER_ESTATE, "classify needs both cascades (str_er_load_cascade)");
     if (!(stages & STR_ER_STAGE_EXTRACT)) return fail(c, STR_ER_EINVAL, "stages must include STR_ER_STAGE_EXTRACT");
@@ -697,11 +726,8 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
     launch_seam(s, bd, !c->tile_sparse);                                        rec(c, "seam");
-    launch_level_prefix(s, bd);
     launch_resolve(s, bd);                            rec(c, "resolve");
-    launch_accumulate_prepare(s, bd);
-    for (int t = 0; t < dp.hi; ++t) launch_accumulate(s, bd, t);
-    rec(c, "accumulate");
+    launch_reduce(s, bd);                             rec(c, "accumulate");
     launch_root(s, bd, dp);
     launch_select(s, bd, dp);
     launch_kept(s, bd, dp);                           rec(c, "select");
@@ -731,6 +757,23 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    {   // a plane ran out of node records: the counters say how many it wanted -- grow the share and do the batch again
+        double need = 0;
+        for (int i = 0; i < np; ++i)
+            if (c->h_ctr[i].overflow & 8u)
+                need = std::max(need, (double)c->h_ctr[i].n_nodes / (double)((size_t)b.planes[i].tiles_x * b.planes[i].tiles_y * TILE_PX));
+        if (need > 0) {
+            if (c->node_share >= 1.0) return fail(c, STR_ER_ECAPACITY, "node records exhausted at one record per pixel (internal error)");
+            c->node_share = std::min(1.0, std::max(c->node_share * 1.5, need * 1.25));
+            const size_t want = (size_t)std::ceil((double)c->slots * c->node_share) + 256 * (size_t)c->max_planes;
+            if (want > c->node_slots) {
+                const int rcn = alloc_node_records(c, want);
+                if (rcn != STR_ER_OK) return rcn;
+            }
+            if (ev_entry >= 0) { c->n_ev = ev_entry; c->profile.resize((size_t)ev_entry); }
+            return run_batch(c, b_in, stages, out, t_start, pre_recorded);
+        }
+    }
     if ((stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0) {
         bool replayed = false;
         const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed);
@@ -746,20 +789,16 @@ int run_batch(str_er_ctx *c, const Batch &b, uint32_t stages, str_er_result **ou
     }
 
     if (c->dbg_stats) {     // developer aid: how many nodes left the tiles
-        std::vector<uint32_t> tc(b.n_tiles);
-        if (hipMemcpy(tc.data(), c->d_tile_cnt, 4 * (size_t)b.n_tiles, hipMemcpyDeviceToHost) == hipSuccess) {
-            unsigned long long tot = 0, mx = 0, created = 0;
-            for (uint32_t v : tc) { tot += v; mx = std::max<unsigned long long>(mx, v); }
-            for (int i = 0; i < np; ++i) created += c->h_ctr[i].n_created;
-            std::fprintf(stderr, "[str_er] tiles %u exported nodes %llu (max/tile %llu) created %llu seam pairs %u\n", b.n_tiles, tot, mx, created, b.n_pairs);
-        }
+        unsigned long long tot = 0, created = 0;
+        for (int i = 0; i < np; ++i) { created += c->h_ctr[i].n_created; tot += c->h_ctr[i].n_nodes; }
+        std::fprintf(stderr, "[str_er] tiles %u exported nodes %llu (%.1f per tile; share %.3f of %.3f) created %llu seam pairs %u\n", b.n_tiles, tot,
+                     (double)tot / b.n_tiles, (double)tot / (double)b.slots, c->node_share, created, b.n_pairs);
     }
     for (int i = 0; i < np; ++i) {
         if (c->h_ctr[i].overflow & 1u)
             return fail(c, STR_ER_ECAPACITY, "kept-node table overflow: plane " + std::to_string(i) + " has " +
                         std::to_string(c->h_ctr[i].n_kept) + " kept nodes, kept_cap = " + std::to_string(c->kept_cap));
         if (c->h_ctr[i].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
-        if (c->h_ctr[i].overflow & 4u) return fail(c, STR_ER_ECAPACITY, "exported-node list overflow (more than half of the pixels are open tree nodes)");
     }
     if (c->tile_mode == 0 && b.n_tiles) {      // text-like frames make a few dozen nodes per tile, noise several hundred
         unsigned long long created = 0;
@@ -990,6 +1029,8 @@ void str_er_destroy(str_er_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_replay) (void)hipFree(c->d_replay);
+    if (c->na.rec) (void)hipFree(c->na.rec);
+    if (c->na.aux) (void)hipFree(c->na.aux);
     if (c->d_group) (void)hipFree(c->d_group);
     if (c->d_group_pairs) (void)hipFree(c->d_group_pairs);
     for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
@@ -1063,10 +1104,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_pix, c->pix_bytes));
     A(dev_alloc(c, c->d_planes, (size_t)c->max_planes));
     A(dev_alloc(c, c->d_ctr, (size_t)c->max_planes));
-    A(dev_alloc(c, c->na.par, S)); A(dev_alloc(c, c->na.lvl, S)); A(dev_alloc(c, c->na.dead, S));
-    A(dev_alloc(c, c->na.cnt, S)); A(dev_alloc(c, c->na.nod, S));
-    A(dev_alloc(c, c->na.x0, S)); A(dev_alloc(c, c->na.y0, S)); A(dev_alloc(c, c->na.x1, S)); A(dev_alloc(c, c->na.y1, S));
-    A(dev_alloc(c, c->na.key, S)); A(dev_alloc(c, c->na.kmap, S));
+    A(alloc_node_records(c, (size_t)std::ceil((double)S * c->node_share) + 256 * (size_t)c->max_planes));
     A(dev_alloc(c, c->ka.node, KP)); A(dev_alloc(c, c->ka.key, KP)); A(dev_alloc(c, c->ka.area, KP));
     A(dev_alloc(c, c->ka.parent, KP)); A(dev_alloc(c, c->ka.box, 4 * KP)); A(dev_alloc(c, c->ka.level, KP));
     A(dev_alloc(c, c->ka.start, KP)); A(dev_alloc(c, c->ka.ncand, KP)); A(dev_alloc(c, c->ka.best, KP));
@@ -1074,10 +1112,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     c->tile_slots = c->slots / TILE_PX + 16;
     c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
-    c->node_list_cap = c->slots / 2 + 4096;
-    A(dev_alloc(c, c->d_lvl, 8192 + 64)); A(dev_alloc(c, c->d_node_list, c->node_list_cap)); A(dev_alloc(c, c->d_list_key, c->node_list_cap)); A(dev_alloc(c, c->d_acc_list, c->node_list_cap)); A(dev_alloc(c, c->d_acc_parent, c->node_list_cap)); A(dev_alloc(c, c->d_lvl_tab, 520));   // chunk sums of the offset scan + total
-    A(dev_alloc(c, c->d_tile_off, c->tile_slots));
-    A(dev_alloc(c, c->d_tile_cnt, c->tile_slots)); A(dev_alloc(c, c->d_tile_lo, c->tile_slots)); A(dev_alloc(c, c->d_tile_hi, c->tile_slots));
+    A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
     A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
