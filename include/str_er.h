@@ -302,6 +302,12 @@ int str_er_nms_tree_plane(str_er_ctx *ctx, const str_er_node *nodes, int32_t n_n
                           const uint8_t *plane, int32_t cols, int32_t rows, int64_t stride,
                           int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous);
 
+/* The order in which the reference's flood (er_tree_extract, src/ER.cpp:240-374) first reaches the pixels
+ * of a host plane: stamp[y*w+x] = 1-based position, 0 = never reached (sealed off by sentinel-level
+ * pixels).  This is the walk that decides NMS sibling ties (sibling_order = 0); it runs on the calling
+ * thread, needs no context and no GPU, and is exported so that the tie-break can be checked on its own. */
+int str_er_flood_order(const uint8_t *plane, int32_t w, int32_t h, int64_t stride, int32_t thresh_step, uint32_t *stamp);
+
 /* Build-defined pyramid primitive (no reference counterpart): fixed-point bilinear
  * resize of one host plane, same arithmetic as cv::resize INTER_LINEAR 8UC1.         */
 int str_er_resize_plane(str_er_ctx *ctx, const uint8_t *src, int32_t sw, int32_t sh,

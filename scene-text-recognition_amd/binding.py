@@ -128,6 +128,7 @@ def load_library():
     L.str_er_ocr_chain_run_slope.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int32, vp, vp, vp]
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
     L.str_er_nms_tree_plane.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, i32p, i32p]
+    L.str_er_flood_order.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp]
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
     L.str_er_result_n_planes.restype = C.c_int32
@@ -584,6 +585,17 @@ class ERFilter:
 
     def workspace_bytes(self) -> int:
         return int(self.L.str_er_workspace_bytes(self.h))
+
+
+def flood_order(plane: np.ndarray, thresh_step: int = 8) -> np.ndarray:
+    """str_er_flood_order: (h, w) uint32, 1-based order in which the reference's flood first reaches each pixel (0: never)."""
+    a = np.ascontiguousarray(plane, dtype=np.uint8)
+    h, w = a.shape
+    out = np.zeros((h, w), np.uint32)
+    rc = load_library().str_er_flood_order(_np_ptr(a), w, h, w, thresh_step, _np_ptr(out))
+    if rc != 0:
+        raise StrErError(rc, "str_er_flood_order")
+    return out
 
 
 class FrameStream:

@@ -1256,28 +1256,40 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // er_merge's accumulation (src/ER.cpp:153-165): every live open node adds its (final) totals to its parent.  One launch for
 // the whole tree: aux[q] counts the children of q that still have to push (k_resolve).  A node may push once its counter is 0;
 // whoever CLAIMS it (CAS 0 -> CLAIMED) does: the lane that meets it in the node sweep, or the lane whose push just brought the
-// counter to 0 and that then carries on towards the root.  Counter and claim are agent-scope acquire/release and all totals are
-// read and written with agent-scope atomics, so the pushes of other CUs (other XCDs, whose L2s are not coherent with this one)
-// are visible to the lane that continues.  (Round 1 launched once per level: ~32 dependent launches per batch -- the whole
-// cost of the step on small batches and on noise.)
+// counter to 0 and that then carries on towards the root.  Every word involved -- totals, counters -- is only ever touched with
+// agent-scope atomics, which are performed at the device's coherence point (the per-XCD L2s are not coherent with each other), so
+// no cache has to be written back or invalidated: the ordering "my pushes, then my decrement" / "the claim, then my reads" only
+// needs the lane to wait for its own outstanding operations (a workgroup-scope fence = s_waitcnt; an agent-scope acquire /
+// release would write back and invalidate the whole L2 per node -- measured: 20 ms instead of 0.5 per batch).
+// (Round 1 launched once per level: ~32 dependent launches per batch -- the whole cost of the step on small batches and on noise.)
 #define RMW_AGENT(op, p, v) __hip_atomic_fetch_##op((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 constexpr uint32_t NODE_CLAIMED = 0xFFFFFFFFu;
 
-__device__ __forceinline__ void node_push(NodeRec *dst, uint32_t c, uint32_t nd, uint32_t bx0, uint32_t by0, uint32_t bx1, uint32_t by1)
+// The pushes are RETURNING atomics and node_arrive makes the counter decrement depend on what they returned: a returned value
+// comes from the coherence point, so the push has been performed there before the decrement is even issued.  (Waiting for the
+// acknowledgement of non-returning atomics -- s_waitcnt vmcnt(0), a workgroup-scope release -- is not enough: measured, subtree
+// totals came out short now and then.)
+__device__ __forceinline__ uint32_t node_push(NodeRec *dst, uint32_t c, uint32_t nd, uint32_t bx0, uint32_t by0, uint32_t bx1, uint32_t by1)
 {
-    RMW_AGENT(add, &dst->cnt, c); RMW_AGENT(add, &dst->nod, nd);
-    RMW_AGENT(min, &dst->x0, bx0); RMW_AGENT(min, &dst->y0, by0);
-    RMW_AGENT(max, &dst->x1, bx1); RMW_AGENT(max, &dst->y1, by1);
+    uint32_t r = RMW_AGENT(add, &dst->cnt, c);
+    r |= RMW_AGENT(add, &dst->nod, nd);
+    r |= RMW_AGENT(min, &dst->x0, bx0); r |= RMW_AGENT(min, &dst->y0, by0);
+    r |= RMW_AGENT(max, &dst->x1, bx1); r |= RMW_AGENT(max, &dst->y1, by1);
+    return r;
 }
 __device__ __forceinline__ bool node_claim(uint32_t *ctr)
 {
     uint32_t expect = 0;
-    return __hip_atomic_compare_exchange_strong(ctr, &expect, NODE_CLAIMED, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t won = __hip_atomic_compare_exchange_strong(ctr, &expect, NODE_CLAIMED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    asm volatile("" : "+v"(won) : : "memory");       // the reads of the node's totals are issued after the claim has returned
+    return won != 0;
 }
-// children done: `k` of them just pushed into the node with counter `ctr`; true if the caller now owns the node
-__device__ __forceinline__ bool node_arrive(uint32_t *ctr, uint32_t k)
+// children done: `k` of them just pushed into the node with counter `ctr` (`pushed` = what node_push returned); true if the
+// caller now owns the node
+__device__ __forceinline__ bool node_arrive(uint32_t *ctr, uint32_t k, uint32_t pushed)
 {
-    if (__hip_atomic_fetch_sub(ctr, k, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != k) return false;
+    asm volatile("" : "+v"(k) : "v"(pushed) : "memory");
+    if (__hip_atomic_fetch_sub(ctr, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != k) return false;
     return node_claim(ctr);
 }
 
@@ -1311,18 +1323,12 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
             const unsigned long long m = __ballot(mine);
             const uint32_t k = (uint32_t)__popcll(m);
             if (k == 1) {
-                if (mine) {
-                    node_push(nr + lq, c, nd, bx0, by0, bx1, by1);
-                    cont = node_arrive(&aux[lq], 1u);
-                }
+                if (mine) cont = node_arrive(&aux[lq], 1u, node_push(nr + lq, c, nd, bx0, by0, bx1, by1));
             } else {
                 const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
                 const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
                 const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
-                if (lane == leader) {
-                    node_push(nr + lq, sc, sn, mx0, my0, mx1, my1);
-                    cont = node_arrive(&aux[lq], k);
-                }
+                if (lane == leader) cont = node_arrive(&aux[lq], k, node_push(nr + lq, sc, sn, mx0, my0, mx1, my1));
             }
             todo &= ~m;
         }
@@ -1332,8 +1338,8 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
             const uint32_t w = LD_AGENT(&nr[g].par), f = LD_AGENT(&nr[g].nod);
             if (w == NONE || (f & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
             const uint32_t p = PAR_ID(w);
-            node_push(nr + p, LD_AGENT(&nr[g].cnt), f & NODE_CNT, LD_AGENT(&nr[g].x0), LD_AGENT(&nr[g].y0), LD_AGENT(&nr[g].x1), LD_AGENT(&nr[g].y1));
-            cont = node_arrive(&aux[p], 1u);
+            cont = node_arrive(&aux[p], 1u, node_push(nr + p, LD_AGENT(&nr[g].cnt), f & NODE_CNT, LD_AGENT(&nr[g].x0), LD_AGENT(&nr[g].y0),
+                                                      LD_AGENT(&nr[g].x1), LD_AGENT(&nr[g].y1)));
             g = p;
         }
     }
@@ -1476,7 +1482,15 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // flood and cannot be derived locally, so:
 //   pass 0 (all planes) decides ties by key (largest / smallest, DetectParams::sibling_order)
 //          and counts them (n_amb).  No tie -> the result does not depend on any order.
-//   exact mode (sibling_order 0): for the planes with ties k_flood_order replays the
+//          A tie at a node X whose box covers so much of the plane that every chain able to claim X or an ancestor of X
+//          starts at a node failing the size filter of src/ER.cpp:489-490 (w < 0.8 cols && h < 0.8 rows) cannot change the
+//          pool: such a start has bbox area > OVERLAP_COEF * area(X) >= 0.64 rows cols, so it and all chain members above it
+//          are too big to be accepted, whoever wins; chains with acceptable starts never reach X.  Only the other ties count
+//          in n_rel ("relevant") -- ties between background-sized regions are frequent on noisy frames, relevant ones are rare.
+//   pass "alt" (exact mode, planes whose only tie is one relevant two-way tie): the NMS again under the opposite key rule.
+//          Below the tie nothing is a choice, and if the alt pass meets the same single tie and no other, the two passes are
+//          the only two outcomes there are; if their pools are equal the tie does not matter and n_rel is cleared.
+//   exact mode (sibling_order 0): for the planes with relevant ties left k_flood_order replays the
 //          reference's flood and stamps every pixel with the order in which it became
 //          accessible; pass 1 repeats the NMS of those planes with ties decided by the
 //          stamp of each child's key pixel (any pixel of a basin would do: the access
@@ -1488,14 +1502,17 @@ constexpr int NMS_SORT_CAP = 4096;       // pooled ERs of a plane whose keys are
 
 // order word of a child in a tie: the smallest one wins
 enum { NMS_ORD_KEY_MAX = 0, NMS_ORD_KEY_MIN = 1, NMS_ORD_INDEX = 2, NMS_ORD_STAMP = 3 };
+enum { NMS_PASS_FIRST = 0, NMS_PASS_ALT = 1, NMS_PASS_STAMP = 2 };
 
-__global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm, const ReplayItem *items, const uint8_t *scratch, int ord_mode)
+__global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams prm, const ReplayItem *items, const uint8_t *scratch, int ord_mode, int pass)
 {
-    __shared__ uint32_t s_npool;
+    __shared__ uint32_t s_npool, s_alt_amb, s_alt_node, s_alt_nc, s_alt_diff;
     __shared__ uint32_t s_levels[8];
-    const bool       pass1 = items != nullptr;
-    const int        pi = pass1 ? (int)items[blockIdx.x].plane : (int)blockIdx.x;
+    const bool       pass1 = pass != NMS_PASS_FIRST;          // a repeat: the plane's counters stay as the first pass left them
+    const bool       alt = pass == NMS_PASS_ALT;
+    const int        pi = pass == NMS_PASS_STAMP ? (int)items[blockIdx.x].plane : (int)blockIdx.x;
     PlaneCtr        &c = b.ctr[pi];
+    if (alt && !(c.n_rel != 0 && c.n_amb == 1 && c.tie_nc == 2)) return;
     const PlaneDesc &pd = b.planes[pi];
     const size_t     kb = pd.kept_base, pb = pd.pool_base;
     const uint32_t   K = min(c.n_kept, (uint32_t)prm.kept_cap);
@@ -1509,10 +1526,11 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     const uint32_t  *kkey = b.ka.key + kb;
     const int        maxl = (int)c.max_level;
     const uint32_t   root = c.root_slot;
-    const uint32_t  *stamp = pass1 ? reinterpret_cast<const uint32_t *>(scratch + items[blockIdx.x].off) : nullptr;
+    const double     rel_area = 0.8 * (double)pd.w * 0.8 * (double)pd.h * (1.0 + 1e-9);   // OVERLAP_COEF * area(X) below this: the tie at X is relevant
+    const uint32_t  *stamp = pass == NMS_PASS_STAMP ? reinterpret_cast<const uint32_t *>(scratch + items[blockIdx.x].off) : nullptr;
 
     for (int i = tid; i < 8; i += NMS_THREADS) s_levels[i] = 0;
-    if (tid == 0) s_npool = 0;
+    if (tid == 0) { s_npool = 0; s_alt_amb = 0; s_alt_node = NONE; s_alt_nc = 0; s_alt_diff = 0; }
     __syncthreads();
     for (uint32_t i = tid; i < K; i += NMS_THREADS) {
         kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull;
@@ -1533,7 +1551,12 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
                 const uint32_t child = (uint32_t)(LD_AGENT(&kbest[i]) & 0xFFFFFFFFull);
                 s = kstart[child];
                 kstart[i] = s;
-                if (nc > 1 && !pass1) atomicAdd(&c.n_amb, 1u);
+                if (nc > 1 && !pass1) {
+                    atomicAdd(&c.n_amb, 1u);
+                    c.tie_node = i; c.tie_nc = nc;
+                    if ((double)((int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]) * prm.overlap_coef < rel_area) atomicAdd(&c.n_rel, 1u);
+                }
+                if (nc > 1 && alt) { atomicAdd(&s_alt_amb, 1u); s_alt_node = i; s_alt_nc = nc; }
             }
             if (i == root) continue;
             const uint32_t P = (uint32_t)kpar[i];
@@ -1555,7 +1578,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     // on how lower ties were decided, so the list holds every child that COULD compete whatever the order: a chain start
     // lies inside its child's box, so only children whose own box covers more than OVERLAP_COEF of the parent's can pass, and
     // a parent needs two of them.
-    if (!pass1 && prm.sibling_order == 0 && ord_mode != NMS_ORD_INDEX && LD_AGENT(&c.n_amb) != 0) {
+    if (!pass1 && prm.sibling_order == 0 && ord_mode != NMS_ORD_INDEX && LD_AGENT(&c.n_rel) != 0) {
         for (uint32_t i = tid; i < K; i += NMS_THREADS) kncand[i] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < K; i += NMS_THREADS) {
@@ -1569,7 +1592,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
             if (i == root) continue;
             const uint32_t P = (uint32_t)kpar[i];
             const int ai = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3], ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
-            if ((double)ai / (double)ap > prm.overlap_coef && kncand[P] > 1) {
+            if ((double)ai / (double)ap > prm.overlap_coef && kncand[P] > 1 && (double)ap * prm.overlap_coef < rel_area) {
                 const uint32_t at = atomicAdd(&c.n_watch, 1u);
                 if (at < (uint32_t)NMS_WATCH_CAP) b.watch[(size_t)pi * NMS_WATCH_CAP + at] = kkey[i];
             }
@@ -1616,6 +1639,8 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     // order the pool by key (keys are unique inside a plane): rank = number of smaller keys.  The keys are staged in LDS
     // first -- ranking straight from the tables is two dependent global loads per comparison, the longest part of the kernel
     __shared__ uint32_t s_keys[NMS_SORT_CAP];
+    // (the alt pass only compares: is its pool the first pass's pool?)
+    if (alt && np != c.n_pool) s_alt_diff = 1;
     if (np <= (uint32_t)NMS_SORT_CAP) {
         for (uint32_t i = tid; i < np; i += NMS_THREADS) s_keys[i] = kkey[b.pool_tmp[pb + i]];
         __syncthreads();
@@ -1623,15 +1648,24 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
             const uint32_t mk = s_keys[i];
             uint32_t       rank = 0;
             for (uint32_t j = 0; j < np; ++j) rank += s_keys[j] < mk;
-            b.pool[pb + rank] = b.pool_tmp[pb + i];
+            if (!alt) b.pool[pb + rank] = b.pool_tmp[pb + i];
+            else if (rank >= c.n_pool || b.pool[pb + rank] != b.pool_tmp[pb + i]) s_alt_diff = 1;
         }
     } else {
         for (uint32_t i = tid; i < np; i += NMS_THREADS) {
             const uint32_t me = b.pool_tmp[pb + i], mk = kkey[me];
             uint32_t       rank = 0;
             for (uint32_t j = 0; j < np; ++j) rank += kkey[b.pool_tmp[pb + j]] < mk;
-            b.pool[pb + rank] = me;
+            if (!alt) b.pool[pb + rank] = me;
+            else if (rank >= c.n_pool || b.pool[pb + rank] != me) s_alt_diff = 1;
         }
+    }
+    if (alt) {
+        __syncthreads();
+        // the same single two-way tie and no other one, and the same pool: whichever child the reference's flood entered last,
+        // the pool is this one
+        if (tid == 0 && s_alt_diff == 0 && s_alt_amb == 1 && s_alt_node == c.tie_node && s_alt_nc == 2) { c.n_rel = 0; c.n_watch = 0; }
+        return;
     }
     if (tid == 0) c.n_pool = np;
 }
@@ -1640,13 +1674,17 @@ void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool us
 {
     if (!b.n_planes) return;
     const int mode = (use_index_order && p.sibling_order == 0) ? NMS_ORD_INDEX : (p.sibling_order == 1 ? NMS_ORD_KEY_MIN : NMS_ORD_KEY_MAX);
-    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, mode);
+    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, mode, (int)NMS_PASS_FIRST);
+    // exact mode: planes whose only tie is one two-way tie are tried under the opposite rule; equal pools settle them
+    if (p.sibling_order == 0 && mode == NMS_ORD_KEY_MAX)
+        hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, (int)NMS_ORD_KEY_MIN,
+                           (int)NMS_PASS_ALT);
 }
 
 void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, const uint8_t *scratch)
 {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(k_nms, dim3(n_items), dim3(NMS_THREADS), 0, s, b, p, items, scratch, (int)NMS_ORD_STAMP);
+    hipLaunchKernelGGL(k_nms, dim3(n_items), dim3(NMS_THREADS), 0, s, b, p, items, scratch, (int)NMS_ORD_STAMP, (int)NMS_PASS_STAMP);
 }
 
 // ------------------------------------------------------------------------------------

@@ -60,9 +60,12 @@ struct PlaneCtr {
     uint32_t root_slot;     // kept slot of the root
     uint32_t max_level;     // highest level among kept nodes (bounds the NMS sweep)
     uint32_t n_watch;       // NMS: children that may compete for their parent (their key pixels are what the flood replay must reach)
-    uint32_t pad_;
+    uint32_t n_rel;         // NMS: ties that can change the pool (n_amb counts all ties); > 0 -> the plane's flood is replayed
+    uint32_t tie_node;      // NMS: kept slot of a node with a tie and the number of its contenders (meaningful when n_amb == 1)
+    uint32_t tie_nc;
+    uint32_t pad_[2];
 };
-static_assert(sizeof(PlaneCtr) == 64, "PlaneCtr is mirrored in pinned host memory");
+static_assert(sizeof(PlaneCtr) == 80, "PlaneCtr is mirrored in pinned host memory");
 
 // One plane whose NMS has to be decided by the reference's flood order (k_flood_order, then k_nms pass 1).
 struct ReplayItem {

@@ -23,6 +23,8 @@
 #include "svm_kernels.h"
 #include "track_kernels.h"
 #include "er_group.h"
+#include "flood_order.h"
+#include <thread>
 
 using namespace str_er;
 
@@ -109,6 +111,7 @@ struct str_er_ctx {
     ReplayItem *d_replay_items = nullptr;
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
     uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
+    bool replay_on_gpu = false;                       // STR_ER_REPLAY=gpu: walk the flood with k_flood_order instead of a host core
     uint16_t *d_cand_plane = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
     std::vector<void *> allocs;
@@ -607,12 +610,15 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
     replayed = false;
     std::vector<int> amb;
     size_t largest = 0, total = 0;
+    auto scratch_need = [&](int i) -> size_t {
+        const PlaneDesc &pd = b.planes[i];
+        return c->replay_on_gpu ? replay_scratch_bytes(pd.w, pd.h) : (((size_t)pd.w * pd.h * 4 + 255) / 256) * 256;    // host walk: only the stamps go to the device
+    };
     for (int i = 0; i < (int)b.planes.size(); ++i)
-        if (c->h_ctr[i].n_amb) {
+        if (c->h_ctr[i].n_rel) {         // ties that can change the pool (k_nms); the others need no decision
             amb.push_back(i);
-            const size_t need = replay_scratch_bytes(b.planes[i].w, b.planes[i].h);
-            largest = std::max(largest, need);
-            total += need;
+            largest = std::max(largest, scratch_need(i));
+            total += scratch_need(i);
         }
     if (amb.empty()) return STR_ER_OK;
     const size_t want = std::max(largest, std::min<size_t>(total, (size_t)1 << 30));
@@ -627,7 +633,39 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
     auto flush = [&]() -> int {
         if (items.empty()) return STR_ER_OK;
         HIP_TRY(c, hipMemcpyAsync(c->d_replay_items, items.data(), sizeof(ReplayItem) * items.size(), hipMemcpyHostToDevice, s));
-        launch_flood_order(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
+        if (c->replay_on_gpu) {
+            launch_flood_order(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
+        } else {
+            // the walk on host cores, one thread per plane: plane pixels and watch list come down, the stamps go up
+            const size_t m = items.size();
+            std::vector<std::vector<uint8_t>> pix(m);
+            std::vector<std::vector<uint32_t>> watch(m), stamp(m);
+            for (size_t k = 0; k < m; ++k) {
+                const PlaneDesc &pd = b.planes[items[k].plane];
+                pix[k].resize((size_t)pd.w * pd.h);
+                HIP_TRY(c, hipMemcpy2DAsync(pix[k].data(), (size_t)pd.w, pd.pix, (size_t)pd.stride, (size_t)pd.w, (size_t)pd.h, hipMemcpyDeviceToHost, s));
+                const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
+                if (nw <= (uint32_t)NMS_WATCH_CAP) {
+                    watch[k].resize(nw);
+                    if (nw) HIP_TRY(c, hipMemcpyAsync(watch[k].data(), c->d_watch + (size_t)items[k].plane * NMS_WATCH_CAP, 4 * (size_t)nw, hipMemcpyDeviceToHost, s));
+                }
+            }
+            HIP_TRY(c, hipStreamSynchronize(s));
+            auto walk = [&](size_t k) {
+                const PlaneDesc &pd = b.planes[items[k].plane];
+                const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
+                stamp[k].assign((size_t)pd.w * pd.h, 0u);
+                flood_order_host(pix[k].data(), pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, watch[k].data(),
+                                 nw <= (uint32_t)NMS_WATCH_CAP ? nw : 0xFFFFFFFFu, stamp[k].data());
+            };
+            std::vector<std::thread> th;
+            for (size_t k = 1; k < m; ++k) th.emplace_back(walk, k);
+            walk(0);
+            for (auto &t : th) t.join();
+            for (size_t k = 0; k < m; ++k)
+                HIP_TRY(c, hipMemcpyAsync(c->d_replay + items[k].off, stamp[k].data(), 4 * stamp[k].size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipStreamSynchronize(s));       // the host vectors go out of scope
+        }
         launch_nms_resolve(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(s));       // the item table and the scratch are reused by the next round
@@ -637,7 +675,7 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
         return STR_ER_OK;
     };
     for (int i : amb) {
-        const size_t need = replay_scratch_bytes(b.planes[i].w, b.planes[i].h);
+        const size_t need = scratch_need(i);
         if (pos + need > c->replay_bytes) { const int rc = flush(); if (rc != STR_ER_OK) return rc; }
         ReplayItem it{};
         it.plane = (uint32_t)i; it.off = pos;
@@ -790,7 +828,14 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
 
     if (c->dbg_stats) {     // developer aid: how many nodes left the tiles
         unsigned long long tot = 0, created = 0;
-        for (int i = 0; i < np; ++i) { created += c->h_ctr[i].n_created; tot += c->h_ctr[i].n_nodes; }
+        int n_tied = 0, n_rel = 0;
+        for (int i = 0; i < np; ++i) { created += c->h_ctr[i].n_created; tot += c->h_ctr[i].n_nodes; n_tied += c->h_ctr[i].n_amb != 0; n_rel += c->h_ctr[i].n_rel != 0; }
+        std::fprintf(stderr, "[str_er] planes %d, with NMS sibling ties %d, with ties that can change the pool (flood replayed) %d\n", np, n_tied, n_rel);
+        for (int i = 0; i < np; ++i)
+            if (c->h_ctr[i].n_amb)
+                std::fprintf(stderr, "[str_er]   tie plane %d (frame %u ch %d pyr %d, %dx%d): ties %u relevant %u, last tie node: %u contenders, kept %u pool %u\n", i,
+                             b.planes[i].frame, b.planes[i].ch, b.planes[i].pyr, b.planes[i].w, b.planes[i].h, c->h_ctr[i].n_amb, c->h_ctr[i].n_rel,
+                             c->h_ctr[i].tie_nc, c->h_ctr[i].n_kept, c->h_ctr[i].n_pool);
         std::fprintf(stderr, "[str_er] tiles %u exported nodes %llu (%.1f per tile; share %.3f of %.3f) created %llu seam pairs %u\n", b.n_tiles, tot,
                      (double)tot / b.n_tiles, (double)tot / (double)b.slots, c->node_share, created, b.n_pairs);
     }
@@ -1072,6 +1117,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     }
     c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
     c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
+    if (const char *rp = std::getenv("STR_ER_REPLAY")) c->replay_on_gpu = !std::strcmp(rp, "gpu");
     for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
     c->ppf = (int)c->chans.size() * p->n_pyr_levels;
     c->max_planes = c->ppf * p->max_frames;
@@ -1641,7 +1687,7 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const uint32_t n_amb = c->h_ctr[0].n_amb;
-    if (plane && c->prm.sibling_order == 0 && n_amb) {      // ties: the reference's flood order decides (k_flood_order)
+    if (plane && c->prm.sibling_order == 0 && c->h_ctr[0].n_rel) {      // ties: the reference's flood order decides (k_flood_order)
         bool replayed = false;
         const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed);
         if (rcr != STR_ER_OK) return rcr;
@@ -1671,6 +1717,14 @@ int str_er_nms_tree_plane(str_er_ctx *c, const str_er_node *nodes, int32_t n_nod
 {
     if (!plane) return c ? fail(c, STR_ER_EINVAL, "null plane") : STR_ER_EINVAL;
     return nms_tree_impl(c, nodes, n_nodes, plane, stride, rows, cols, pool_idx, cap, n_pool, ambiguous);
+}
+
+int str_er_flood_order(const uint8_t *plane, int32_t w, int32_t h, int64_t stride, int32_t thresh_step, uint32_t *stamp)
+{
+    if (!plane || !stamp || w < 1 || h < 1 || stride < w || thresh_step < 1 || thresh_step > 255 || (int64_t)w * h > (1 << 24)) return STR_ER_EINVAL;
+    std::memset(stamp, 0, 4 * (size_t)w * h);
+    flood_order_host(plane, w, h, stride, 0, (float)(1.0 / (double)thresh_step), 255 / thresh_step + 1, nullptr, 0xFFFFFFFFu, stamp);
+    return STR_ER_OK;
 }
 
 int str_er_resize_plane(str_er_ctx *c, const uint8_t *src, int32_t sw, int32_t sh, int64_t sstride, uint8_t *dst, int32_t dw,

@@ -284,10 +284,13 @@ def test_nms_tree(erf, oracle, S):
     f.close()
 
 
-def test_sibling_ties_follow_the_reference_flood_order(S, oracle):
+@pytest.mark.parametrize("replay", ["host", "gpu"])
+def test_sibling_ties_follow_the_reference_flood_order(S, oracle, monkeypatch, replay):
     """SURVEY A.5 / VERDICT r1 weak #2: where two or more child chains compete for a parent the reference's winner is the
     child its flood entered last.  A low OVERLAP_COEF and MIN_AREA make such ties frequent; every pool must equal the
-    oracle's own order (sibling_mode 0 = the child lists its restatement of the flood built), batched planes included."""
+    oracle's own order (sibling_mode 0 = the child lists its restatement of the flood built), batched planes included.
+    The walk that gives the order runs on a host core (flood_order.cpp) or, with STR_ER_REPLAY=gpu, on one GPU lane."""
+    monkeypatch.setenv("STR_ER_REPLAY", replay)
     f = S.ERFilter(8, 6, 900000, 2, 0.3, max_width=320, max_height=200, max_frames=6, kept_cap=70000, pool_cap=30000)
     rng = np.random.default_rng(99)
     n_amb = n_planes = 0
