@@ -116,8 +116,10 @@ def main():
     ap.add_argument("--ocr", action="store_true",
                     help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
                          "(synthetic stand-in for the missing classifier/OCR.model: tests/golden/ocr_synth.model.gz)")
-    ap.add_argument("--pipelines", type=int, default=3,
-                    help="independent batches in flight per GPU (each has its own context, stream and workspace)")
+    ap.add_argument("--pipelines", type=int, default=6,
+                    help="independent batches in flight per GPU (each has its own context, stream and workspace).  Three hide the "
+                         "host-side result handling and the low-parallelism tails of a batch; the flood order walk that decides an NMS "
+                         "sibling tie (about one plane per 48 S-text frames, 20-50 ms on a host core) needs a few more")
     args = ap.parse_args()
 
     import torch

@@ -83,7 +83,8 @@ _LIB = None
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "lib", "libstr_er_hip.so")
+    # STR_ER_LIB: developer switch, load another build of the same library (tools/dev_stop_all.sh)
+    return os.environ.get("STR_ER_LIB") or os.path.join(HERE, "lib", "libstr_er_hip.so")
 
 
 def load_library():

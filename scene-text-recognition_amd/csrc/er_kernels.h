@@ -12,6 +12,7 @@ struct BatchDev {
     int32_t          n_planes;
     uint32_t         n_tiles;  // batch-wide
     uint32_t         n_pairs;  // batch-wide seam pixel pairs
+    uint32_t         node_blocks; // workgroups per plane of the per-record kernels
     NodeArrays       na;
     KeptArrays       ka;
     const uint16_t  *tile_plane;        // plane of every tile
@@ -26,6 +27,7 @@ struct BatchDev {
     uint32_t        *total_cands;
     uint16_t        *cand_plane; // plane of every packed candidate
     uint32_t        *watch;      // [n_planes x NMS_WATCH_CAP] key pixels of the children that may compete for a parent
+    uint32_t        *wstamp;     // ... and, after the flood order walk, their stamps (order of first access)
 };
 
 // compute_channels (src/ER.cpp:114-128): interleaved BGR -> Y, Cr, Cb planes.
@@ -52,6 +54,7 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);
 // pass 0: every plane; sibling ties by key (exact mode: provisional, planes with ties are counted in n_amb and get a watch list).
 // use_index_order: exact mode on an uploaded tree -- the table order is the child-list order.
 void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool use_index_order = false);
+void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p);
 // exact mode, planes with sibling ties: replay the reference's flood (src/ER.cpp:240-374) to stamp every pixel with the order in
 // which it becomes accessible, then NMS again with the ties decided by those stamps.  scratch: see ReplayItem.
 size_t replay_scratch_bytes(int w, int h);

@@ -436,6 +436,10 @@ __device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_
     }
 }
 
+// (Measured and not adopted, round 2: restricting this loop to fewer waves so that every iteration is fuller -- 1 / 2 / 3 / 4 waves:
+// 5.06 / 4.13 / 3.84 / 3.71 ms per 32 frames, the loop is bound by LDS latency, not by issue; and a flat form with two edges per lane
+// in flight, every step "load both parent words of both edges, then hop or CAS" -- 4.87 ms: the hops become steps of their own and
+// every step pays the refill logic.)
 // All edges of a worklist, with the lanes kept busy: a connect takes anything from one to a dozen passes of its loop,
 // so "lane i does edge i, then everybody waits for the slowest lane" leaves most lanes idle most of the time.  Here a
 // lane that finishes its edge takes the next one from a workgroup-wide cursor straight away (one LDS atomic per wave and
@@ -1178,7 +1182,7 @@ void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 // ------------------------------------------------------------------------------------
 // Part 3: per-node passes over the plane's records.  Grid = (NODE_BLOCKS, planes); a block strides over its plane's nodes.
 // ------------------------------------------------------------------------------------
-constexpr int NODE_BLOCKS = 12;       // x 256 lanes per plane: a 1920x1080 plane of text-like frames exports ~12 000 nodes
+// (BatchDev::node_blocks x 256 lanes per plane, chosen by the host from the record counts of the previous batch)
 
 __device__ __forceinline__ uint32_t plane_nodes(const BatchDev &b, int pi)
 {
@@ -1195,7 +1199,10 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
     const uint32_t  n = plane_nodes(b, pi);
     NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
     uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+    for (uint32_t x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += gridDim.x * blockDim.x) {
+        const uint32_t  x = x0 + (threadIdx.x & 63u);
+        uint32_t        push_to = NONE;         // the parent this node will push its totals to
+        if (x < n) {
         const uint32_t  l = nr[x].key >> 24;
         const uint32_t  w = LD_AGENT(&nr[x].par);
         if (w != NONE && PAR_LVL(w) == l) {
@@ -1223,7 +1230,18 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
                 q = PAR_ID(w2);
             }
             if (q != PAR_ID(w)) ST_AGENT(&nr[x].par, PAR_MAKE(lq, q));
-            if (!(nr[x].nod & NODE_CLOSED)) atomicAdd(&aux[q], 1u);      // closed nodes never push (their totals are final)
+            if (!(nr[x].nod & NODE_CLOSED)) push_to = q;                 // closed nodes never push (their totals are final)
+        }
+        }
+        // count the pushing children per parent; the lanes of a wave that share a parent (the background node of a tile has
+        // hundreds of children) bring one increment together
+        unsigned long long todo = __ballot(push_to != NONE);
+        while (todo) {
+            const int      leader = __ffsll((long long)todo) - 1;
+            const uint32_t lq = __shfl(push_to, leader);
+            const unsigned long long m = __ballot(push_to == lq);
+            if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&aux[lq], (uint32_t)__popcll(m));
+            todo &= ~m;
         }
     }
 }
@@ -1231,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 void launch_resolve(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_resolve, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_resolve, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -1348,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
 void launch_reduce(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_reduce, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_reduce, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b);
 }
 
 // Root of the tree that holds the flood's start pixel (er_stack.back(), src/ER.cpp:346).
@@ -1429,7 +1447,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_select, dim3(NODE_BLOCKS, b.n_planes), dim3(256), 0, s, b, p);
+    hipLaunchKernelGGL(k_select, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b, p);
 }
 
 // Kept-node records (flat form of struct ER, inc/ER.h:42-80).
@@ -1527,7 +1545,17 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     const int        maxl = (int)c.max_level;
     const uint32_t   root = c.root_slot;
     const double     rel_area = 0.8 * (double)pd.w * 0.8 * (double)pd.h * (1.0 + 1e-9);   // OVERLAP_COEF * area(X) below this: the tie at X is relevant
-    const uint32_t  *stamp = pass == NMS_PASS_STAMP ? reinterpret_cast<const uint32_t *>(scratch + items[blockIdx.x].off) : nullptr;
+    // stamps of the flood order walk: per watched key (the usual case) or, when the plane had more candidates than the watch
+    // list holds, one per pixel
+    __shared__ uint32_t s_wkey[NMS_WATCH_CAP], s_wstamp[NMS_WATCH_CAP];
+    const uint32_t   n_watch = c.n_watch;
+    const bool       sparse = n_watch <= (uint32_t)NMS_WATCH_CAP;
+    const uint32_t  *stamp = (pass == NMS_PASS_STAMP && !sparse) ? reinterpret_cast<const uint32_t *>(scratch + items[blockIdx.x].off) : nullptr;
+    if (pass == NMS_PASS_STAMP && sparse)
+        for (uint32_t i = threadIdx.x; i < n_watch; i += NMS_THREADS) {
+            s_wkey[i] = b.watch[(size_t)pi * NMS_WATCH_CAP + i];
+            s_wstamp[i] = b.wstamp[(size_t)pi * NMS_WATCH_CAP + i];
+        }
 
     for (int i = tid; i < 8; i += NMS_THREADS) s_levels[i] = 0;
     if (tid == 0) { s_npool = 0; s_alt_amb = 0; s_alt_node = NONE; s_alt_nc = 0; s_alt_diff = 0; }
@@ -1565,7 +1593,15 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
             if ((double)as / (double)ap > prm.overlap_coef) {
                 atomicAdd(&kncand[P], 1u);
                 uint32_t ord;
-                if (ord_mode == NMS_ORD_STAMP) ord = ~stamp[kkey[i]];       // entered last = first in the child list
+                if (ord_mode == NMS_ORD_STAMP) {                             // entered last = first in the child list
+                    uint32_t st = 0;
+                    if (!sparse) st = stamp[kkey[i]];
+                    else if ((double)((int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]) / (double)ap > prm.overlap_coef) {   // (only such children are watched)
+                        const uint32_t key = kkey[i];
+                        for (uint32_t j = 0; j < n_watch; ++j) if (s_wkey[j] == key) { st = s_wstamp[j]; break; }
+                    }
+                    ord = ~st;
+                }
                 else if (ord_mode == NMS_ORD_INDEX) ord = i;
                 else ord = ord_mode == NMS_ORD_KEY_MAX ? ~kkey[i] : kkey[i];
                 atomicMin(&kbest[P], ((unsigned long long)ord << 32) | i);
@@ -1675,10 +1711,15 @@ void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool us
     if (!b.n_planes) return;
     const int mode = (use_index_order && p.sibling_order == 0) ? NMS_ORD_INDEX : (p.sibling_order == 1 ? NMS_ORD_KEY_MIN : NMS_ORD_KEY_MAX);
     hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, mode, (int)NMS_PASS_FIRST);
-    // exact mode: planes whose only tie is one two-way tie are tried under the opposite rule; equal pools settle them
-    if (p.sibling_order == 0 && mode == NMS_ORD_KEY_MAX)
-        hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, (int)NMS_ORD_KEY_MIN,
-                           (int)NMS_PASS_ALT);
+}
+
+// exact mode: planes whose only tie is one two-way tie are tried under the opposite rule; equal pools settle them (n_rel = 0).
+// Touches only NMS scratch and the counters n_rel / n_watch, so it may run beside the kernels that consume the pools.
+void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p)
+{
+    if (!b.n_planes || p.sibling_order != 0) return;
+    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, (int)NMS_ORD_KEY_MIN,
+                       (int)NMS_PASS_ALT);
 }
 
 void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, const uint8_t *scratch)
@@ -1743,9 +1784,9 @@ __global__ __launch_bounds__(FLOOD_THREADS) void k_flood_order(BatchDev b, Detec
     {
         const uint32_t old = stamp[0];
         stamp[0] = ++counter;
-        if (old == FLOOD_WATCH && --remaining == 0) return;
+        if (old == FLOOD_WATCH) --remaining;
     }
-    for (;;) {
+    while (remaining != 0) {
         // 4. explore the remaining edges of the current pixel
         const uint32_t x = cur % (uint32_t)w;
         uint32_t nb[4], st[4], nl[4];
@@ -1774,10 +1815,10 @@ __global__ __launch_bounds__(FLOOD_THREADS) void k_flood_order(BatchDev b, Detec
                 descended = true;
             }
         }
-        if (remaining == 0) return;
+        if (remaining == 0) break;
         if (descended) continue;
         // 5./6. the current pixel is done; pop the lowest boundary pixel
-        if (priority == hi) return;
+        if (priority == hi) break;
         cur = s_head[priority];
         const uint32_t v = link[cur];
         edge = v & 7u;
@@ -1785,6 +1826,12 @@ __global__ __launch_bounds__(FLOOD_THREADS) void k_flood_order(BatchDev b, Detec
         cl = priority;
         while (priority < hi && s_head[priority] == FLOOD_NIL) ++priority;
     }
+    // what the NMS pass reads: the stamps of the watched pixels (a watched pixel the walk never reached keeps the mark: 0)
+    if (watching)
+        for (uint32_t i = 0; i < n_watch; ++i) {
+            const uint32_t v = stamp[b.watch[(size_t)it.plane * NMS_WATCH_CAP + i]];
+            b.wstamp[(size_t)it.plane * NMS_WATCH_CAP + i] = v == FLOOD_WATCH ? 0u : v;
+        }
 }
 
 void launch_flood_order(hipStream_t s, const BatchDev &b, const DetectParams &p, const ReplayItem *items, int n_items, uint8_t *scratch)

@@ -23,67 +23,80 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
 {
     const uint32_t n = (uint32_t)w * (uint32_t)h;
     if (n == 0) return;
-    // quantised levels (src/ER.cpp:250: 8U -> 8U convertTo with scale 1/step = round-half-even of float(p) * float(1/step))
+    const bool all = n_watch == 0xFFFFFFFFu;
+    // per pixel: quantised level (src/ER.cpp:250: 8U -> 8U convertTo with scale 1/step = round-half-even of float(p) * float(1/step))
+    // in bits 0..8, "watched" in bit 14, "accessible" in bit 15 -- one 16-bit word is all the walk reads per neighbour
+    constexpr uint16_t ACC = 0x8000u, WATCH = 0x4000u, LEVEL = 0x01FFu;
     uint16_t lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (uint16_t)std::lrintf((float)v * qscale);
-    std::vector<uint16_t> lv(n);
+    std::vector<uint16_t> st(n);
     for (int y = 0; y < h; ++y) {
         const uint8_t *row = pix + (size_t)y * stride;
-        uint16_t      *o = lv.data() + (size_t)y * w;
+        uint16_t      *o = st.data() + (size_t)y * w;
         for (int x = 0; x < w; ++x) o[x] = lut[row[x] ^ invert];
     }
-    constexpr uint32_t WATCH = 0x80000000u;
     uint32_t remaining = 0xFFFFFFFFu;
-    if (n_watch != 0xFFFFFFFFu) {
+    if (!all) {
         remaining = 0;
         for (uint32_t i = 0; i < n_watch; ++i)
-            if (watch[i] < n && stamp[watch[i]] != WATCH) { stamp[watch[i]] = WATCH; ++remaining; }
+            if (watch[i] < n && !(st[watch[i]] & WATCH)) { st[watch[i]] |= WATCH; ++remaining; }
         if (remaining == 0) return;
     }
-    std::vector<std::vector<uint32_t>> bucket((size_t)hi + 1);      // entries: pixel << 3 | next edge
+    // the 256 LIFO buckets of src/ER.cpp:254-255 as linked lists through one array (a pixel is in at most one bucket at a time):
+    // link[p] = next entry << 3 | the edge at which p resumes
+    constexpr uint32_t NIL = 0x1FFFFFFFu;
+    std::vector<uint32_t> link(n);
+    uint32_t head[257];
+    for (uint32_t &v : head) v = NIL;
     uint32_t priority = (uint32_t)hi, counter = 0;
-    uint32_t cur = 0, edge = 0, cl = lv[0];
-    auto mark = [&](uint32_t p) {
-        if (stamp[p] == WATCH) --remaining;
-        stamp[p] = ++counter;
+    uint32_t cur = 0, edge = 0, cl = st[0] & LEVEL;
+    const uint32_t W = (uint32_t)w, HI = (uint32_t)hi;
+    auto mark = [&](uint32_t p, uint16_t s) {
+        ++counter;
+        st[p] = (uint16_t)(s | ACC);
+        if (all) stamp[p] = counter;
+        else if (s & WATCH) {
+            for (uint32_t j = 0; j < n_watch; ++j) if (watch[j] == p) stamp[j] = counter;     // (a handful per plane)
+            --remaining;
+        }
     };
-    mark(0);
+    mark(0, st[0]);
+    uint32_t x = 0;       // column of `cur`
     while (remaining != 0) {
-        const uint32_t x = cur % (uint32_t)w;
         bool descended = false;
         for (; edge < 4; ++edge) {
             uint32_t q;
             switch (edge) {
-            case 0: q = (x + 1 < (uint32_t)w) ? cur + 1 : cur; break;
-            case 1: q = (cur + (uint32_t)w < n) ? cur + (uint32_t)w : cur; break;
-            case 2: q = (x > 0) ? cur - 1 : cur; break;
-            default: q = (cur >= (uint32_t)w) ? cur - (uint32_t)w : cur; break;
+            case 0: if (x + 1 >= W) continue; q = cur + 1; break;
+            case 1: if (cur + W >= n) continue; q = cur + W; break;
+            case 2: if (x == 0) continue; q = cur - 1; break;
+            default: if (cur < W) continue; q = cur - W; break;
             }
-            const uint32_t s = stamp[q];
-            if (q == cur || (s != 0 && s != WATCH)) continue;
-            mark(q);
-            const uint32_t l = lv[q];
+            const uint16_t s = st[q];
+            if (s & ACC) continue;
+            mark(q, s);
+            const uint32_t l = s & LEVEL;
             if (l >= cl) {
-                if (l < (uint32_t)hi) bucket[l].push_back(q << 3);      // (the bucket of the sentinel level is never popped)
+                if (l < HI) { link[q] = head[l] << 3; head[l] = q; }      // (the bucket of the sentinel level is never popped)
                 if (l < priority) priority = l;
             } else {
-                if (cl < (uint32_t)hi) bucket[cl].push_back((cur << 3) | (edge + 1));
+                if (cl < HI) { link[cur] = (head[cl] << 3) | (edge + 1); head[cl] = cur; }
                 if (cl < priority) priority = cl;
-                cur = q; cl = l; edge = 0;
+                cur = q; cl = l;
+                x = edge == 0 ? x + 1 : edge == 2 ? x - 1 : x;
+                edge = 0;
                 descended = true;
                 break;
             }
         }
         if (descended) continue;
-        if (priority == (uint32_t)hi) break;
-        const uint32_t v = bucket[priority].back();
-        bucket[priority].pop_back();
-        cur = v >> 3; edge = v & 7u; cl = priority;
-        while (priority < (uint32_t)hi && bucket[priority].empty()) ++priority;
+        if (priority == HI) break;
+        cur = head[priority];
+        const uint32_t v = link[cur];
+        head[priority] = v >> 3; edge = v & 7u; cl = priority;
+        x = cur % W;
+        while (priority < HI && head[priority] == NIL) ++priority;
     }
-    if (n_watch != 0xFFFFFFFFu)
-        for (uint32_t i = 0; i < n_watch; ++i)
-            if (watch[i] < n && stamp[watch[i]] == WATCH) stamp[watch[i]] = 0;      // not reached (sealed off by sentinel pixels)
 }
 
 } // namespace str_er

@@ -7,8 +7,10 @@
 namespace str_er {
 
 // pix: the plane (w x h, `stride` bytes per row), `invert` 0 or 0xFF, qscale = float(1/THRESH_STEP), hi = 255/THRESH_STEP + 1.
-// watch[0..n_watch): pixels whose stamps are wanted -- the walk stops once all of them are stamped; n_watch = 0xFFFFFFFF: all pixels.
-// stamp[w*h] must be zero on entry; on return stamp[p] = 1-based position of p in the order of first access (0: not reached).
+// The stamp of a pixel = its 1-based position in the order of first access (0: not reached).
+// n_watch = 0xFFFFFFFF: stamp[w*h] (zero on entry) receives the stamp of every pixel.
+// otherwise: watch[0..n_watch) are the pixels whose stamps are wanted, stamp[j] (zero on entry) receives the stamp of watch[j],
+// and the walk stops as soon as all of them are stamped.
 void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch,
                       uint32_t n_watch, uint32_t *stamp);
 

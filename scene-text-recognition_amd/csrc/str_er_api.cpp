@@ -76,6 +76,8 @@ struct str_er_ctx {
     str_er_params prm{};
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // the opposite-rule NMS pass runs here, beside classify
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool own_stream = false;
     int ppf = 0;                     // logical planes per frame
     std::vector<int> chans;          // channel indices selected by the mask
@@ -97,6 +99,7 @@ struct str_er_ctx {
     KeptArrays ka{};
     uint16_t *d_seam = nullptr; size_t seam_slots = 0;
     size_t node_slots = 0;            // node records allocated (NodeArrays::rec / aux)
+    uint32_t node_blocks = 12;        // workgroups per plane of the per-record kernels: from the record counts of the previous batch
     double node_share = 0.25;         // records per padded plane pixel; grown (and the batch repeated) when a plane runs out
     uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
     std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
@@ -107,7 +110,7 @@ struct str_er_ctx {
     TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
     uint32_t *d_group = nullptr, *d_group_pairs = nullptr; size_t group_words = 0, group_pair_cap = 0;   // STR_ER_STAGE_GROUP, grown on demand
     uint32_t *d_total = nullptr;
-    uint32_t *d_watch = nullptr;                      // NMS: watched key pixels per plane (k_nms -> k_flood_order)
+    uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
     ReplayItem *d_replay_items = nullptr;
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
     uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
@@ -371,11 +374,11 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
 {
     BatchDev d{};
     d.planes = c->d_planes; d.ctr = c->d_ctr; d.n_planes = (int32_t)b.planes.size();
-    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs;
+    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.node_blocks = c->node_blocks;
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
     d.na = c->na; d.ka = c->ka; d.tile_nbase = c->d_tile_nbase; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
-    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch;
+    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch; d.wstamp = c->d_wstamp;
     return d;
 }
 
@@ -612,7 +615,9 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
     size_t largest = 0, total = 0;
     auto scratch_need = [&](int i) -> size_t {
         const PlaneDesc &pd = b.planes[i];
-        return c->replay_on_gpu ? replay_scratch_bytes(pd.w, pd.h) : (((size_t)pd.w * pd.h * 4 + 255) / 256) * 256;    // host walk: only the stamps go to the device
+        if (c->replay_on_gpu) return replay_scratch_bytes(pd.w, pd.h);
+        // host walk: only stamps go to the device -- those of the watched pixels, or all of them when the watch list overflowed
+        return c->h_ctr[i].n_watch <= (uint32_t)NMS_WATCH_CAP ? 0 : (((size_t)pd.w * pd.h * 4 + 255) / 256) * 256;
     };
     for (int i = 0; i < (int)b.planes.size(); ++i)
         if (c->h_ctr[i].n_rel) {         // ties that can change the pool (k_nms); the others need no decision
@@ -654,16 +659,26 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
             auto walk = [&](size_t k) {
                 const PlaneDesc &pd = b.planes[items[k].plane];
                 const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
-                stamp[k].assign((size_t)pd.w * pd.h, 0u);
-                flood_order_host(pix[k].data(), pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, watch[k].data(),
-                                 nw <= (uint32_t)NMS_WATCH_CAP ? nw : 0xFFFFFFFFu, stamp[k].data());
+                if (nw <= (uint32_t)NMS_WATCH_CAP) {
+                    stamp[k].assign(nw, 0u);
+                    flood_order_host(pix[k].data(), pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, watch[k].data(), nw, stamp[k].data());
+                } else {
+                    stamp[k].assign((size_t)pd.w * pd.h, 0u);
+                    flood_order_host(pix[k].data(), pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, nullptr, 0xFFFFFFFFu, stamp[k].data());
+                }
             };
             std::vector<std::thread> th;
             for (size_t k = 1; k < m; ++k) th.emplace_back(walk, k);
             walk(0);
             for (auto &t : th) t.join();
-            for (size_t k = 0; k < m; ++k)
-                HIP_TRY(c, hipMemcpyAsync(c->d_replay + items[k].off, stamp[k].data(), 4 * stamp[k].size(), hipMemcpyHostToDevice, s));
+            for (size_t k = 0; k < m; ++k) {
+                const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
+                if (nw <= (uint32_t)NMS_WATCH_CAP) {
+                    if (nw) HIP_TRY(c, hipMemcpyAsync(c->d_wstamp + (size_t)items[k].plane * NMS_WATCH_CAP, stamp[k].data(), 4 * (size_t)nw, hipMemcpyHostToDevice, s));
+                } else {
+                    HIP_TRY(c, hipMemcpyAsync(c->d_replay + items[k].off, stamp[k].data(), 4 * stamp[k].size(), hipMemcpyHostToDevice, s));
+                }
+            }
             HIP_TRY(c, hipStreamSynchronize(s));       // the host vectors go out of scope
         }
         launch_nms_resolve(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
@@ -773,6 +788,13 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     if (stages & STR_ER_STAGE_NMS) launch_nms(s, bd, dp);
     rec(c, "nms");
     const int i_nms = c->n_ev - 1;
+    const bool alt_pass = (stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0;
+    if (alt_pass) {       // beside classify: it only decides whether a tie needs the flood order walk
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        launch_nms_alt(c->side, bd, dp);
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+    }
     // everything after NMS reads the pools: enqueued once, and once more if sibling ties had to be decided by a flood replay
     auto after_nms = [&](bool record) {
         if (stages & STR_ER_STAGE_NMS) {
@@ -791,6 +813,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     after_nms(true);
     const int i_cls = (stages & STR_ER_STAGE_TRACK) ? c->n_ev - 2 : c->n_ev - 1;
     const int i_trk = c->n_ev - 1;
+    if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -844,6 +867,13 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             return fail(c, STR_ER_ECAPACITY, "kept-node table overflow: plane " + std::to_string(i) + " has " +
                         std::to_string(c->h_ctr[i].n_kept) + " kept nodes, kept_cap = " + std::to_string(c->kept_cap));
         if (c->h_ctr[i].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
+    }
+    {
+        uint32_t most = 0;
+        for (int i = 0; i < np; ++i) most = std::max(most, c->h_ctr[i].n_nodes);
+        // (more lanes than this in flight only queue up behind the same hot parent words: measured on noise, 256 workgroups per
+        // plane made k_resolve 4x slower than 12)
+        c->node_blocks = std::min<uint32_t>(12, std::max<uint32_t>(4, (most + 255) / 256));
     }
     if (c->tile_mode == 0 && b.n_tiles) {      // text-like frames make a few dozen nodes per tile, noise several hundred
         unsigned long long created = 0;
@@ -1084,6 +1114,9 @@ void str_er_destroy(str_er_ctx *c)
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_total) (void)hipHostFree(c->h_total);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1143,6 +1176,9 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         c->own_stream = true;
     }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { A(fail(nullptr, STR_ER_EHIP, "hipEventCreate failed")); break; }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+        A(fail(nullptr, STR_ER_EHIP, "side stream creation failed"));
     c->in_bytes = std::max((size_t)p->max_frames * plane_px * 3, c->slots);
     c->pix_bytes = std::max(phys_frame * p->max_frames, c->slots + 4096);
     const size_t S = c->slots, KP = (size_t)c->max_planes * c->kept_cap, PP = (size_t)c->max_planes * c->pool_cap;
@@ -1163,7 +1199,8 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
     A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
-    A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
+    A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP));
+    A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
@@ -1683,6 +1720,7 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     bd.n_seam_blocks = 0;
     const DetectParams dp = make_dp(c);
     launch_nms(s, bd, dp, /*use_index_order=*/plane == nullptr);
+    if (plane) launch_nms_alt(s, bd, dp);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
