@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-host-frames", action="store_true",
                     help="skip the PCIe-inclusive leg (`pcie_inclusive`: frames start in page-locked host memory and go through the "
                          "ingest stream str_er_stream_*, uploads overlapping compute); it is never the reported `value`")
+    ap.add_argument("--sibling-order", type=int, default=0, help="developer knob: 0 = exact NMS ties (default), 2 = largest-key rule (no flood order walk)")
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-frame-per-call latency leg (`latency_1frame`)")
     ap.add_argument("--ocr", action="store_true",
                     help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
@@ -156,7 +157,7 @@ def main():
     filters = []
     for _ in range(P):
         f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
-                                       channel_mask=cfg["channel_mask"], device=dev_index))
+                                       channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order))
         f.load_cascade(0, cascades[0])
         f.load_cascade(1, cascades[1])
         if args.ocr:
@@ -244,7 +245,7 @@ def main():
             f.close()
         filters = filters[:1]
         f1 = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, n_pyr_levels=cfg["n_pyr_levels"],
-                                        channel_mask=cfg["channel_mask"], device=dev_index))
+                                        channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order))
         f1.load_cascade(0, cascades[0]); f1.load_cascade(1, cascades[1])
         if args.ocr:
             import gzip
@@ -277,7 +278,7 @@ def main():
         for f in filters:
             f.close()
         st = S.FrameStream(S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
-                                    channel_mask=cfg["channel_mask"], device=dev_index), depth=P)
+                                    channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order), depth=P)
         st.load_cascade(0, cascades[0]); st.load_cascade(1, cascades[1])
 
         def stream_steps(n):

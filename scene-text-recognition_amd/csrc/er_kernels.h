@@ -27,7 +27,8 @@ struct BatchDev {
     uint32_t        *total_cands;
     uint16_t        *cand_plane; // plane of every packed candidate
     uint32_t        *watch;      // [n_planes x NMS_WATCH_CAP] key pixels of the children that may compete for a parent
-    uint32_t        *wstamp;     // ... and, after the flood order walk, their stamps (order of first access)
+    uint32_t        *wstamp;     // ... and, after the flood order walk, their stamps (order of first access; 0xFFFFFFFF: later than all stamped ones)
+    uint32_t        *wparent;    // ... and the kept slot of the parent each one may compete for (the walk stops once every parent's order is decided)
 };
 
 // compute_channels (src/ER.cpp:114-128): interleaved BGR -> Y, Cr, Cb planes.
@@ -55,6 +56,8 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);
 // use_index_order: exact mode on an uploaded tree -- the table order is the child-list order.
 void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool use_index_order = false);
 void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p);
+// planes with ties left (PlaneCtr::n_rel) -> host-addressable memory: pixels, watch keys, watch parents per slot (see er_kernels.hip)
+void launch_export_tie_planes(hipStream_t s, const BatchDev &b, uint8_t *host_buf, size_t slot_bytes, int n_slots, uint32_t *count, uint32_t *slot_plane);
 // exact mode, planes with sibling ties: replay the reference's flood (src/ER.cpp:240-374) to stamp every pixel with the order in
 // which it becomes accessible, then NMS again with the ties decided by those stamps.  scratch: see ReplayItem.
 size_t replay_scratch_bytes(int w, int h);

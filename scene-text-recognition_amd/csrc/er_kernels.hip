@@ -1204,11 +1204,12 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
         uint32_t        push_to = NONE;         // the parent this node will push its totals to
         if (x < n) {
         const uint32_t  l = nr[x].key >> 24;
-        const uint32_t  w = LD_AGENT(&nr[x].par);
+        const uint32_t  w = nr[x].par;        // (plain loads: k_seam's writes are visible since the kernel boundary, and a
+                                              //  parent word rewritten by a lane of THIS kernel points to the same node either way)
         if (w != NONE && PAR_LVL(w) == l) {
             uint32_t r = PAR_ID(w);
             for (;;) {
-                const uint32_t w2 = LD_AGENT(&nr[r].par);
+                const uint32_t w2 = nr[r].par;
                 if (w2 == NONE || PAR_LVL(w2) != l) break;
                 r = PAR_ID(w2);
             }
@@ -1225,11 +1226,11 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
             uint32_t       q = PAR_ID(w);
             const uint32_t lq = PAR_LVL(w);
             for (;;) {
-                const uint32_t w2 = LD_AGENT(&nr[q].par);
+                const uint32_t w2 = nr[q].par;
                 if (w2 == NONE || PAR_LVL(w2) != lq) break;
                 q = PAR_ID(w2);
             }
-            if (q != PAR_ID(w)) ST_AGENT(&nr[x].par, PAR_MAKE(lq, q));
+            if (q != PAR_ID(w)) nr[x].par = PAR_MAKE(lq, q);
             if (!(nr[x].nod & NODE_CLOSED)) push_to = q;                 // closed nodes never push (their totals are final)
         }
         }
@@ -1630,7 +1631,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
             const int ai = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3], ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
             if ((double)ai / (double)ap > prm.overlap_coef && kncand[P] > 1 && (double)ap * prm.overlap_coef < rel_area) {
                 const uint32_t at = atomicAdd(&c.n_watch, 1u);
-                if (at < (uint32_t)NMS_WATCH_CAP) b.watch[(size_t)pi * NMS_WATCH_CAP + at] = kkey[i];
+                if (at < (uint32_t)NMS_WATCH_CAP) { b.watch[(size_t)pi * NMS_WATCH_CAP + at] = kkey[i]; b.wparent[(size_t)pi * NMS_WATCH_CAP + at] = P; }
             }
         }
         __syncthreads();
@@ -1726,6 +1727,52 @@ void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p,
 {
     if (n_items <= 0) return;
     hipLaunchKernelGGL(k_nms, dim3(n_items), dim3(NMS_THREADS), 0, s, b, p, items, scratch, (int)NMS_ORD_STAMP, (int)NMS_PASS_STAMP);
+}
+
+// The planes whose ties need the flood order walk, handed to the host without a round trip: straight after the opposite-rule pass
+// every such plane (rare: about one in a thousand) is written into page-locked host memory the device can address -- pixels,
+// then its watch list (keys, parents) -- so that it is already there when the host learns, from the plane counters, that it
+// needs it.  slot_plane[slot] = plane index; planes beyond n_slots are fetched by an explicit copy later.
+__global__ __launch_bounds__(1024) void k_export_tie_planes(BatchDev b, uint8_t *host_buf, size_t slot_bytes, int n_slots, uint32_t *count, uint32_t *slot_plane)
+{
+    const int        pi = blockIdx.x;
+    const PlaneCtr  &c = b.ctr[pi];
+    if (c.n_rel == 0) return;
+    __shared__ uint32_t s_slot;
+    if (threadIdx.x == 0) s_slot = atomicAdd(count, 1u);
+    __syncthreads();
+    const uint32_t slot = s_slot;
+    if (slot >= (uint32_t)n_slots) return;
+    const PlaneDesc &pd = b.planes[pi];
+    uint8_t *dst = host_buf + (size_t)slot * slot_bytes;
+    const size_t n = (size_t)pd.w * pd.h;
+    if (n + 2 * 4 * (size_t)NMS_WATCH_CAP + 256 > slot_bytes) { if (threadIdx.x == 0) slot_plane[slot] = NONE; return; }
+    // rows as dwords where the geometry allows (the planes the library builds have 64-byte aligned rows)
+    if ((pd.w & 3) == 0 && (pd.stride & 3) == 0 && (reinterpret_cast<uintptr_t>(pd.pix) & 3) == 0) {
+        const uint32_t wq = (uint32_t)pd.w / 4u;
+        for (size_t i = threadIdx.x; i < n / 4; i += 1024) {
+            const uint32_t y = (uint32_t)(i / wq), x = (uint32_t)(i - (size_t)y * wq);
+            reinterpret_cast<uint32_t *>(dst)[i] = *reinterpret_cast<const uint32_t *>(pd.pix + (size_t)y * pd.stride + 4 * x);
+        }
+    } else {
+        for (size_t i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t y = (uint32_t)(i / (uint32_t)pd.w), x = (uint32_t)(i - (size_t)y * pd.w);
+            dst[i] = pd.pix[(size_t)y * pd.stride + x];
+        }
+    }
+    uint32_t *wl = reinterpret_cast<uint32_t *>(dst + ((n + 255) / 256) * 256);
+    const uint32_t nw = min(c.n_watch, (uint32_t)NMS_WATCH_CAP);
+    for (uint32_t i = threadIdx.x; i < nw; i += 1024) {
+        wl[i] = b.watch[(size_t)pi * NMS_WATCH_CAP + i];
+        wl[NMS_WATCH_CAP + i] = b.wparent[(size_t)pi * NMS_WATCH_CAP + i];
+    }
+    if (threadIdx.x == 0) slot_plane[slot] = (uint32_t)pi;
+}
+
+void launch_export_tie_planes(hipStream_t s, const BatchDev &b, uint8_t *host_buf, size_t slot_bytes, int n_slots, uint32_t *count, uint32_t *slot_plane)
+{
+    if (!b.n_planes || !host_buf || n_slots <= 0) return;
+    hipLaunchKernelGGL(k_export_tie_planes, dim3(b.n_planes), dim3(1024), 0, s, b, host_buf, slot_bytes, n_slots, count, slot_plane);
 }
 
 // ------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@
 namespace str_er {
 
 void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch,
-                      uint32_t n_watch, uint32_t *stamp)
+                      uint32_t n_watch, uint32_t *stamp, const uint32_t *group)
 {
     const uint32_t n = (uint32_t)w * (uint32_t)h;
     if (n == 0) return;
@@ -35,11 +35,30 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
         uint16_t      *o = st.data() + (size_t)y * w;
         for (int x = 0; x < w; ++x) o[x] = lut[row[x] ^ invert];
     }
+    // `remaining` = watched pixels whose stamps are still needed.  With groups (the children competing for one parent) only the
+    // LAST one entered matters: once all but one member of a group are stamped that one is known to come later, so a group of k
+    // needs k - 1 stamps; members left unstamped get 0xFFFFFFFF ("later than every stamped one").
     uint32_t remaining = 0xFFFFFFFFu;
+    std::vector<uint32_t> open_in_group;        // per watch entry: index of its group's counter
+    std::vector<uint32_t> group_left;           // per group: members not stamped yet
     if (!all) {
         remaining = 0;
+        if (group) {
+            open_in_group.resize(n_watch);
+            for (uint32_t i = 0; i < n_watch; ++i) {
+                uint32_t g = 0;
+                while (g < i && group[g] != group[i]) ++g;          // (first entry with the same parent; a handful of entries)
+                open_in_group[i] = g;
+            }
+            group_left.assign(n_watch, 0);
+        }
         for (uint32_t i = 0; i < n_watch; ++i)
-            if (watch[i] < n && !(st[watch[i]] & WATCH)) { st[watch[i]] |= WATCH; ++remaining; }
+            if (watch[i] < n && !(st[watch[i]] & WATCH)) {
+                st[watch[i]] |= WATCH;
+                if (group) { if (group_left[open_in_group[i]]++ > 0) ++remaining; }      // k members -> k - 1 needed
+                else ++remaining;
+            }
+        if (group) for (uint32_t i = 0; i < n_watch; ++i) stamp[i] = 0xFFFFFFFFu;
         if (remaining == 0) return;
     }
     // the 256 LIFO buckets of src/ER.cpp:254-255 as linked lists through one array (a pixel is in at most one bucket at a time):
@@ -56,8 +75,13 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
         st[p] = (uint16_t)(s | ACC);
         if (all) stamp[p] = counter;
         else if (s & WATCH) {
-            for (uint32_t j = 0; j < n_watch; ++j) if (watch[j] == p) stamp[j] = counter;     // (a handful per plane)
-            --remaining;
+            for (uint32_t j = 0; j < n_watch; ++j)
+                if (watch[j] == p) {          // (a handful per plane)
+                    stamp[j] = counter;
+                    if (!group) --remaining;
+                    else if (--group_left[open_in_group[j]] >= 1) --remaining;       // the group's last member needs no stamp
+                    break;
+                }
         }
     };
     mark(0, st[0]);

@@ -11,7 +11,9 @@ namespace str_er {
 // n_watch = 0xFFFFFFFF: stamp[w*h] (zero on entry) receives the stamp of every pixel.
 // otherwise: watch[0..n_watch) are the pixels whose stamps are wanted, stamp[j] (zero on entry) receives the stamp of watch[j],
 // and the walk stops as soon as all of them are stamped.
+// group (optional, watch mode): group[j] = id of the set watch[j] belongs to (the parent its node competes for).  Only the member
+// entered LAST matters per set, so the walk stops once every set has at most one unstamped member; those keep 0xFFFFFFFF.
 void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch,
-                      uint32_t n_watch, uint32_t *stamp);
+                      uint32_t n_watch, uint32_t *stamp, const uint32_t *group = nullptr);
 
 } // namespace str_er

@@ -31,6 +31,7 @@ using namespace str_er;
 namespace {
 
 thread_local std::string g_create_error;
+constexpr int TIE_SLOTS = 4;       // planes per batch the device hands to the host for the flood order walk without a round trip
 
 struct HostCascade {
     bool loaded = false;
@@ -77,6 +78,7 @@ struct str_er_ctx {
     std::string err;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // the opposite-rule NMS pass runs here, beside classify
+    hipStream_t prio = nullptr;          // high priority: the few small operations that settle an NMS tie (they would queue behind other contexts' big kernels)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool own_stream = false;
     int ppf = 0;                     // logical planes per frame
@@ -110,6 +112,11 @@ struct str_er_ctx {
     TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
     uint32_t *d_group = nullptr, *d_group_pairs = nullptr; size_t group_words = 0, group_pair_cap = 0;   // STR_ER_STAGE_GROUP, grown on demand
     uint32_t *d_total = nullptr;
+    uint32_t *d_wparent = nullptr;
+    // tie planes exported by the device itself (k_export_tie_planes): TIE_SLOTS x tie_slot_bytes of page-locked, device-addressable memory,
+    // then the slot -> plane table and the slot counter
+    uint8_t *h_tie = nullptr; size_t tie_slot_bytes = 0; uint32_t *h_tie_plane = nullptr, *h_tie_count = nullptr;
+    uint8_t *h_replay = nullptr; size_t h_replay_bytes = 0;   // page-locked: the planes (and watch lists) the flood order walk reads
     uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
     ReplayItem *d_replay_items = nullptr;
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
@@ -378,7 +385,7 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
     d.na = c->na; d.ka = c->ka; d.tile_nbase = c->d_tile_nbase; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
-    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch; d.wstamp = c->d_wstamp;
+    d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch; d.wstamp = c->d_wstamp; d.wparent = c->d_wparent;
     return d;
 }
 
@@ -608,97 +615,129 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
 // Exact NMS where the reference's answer depends on its flood's sibling order (DetectParams::sibling_order == 0): for every plane
 // whose first NMS pass met a tie, replay the reference's flood on the GPU (k_flood_order) and repeat the plane's NMS with the ties
 // decided by the replayed order.  h_ctr holds the counters of the first pass.  Planes go in rounds that fit the scratch buffer.
-int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, const DetectParams &dp, bool &replayed)
+int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, const DetectParams &dp, bool &replayed, bool from_tree = false)
 {
+    // (from_tree: str_er_nms_tree_plane -- no batch ran, nothing was exported)
     replayed = false;
     std::vector<int> amb;
-    size_t largest = 0, total = 0;
-    auto scratch_need = [&](int i) -> size_t {
-        const PlaneDesc &pd = b.planes[i];
-        if (c->replay_on_gpu) return replay_scratch_bytes(pd.w, pd.h);
-        // host walk: only stamps go to the device -- those of the watched pixels, or all of them when the watch list overflowed
-        return c->h_ctr[i].n_watch <= (uint32_t)NMS_WATCH_CAP ? 0 : (((size_t)pd.w * pd.h * 4 + 255) / 256) * 256;
-    };
     for (int i = 0; i < (int)b.planes.size(); ++i)
-        if (c->h_ctr[i].n_rel) {         // ties that can change the pool (k_nms); the others need no decision
-            amb.push_back(i);
-            largest = std::max(largest, scratch_need(i));
-            total += scratch_need(i);
-        }
+        if (c->h_ctr[i].n_rel) amb.push_back(i);         // ties that can change the pool (k_nms); the others need no decision
     if (amb.empty()) return STR_ER_OK;
+    // (the context's own stream is idle here -- the caller has just synchronised it -- and other contexts keep the GPU's queues
+    // full: on the high-priority stream these few small operations do not wait behind their tile kernels)
+    hipStream_t s = c->prio ? c->prio : c->stream;
+    const auto plane_px = [&](int i) { return (size_t)b.planes[i].w * b.planes[i].h; };
+    const auto dense = [&](int i) { return c->h_ctr[i].n_watch > (uint32_t)NMS_WATCH_CAP; };    // watch list overflowed: a stamp per pixel
+
+    // ---- device scratch: the GPU walk needs 9 bytes per pixel, the host walk only room for dense stamp arrays -------------
+    auto scratch_need = [&](int i) -> size_t {
+        if (c->replay_on_gpu) return replay_scratch_bytes(b.planes[i].w, b.planes[i].h);
+        return dense(i) ? ((plane_px(i) * 4 + 255) / 256) * 256 : 0;
+    };
+    size_t largest = 0, total = 0;
+    for (int i : amb) { largest = std::max(largest, scratch_need(i)); total += scratch_need(i); }
     const size_t want = std::max(largest, std::min<size_t>(total, (size_t)1 << 30));
     if (want > c->replay_bytes) {
         if (c->d_replay) { (void)hipFree(c->d_replay); c->d_replay = nullptr; c->replay_bytes = 0; }
         if (hipMalloc(reinterpret_cast<void **>(&c->d_replay), want) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (flood replay scratch)");
         c->replay_bytes = want;
     }
-    hipStream_t s = c->stream;
-    std::vector<ReplayItem> items;
-    size_t pos = 0;
-    auto flush = [&]() -> int {
-        if (items.empty()) return STR_ER_OK;
-        HIP_TRY(c, hipMemcpyAsync(c->d_replay_items, items.data(), sizeof(ReplayItem) * items.size(), hipMemcpyHostToDevice, s));
+
+    // Planes go in rounds that fit the scratch (one round unless dozens of planes have dense stamps).  A round of the host walk is
+    // two device round trips: planes + watch lists down, [walk], stamps up + the tie pass of the NMS; everything the device reads or
+    // writes on the host side lives in one page-locked arena (copies to pageable memory go through bounce buffers under a lock).
+    size_t at = 0;
+    while (at < amb.size()) {
+        std::vector<ReplayItem> items;
+        size_t pos = 0, hneed = ((sizeof(ReplayItem) * amb.size() + 255) / 256) * 256;
+        std::vector<size_t> hoff;
+        while (at < amb.size() && (items.empty() || pos + scratch_need(amb[at]) <= c->replay_bytes)) {
+            const int i = amb[at++];
+            ReplayItem it{};
+            it.plane = (uint32_t)i; it.off = pos;
+            items.push_back(it);
+            pos += scratch_need(i);
+            hoff.push_back(hneed);
+            hneed += ((plane_px(i) + 255) / 256) * 256 + 3 * 4 * (size_t)NMS_WATCH_CAP + (dense(i) && !c->replay_on_gpu ? plane_px(i) * 4 : 0);
+        }
+        const size_t m = items.size();
+        if (hneed > c->h_replay_bytes) {
+            if (c->h_replay) { (void)hipHostFree(c->h_replay); c->h_replay = nullptr; c->h_replay_bytes = 0; }
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->h_replay), hneed, hipHostMallocDefault) != hipSuccess)
+                return fail(c, STR_ER_ENOMEM, "hipHostMalloc (flood order walk staging)");
+            c->h_replay_bytes = hneed;
+        }
+        ReplayItem *h_items = reinterpret_cast<ReplayItem *>(c->h_replay);
+        std::memcpy(h_items, items.data(), sizeof(ReplayItem) * m);
+        HIP_TRY(c, hipMemcpyAsync(c->d_replay_items, h_items, sizeof(ReplayItem) * m, hipMemcpyHostToDevice, s));
         if (c->replay_on_gpu) {
-            launch_flood_order(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
+            launch_flood_order(s, bd, dp, c->d_replay_items, (int)m, c->d_replay);
         } else {
-            // the walk on host cores, one thread per plane: plane pixels and watch list come down, the stamps go up
-            const size_t m = items.size();
-            std::vector<std::vector<uint8_t>> pix(m);
-            std::vector<std::vector<uint32_t>> watch(m), stamp(m);
+            struct HostPlane { uint8_t *pix; uint32_t *watch, *group, *stamp; uint32_t n_watch; };
+            std::vector<HostPlane> hp(m);
+            bool need_sync = false;
             for (size_t k = 0; k < m; ++k) {
-                const PlaneDesc &pd = b.planes[items[k].plane];
-                pix[k].resize((size_t)pd.w * pd.h);
-                HIP_TRY(c, hipMemcpy2DAsync(pix[k].data(), (size_t)pd.w, pd.pix, (size_t)pd.stride, (size_t)pd.w, (size_t)pd.h, hipMemcpyDeviceToHost, s));
-                const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
-                if (nw <= (uint32_t)NMS_WATCH_CAP) {
-                    watch[k].resize(nw);
-                    if (nw) HIP_TRY(c, hipMemcpyAsync(watch[k].data(), c->d_watch + (size_t)items[k].plane * NMS_WATCH_CAP, 4 * (size_t)nw, hipMemcpyDeviceToHost, s));
+                const int        i = (int)items[k].plane;
+                const PlaneDesc &pd = b.planes[i];
+                HostPlane       &h = hp[k];
+                h.pix = c->h_replay + hoff[k];
+                h.watch = reinterpret_cast<uint32_t *>(h.pix + ((plane_px(i) + 255) / 256) * 256);
+                h.group = h.watch + NMS_WATCH_CAP;
+                h.stamp = h.group + NMS_WATCH_CAP;          // NMS_WATCH_CAP entries, or w * h when dense
+                h.n_watch = c->h_ctr[i].n_watch;
+                // already here?  (k_export_tie_planes wrote the first TIE_SLOTS tie planes of the batch into host memory)
+                int slot = -1;
+                if (c->h_tie && !from_tree)
+                    for (uint32_t q = 0; q < std::min<uint32_t>(*c->h_tie_count, TIE_SLOTS); ++q) if (c->h_tie_plane[q] == (uint32_t)i) slot = (int)q;
+                if (slot >= 0) {
+                    h.pix = c->h_tie + (size_t)slot * c->tie_slot_bytes;
+                    uint32_t *wl = reinterpret_cast<uint32_t *>(h.pix + ((plane_px(i) + 255) / 256) * 256);
+                    if (!dense(i)) { std::memcpy(h.watch, wl, 4 * (size_t)h.n_watch); std::memcpy(h.group, wl + NMS_WATCH_CAP, 4 * (size_t)h.n_watch); }
+                    continue;
+                }
+                need_sync = true;
+                HIP_TRY(c, hipMemcpy2DAsync(h.pix, (size_t)pd.w, pd.pix, (size_t)pd.stride, (size_t)pd.w, (size_t)pd.h, hipMemcpyDeviceToHost, s));
+                if (h.n_watch && !dense(i)) {
+                    HIP_TRY(c, hipMemcpyAsync(h.watch, c->d_watch + (size_t)i * NMS_WATCH_CAP, 4 * (size_t)h.n_watch, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(h.group, c->d_wparent + (size_t)i * NMS_WATCH_CAP, 4 * (size_t)h.n_watch, hipMemcpyDeviceToHost, s));
                 }
             }
-            HIP_TRY(c, hipStreamSynchronize(s));
+            if (need_sync) HIP_TRY(c, hipStreamSynchronize(s));
+            const auto tw0 = std::chrono::steady_clock::now();
             auto walk = [&](size_t k) {
-                const PlaneDesc &pd = b.planes[items[k].plane];
-                const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
-                if (nw <= (uint32_t)NMS_WATCH_CAP) {
-                    stamp[k].assign(nw, 0u);
-                    flood_order_host(pix[k].data(), pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, watch[k].data(), nw, stamp[k].data());
+                const int        i = (int)items[k].plane;
+                const PlaneDesc &pd = b.planes[i];
+                HostPlane       &h = hp[k];
+                if (!dense(i)) {
+                    std::memset(h.stamp, 0, 4 * (size_t)NMS_WATCH_CAP);
+                    flood_order_host(h.pix, pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, h.watch, h.n_watch, h.stamp, h.group);
                 } else {
-                    stamp[k].assign((size_t)pd.w * pd.h, 0u);
-                    flood_order_host(pix[k].data(), pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, nullptr, 0xFFFFFFFFu, stamp[k].data());
+                    std::memset(h.stamp, 0, 4 * plane_px(i));
+                    flood_order_host(h.pix, pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, nullptr, 0xFFFFFFFFu, h.stamp);
                 }
             };
             std::vector<std::thread> th;
             for (size_t k = 1; k < m; ++k) th.emplace_back(walk, k);
             walk(0);
             for (auto &t : th) t.join();
+            if (c->dbg_stats)
+                std::fprintf(stderr, "[str_er] flood order walk: %zu plane(s), %.1f ms on the host\n", m,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
             for (size_t k = 0; k < m; ++k) {
-                const uint32_t nw = c->h_ctr[items[k].plane].n_watch;
-                if (nw <= (uint32_t)NMS_WATCH_CAP) {
-                    if (nw) HIP_TRY(c, hipMemcpyAsync(c->d_wstamp + (size_t)items[k].plane * NMS_WATCH_CAP, stamp[k].data(), 4 * (size_t)nw, hipMemcpyHostToDevice, s));
+                const int i = (int)items[k].plane;
+                if (!dense(i)) {
+                    if (hp[k].n_watch) HIP_TRY(c, hipMemcpyAsync(c->d_wstamp + (size_t)i * NMS_WATCH_CAP, hp[k].stamp, 4 * (size_t)hp[k].n_watch, hipMemcpyHostToDevice, s));
                 } else {
-                    HIP_TRY(c, hipMemcpyAsync(c->d_replay + items[k].off, stamp[k].data(), 4 * stamp[k].size(), hipMemcpyHostToDevice, s));
+                    HIP_TRY(c, hipMemcpyAsync(c->d_replay + items[k].off, hp[k].stamp, 4 * plane_px(i), hipMemcpyHostToDevice, s));
                 }
             }
-            HIP_TRY(c, hipStreamSynchronize(s));       // the host vectors go out of scope
         }
-        launch_nms_resolve(s, bd, dp, c->d_replay_items, (int)items.size(), c->d_replay);
+        launch_nms_resolve(s, bd, dp, c->d_replay_items, (int)m, c->d_replay);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(s));       // the item table and the scratch are reused by the next round
-        c->n_replayed += items.size();
-        items.clear();
-        pos = 0;
-        return STR_ER_OK;
-    };
-    for (int i : amb) {
-        const size_t need = scratch_need(i);
-        if (pos + need > c->replay_bytes) { const int rc = flush(); if (rc != STR_ER_OK) return rc; }
-        ReplayItem it{};
-        it.plane = (uint32_t)i; it.off = pos;
-        items.push_back(it);
-        pos += need;
+        c->n_replayed += m;
+        // (the arena and the item table are reused by the next round; the last round is left to the caller's synchronisation)
+        if (at < amb.size()) HIP_TRY(c, hipStreamSynchronize(s));
     }
-    const int rc = flush();
-    if (rc != STR_ER_OK) return rc;
     replayed = true;
     return STR_ER_OK;
 }
@@ -793,24 +832,28 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         launch_nms_alt(c->side, bd, dp);
+        if (c->h_tie && !c->replay_on_gpu) {
+            *c->h_tie_count = 0;        // (the previous batch of this context is done: nothing on the device touches it any more)
+            launch_export_tie_planes(c->side, bd, c->h_tie, c->tie_slot_bytes, TIE_SLOTS, c->h_tie_count, c->h_tie_plane);
+        }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
     }
     // everything after NMS reads the pools: enqueued once, and once more if sibling ties had to be decided by a flood replay
-    auto after_nms = [&](bool record) {
+    auto after_nms = [&](bool record, hipStream_t st) {
         if (stages & STR_ER_STAGE_NMS) {
-            launch_cand_prefix(s, bd);
-            launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
+            launch_cand_prefix(st, bd);
+            launch_classify(st, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
         }
         if (record) rec(c, "classify");
         if (stages & STR_ER_STAGE_TRACK) {
             const int n_img = np / b.planes_per_image;
-            launch_calc_color_batch(s, bd, c->d_track);
-            launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
-            launch_er_track(s, c->d_cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
+            launch_calc_color_batch(st, bd, c->d_track);
+            launch_group_ranges(st, bd, b.planes_per_image, n_img, c->d_ranges);
+            launch_er_track(st, c->d_cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
             if (record) rec(c, "track");
         }
     };
-    after_nms(true);
+    after_nms(true, s);
     const int i_cls = (stages & STR_ER_STAGE_TRACK) ? c->n_ev - 2 : c->n_ev - 1;
     const int i_trk = c->n_ev - 1;
     if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -837,15 +880,20 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     }
     if ((stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0) {
         bool replayed = false;
+        const auto tr0 = std::chrono::steady_clock::now();
         const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed);
         if (rcr != STR_ER_OK) return rcr;
+        const auto tr1 = std::chrono::steady_clock::now();
+        if (replayed && c->dbg_stats) std::fprintf(stderr, "[str_er] tie resolution (copies + walk + NMS pass): %.1f ms\n", std::chrono::duration<double, std::milli>(tr1 - tr0).count());
         if (replayed) {
-            HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
-            after_nms(false);
+            hipStream_t sp = c->prio ? c->prio : s;         // same stream as the tie pass: ordered behind it
+            HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), sp));
+            after_nms(false, sp);
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
+            HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
+            HIP_TRY(c, hipStreamSynchronize(sp));
+            if (c->dbg_stats) std::fprintf(stderr, "[str_er] classify again after the tie pass: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count());
         }
     }
 
@@ -1104,6 +1152,8 @@ void str_er_destroy(str_er_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_replay) (void)hipFree(c->d_replay);
+    if (c->h_replay) (void)hipHostFree(c->h_replay);
+    if (c->h_tie) (void)hipHostFree(c->h_tie);
     if (c->na.rec) (void)hipFree(c->na.rec);
     if (c->na.aux) (void)hipFree(c->na.aux);
     if (c->d_group) (void)hipFree(c->d_group);
@@ -1115,6 +1165,7 @@ void str_er_destroy(str_er_ctx *c)
     if (c->h_total) (void)hipHostFree(c->h_total);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->prio) { (void)hipStreamSynchronize(c->prio); (void)hipStreamDestroy(c->prio); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1176,6 +1227,20 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         c->own_stream = true;
     }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { A(fail(nullptr, STR_ER_EHIP, "hipEventCreate failed")); break; }
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (numerically lower = higher priority)
+        if (hipStreamCreateWithPriority(&c->prio, hipStreamNonBlocking, hi) != hipSuccess) A(fail(nullptr, STR_ER_EHIP, "priority stream creation failed"));
+    }
+    if (p->sibling_order == 0) {
+        c->tie_slot_bytes = ((plane_px + 255) / 256) * 256 + 2 * 4 * (size_t)NMS_WATCH_CAP + 256;
+        const size_t tb = (size_t)TIE_SLOTS * c->tie_slot_bytes + 4 * (size_t)TIE_SLOTS + 64;
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_tie), tb, hipHostMallocMapped) != hipSuccess) A(fail(nullptr, STR_ER_ENOMEM, "hipHostMalloc (tie plane export)"));
+        else {
+            c->h_tie_plane = reinterpret_cast<uint32_t *>(c->h_tie + (size_t)TIE_SLOTS * c->tie_slot_bytes);
+            c->h_tie_count = c->h_tie_plane + TIE_SLOTS;
+        }
+    }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
         A(fail(nullptr, STR_ER_EHIP, "side stream creation failed"));
@@ -1199,7 +1264,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
     A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
-    A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP));
+    A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
     A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
@@ -1727,8 +1792,9 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     const uint32_t n_amb = c->h_ctr[0].n_amb;
     if (plane && c->prm.sibling_order == 0 && c->h_ctr[0].n_rel) {      // ties: the reference's flood order decides (k_flood_order)
         bool replayed = false;
-        const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed);
+        const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed, /*from_tree=*/true);
         if (rcr != STR_ER_OK) return rcr;
+        if (c->prio) HIP_TRY(c, hipStreamSynchronize(c->prio));       // the tie pass ran there
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
