@@ -1190,69 +1190,6 @@ __device__ __forceinline__ uint32_t plane_nodes(const BatchDev &b, int pi)
     return (b.ctr[pi].overflow & 8u) ? 0u : b.ctr[pi].n_nodes;
 }
 
-// Nodes that were unified into another node of the same level hand their own statistics to the surviving level root;
-// surviving nodes get a canonical parent (the parent node's level root).  Every node that will push its totals to a parent
-// -- open, alive, not a tree root -- is counted in the parent's dependency counter (aux).
-__global__ __launch_bounds__(256) void k_resolve(BatchDev b)
-{
-    const int       pi = blockIdx.y;
-    const uint32_t  n = plane_nodes(b, pi);
-    NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
-    uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
-    for (uint32_t x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += gridDim.x * blockDim.x) {
-        const uint32_t  x = x0 + (threadIdx.x & 63u);
-        uint32_t        push_to = NONE;         // the parent this node will push its totals to
-        if (x < n) {
-        const uint32_t  l = nr[x].key >> 24;
-        const uint32_t  w = nr[x].par;        // (plain loads: k_seam's writes are visible since the kernel boundary, and a
-                                              //  parent word rewritten by a lane of THIS kernel points to the same node either way)
-        if (w != NONE && PAR_LVL(w) == l) {
-            uint32_t r = PAR_ID(w);
-            for (;;) {
-                const uint32_t w2 = nr[r].par;
-                if (w2 == NONE || PAR_LVL(w2) != l) break;
-                r = PAR_ID(w2);
-            }
-            const uint32_t nodw = nr[x].nod;
-            atomicOr(&nr[x].nod, NODE_DEAD);
-            atomicAdd(&nr[r].cnt, nr[x].cnt);
-            if ((nodw & NODE_CNT) > 1) atomicAdd(&nr[r].nod, (nodw & NODE_CNT) - 1);   // folded descendants
-            atomicMin(&nr[r].x0, nr[x].x0);
-            atomicMin(&nr[r].y0, nr[x].y0);
-            atomicMax(&nr[r].x1, nr[x].x1);
-            atomicMax(&nr[r].y1, nr[x].y1);
-            atomicMin(&nr[r].key, nr[x].key);          // same level: the top byte is equal, the minimum is over the pixel index
-        } else if (w != NONE) {
-            uint32_t       q = PAR_ID(w);
-            const uint32_t lq = PAR_LVL(w);
-            for (;;) {
-                const uint32_t w2 = nr[q].par;
-                if (w2 == NONE || PAR_LVL(w2) != lq) break;
-                q = PAR_ID(w2);
-            }
-            if (q != PAR_ID(w)) nr[x].par = PAR_MAKE(lq, q);
-            if (!(nr[x].nod & NODE_CLOSED)) push_to = q;                 // closed nodes never push (their totals are final)
-        }
-        }
-        // count the pushing children per parent; the lanes of a wave that share a parent (the background node of a tile has
-        // hundreds of children) bring one increment together
-        unsigned long long todo = __ballot(push_to != NONE);
-        while (todo) {
-            const int      leader = __ffsll((long long)todo) - 1;
-            const uint32_t lq = __shfl(push_to, leader);
-            const unsigned long long m = __ballot(push_to == lq);
-            if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&aux[lq], (uint32_t)__popcll(m));
-            todo &= ~m;
-        }
-    }
-}
-
-void launch_resolve(hipStream_t s, const BatchDev &b)
-{
-    if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_resolve, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b);
-}
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll
@@ -1270,6 +1207,94 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
     return v;
+}
+
+// Nodes that were unified into another node of the same level hand their own statistics to the surviving level root;
+// surviving nodes get a canonical parent (the parent node's level root).  Every node that will push its totals to a parent
+// -- open, alive, not a tree root -- is counted in the parent's dependency counter (aux).
+__global__ __launch_bounds__(256) void k_resolve(BatchDev b)
+{
+    const int       pi = blockIdx.y;
+    const uint32_t  n = plane_nodes(b, pi);
+    NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
+    uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
+    const int       lane = threadIdx.x & 63;
+    for (uint32_t x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += gridDim.x * blockDim.x) {
+        const uint32_t  x = x0 + (uint32_t)lane;
+        uint32_t        push_to = NONE;         // the parent this node will push its totals to
+        uint32_t        hand_to = NONE;         // the surviving level root this (unified) node hands its own statistics to
+        uint32_t        c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0, ky = 0xFFFFFFFFu;
+        if (x < n) {
+            const NodeRec   me = nr[x];          // (plain loads: k_seam's writes are visible since the kernel boundary, and a parent
+            const uint32_t  l = me.key >> 24;    //  word rewritten by a lane of THIS kernel points to the same node either way)
+            const uint32_t  w = me.par;
+            if (w != NONE && PAR_LVL(w) == l) {
+                uint32_t r = PAR_ID(w);
+                for (;;) {
+                    const uint32_t w2 = nr[r].par;
+                    if (w2 == NONE || PAR_LVL(w2) != l) break;
+                    r = PAR_ID(w2);
+                }
+                hand_to = r;
+                c = me.cnt; nd = (me.nod & NODE_CNT) - 1u;      // (its folded descendants; the node itself is the survivor's)
+                bx0 = me.x0; by0 = me.y0; bx1 = me.x1; by1 = me.y1; ky = me.key;
+                atomicOr(&nr[x].nod, NODE_DEAD);
+            } else if (w != NONE) {
+                uint32_t       q = PAR_ID(w);
+                const uint32_t lq = PAR_LVL(w);
+                for (;;) {
+                    const uint32_t w2 = nr[q].par;
+                    if (w2 == NONE || PAR_LVL(w2) != lq) break;
+                    q = PAR_ID(w2);
+                }
+                if (q != PAR_ID(w)) nr[x].par = PAR_MAKE(lq, q);
+                if (!(me.nod & NODE_CLOSED)) push_to = q;                 // closed nodes never push (their totals are final)
+            }
+        }
+        // The pieces a seam cut a big node into all hand over to ONE survivor, and the children of a big node all count into ONE
+        // parent: the lanes of a wave that share a target combine first (ballot + butterfly) -- one set of atomics per distinct
+        // target and wave; without it these few hot words serialise the whole kernel.
+        unsigned long long todo = __ballot(hand_to != NONE);
+        while (todo) {
+            const int      leader = __ffsll((long long)todo) - 1;
+            const uint32_t lr = __shfl(hand_to, leader);
+            const bool     mine = hand_to == lr;
+            const unsigned long long m = __ballot(mine);
+            if (__popcll(m) == 1) {
+                if (mine) {
+                    atomicAdd(&nr[lr].cnt, c);
+                    if (nd) atomicAdd(&nr[lr].nod, nd);
+                    atomicMin(&nr[lr].x0, bx0); atomicMin(&nr[lr].y0, by0); atomicMax(&nr[lr].x1, bx1); atomicMax(&nr[lr].y1, by1);
+                    atomicMin(&nr[lr].key, ky);          // same level: the top byte is equal, the minimum is over the pixel index
+                }
+            } else {
+                const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
+                const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
+                const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u), mk = wave_min(mine ? ky : 0xFFFFFFFFu);
+                if (lane == leader) {
+                    atomicAdd(&nr[lr].cnt, sc);
+                    if (sn) atomicAdd(&nr[lr].nod, sn);
+                    atomicMin(&nr[lr].x0, mx0); atomicMin(&nr[lr].y0, my0); atomicMax(&nr[lr].x1, mx1); atomicMax(&nr[lr].y1, my1);
+                    atomicMin(&nr[lr].key, mk);
+                }
+            }
+            todo &= ~m;
+        }
+        todo = __ballot(push_to != NONE);
+        while (todo) {
+            const int      leader = __ffsll((long long)todo) - 1;
+            const uint32_t lq = __shfl(push_to, leader);
+            const unsigned long long m = __ballot(push_to == lq);
+            if (lane == leader) atomicAdd(&aux[lq], (uint32_t)__popcll(m));
+            todo &= ~m;
+        }
+    }
+}
+
+void launch_resolve(hipStream_t s, const BatchDev &b)
+{
+    if (!b.n_planes) return;
+    hipLaunchKernelGGL(k_resolve, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b);
 }
 
 // er_merge's accumulation (src/ER.cpp:153-165): every live open node adds its (final) totals to its parent.  One launch for

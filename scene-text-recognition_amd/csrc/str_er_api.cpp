@@ -101,6 +101,7 @@ struct str_er_ctx {
     KeptArrays ka{};
     uint16_t *d_seam = nullptr; size_t seam_slots = 0;
     size_t node_slots = 0;            // node records allocated (NodeArrays::rec / aux)
+    uint32_t node_blocks_cap = 12;
     uint32_t node_blocks = 12;        // workgroups per plane of the per-record kernels: from the record counts of the previous batch
     double node_share = 0.25;         // records per padded plane pixel; grown (and the batch repeated) when a plane runs out
     uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
@@ -921,7 +922,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         for (int i = 0; i < np; ++i) most = std::max(most, c->h_ctr[i].n_nodes);
         // (more lanes than this in flight only queue up behind the same hot parent words: measured on noise, 256 workgroups per
         // plane made k_resolve 4x slower than 12)
-        c->node_blocks = std::min<uint32_t>(12, std::max<uint32_t>(4, (most + 255) / 256));
+        c->node_blocks = std::min<uint32_t>(c->node_blocks_cap, std::max<uint32_t>(4, (most + 255) / 256));
     }
     if (c->tile_mode == 0 && b.n_tiles) {      // text-like frames make a few dozen nodes per tile, noise several hundred
         unsigned long long created = 0;
@@ -1201,6 +1202,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     }
     c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
     c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
+    if (const char *nb = std::getenv("STR_ER_NODE_BLOCKS")) c->node_blocks_cap = (uint32_t)std::max(1, std::atoi(nb));
     if (const char *rp = std::getenv("STR_ER_REPLAY")) c->replay_on_gpu = !std::strcmp(rp, "gpu");
     for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
     c->ppf = (int)c->chans.size() * p->n_pyr_levels;
