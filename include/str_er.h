@@ -202,6 +202,15 @@ int str_er_detect_bgr(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h,
                       int64_t stride, int64_t frame_pitch, int32_t n_frames,
                       int mem_kind, uint32_t stages, str_er_result **out);
 
+/* The same for a SUBSET of the logical planes of every frame: plane_select[level * n_channels + k] != 0 selects the
+ * k-th channel of the context's channel_mask at that pyramid level (n_select = n_pyr_levels * popcount(channel_mask)).
+ * Channels and the pyramid are built on the device as far as the deepest selected level; the result holds the selected
+ * planes only, in the usual order.  This is how one large frame is split over GPUs plane by plane without a
+ * host copy of any plane.  Not with STR_ER_STAGE_TRACK / _GROUP (they read every plane of an image).                        */
+int str_er_detect_bgr_planes(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                             int32_t n_frames, int mem_kind, uint32_t stages, const uint8_t *plane_select,
+                             int32_t n_select, str_er_result **out);
+
 /* The loop body (src/ER.cpp:52-59) for n_planes independent 8UC1 planes of w*h
  * pixels (plane_pitch = bytes between planes).  This is what the reference's direct
  * callers use (src/utils.cpp:680-684, 716-720, 763-769, 940-947, 1386-1388).        */
@@ -370,6 +379,50 @@ const double *str_er_result_times(const str_er_result *r);
 int  str_er_result_cands_to_device(str_er_ctx *ctx, const str_er_result *r, void *dst_dev,
                                    int32_t cap, int32_t *n);
 void str_er_result_free(str_er_result *r);
+
+/* ---- one plane in strips over several GPUs (no reference counterpart) -----------------------
+ * The level-0 planes of ONE frame cut into n_strips bands of tile rows.  Every participant calls str_er_strip_extract with the
+ * frame and its strip number: compute_channels, the tile trees of the strip and the seams inside it, for every channel of the
+ * context; *blob (malloc'ed, str_er_strip_free) holds the strip's node records and the node of every pixel of its first and
+ * last row -- plain bytes, to be sent to the plane's owner by any transport.  The owner calls str_er_strip_merge with the
+ * frame and all n_strips blobs (in strip order): records behind one another, seams across the cuts joined, then the usual
+ * passes; the result is the one str_er_detect_bgr gives for the frame (same planes, same records).  Contexts need
+ * n_pyr_levels = 1 and equal parameters on all participants.                                                                  */
+int  str_er_strip_extract(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind,
+                          int32_t strip, int32_t n_strips, void **blob, int64_t *blob_bytes);
+void str_er_strip_free(void *blob);
+int  str_er_strip_merge(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind,
+                        const void *const *blobs, const int64_t *blob_bytes, int32_t n_strips, uint32_t stages,
+                        str_er_result **out);
+
+/* ---- multi-GPU: the one exchange of the path ------------------------------------------
+ * One process per GPU; frames (or planes) are dealt out to the ranks and only the candidate records travel, where the
+ * reference's er_track reads the strong / weak lists of every plane (src/ER.cpp:63):
+ *     all_gather(my count) -> all_gather(records padded to the largest count) -> padding dropped, frame offsets added.
+ * A communicator is an RCCL communicator (librccl.so is loaded on first use; ncclAllGather over xGMI on a stream of its own)
+ * or a member of an in-process group that exchanges through host memory (tests without a GPU; one thread per rank).     */
+typedef struct str_er_comm str_er_comm;
+typedef struct str_er_comm_group str_er_comm_group;
+/* RCCL: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the others by any means; all ranks then create. */
+int  str_er_comm_unique_id(void *id128);
+int  str_er_comm_create(int32_t device, int32_t rank, int32_t world, const void *id128, str_er_comm **out);
+/* in-process group of `world` ranks */
+int  str_er_comm_local_group(int32_t world, str_er_comm_group **out);
+int  str_er_comm_create_local(str_er_comm_group *g, int32_t rank, str_er_comm **out);
+void str_er_comm_local_group_free(str_er_comm_group *g);
+void str_er_comm_destroy(str_er_comm *c);
+int32_t str_er_comm_rank(const str_er_comm *c);
+int32_t str_er_comm_world(const str_er_comm *c);
+const char *str_er_comm_last_error(const str_er_comm *c);
+/* Collective: every rank passes its records (host memory) and the number to add to their `frame` field; every rank receives
+ * all records ordered by rank (*all, free with str_er_gather_free) and, if counts != NULL, the per-rank counts.            */
+int  str_er_gather_cands(str_er_comm *c, const str_er_cand *local, int32_t n_local, uint32_t frame_offset,
+                         str_er_cand **all, int32_t *n_all, int32_t *counts);
+/* The same for the candidates of ctx's last detect call, taken from the device array they are still in: no host hop on
+ * the sending side (RCCL communicators only).                                                                             */
+int  str_er_gather_last(str_er_comm *c, str_er_ctx *ctx, uint32_t frame_offset, str_er_cand **all, int32_t *n_all,
+                        int32_t *counts);
+void str_er_gather_free(str_er_cand *p);
 
 /* ---- introspection / measurement --------------------------------------------------- */
 /* Per-kernel-group GPU time of the LAST detect call, measured with HIP events on the

@@ -115,6 +115,12 @@ def load_library():
     L.str_er_cascade_info.argtypes = [vp, C.c_int, i32p, i32p]
     L.str_er_detect_bgr.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int,
                                     C.c_uint32, C.POINTER(vp)]
+    L.str_er_detect_bgr_planes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int,
+                                           C.c_uint32, vp, C.c_int32, C.POINTER(vp)]
+    L.str_er_strip_extract.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.str_er_strip_free.argtypes = [vp]
+    L.str_er_strip_free.restype = None
+    L.str_er_strip_merge.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int, vp, vp, C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.str_er_detect_planes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int,
                                        C.c_uint32, C.POINTER(vp)]
     L.str_er_compute_channels.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]
@@ -130,6 +136,20 @@ def load_library():
     L.str_er_nms_tree.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, i32p, i32p]
     L.str_er_nms_tree_plane.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, i32p, i32p]
     L.str_er_flood_order.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp]
+    L.str_er_comm_unique_id.argtypes = [vp]
+    L.str_er_comm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, C.POINTER(vp)]
+    L.str_er_comm_local_group.argtypes = [C.c_int32, C.POINTER(vp)]
+    L.str_er_comm_create_local.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.str_er_comm_local_group_free.argtypes = [vp]
+    L.str_er_comm_local_group_free.restype = None
+    L.str_er_comm_destroy.argtypes = [vp]
+    L.str_er_comm_destroy.restype = None
+    L.str_er_comm_last_error.argtypes = [vp]
+    L.str_er_comm_last_error.restype = C.c_char_p
+    L.str_er_gather_cands.argtypes = [vp, vp, C.c_int32, C.c_uint32, C.POINTER(vp), i32p, i32p]
+    L.str_er_gather_last.argtypes = [vp, vp, C.c_uint32, C.POINTER(vp), i32p, i32p]
+    L.str_er_gather_free.argtypes = [vp]
+    L.str_er_gather_free.restype = None
     L.str_er_resize_plane.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
     L.str_er_result_n_planes.argtypes = [vp]
     L.str_er_result_n_planes.restype = C.c_int32
@@ -397,6 +417,43 @@ class ERFilter:
                                              stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
         return self._collect(rh)
 
+    def text_detect_planes(self, src: np.ndarray, select, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:
+        """text_detect for a subset of the logical planes (str_er_detect_bgr_planes): select[level * n_channels + k] flags."""
+        a = np.ascontiguousarray(src, dtype=np.uint8)
+        if a.ndim == 3:
+            a = a[None]
+        f, h, w, _ = a.shape
+        sel = np.ascontiguousarray(select, dtype=np.uint8)
+        rh = C.c_void_p()
+        self._check(self.L.str_er_detect_bgr_planes(self.h, _np_ptr(a), w, h, 3 * w, 3 * w * h, f, MEM_HOST,
+                                                    stages | (WANT_NODES if want_nodes else 0), _np_ptr(sel), len(sel), C.byref(rh)))
+        return self._collect(rh)
+
+    # ---- SURVEY 8(f)-4: the level-0 planes of one frame in strips over several GPUs ---------------------------
+    def strip_extract(self, frame: np.ndarray, strip: int, n_strips: int) -> bytes:
+        """Tile trees of strip `strip` of `n_strips` of every channel's level-0 plane: the bytes to send to the plane's owner."""
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, _ = a.shape
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.L.str_er_strip_extract(self.h, _np_ptr(a), w, h, 3 * w, MEM_HOST, strip, n_strips, C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p.value, n.value)
+        finally:
+            self.L.str_er_strip_free(p)
+
+    def strip_merge(self, frame: np.ndarray, blobs, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:
+        """The owner's half: all strips' blobs (in strip order) -> the result text_detect gives for the frame."""
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, _ = a.shape
+        k = len(blobs)
+        bufs = [C.create_string_buffer(bytes(x), len(x)) for x in blobs]
+        ptrs = (C.c_void_p * k)(*[C.cast(x, C.c_void_p) for x in bufs])
+        sizes = (C.c_int64 * k)(*[len(x) for x in blobs])
+        rh = C.c_void_p()
+        self._check(self.L.str_er_strip_merge(self.h, _np_ptr(a), w, h, 3 * w, MEM_HOST, ptrs, sizes, k,
+                                              stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
+        return self._collect(rh)
+
     def detect_bgr_device(self, dptr: int, w: int, h: int, n_frames: int, stages: int = STAGE_ALL,
                           stride: Optional[int] = None, frame_pitch: Optional[int] = None) -> Result:
         """Same, for frames already resident in HBM (dptr = device address)."""
@@ -597,6 +654,84 @@ def flood_order(plane: np.ndarray, thresh_step: int = 8) -> np.ndarray:
     if rc != 0:
         raise StrErError(rc, "str_er_flood_order")
     return out
+
+
+class Comm:
+    """One rank of the candidate gather (include/str_er.h, str_er_comm_* / str_er_gather_*): an RCCL communicator
+    (`Comm.rccl`) or a member of an in-process group that exchanges through host memory (`Comm.local_group`)."""
+
+    def __init__(self, handle, world: int, rank: int, group=None):
+        self.L, self.h, self.world, self.rank, self._group = load_library(), handle, world, rank, group
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = load_library().str_er_comm_unique_id(buf)
+        if rc != 0:
+            raise StrErError(rc, "str_er_comm_unique_id (is librccl.so there?)")
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, device: int, rank: int, world: int, uid: bytes) -> "Comm":
+        h = C.c_void_p()
+        rc = load_library().str_er_comm_create(device, rank, world, C.create_string_buffer(uid, 128), C.byref(h))
+        if rc != 0:
+            raise StrErError(rc, "str_er_comm_create")
+        return cls(h, world, rank)
+
+    @classmethod
+    def local_group(cls, world: int):
+        """`world` communicators of one in-process group (use one per thread)."""
+        L = load_library()
+        g = C.c_void_p()
+        rc = L.str_er_comm_local_group(world, C.byref(g))
+        if rc != 0:
+            raise StrErError(rc, "str_er_comm_local_group")
+        out = []
+        for r in range(world):
+            h = C.c_void_p()
+            rc = L.str_er_comm_create_local(g, r, C.byref(h))
+            if rc != 0:
+                raise StrErError(rc, "str_er_comm_create_local")
+            out.append(cls(h, world, r, group=g))
+        L.str_er_comm_local_group_free(g)        # the communicators keep the group alive
+        return out
+
+    def _take(self, rc, p, n, counts):
+        if rc != 0:
+            raise StrErError(rc, (self.L.str_er_comm_last_error(self.h) or b"").decode())
+        try:
+            out = (np.frombuffer((C.c_char * (48 * n.value)).from_address(p.value), dtype=CAND_DTYPE).copy()
+                   if n.value else np.zeros(0, CAND_DTYPE))
+        finally:
+            self.L.str_er_gather_free(p)
+        return out, np.array(counts[:], np.int32)
+
+    def gather(self, cands: np.ndarray, frame_offset: int = 0):
+        """Collective: (all ranks' records ordered by rank, per-rank counts); `frame_offset` is added to this rank's frames."""
+        a = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        p, n = C.c_void_p(), C.c_int32()
+        counts = (C.c_int32 * self.world)()
+        rc = self.L.str_er_gather_cands(self.h, _np_ptr(a) if len(a) else None, len(a), frame_offset, C.byref(p), C.byref(n), counts)
+        return self._take(rc, p, n, counts)
+
+    def gather_last(self, erf: "ERFilter", frame_offset: int = 0):
+        """The same for the candidates of erf's last detect call, straight from the device array (RCCL only)."""
+        p, n = C.c_void_p(), C.c_int32()
+        counts = (C.c_int32 * self.world)()
+        rc = self.L.str_er_gather_last(self.h, erf.h, frame_offset, C.byref(p), C.byref(n), counts)
+        return self._take(rc, p, n, counts)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.str_er_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FrameStream:

@@ -46,6 +46,9 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);
 void launch_resolve(hipStream_t s, const BatchDev &b);
+// strips of a plane extracted elsewhere: make a strip's record ids plane-wide; join pixel pairs (plane-local ids) across a cut
+void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add);
+void launch_connect_pairs(hipStream_t s, NodeRec *plane_rec, const uint32_t *pairs, uint32_t n_pairs);
 // er_merge's accumulation (src/ER.cpp:153-165) for the whole batch in ONE launch: a node pushes its totals to its parent when its
 // last open child has pushed (dependency counters, agent-scope release/acquire)
 void launch_reduce(hipStream_t s, const BatchDev &b);

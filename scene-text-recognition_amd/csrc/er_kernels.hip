@@ -591,6 +591,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     {
         uint8_t px[TILE_PPT];
         int     nvalid = 0;
+        // (rows above y_lo are not part of the image either: the phantom tile row on top of a strip of a plane)
         if (gy < pd.h && gx < pd.w) {
             const uint8_t *row = pd.pix + (size_t)gy * pd.stride + gx;
             nvalid = min(TILE_PPT, pd.w - gx);
@@ -1177,6 +1178,36 @@ void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 {
     if (!b.n_seam_blocks) return;
     hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(SEAM_BLOCK), 0, s, b, xcd_affine ? 1 : 0);
+}
+
+// ---- a plane put together from strips that other GPUs extracted ---------------------------------------------
+// The records of a strip arrive with ids, keys and rows local to the strip (a strip is extracted like a plane of its own: the tile
+// kernel knows nothing of the rows above it).  `delta` makes the ids those of the whole plane (the strip's records sit behind those
+// of the strips above it), key_add = first row * width and y_add = first row put keys and boxes into the whole plane's coordinates.
+__global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        NodeRec r = rec[i];
+        if (r.par != NONE) r.par = PAR_MAKE(PAR_LVL(r.par), PAR_ID(r.par) + delta);
+        r.key += key_add;                 // (bits 0..23; the plane has fewer than 2^24 pixels, the level byte is not reached)
+        r.y0 += y_add; r.y1 += y_add;
+        rec[i] = r;
+        aux[i] = 0;
+    }
+}
+// ... and the pixel pairs across the cut between two strips are joined like any other seam
+__global__ __launch_bounds__(256) void k_connect_pairs(NodeRec *nr, const uint32_t *pairs, uint32_t n_pairs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) node_connect(nr, pairs[2 * i], pairs[2 * i + 1]);
+}
+void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add)
+{
+    if (n) hipLaunchKernelGGL(k_rebase_records, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, rec, aux, n, delta, key_add, y_add);
+}
+void launch_connect_pairs(hipStream_t s, NodeRec *plane_rec, const uint32_t *pairs, uint32_t n_pairs)
+{
+    if (n_pairs) hipLaunchKernelGGL(k_connect_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, s, plane_rec, pairs, n_pairs);
 }
 
 // ------------------------------------------------------------------------------------

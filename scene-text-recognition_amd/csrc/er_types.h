@@ -1,6 +1,7 @@
 // er_types.h -- structures shared by the host API (str_er_api.cpp) and the gfx950
 // kernels (er_kernels.hip).  Internal; the public boundary is include/str_er.h.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace str_er {
@@ -38,10 +39,12 @@ struct PlaneDesc {
     uint32_t kept_base;     // offset in the kept-node arrays (capacity kept_cap)
     uint32_t pool_base;     // offset in the pool arrays (capacity pool_cap)
     uint32_t frame;
-    uint8_t  ch, pyr, pad0, pad1;
+    uint8_t  ch, pyr;
+    uint8_t  pad0, pad1;
     uint32_t color_pitch;   // BGR frames: bytes between the Y, Cr, Cb planes of this level (pix - (ch % 3) * color_pitch is Y); 0 = no colour image
     uint32_t node_cap;      // node records this plane may use (a share of its pixel count; overflow -> the host grows the share and repeats)
 };
+static_assert(sizeof(PlaneDesc) == 80 && offsetof(PlaneDesc, node_cap) == 76, "PlaneDesc layout (host and device)");
 
 // Per-plane device counters, zeroed before every batch.
 struct PlaneCtr {

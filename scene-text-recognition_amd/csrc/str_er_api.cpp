@@ -24,6 +24,7 @@
 #include "track_kernels.h"
 #include "er_group.h"
 #include "flood_order.h"
+#include <functional>
 #include <thread>
 
 using namespace str_er;
@@ -121,6 +122,7 @@ struct str_er_ctx {
     uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
     ReplayItem *d_replay_items = nullptr;
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
+    uint32_t last_total = 0; bool last_valid = false;   // candidates of the last detect call, still in d_cands (str_er_gather_last)
     uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
     bool replay_on_gpu = false;                       // STR_ER_REPLAY=gpu: walk the flood with k_flood_order instead of a host core
     uint16_t *d_cand_plane = nullptr;
@@ -743,9 +745,47 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
     return STR_ER_OK;
 }
 
+// Plane descriptors, zeroed counters and the tile / seam-block lookup tables of a laid-out batch go to the device.
+int upload_layout(str_er_ctx *c, const Batch &b)
+{
+    hipStream_t s = c->stream;
+    const int np = (int)b.planes.size();
+    std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
+    HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+    {   // tile -> plane and seam-block -> (plane, first pair) tables; re-uploaded only when the layout changes
+        std::vector<uint32_t> key;
+        key.reserve(np * 2 + 1);
+        key.push_back((uint32_t)np);
+        for (const PlaneDesc &pd : b.planes) { key.push_back((uint32_t)pd.w); key.push_back((uint32_t)pd.h); }
+        if (key != c->layout_key) {
+            c->layout_key.clear();          // the tables are being rebuilt: a failure below must not leave the old key naming them
+            c->h_tile_plane.clear(); c->h_sb_plane.clear(); c->h_sb_first.clear();
+            for (int i = 0; i < np; ++i) {
+                const PlaneDesc &pd = b.planes[i];
+                c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
+                for (uint32_t f0 = 0; f0 < pd.n_pairs; f0 += (uint32_t)SEAM_BLOCK) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
+            }
+            if (c->h_sb_plane.size() > c->sb_slots) return fail(c, STR_ER_ECAPACITY, "seam block table capacity exceeded");
+            HIP_TRY(c, hipMemcpyAsync(c->d_tile_plane, c->h_tile_plane.data(), 2 * c->h_tile_plane.size(), hipMemcpyHostToDevice, s));
+            if (!c->h_sb_plane.empty()) {
+                HIP_TRY(c, hipMemcpyAsync(c->d_sb_plane, c->h_sb_plane.data(), 2 * c->h_sb_plane.size(), hipMemcpyHostToDevice, s));
+                HIP_TRY(c, hipMemcpyAsync(c->d_sb_first, c->h_sb_first.data(), 4 * c->h_sb_first.size(), hipMemcpyHostToDevice, s));
+            }
+            HIP_TRY(c, hipStreamSynchronize(s));   // pageable host vectors: make sure the copies are done
+            c->layout_key = key;
+        }
+    }
+    return STR_ER_OK;
+}
+
 // Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
+// import_trees (optional): the tile trees were built elsewhere (strips of a plane extracted by other GPUs) -- instead of running
+// k_tile_tree / k_seam the hook puts node records and counters in place on the context's stream.
+using ImportHook = std::function<int(const Batch &, const BatchDev &)>;
 int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result **out,
-              std::chrono::steady_clock::time_point t_start, bool pre_recorded)
+              std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees = nullptr)
 {
     Batch b = b_in;
     assign_node_records(b, c->node_share);
@@ -780,37 +820,15 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
 
     const DetectParams dp = make_dp(c);
     hipStream_t s = c->stream;
-    std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
-    HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
-    {   // tile -> plane and seam-block -> (plane, first pair) tables; re-uploaded only when the layout changes
-        std::vector<uint32_t> key;
-        key.reserve(np * 2 + 1);
-        key.push_back((uint32_t)np);
-        for (const PlaneDesc &pd : b.planes) { key.push_back((uint32_t)pd.w); key.push_back((uint32_t)pd.h); }
-        if (key != c->layout_key) {
-            c->layout_key.clear();          // the tables are being rebuilt: a failure below must not leave the old key naming them
-            c->h_tile_plane.clear(); c->h_sb_plane.clear(); c->h_sb_first.clear();
-            for (int i = 0; i < np; ++i) {
-                const PlaneDesc &pd = b.planes[i];
-                c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
-                for (uint32_t f0 = 0; f0 < pd.n_pairs; f0 += (uint32_t)SEAM_BLOCK) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
-            }
-            if (c->h_sb_plane.size() > c->sb_slots) return fail(c, STR_ER_ECAPACITY, "seam block table capacity exceeded");
-            HIP_TRY(c, hipMemcpyAsync(c->d_tile_plane, c->h_tile_plane.data(), 2 * c->h_tile_plane.size(), hipMemcpyHostToDevice, s));
-            if (!c->h_sb_plane.empty()) {
-                HIP_TRY(c, hipMemcpyAsync(c->d_sb_plane, c->h_sb_plane.data(), 2 * c->h_sb_plane.size(), hipMemcpyHostToDevice, s));
-                HIP_TRY(c, hipMemcpyAsync(c->d_sb_first, c->h_sb_first.data(), 4 * c->h_sb_first.size(), hipMemcpyHostToDevice, s));
-            }
-            HIP_TRY(c, hipStreamSynchronize(s));   // pageable host vectors: make sure the copies are done
-            c->layout_key = key;
-        }
-    }
+    { const int rcu = upload_layout(c, b); if (rcu != STR_ER_OK) return rcu; }
     const BatchDev bd = make_batchdev(c, b);
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
 
-    launch_tile_tree(s, bd, dp, c->tile_sparse);      rec(c, "tile_tree");
+    if (import_trees) {
+        const int rci = (*import_trees)(b, bd);
+        if (rci != STR_ER_OK) return rci;
+    } else launch_tile_tree(s, bd, dp, c->tile_sparse);
+    rec(c, "tile_tree");
     if (c->dbg_tile_only) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
         (void)hipStreamSynchronize(s);
@@ -818,7 +836,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         std::fprintf(stderr, "[str_er] tile_tree alone: %.4f ms\n", ms);
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
-    launch_seam(s, bd, !c->tile_sparse);                                        rec(c, "seam");
+    if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
+    rec(c, "seam");
     launch_resolve(s, bd);                            rec(c, "resolve");
     launch_reduce(s, bd);                             rec(c, "accumulate");
     launch_root(s, bd, dp);
@@ -876,7 +895,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
                 if (rcn != STR_ER_OK) return rcn;
             }
             if (ev_entry >= 0) { c->n_ev = ev_entry; c->profile.resize((size_t)ev_entry); }
-            return run_batch(c, b_in, stages, out, t_start, pre_recorded);
+            return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees);
         }
     }
     if ((stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0) {
@@ -934,6 +953,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     str_er_result *r = new (std::nothrow) str_er_result();
     if (!r) return fail(c, STR_ER_ENOMEM, "result allocation");
     const uint32_t total = *c->h_total;
+    c->last_total = total; c->last_valid = (stages & STR_ER_STAGE_NMS) != 0;
     r->cands.resize(total);
     r->cand_off.assign(np + 1, 0);
     r->planes.resize(np);
@@ -1324,8 +1344,31 @@ int str_er_cascade_info(const str_er_ctx *c, int which, int32_t *n_stages, int32
     return STR_ER_OK;
 }
 
+static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                           int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out);
+
 int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                       int32_t n_frames, int mem_kind, uint32_t stages, str_er_result **out)
+{
+    return detect_bgr_impl(c, bgr, w, h, stride, frame_pitch, n_frames, mem_kind, stages, nullptr, out);
+}
+
+int str_er_detect_bgr_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                             int32_t n_frames, int mem_kind, uint32_t stages, const uint8_t *plane_select, int32_t n_select,
+                             str_er_result **out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!plane_select || n_select != c->ppf) return fail(c, STR_ER_EINVAL, "plane_select needs one flag per logical plane of a frame (levels x channels of the context)");
+    if (stages & (STR_ER_STAGE_TRACK | STR_ER_STAGE_GROUP | STR_ER_STAGE_OCR_LINES))
+        return fail(c, STR_ER_EINVAL, "er_track / er_grouping read every plane of an image: not with a plane subset");
+    bool any = false;
+    for (int i = 0; i < n_select; ++i) any |= plane_select[i] != 0;
+    if (!any) return fail(c, STR_ER_EINVAL, "plane_select selects nothing");
+    return detect_bgr_impl(c, bgr, w, h, stride, frame_pitch, n_frames, mem_kind, stages, plane_select, out);
+}
+
+static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                           int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out)
 {
     if (!c) return STR_ER_EINVAL;
     if (!bgr || !out || w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3) return fail(c, STR_ER_EINVAL, "bad frame arguments");
@@ -1351,8 +1394,15 @@ int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, i
     } else if (mem_kind == STR_ER_MEM_DEVICE) dbgr = bgr;
     else return fail(c, STR_ER_EINVAL, "bad mem_kind");
 
-    // physical planes: per level, [Y, Cr, Cb], row stride padded to 64 bytes
-    const int nl = c->prm.n_pyr_levels;
+    // physical planes: per level, [Y, Cr, Cb], row stride padded to 64 bytes (a plane subset builds the pyramid only as far
+    // down as its deepest selected level)
+    int nl = c->prm.n_pyr_levels;
+    if (plane_select) {
+        int deepest = 0;
+        for (int l = 0; l < nl; ++l)
+            for (size_t k = 0; k < c->chans.size(); ++k) if (plane_select[(size_t)l * c->chans.size() + k]) deepest = l;
+        nl = deepest + 1;
+    }
     std::vector<PlaneGeom> geo(nl);
     size_t frame_bytes = 0;
     for (int l = 0; l < nl; ++l) {
@@ -1376,13 +1426,299 @@ int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, i
     Batch b;
     for (int f = 0; f < n_frames; ++f)
         for (int l = 0; l < nl; ++l)
-            for (int ch : c->chans) {
+            for (size_t k = 0; k < c->chans.size(); ++k) {
+                if (plane_select && !plane_select[(size_t)l * c->chans.size() + k]) continue;
+                const int ch = c->chans[k];
                 const uint8_t *pix = c->d_pix + (size_t)f * frame_bytes + geo[l].off + (size_t)(ch % 3) * plane_sz(l);
                 add_plane(b, pix, geo[l].w, geo[l].h, geo[l].stride, ch >= 3, (uint32_t)f, ch, l, c->kept_cap, c->pool_cap);
                 b.planes.back().color_pitch = (uint32_t)plane_sz(l);
             }
-    b.planes_per_image = (int)c->chans.size();
+    b.planes_per_image = plane_select ? 0 : (int)c->chans.size();
     return run_batch(c, b, stages, out, t0, true);
+}
+
+// =================================================================================================
+// one plane in horizontal strips over several GPUs.
+//
+// Whole planes are the unit the path shards by (8(e)); one large frame has few of them and the three level-0 planes bound the
+// speed-up (3840x2160, 12 levels: 6.0x on 8 GPUs).  The tile kernel is 60 % of the work and has no data flow between tiles, so
+// a plane can be cut into strips of tile rows: every GPU builds the tile trees of its strip and joins the seams INSIDE the strip
+// (str_er_strip_extract); what crosses the wire is the strip's node records (32 bytes per exported node: about a quarter of the
+// strip's pixel bytes on text-like frames) and the node of every pixel of its first / last row.  The owner of the plane puts the
+// strips' records behind one another, makes the ids plane-wide, joins the pixel pairs across every cut with the same connect as any
+// other seam and carries on with the usual passes -- resolve, accumulate, prune, NMS, classify (str_er_strip_merge).  The node
+// set of a component tree does not depend on the order in which tiles are joined, so the result is that of the unsplit plane.
+// Level 0 only (contexts with n_pyr_levels = 1); the smaller planes of a pyramid are dealt out whole.
+// =================================================================================================
+namespace {
+
+constexpr uint32_t STRIP_MAGIC = 0x50525453u;      // "STRP"
+struct StripHeader { uint32_t magic, version, w, h, strip, n_strips, row0 /* plane row of the records' row 0 */, rows, n_planes, thresh_step, channel_mask, reserved; };
+struct StripPlane { uint32_t ch, n_nodes, n_walls, start_node, has_top, has_bot; };      // (records: ids, keys and rows local to the strip)
+
+// channels of one BGR frame into the level-0 planes of the pixel pool (what str_er_detect_bgr does for level 0)
+int frame_to_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int &pstride, size_t &psize)
+{
+    const uint8_t *dbgr = nullptr;
+    int64_t dstride = stride;
+    if (mem_kind == STR_ER_MEM_HOST) {
+        dstride = (int64_t)w * 3;
+        if ((size_t)dstride * h > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "staging buffer too small");
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)dstride, bgr, (size_t)stride, (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        dbgr = c->d_in;
+    } else if (mem_kind == STR_ER_MEM_DEVICE) dbgr = bgr;
+    else return fail(c, STR_ER_EINVAL, "bad mem_kind");
+    pstride = (int)align_up((size_t)w, 64);
+    psize = align_up((size_t)pstride * h, 256);
+    if (3 * psize > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
+    launch_bgr_to_ycrcb(c->stream, dbgr, w, h, dstride, dstride * h, 1, c->d_pix, c->d_pix + psize, c->d_pix + 2 * psize, pstride, (int64_t)(3 * psize));
+    return STR_ER_OK;
+}
+
+} // namespace
+
+int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
+                         void **blob, int64_t *blob_bytes)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!bgr || !blob || !blob_bytes || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 || strip < 0 || strip >= n_strips)
+        return fail(c, STR_ER_EINVAL, "bad strip arguments");
+    if (c->prm.n_pyr_levels != 1) return fail(c, STR_ER_EINVAL, "strips are cut from level-0 planes: the context must have n_pyr_levels = 1");
+    if (w > c->prm.max_width || h > c->prm.max_height) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
+    *blob = nullptr; *blob_bytes = 0;
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    int pstride = 0; size_t psize = 0;
+    int rc = frame_to_planes(c, bgr, w, h, stride, mem_kind, pstride, psize);
+    if (rc != STR_ER_OK) return rc;
+    const int ty_all = (h + TILE_H - 1) / TILE_H;
+    const int t0 = (int)((int64_t)strip * ty_all / n_strips), t1 = (int)((int64_t)(strip + 1) * ty_all / n_strips);
+    const int r0 = t0 * TILE_H, r1 = std::min(h, t1 * TILE_H), rows = std::max(0, r1 - r0);
+    const size_t npl = c->chans.size();
+    std::vector<StripPlane> sp(npl);
+    std::vector<std::vector<uint8_t>> recs(npl);
+    std::vector<std::vector<uint32_t>> top(npl), bot(npl);
+    for (size_t k = 0; k < npl; ++k) { sp[k] = StripPlane{}; sp[k].ch = (uint32_t)c->chans[k]; sp[k].start_node = NONE; }
+    if (rows > 0) {
+        // A strip is laid out as a plane with a PHANTOM tile row above and / or below wherever the plane goes on: the strip's first /
+        // last row is then an ordinary tile seam -- its nodes stay open and their ids are in the seam map -- and the tile kernel needs to
+        // know nothing about strips (it is not touched: with ~100 spilled SGPRs it sits on a code-generation cliff -- one more compare in
+        // its load phase made this toolchain emit a kernel that loses seam entries on ordinary planes).  Below, the phantom row is simply
+        // past the image (one tile row more than the height needs).  Above, the strip is copied behind TILE_H rows of pixels at the
+        // sentinel level, which the flood never enters -- hence the restriction to thresh_steps that have such a level.
+        const bool ptop = r0 > 0, pbot = r1 < h;
+        const int  row_off = r0 - (ptop ? TILE_H : 0);          // row of the whole plane that is row 0 of this layout
+        const size_t pad_plane = align_up((size_t)pstride * (size_t)(rows + TILE_H), 256);
+        if (ptop) {
+            if ((int)std::lrintf(255.0f * (float)(1.0 / (double)c->prm.thresh_step)) != 255 / c->prm.thresh_step + 1)
+                return fail(c, STR_ER_EINVAL, "strips need a thresh_step whose top level is the sentinel level (2, 4, 8, 16 ...: round(255/step) = 255/step + 1)");
+            rc = ensure_scratch(c, pad_plane * npl);
+            if (rc != STR_ER_OK) return rc;
+        }
+        Batch b;
+        for (size_t k = 0; k < npl; ++k) {
+            const int ch = c->chans[k];
+            const uint8_t *src = c->d_pix + (size_t)(ch % 3) * psize + (size_t)r0 * pstride;
+            const uint8_t *lay = src;
+            if (ptop) {
+                uint8_t *dst = static_cast<uint8_t *>(c->d_scratch) + k * pad_plane;
+                HIP_TRY(c, hipMemsetAsync(dst, ch >= 3 ? 0x00 : 0xFF, (size_t)TILE_H * pstride, c->stream));      // (inverted channels read pixel ^ 0xFF)
+                HIP_TRY(c, hipMemcpyAsync(dst + (size_t)TILE_H * pstride, src, (size_t)rows * pstride, hipMemcpyDeviceToDevice, c->stream));
+                lay = dst;
+            }
+            add_plane(b, lay, w, rows + (ptop ? TILE_H : 0) + (pbot ? TILE_H : 0), pstride, ch >= 3, 0, ch, 0, c->kept_cap, c->pool_cap);
+            PlaneDesc &pd = b.planes.back();
+            pd.h = rows + (ptop ? TILE_H : 0);                   // (the phantom row below is simply past the image)
+            pd.n_pairs = pd.n_hpairs + (uint32_t)pd.h * (uint32_t)(pd.tiles_x - 1);
+        }
+        const DetectParams dp = make_dp(c);
+        hipStream_t s = c->stream;
+        for (;;) {
+            assign_node_records(b, c->node_share);
+            if (b.nodes > c->node_slots) { rc = alloc_node_records(c, b.nodes + b.nodes / 8); if (rc != STR_ER_OK) return rc; }
+            if (b.seam > c->seam_slots || b.n_tiles > c->tile_slots || b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "strip exceeds the context capacity");
+            c->layout_key.clear();                 // (a strip's layout is not a frame's: never reuse the cached tables for it)
+            rc = upload_layout(c, b);
+            c->layout_key.clear();
+            if (rc != STR_ER_OK) return rc;
+            const BatchDev bd = make_batchdev(c, b);
+            // the seam row of the phantom tile row below lies past the image: no tile writes it, so it is blanked here ("wall")
+            if (pbot)
+                for (const PlaneDesc &pd : b.planes)
+                    HIP_TRY(c, hipMemsetAsync(c->d_seam + pd.seam_base + (size_t)(2 * (pd.tiles_y - 2) + 1) * w, 0xFF, 2 * (size_t)w, s));
+            launch_tile_tree(s, bd, dp, c->tile_sparse);
+            launch_seam(s, bd, !c->tile_sparse);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * npl, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            double need = 0;
+            for (size_t k = 0; k < npl; ++k)
+                if (c->h_ctr[k].overflow & 8u) need = std::max(need, (double)c->h_ctr[k].n_nodes / (double)((size_t)b.planes[k].tiles_x * b.planes[k].tiles_y * TILE_PX));
+            if (need == 0) break;
+            if (c->node_share >= 1.0) return fail(c, STR_ER_ECAPACITY, "node records exhausted at one record per pixel (internal error)");
+            c->node_share = std::min(1.0, std::max(c->node_share * 1.5, need * 1.25));
+        }
+        // what leaves the GPU: the records, and the node of every pixel of the first / last row (seam map: index in the tile's
+        // records; tile_nbase: the tile's first record)
+        hipStream_t s2 = c->stream;
+        for (size_t k = 0; k < npl; ++k) {
+            const PlaneDesc &pd = b.planes[k];
+            const PlaneCtr  &pc = c->h_ctr[k];
+            sp[k].n_nodes = pc.n_nodes; sp[k].n_walls = pc.n_walls; sp[k].start_node = r0 == 0 ? pc.start_node : NONE;
+            sp[k].has_top = ptop; sp[k].has_bot = pbot;
+            recs[k].resize((size_t)pc.n_nodes * sizeof(NodeRec));
+            if (pc.n_nodes) HIP_TRY(c, hipMemcpyAsync(recs[k].data(), c->na.rec + pd.node_base, recs[k].size(), hipMemcpyDeviceToHost, s2));
+            // seam map: boundary j holds pixel row (j+1)*TILE_H - 1 at [2j * w, +w) and pixel row (j+1)*TILE_H at [(2j+1) * w, +w)
+            std::vector<uint16_t> ext(2 * (size_t)w, 0xFFFFu);
+            std::vector<uint32_t> nb_top((size_t)pd.tiles_x, NONE), nb_bot((size_t)pd.tiles_x, NONE);
+            const int jt = 0, jb = pd.tiles_y - 2;               // the seams under the phantom row above / over the phantom row below
+            if (ptop) {
+                HIP_TRY(c, hipMemcpyAsync(ext.data(), c->d_seam + pd.seam_base + (size_t)(2 * jt + 1) * w, 2 * (size_t)w, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(c, hipMemcpyAsync(nb_top.data(), c->d_tile_nbase + pd.tile_base + (size_t)(jt + 1) * pd.tiles_x, 4 * nb_top.size(), hipMemcpyDeviceToHost, s2));
+            }
+            if (pbot) {
+                HIP_TRY(c, hipMemcpyAsync(ext.data() + w, c->d_seam + pd.seam_base + (size_t)(2 * jb) * w, 2 * (size_t)w, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(c, hipMemcpyAsync(nb_bot.data(), c->d_tile_nbase + pd.tile_base + (size_t)jb * pd.tiles_x, 4 * nb_bot.size(), hipMemcpyDeviceToHost, s2));
+            }
+            HIP_TRY(c, hipStreamSynchronize(s2));
+            auto ids = [&](const uint16_t *row, const std::vector<uint32_t> &nb, std::vector<uint32_t> &out) {
+                out.resize((size_t)w);
+                for (int x = 0; x < w; ++x) {
+                    const uint32_t base = nb[(size_t)(x / TILE_W)];
+                    out[(size_t)x] = (row[x] == 0xFFFFu || base == NONE) ? NONE : base + row[x];
+                }
+            };
+            if (ptop) ids(ext.data(), nb_top, top[k]);
+            if (pbot) ids(ext.data() + w, nb_bot, bot[k]);
+        }
+    }
+    size_t bytes = sizeof(StripHeader);
+    for (size_t k = 0; k < npl; ++k) bytes += sizeof(StripPlane) + recs[k].size() + 4 * (top[k].size() + bot[k].size());
+    uint8_t *out = static_cast<uint8_t *>(std::malloc(bytes));
+    if (!out) return fail(c, STR_ER_ENOMEM, "strip blob allocation");
+    StripHeader hd{STRIP_MAGIC, 1u, (uint32_t)w, (uint32_t)h, (uint32_t)strip, (uint32_t)n_strips, (uint32_t)std::max(0, r0 - (r0 > 0 ? TILE_H : 0)), (uint32_t)rows, (uint32_t)npl,
+                   (uint32_t)c->prm.thresh_step, c->prm.channel_mask, 0u};
+    uint8_t *p = out;
+    std::memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
+    for (size_t k = 0; k < npl; ++k) {
+        std::memcpy(p, &sp[k], sizeof(StripPlane)); p += sizeof(StripPlane);
+        if (!recs[k].empty()) { std::memcpy(p, recs[k].data(), recs[k].size()); p += recs[k].size(); }
+        if (!top[k].empty()) { std::memcpy(p, top[k].data(), 4 * top[k].size()); p += 4 * top[k].size(); }
+        if (!bot[k].empty()) { std::memcpy(p, bot[k].data(), 4 * bot[k].size()); p += 4 * bot[k].size(); }
+    }
+    *blob = out; *blob_bytes = (int64_t)bytes;
+    return STR_ER_OK;
+}
+
+void str_er_strip_free(void *blob) { std::free(blob); }
+
+int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
+                       const int64_t *blob_bytes, int32_t n_strips, uint32_t stages, str_er_result **out)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!bgr || !blobs || !blob_bytes || !out || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1) return fail(c, STR_ER_EINVAL, "bad strip arguments");
+    if (c->prm.n_pyr_levels != 1) return fail(c, STR_ER_EINVAL, "strips are cut from level-0 planes: the context must have n_pyr_levels = 1");
+    if (w > c->prm.max_width || h > c->prm.max_height) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
+    *out = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->prm.device));
+    const size_t npl = c->chans.size();
+    struct View { StripPlane sp; const uint8_t *rec; const uint32_t *top, *bot; uint32_t row0; };
+    std::vector<std::vector<View>> view((size_t)n_strips, std::vector<View>(npl));
+    for (int sidx = 0; sidx < n_strips; ++sidx) {
+        const uint8_t *p = static_cast<const uint8_t *>(blobs[sidx]), *end = p + blob_bytes[sidx];
+        StripHeader hd;
+        if (!p || blob_bytes[sidx] < (int64_t)sizeof(hd)) return fail(c, STR_ER_EFORMAT, "strip blob too short");
+        std::memcpy(&hd, p, sizeof(hd)); p += sizeof(hd);
+        if (hd.magic != STRIP_MAGIC || hd.version != 1 || hd.w != (uint32_t)w || hd.h != (uint32_t)h || hd.n_strips != (uint32_t)n_strips ||
+            hd.strip != (uint32_t)sidx || hd.n_planes != npl || hd.thresh_step != (uint32_t)c->prm.thresh_step || hd.channel_mask != c->prm.channel_mask)
+            return fail(c, STR_ER_EFORMAT, "strip blob does not belong to this frame / context (strip " + std::to_string(sidx) + ")");
+        for (size_t k = 0; k < npl; ++k) {
+            View &v = view[(size_t)sidx][k];
+            v.row0 = hd.row0;
+            if (end - p < (int64_t)sizeof(StripPlane)) return fail(c, STR_ER_EFORMAT, "strip blob truncated");
+            std::memcpy(&v.sp, p, sizeof(StripPlane)); p += sizeof(StripPlane);
+            const size_t need = (size_t)v.sp.n_nodes * sizeof(NodeRec) + 4 * (size_t)w * ((v.sp.has_top ? 1 : 0) + (v.sp.has_bot ? 1 : 0));
+            if ((size_t)(end - p) < need || v.sp.ch != (uint32_t)c->chans[k]) return fail(c, STR_ER_EFORMAT, "strip blob truncated");
+            v.rec = p; p += (size_t)v.sp.n_nodes * sizeof(NodeRec);
+            v.top = v.sp.has_top ? reinterpret_cast<const uint32_t *>(p) : nullptr; p += v.sp.has_top ? 4 * (size_t)w : 0;
+            v.bot = v.sp.has_bot ? reinterpret_cast<const uint32_t *>(p) : nullptr; p += v.sp.has_bot ? 4 * (size_t)w : 0;
+        }
+    }
+    int pstride = 0; size_t psize = 0;
+    c->n_ev = 0; c->profile.clear(); rec(c, "begin");
+    int rc = frame_to_planes(c, bgr, w, h, stride, mem_kind, pstride, psize);
+    if (rc != STR_ER_OK) return rc;
+    rec(c, "channels");
+    Batch b;
+    for (int ch : c->chans) {
+        add_plane(b, c->d_pix + (size_t)(ch % 3) * psize, w, h, pstride, ch >= 3, 0, ch, 0, c->kept_cap, c->pool_cap);
+        b.planes.back().color_pitch = (uint32_t)psize;
+    }
+    b.planes_per_image = (int)npl;
+    // the records of all strips of a plane must fit the plane's share
+    std::vector<std::vector<uint32_t>> base(npl, std::vector<uint32_t>((size_t)n_strips + 1, 0));
+    double need = 0;
+    for (size_t k = 0; k < npl; ++k) {
+        for (int sidx = 0; sidx < n_strips; ++sidx) base[k][(size_t)sidx + 1] = base[k][(size_t)sidx] + view[(size_t)sidx][k].sp.n_nodes;
+        need = std::max(need, (double)base[k][(size_t)n_strips] / (double)((size_t)b.planes[k].tiles_x * b.planes[k].tiles_y * TILE_PX));
+        if (base[k][(size_t)n_strips] >= (1u << 24)) return fail(c, STR_ER_ECAPACITY, "more than 2^24 node records in one plane");
+    }
+    if (need > c->node_share) c->node_share = std::min(1.0, need * 1.05);
+    // pixel pairs across the cuts, plane-wide ids; consecutive repeats (a flat region along the cut) once
+    std::vector<std::vector<uint32_t>> pairs(npl);
+    for (size_t k = 0; k < npl; ++k)
+        for (int sidx = 0; sidx + 1 < n_strips; ++sidx) {
+            // (strips without rows have no borders: the cut is between the nearest strips that have)
+            int lo = sidx, hi = sidx + 1;
+            if (!view[(size_t)lo][k].bot) continue;
+            while (hi < n_strips && !view[(size_t)hi][k].top) ++hi;
+            if (hi >= n_strips) continue;
+            const uint32_t *bt = view[(size_t)lo][k].bot, *tp = view[(size_t)hi][k].top;
+            uint32_t pa = NONE, pb = NONE;
+            for (int x = 0; x < w; ++x) {
+                if (bt[x] == NONE || tp[x] == NONE) { pa = pb = NONE; continue; }
+                const uint32_t ia = bt[x] + base[k][(size_t)lo], ib = tp[x] + base[k][(size_t)hi];
+                if (ia == pa && ib == pb) continue;
+                pairs[k].push_back(ia); pairs[k].push_back(ib);
+                pa = ia; pb = ib;
+            }
+        }
+    size_t pair_words = 0;
+    for (auto &v : pairs) pair_words += v.size();
+    rc = ensure_scratch(c, 4 * pair_words + 256);
+    if (rc != STR_ER_OK) return rc;
+    const ImportHook hook = [&](const Batch &bb, const BatchDev &bd) -> int {
+        hipStream_t s = c->stream;
+        uint32_t *d_pairs = static_cast<uint32_t *>(c->d_scratch);
+        size_t poff = 0;
+        for (size_t k = 0; k < npl; ++k) {
+            const PlaneDesc &pd = bb.planes[k];
+            if (base[k][(size_t)n_strips] > pd.node_cap) return fail(c, STR_ER_ECAPACITY, "strip records exceed the plane's share (internal error)");
+            PlaneCtr pc{};
+            pc.n_nodes = base[k][(size_t)n_strips];
+            pc.start_node = NONE;
+            for (int sidx = 0; sidx < n_strips; ++sidx) {
+                const View &v = view[(size_t)sidx][k];
+                pc.n_walls += v.sp.n_walls;
+                if (v.sp.start_node != NONE) pc.start_node = v.sp.start_node + base[k][(size_t)sidx];
+                if (!v.sp.n_nodes) continue;
+                NodeRec *dst = bd.na.rec + pd.node_base + base[k][(size_t)sidx];
+                HIP_TRY(c, hipMemcpyAsync(dst, v.rec, (size_t)v.sp.n_nodes * sizeof(NodeRec), hipMemcpyHostToDevice, s));
+                launch_rebase_records(s, dst, bd.na.aux + pd.node_base + base[k][(size_t)sidx], v.sp.n_nodes, base[k][(size_t)sidx], v.row0 * (uint32_t)w, v.row0);
+            }
+            c->h_ctr[k] = pc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_ctr + k, c->h_ctr + k, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
+            if (!pairs[k].empty()) {
+                HIP_TRY(c, hipMemcpyAsync(d_pairs + poff, pairs[k].data(), 4 * pairs[k].size(), hipMemcpyHostToDevice, s));
+                launch_connect_pairs(s, bd.na.rec + pd.node_base, d_pairs + poff, (uint32_t)(pairs[k].size() / 2));
+                poff += pairs[k].size();
+            }
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(s));       // h_ctr is about to be reused for the counters coming back
+        return STR_ER_OK;
+    };
+    return run_batch(c, b, stages, out, t0, true, &hook);
 }
 
 int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_t h, int64_t stride, int64_t plane_pitch,
@@ -1830,6 +2166,13 @@ int str_er_flood_order(const uint8_t *plane, int32_t w, int32_t h, int64_t strid
     if (!plane || !stamp || w < 1 || h < 1 || stride < w || thresh_step < 1 || thresh_step > 255 || (int64_t)w * h > (1 << 24)) return STR_ER_EINVAL;
     std::memset(stamp, 0, 4 * (size_t)w * h);
     flood_order_host(plane, w, h, stride, 0, (float)(1.0 / (double)thresh_step), 255 / thresh_step + 1, nullptr, 0xFFFFFFFFu, stamp);
+    return STR_ER_OK;
+}
+
+int str_er_internal_last_cands(str_er_ctx *c, const void **d_cands, uint32_t *n, int *device)
+{
+    if (!c || !c->last_valid) return STR_ER_ESTATE;
+    *d_cands = c->d_cands; *n = c->last_total; *device = c->prm.device;
     return STR_ER_OK;
 }
 

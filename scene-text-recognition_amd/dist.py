@@ -98,6 +98,18 @@ def detect_plane_share(erf, bgr: np.ndarray, share: Sequence[int], n_levels: int
     a = np.ascontiguousarray(bgr, dtype=np.uint8)
     h, w = a.shape[:2]
     planes = frame_planes(w, h, n_levels, channel_mask)
+    prm = getattr(erf, "params", None)
+    if prm is not None and hasattr(erf, "text_detect_planes") and prm.n_pyr_levels == n_levels and prm.channel_mask == channel_mask:
+        # the context has this very plane layout: one call with a plane subset -- channels, pyramid and trees stay on the device
+        sel = np.zeros(len(planes), np.uint8)
+        sel[list(share)] = 1
+        if not sel.any():
+            return np.zeros(0, CAND_DTYPE)
+        res = erf.text_detect_planes(a, sel, stages)
+        out = res.cands.copy()
+        idx = {(ch, lvl): i for i, (ch, lvl, _, _) in enumerate(planes)}
+        out["node"] = np.array([idx[(int(c["ch"]), int(c["pyr"]))] for c in out], np.int32) if len(out) else out["node"]
+        return out
     six = erf.compute_channels(a)
     chain: Dict[Tuple[int, int], np.ndarray] = {}
 

@@ -1,0 +1,87 @@
+"""The C-ABI candidate gather (gather.cpp: str_er_comm_* / str_er_gather_*).  On the CPU the packing code -- counts,
+padding to the largest count, dropping the padding, frame offsets -- runs over the in-process transport with one thread per
+rank (world size 2 and 3, ragged and empty shares); on the GPU box the RCCL transport runs with a world of one and takes the
+records straight from the device array of the last detect call."""
+import threading
+
+import numpy as np
+import pytest
+
+
+def _fake_cands(S, rank, n, step):
+    c = np.zeros(n, S.CAND_DTYPE)
+    c["frame"] = np.arange(n) % 3
+    c["key"] = 1000 * rank + np.arange(n) + 7 * step
+    c["cls"] = (np.arange(n) + rank) % 3
+    c["x"], c["y"], c["w"], c["h"] = rank, step, 5, 9
+    c["score_strong"] = rank + np.arange(n) * 0.25
+    c["score_weak"] = -1.5 * step
+    return c
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_gather_in_process_group(S, world):
+    comms = S.Comm.local_group(world)
+    sizes = lambda step: [(5 + step, 0, 3, 11)[(r + step) % 4] for r in range(world)]        # ragged, with empty shares
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            res = []
+            for step in range(4):                                   # several rounds over the same communicators
+                mine = _fake_cands(S, r, sizes(step)[r], step)
+                res.append(comms[r].gather(mine, frame_offset=100 * r))
+            out[r] = res
+        except Exception as e:                                       # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert not errs, errs
+    for step in range(4):
+        exp = []
+        for r in range(world):
+            e = _fake_cands(S, r, sizes(step)[r], step)
+            e["frame"] += 100 * r
+            exp.append(e)
+        exp = np.concatenate(exp) if exp else np.zeros(0, S.CAND_DTYPE)
+        for r in range(world):
+            got, counts = out[r][step]
+            assert counts.tolist() == sizes(step)
+            assert got.tobytes() == exp.tobytes()          # every rank receives all records, ordered by rank
+    for c in comms:
+        c.close()
+
+
+def test_native_gather_errors(S):
+    import ctypes as C
+    L = S.load_library()
+    h = C.c_void_p()
+    assert L.str_er_comm_local_group(0, C.byref(h)) == -1
+    comms = S.Comm.local_group(1)
+    with pytest.raises(S.StrErError):
+        comms[0].gather_last(type("X", (), {"h": None})())          # no context
+    comms[0].close()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_world_of_one(S, erf):
+    """RCCL transport (librccl.so through dlopen): unique id, communicator, ncclAllGather of counts and records; the records
+    come from the device array the detect call left them in (str_er_gather_last) and equal the result's own copy."""
+    uid = S.Comm.unique_id()
+    assert len(uid) == 128
+    comm = S.Comm.rccl(0, 0, 1, uid)
+    frame = S.synth.stext_bgr(S.synth.frame_seed(2), 640, 480)
+    res = erf.text_detect(frame)
+    got, counts = comm.gather_last(erf, frame_offset=40)
+    exp = res.cands.copy()
+    exp["frame"] += 40
+    exp["node"] = got["node"]                       # (the host copy of the result has node = -1 without WANT_NODES; the device records keep the kept slot)
+    assert counts.tolist() == [len(exp)] and len(exp) > 0
+    assert got.tobytes() == exp.tobytes()
+    got2, _ = comm.gather(res.cands, frame_offset=0)               # host records through the same transport
+    assert got2.tobytes() == res.cands.tobytes()
+    comm.close()

@@ -498,3 +498,41 @@ def test_both_tile_kernel_sizes_give_the_same_answer(S, cascade_paths, monkeypat
             for pa, pb in zip(a.planes, b.planes):
                 assert pa.nodes.tobytes() == pb.nodes.tobytes()
     assert len(out[""][0].cands) > 0
+
+
+# ---- one plane in strips over several GPUs ------------------------------------------------------------------
+@pytest.mark.parametrize("n_strips", [2, 3, 5])
+def test_strips_of_a_plane_merge_into_the_unsplit_result(S, cascade_paths, oracle, oracle_cascades, n_strips):
+    """Every strip is extracted by a context of its own (as another GPU would), the blobs travel as plain bytes, the owner
+    merges them: node tables, pools, classes and scores equal the fused call's and the oracle's, for text-like, noisy and
+    walled-in frames, incl. a frame with fewer tile rows than strips."""
+    W, H = 448, 300
+    owner = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, kept_cap=40000, pool_cap=10000))
+    owner.load_cascade(0, cascade_paths[0]); owner.load_cascade(1, cascade_paths[1])
+    workers = [S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, kept_cap=40000, pool_cap=10000)) for _ in range(n_strips)]
+    rng = np.random.default_rng(17)
+    frames = [S.synth.stext_bgr(S.synth.frame_seed(31), W, H), rng.integers(0, 256, (H, W, 3), dtype=np.uint8),
+              S.synth.stext_bgr(S.synth.frame_seed(32), 200, 70), rng.integers(0, 256, (33, 130, 3), dtype=np.uint8)]
+    walled = S.synth.stext_bgr(S.synth.frame_seed(33), W, H)
+    walled[140:150, :, :] = 255                                   # a band at the sentinel level right across: seals the lower part off
+    walled[0, 0, :] = 255
+    frames.append(walled)
+    fields = ["frame", "ch", "pyr", "level", "cls", "x", "y", "w", "h", "area", "key", "score_strong", "score_weak"]
+    for frame in frames:
+        blobs = [workers[s].strip_extract(frame, s, n_strips) for s in range(n_strips)]
+        merged = owner.strip_merge(frame, blobs, want_nodes=True)
+        fused = owner.text_detect(frame, want_nodes=True)
+        assert merged.cands[fields].tolist() == fused.cands[fields].tolist()
+        assert merged.info.tobytes() == fused.info.tobytes()
+        six = oracle.compute_channels(frame)
+        for pm, pf in zip(merged.planes, fused.planes):
+            assert pm.nodes.tobytes() == pf.nodes.tobytes()
+            check_plane_against_oracle(oracle, pm, six[pm.ch], oracle_cascades)
+    # blobs of another frame / a wrong order are refused
+    other = [workers[s].strip_extract(frames[0], s, n_strips) for s in range(n_strips)]
+    with pytest.raises(S.StrErError):
+        owner.strip_merge(frames[0], other[::-1] if n_strips > 1 else [other[0][:20]])
+    with pytest.raises(S.StrErError):
+        owner.strip_merge(frames[2], other)
+    for f in workers + [owner]:
+        f.close()
