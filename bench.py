@@ -149,6 +149,28 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # the candidate gather: the library's own (RCCL through the C ABI, records taken from the device array of the detect call);
+    # if it cannot be set up on every rank, torch.distributed carries the same exchange
+    comm = None
+    if world > 1:
+        ok = 1
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=gather_device)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(S.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            if backend != "nccl":
+                raise RuntimeError("not an RCCL run")
+            comm = S.Comm.rccl(dev_index, rank, world, uid.cpu().numpy().tobytes())
+        except Exception as e:                                    # noqa: BLE001
+            print(f"[bench] rank {rank}: native RCCL gather not available ({e}); using torch.distributed", file=sys.stderr, flush=True)
+            ok, comm = 0, None
+        flag = torch.tensor([ok], dtype=torch.int32, device=gather_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+
     cfg = WORKLOADS[args.workload]
     F = args.frames_per_gpu
     P = max(1, args.pipelines)
@@ -169,6 +191,7 @@ def main():
     if args.ocr:
         stages |= S.STAGE_OCR_LINES if args.group else S.STAGE_OCR
 
+    ws_bytes = filters[0].workspace_bytes()
     # synthetic frames of this rank's shard: F DISTINCT frames, global frame index = rank*F + i, seed = 0x5EED0000 + index
     # (SURVEY 8(d)); generated on host threads (numpy releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
@@ -186,11 +209,22 @@ def main():
     def run(n_batches):
         results = [None] * n_batches
         done = [threading.Event() for _ in range(n_batches)]
+        turn = threading.Condition()
+        state = {"next": 0}
 
         def worker(p):
             torch.cuda.set_device(dev_index)
             for i in range(p, n_batches, P):
                 results[i] = filters[p].detect_bgr_device(d_frames.data_ptr(), W, H, F, stages)
+                if comm is not None:
+                    # the records are still in this context's device array: gather them before the context takes its next
+                    # batch, and in batch order -- every rank issues its collectives in the same order
+                    with turn:
+                        turn.wait_for(lambda: state["next"] == i)
+                    comm.gather_last(filters[p], frame_offset=rank * F)
+                    with turn:
+                        state["next"] = i + 1
+                        turn.notify_all()
                 done[i].set()
 
         threads = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
@@ -201,7 +235,7 @@ def main():
             done[i].wait()
             r = results[i]
             results[i] = None
-            if world > 1:
+            if world > 1 and comm is None:
                 S.dist.gather_candidates(r.cands, gather_device, frame_offset=rank * F)
             for k, v in r.profile.items():
                 prof[k] = prof.get(k, 0.0) + v
@@ -340,7 +374,9 @@ def main():
                        "frames_per_gpu_per_step": F,
                        "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
-                       "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P},
+                       "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P,
+                       "workspace_bytes_per_batch_in_flight": ws_bytes, "nms_sibling_ties": "exact (reference flood order)" if args.sibling_order == 0 else "key rule",
+                       **({"gather": "RCCL through the C ABI (str_er_gather_last)" if comm is not None else "torch.distributed all_gather"} if world > 1 else {})},
             **({"pcie_inclusive": pcie} if pcie else {}),
             **({"latency_1frame": latency} if latency else {}),
             "roofline": {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

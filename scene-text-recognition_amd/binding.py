@@ -674,9 +674,10 @@ class Comm:
     @classmethod
     def rccl(cls, device: int, rank: int, world: int, uid: bytes) -> "Comm":
         h = C.c_void_p()
-        rc = load_library().str_er_comm_create(device, rank, world, C.create_string_buffer(uid, 128), C.byref(h))
+        L = load_library()
+        rc = L.str_er_comm_create(device, rank, world, C.create_string_buffer(uid, 128), C.byref(h))
         if rc != 0:
-            raise StrErError(rc, "str_er_comm_create")
+            raise StrErError(rc, "str_er_comm_create: " + (L.str_er_comm_last_error(None) or b"").decode())
         return cls(h, world, rank)
 
     @classmethod

@@ -101,7 +101,8 @@ struct str_er_comm_group { std::shared_ptr<LocalGroup> g; };
 
 namespace {
 
-int cfail(str_er_comm *c, int code, const std::string &msg) { if (c) c->err = msg; return code; }
+thread_local std::string g_comm_create_error;
+int cfail(str_er_comm *c, int code, const std::string &msg) { if (c) c->err = msg; else g_comm_create_error = msg; return code; }
 
 // all ranks contribute `bytes` each; recv gets world * bytes, rank-major.  Host memory, in-process.
 int local_all_gather(str_er_comm *c, const void *send, void *recv, size_t bytes)
@@ -170,8 +171,17 @@ int str_er_comm_create(int32_t device, int32_t rank, int32_t world, const void *
     c->rank = rank; c->world = world; c->device = device;
     Id128 id;
     std::memcpy(id.b, id128, 128);
-    if (r->CommInitRank(&c->nccl, world, id, rank) != 0 || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    (void)hipGetLastError();          // (RCCL checks the thread's last HIP error after its launches: a stale one from an earlier, handled failure would fail it)
+    const int nrc = r->CommInitRank(&c->nccl, world, id, rank);
+    if (nrc != 0) {
+        cfail(nullptr, STR_ER_EHIP, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(nrc) : "error") + " (" + std::to_string(nrc) + ")");
+        c->nccl = nullptr;
+        str_er_comm_destroy(c);
+        return STR_ER_EHIP;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->d_count), 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&c->d_counts), 4 * (size_t)world) != hipSuccess) {
+        cfail(nullptr, STR_ER_EHIP, "stream / buffer creation for the communicator failed");
         str_er_comm_destroy(c);
         return STR_ER_EHIP;
     }
@@ -216,7 +226,7 @@ void str_er_comm_destroy(str_er_comm *c)
     delete c;
 }
 
-const char *str_er_comm_last_error(const str_er_comm *c) { return c ? c->err.c_str() : ""; }
+const char *str_er_comm_last_error(const str_er_comm *c) { return c ? c->err.c_str() : g_comm_create_error.c_str(); }
 int32_t str_er_comm_rank(const str_er_comm *c) { return c ? c->rank : -1; }
 int32_t str_er_comm_world(const str_er_comm *c) { return c ? c->world : 0; }
 
