@@ -17,13 +17,15 @@ Workloads (BASELINE.json `configs`):
             native resolution (6 planes, 12.44 Mpx/frame; src/ER.cpp:114-128)
 
 Extra objects on the JSON line:
-  roofline     : HBM roofline of the dominant kernel (k_tile_tree), from HIP events recorded
-                 by the library on the stream the kernels run on.  With --pipelines 3 (default) three
-                 batches share the GPU, so a kernel's event-to-event time in the timed region is
-                 stretched by its neighbours; `serial_*` repeats the measurement with one batch in flight.
-  cpu_baseline : the oracle (a plain-C port of the reference's CPU algorithm) timed on this
-                 box's host cores on a bounded sample, threads over planes like the
-                 reference's `#pragma omp parallel for` (src/ER.cpp:50).
+  roofline       : HBM roofline of the dominant kernel (k_tile_tree): algorithmic bytes per launch over its ISOLATED
+                   launch duration (HIP events recorded by the library on the stream the kernel runs on, one batch in
+                   flight, mean of 3 launches after the timed region).  With several batches sharing the GPU an
+                   event-to-event time also contains the other batches' kernels (`overlapped_event_ms`).
+  cpu_baseline   : the oracle (a plain-C port of the reference's CPU algorithm) timed on this box's host cores on a
+                   bounded sample, threads over planes like the reference's `#pragma omp parallel for` (src/ER.cpp:50).
+  pcie_inclusive : the same step with the frames starting in page-locked HOST memory (ingest stream, uploads
+                   overlapping compute); never the reported `value`.
+  latency_1frame : one frame per call, one call in flight: call-to-return wall time.
 """
 import argparse
 import importlib
