@@ -61,6 +61,7 @@ extern "C" {
 #define STR_ER_STAGE_TRACK    32u  /* calc_color + ERFilter::er_track on the strong/weak ERs of every image (src/ER.cpp:530-590) */
 #define STR_ER_STAGE_GROUP    64u  /* ERFilter::er_grouping(tracked, text, false, false) (src/ER.cpp:612-692); needs STR_ER_STAGE_TRACK */
 #define STR_ER_GROUP_INNER_SUP 128u /* ... with inner_sup = true, as text_detect calls it when DO_OCR is defined (src/ER.cpp:69) */
+#define STR_ER_GROUP_OVERLAP_SUP 512u /* ... with overlap_sup = true, as video_mode calls it (er_grouping(tracked, text, true, true), src/utils.cpp:196) */
 #define STR_ER_STAGE_OCR_LINES 256u /* er_ocr's per-line scoring (src/ER.cpp:695-747): chain_run with the line's slope on every member;
                                       needs STR_ER_STAGE_GROUP + an SVM model */
 
@@ -280,8 +281,10 @@ int str_er_er_track(str_er_ctx *ctx, const str_er_cand *cands, const double *col
 /* ERFilter::er_grouping(all_er, text, false, inner_sup) (src/ER.cpp:612-692) on caller-supplied ERs of ONE image:
  * cands[i].{x,y,w,h,area} and tracks[i].{color1-3, cx, cy, tracked} (all_er = the ones with tracked != 0).  The
  * result holds copies of cands and tracks plus the lines (str_er_result_texts / _text_ers / _group_bounds);
- * free it with str_er_result_free.  overlap_sup = true (only video_mode without DO_OCR asks for it,
- * src/utils.cpp:196) is not built: STR_ER_EINVAL.                                                      */
+ * free it with str_er_result_free.  overlap_sup = true (video_mode without DO_OCR asks for it,
+ * src/utils.cpp:196): sort + overlap_suppression (src/ER.cpp:614-617, sequential -- a merge rewrites the survivor's box) run
+ * on the host, the survivors then take the same GPU stages; the merged boxes are in str_er_result_gbounds, the surviving
+ * list (all_er as the reference leaves it) in str_er_result_group_all.                                    */
 int str_er_er_grouping(str_er_ctx *ctx, const str_er_cand *cands, const str_er_track *tracks, int32_t n, int overlap_sup,
                        int inner_sup, str_er_result **out);
 

@@ -13,7 +13,7 @@ of the path, and loading fails loudly if the HIP library has not been built.
 from __future__ import annotations
 
 from .binding import (  # noqa: F401
-    CLS_POOL, CLS_STRONG, CLS_WEAK, STAGE_ALL, STAGE_CLASSIFY, STAGE_OCR, STAGE_EXTRACT, STAGE_NMS, STAGE_TRACK, STAGE_GROUP, GROUP_INNER_SUP, STAGE_OCR_LINES, TRACK_DTYPE, TEXT_DTYPE, GBOUND_DTYPE, WANT_NODES,
+    CLS_POOL, CLS_STRONG, CLS_WEAK, STAGE_ALL, STAGE_CLASSIFY, STAGE_OCR, STAGE_EXTRACT, STAGE_NMS, STAGE_TRACK, STAGE_GROUP, GROUP_INNER_SUP, GROUP_OVERLAP_SUP, STAGE_OCR_LINES, TRACK_DTYPE, TEXT_DTYPE, GBOUND_DTYPE, WANT_NODES,
     CAND_DTYPE, NODE_DTYPE, PLANE_DTYPE, ERFilter, FrameStream, PlaneResult, Params, Result, StrErError, lib_path, load_library,
     flood_order, Comm,
 )

@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES, STAGE_TRACK = 1, 2, 4, 7, 8, 16, 32
-STAGE_GROUP, GROUP_INNER_SUP, STAGE_OCR_LINES = 64, 128, 256
+STAGE_GROUP, GROUP_INNER_SUP, STAGE_OCR_LINES, GROUP_OVERLAP_SUP = 64, 128, 256, 512
 TEXT_DTYPE = np.dtype([("frame", "<u4"), ("pyr", "u1"), ("r0", "u1"), ("r1", "u1"), ("r2", "u1"), ("first", "<i4"), ("count", "<i4"),
                        ("slope", "<f8"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4")])
 GBOUND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("cx", "<i4"), ("cy", "<i4")])

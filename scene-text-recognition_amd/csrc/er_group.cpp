@@ -80,6 +80,12 @@ double fitline_avgslope(const std::vector<int32_t> &px, const std::vector<int32_
 
 } // namespace
 
+void sort_and_overlap_suppress(std::vector<GroupEr> &ers, std::vector<int32_t> &order)
+{
+    sort_by_cx(ers, order);                 // :614
+    overlap_suppression(ers, order);        // :616-617
+}
+
 void group_lines(std::vector<GroupEr> &ers, const uint32_t *pairs, size_t n_pairs, std::vector<TextLine> &lines)
 {
     lines.clear();

@@ -22,4 +22,9 @@ struct TextLine {
 // ers: all_er after sort (+ inner_suppression); pairs: (i << 16 | j), i < j, in the reference's visiting order.
 void group_lines(std::vector<GroupEr> &ers, const uint32_t *pairs, size_t n_pairs, std::vector<TextLine> &lines);
 
+// er_grouping(all_er, text, overlap_sup = true, ...): the first two statements of src/ER.cpp:612-617 on the host -- `order` (indices into
+// ers, in all_er's order) is sorted by center.x (stably) and overlap_suppression merges boxes into the survivors (rewriting their bound /
+// center in `ers`) and drops the merged ones.  The list is NOT sorted again afterwards (the reference does not either).
+void sort_and_overlap_suppress(std::vector<GroupEr> &ers, std::vector<int32_t> &order);
+
 } // namespace str_er

@@ -529,7 +529,7 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
 // hold the same records the host has in r->cands / r->tracks).  GPU: sort ranks, inner_suppression flags, pair list;
 // host: the greedy line assignment and the per-line steps (er_group.cpp).
 int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, const std::vector<uint32_t> &img, bool inner_sup,
-                str_er_result *r)
+                str_er_result *r, bool presorted = false)
 {
     const int    G = (int)(img.size() / 2);
     const size_t n_c = r->cands.size();
@@ -565,7 +565,7 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
     uint32_t *d_rng = gb.pair_off + G + 1;
     gb.pairs = c->d_group_pairs; gb.pair_cap = (uint32_t)std::min<size_t>(c->group_pair_cap, 0xFFFFFFFFu);
     HIP_TRY(c, hipMemcpyAsync(d_rng, img.data(), 4 * img.size(), hipMemcpyHostToDevice, s));
-    launch_group_prepare(s, d_cands, d_track, d_rng, G, inner_sup ? 1 : 0, gb);
+    launch_group_prepare(s, d_cands, d_track, d_rng, G, (inner_sup ? 1 : 0) | (presorted ? 2 : 0), gb);
     launch_group_pairs_count(s, d_cands, d_track, d_rng, G, gb);
     launch_group_pairs_fill(s, d_cands, d_track, d_rng, G, gb);
     HIP_TRY(c, hipGetLastError());
@@ -745,6 +745,66 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
     return STR_ER_OK;
 }
 
+// er_grouping(all_er, text, overlap_sup = true, inner_sup) (src/ER.cpp:612-692; video_mode calls it so, src/utils.cpp:196): sort and
+// overlap_suppression are sequential (a merge rewrites the survivor's box, which the next comparison reads), so they run on the host over the
+// records the result already holds; the survivors -- with their rewritten boxes, in list order -- then go through the same GPU stages as
+// before (inner_suppression flags, pair rule) and the host's greedy line assignment.  Indices in the result refer to r's candidates.
+int group_phase_overlap(str_er_ctx *c, const std::vector<uint32_t> &img, bool inner_sup, str_er_result *r)
+{
+    const size_t n_c = r->cands.size();
+    str_er_result tmp;
+    std::vector<int32_t> orig;                          // candidate index in r of every record of tmp
+    std::vector<uint32_t> img2;
+    for (size_t g = 0; g + 1 < img.size(); g += 2) {
+        std::vector<GroupEr> ers;
+        std::vector<int32_t> order, src;
+        for (uint32_t i = img[g]; i < img[g + 1]; ++i)
+            if (r->tracks[i].tracked) {
+                const str_er_cand &cd = r->cands[i];
+                ers.push_back(GroupEr{cd.x, cd.y, cd.w, cd.h, r->tracks[i].cx, r->tracks[i].cy});
+                order.push_back((int32_t)src.size());
+                src.push_back((int32_t)i);
+            }
+        sort_and_overlap_suppress(ers, order);
+        img2.push_back((uint32_t)tmp.cands.size());
+        for (int32_t k : order) {
+            str_er_cand  cd = r->cands[(size_t)src[(size_t)k]];
+            str_er_track tk = r->tracks[(size_t)src[(size_t)k]];
+            const GroupEr &e = ers[(size_t)k];
+            if (e.x < 0 || e.y < 0 || e.w < 0 || e.h < 0 || e.x > 65535 || e.y > 65535 || e.w > 65535 || e.h > 65535) return fail(c, STR_ER_EINVAL, "box out of range");
+            cd.x = (uint16_t)e.x; cd.y = (uint16_t)e.y; cd.w = (uint16_t)e.w; cd.h = (uint16_t)e.h;
+            tk.cx = e.cx; tk.cy = e.cy; tk.tracked = 1;
+            tmp.cands.push_back(cd); tmp.tracks.push_back(tk);
+            orig.push_back(src[(size_t)k]);
+        }
+        img2.push_back((uint32_t)tmp.cands.size());
+    }
+    r->have_texts = true;
+    r->gbounds.resize(n_c);
+    for (size_t i = 0; i < n_c; ++i) {
+        const str_er_cand &cd = r->cands[i];
+        r->gbounds[i] = str_er_gbound{cd.x, cd.y, cd.w, cd.h, r->tracks[i].cx, r->tracks[i].cy};
+    }
+    const size_t m = tmp.cands.size();
+    if (m == 0) return STR_ER_OK;
+    const size_t o_tr = align_up(sizeof(CandRec) * m, 256);
+    int rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * m);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(sc, tmp.cands.data(), sizeof(CandRec) * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sc + o_tr, tmp.tracks.data(), sizeof(TrackRec) * m, hipMemcpyHostToDevice, c->stream));
+    rc = group_phase(c, reinterpret_cast<const CandRec *>(sc), reinterpret_cast<const TrackRec *>(sc + o_tr), img2, inner_sup, &tmp, /*presorted=*/true);
+    if (rc != STR_ER_OK) return rc;
+    // back to r's numbering
+    r->texts = tmp.texts;
+    r->text_ers.clear();
+    for (int32_t k : tmp.text_ers) r->text_ers.push_back(orig[(size_t)k]);
+    r->group_all.clear();
+    for (int32_t k : tmp.group_all) r->group_all.push_back(orig[(size_t)k]);
+    for (size_t k = 0; k < m; ++k) r->gbounds[(size_t)orig[k]] = tmp.gbounds[k];
+    return STR_ER_OK;
+}
+
 // Plane descriptors, zeroed counters and the tile / seam-block lookup tables of a laid-out batch go to the device.
 int upload_layout(str_er_ctx *c, const Batch &b)
 {
@@ -810,8 +870,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         return fail(c, STR_ER_ESTATE, "STR_ER_STAGE_OCR needs an SVM model loaded with dim = 1800 (str_er_load_svm_model)");
 
     if ((stages & STR_ER_STAGE_TRACK) && !(stages & STR_ER_STAGE_CLASSIFY)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_TRACK needs STR_ER_STAGE_CLASSIFY");
-    if ((stages & (STR_ER_STAGE_GROUP | STR_ER_GROUP_INNER_SUP)) && !(stages & STR_ER_STAGE_TRACK)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_GROUP needs STR_ER_STAGE_TRACK");
-    if ((stages & STR_ER_GROUP_INNER_SUP) && !(stages & STR_ER_STAGE_GROUP)) return fail(c, STR_ER_EINVAL, "STR_ER_GROUP_INNER_SUP modifies STR_ER_STAGE_GROUP");
+    if ((stages & (STR_ER_STAGE_GROUP | STR_ER_GROUP_INNER_SUP | STR_ER_GROUP_OVERLAP_SUP)) && !(stages & STR_ER_STAGE_TRACK)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_GROUP needs STR_ER_STAGE_TRACK");
+    if ((stages & (STR_ER_GROUP_INNER_SUP | STR_ER_GROUP_OVERLAP_SUP)) && !(stages & STR_ER_STAGE_GROUP)) return fail(c, STR_ER_EINVAL, "STR_ER_GROUP_INNER_SUP / _OVERLAP_SUP modify STR_ER_STAGE_GROUP");
     if ((stages & STR_ER_STAGE_OCR_LINES) && !(stages & STR_ER_STAGE_GROUP)) return fail(c, STR_ER_EINVAL, "STR_ER_STAGE_OCR_LINES needs STR_ER_STAGE_GROUP");
     if ((stages & STR_ER_STAGE_OCR_LINES) && !(c->svm_loaded && c->svm.dim == 1800))
         return fail(c, STR_ER_ESTATE, "STR_ER_STAGE_OCR_LINES needs an SVM model loaded with dim = 1800 (str_er_load_svm_model)");
@@ -981,7 +1041,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             for (int k = 0; k < b.planes_per_image; ++k) off2 += c->h_ctr[g * b.planes_per_image + k].n_pool;
             img.push_back(off2);
         }
-        const int rcg = group_phase(c, c->d_cands, c->d_track, img, (stages & STR_ER_GROUP_INNER_SUP) != 0, r);
+        const int rcg = (stages & STR_ER_GROUP_OVERLAP_SUP) ? group_phase_overlap(c, img, (stages & STR_ER_GROUP_INNER_SUP) != 0, r)
+                                                            : group_phase(c, c->d_cands, c->d_track, img, (stages & STR_ER_GROUP_INNER_SUP) != 0, r);
         if (rcg != STR_ER_OK) { delete r; return rcg; }
         t_group_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     }
@@ -1506,7 +1567,6 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
         // past the image (one tile row more than the height needs).  Above, the strip is copied behind TILE_H rows of pixels at the
         // sentinel level, which the flood never enters -- hence the restriction to thresh_steps that have such a level.
         const bool ptop = r0 > 0, pbot = r1 < h;
-        const int  row_off = r0 - (ptop ? TILE_H : 0);          // row of the whole plane that is row 0 of this layout
         const size_t pad_plane = align_up((size_t)pstride * (size_t)(rows + TILE_H), 256);
         if (ptop) {
             if ((int)std::lrintf(255.0f * (float)(1.0 / (double)c->prm.thresh_step)) != 255 / c->prm.thresh_step + 1)
@@ -2331,7 +2391,6 @@ int str_er_er_grouping(str_er_ctx *c, const str_er_cand *cands, const str_er_tra
 {
     if (!c) return STR_ER_EINVAL;
     if (!out || n < 0 || (n > 0 && (!cands || !tracks))) return fail(c, STR_ER_EINVAL, "bad arguments");
-    if (overlap_sup) return fail(c, STR_ER_EINVAL, "er_grouping with overlap_sup = true is not built");
     *out = nullptr;
     HIP_TRY(c, hipSetDevice(c->prm.device));
     str_er_result *r = new (std::nothrow) str_er_result();
@@ -2344,7 +2403,9 @@ int str_er_er_grouping(str_er_ctx *c, const str_er_cand *cands, const str_er_tra
     std::memset(&r->planes[0], 0, sizeof(str_er_plane_info));
     r->planes[0].n_pool = n; r->planes[0].root = -1;
     int rc = STR_ER_OK;
-    if (n > 0) {
+    if (n > 0 && overlap_sup) {
+        rc = group_phase_overlap(c, std::vector<uint32_t>{0u, (uint32_t)n}, inner_sup != 0, r);
+    } else if (n > 0) {
         const size_t o_c = 0, o_tr = align_up(sizeof(CandRec) * (size_t)n, 256);
         rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * (size_t)n);
         if (rc == STR_ER_OK) {

@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void k_group_prepare(const CandRec *__restrict
         n_t += tot;
     }
     __syncthreads();
-    // 2. sort(all_er, center.x) (:614), stable: position = how many come before
+    // 2. sort(all_er, center.x) (:614), stable: position = how many come before.  (inner_sup bit 1: the list comes sorted and
+    //    overlap-suppressed from the host and keeps its order -- the reference does not sort again after overlap_suppression)
+    if (inner_sup & 2) for (uint32_t k = tid; k < n_t; k += 256) B[k] = A[k];
+    else
     for (uint32_t k = tid; k < n_t; k += 256) {
         const int ck = tr[A[k]].cx;
         uint32_t  rank = 0;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void k_group_prepare(const CandRec *__restrict
         uint32_t       keep = 0;
         if (j < n_t) {
             keep = 1;
-            if (inner_sup) {
+            if (inner_sup & 1) {
                 const GEr b = load_ger(cands, tr, B[j]);
                 for (uint32_t i = 0; i < n_t && keep; ++i) {
                     const GEr    a = load_ger(cands, tr, B[i]);

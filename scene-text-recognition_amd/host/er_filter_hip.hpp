@@ -247,7 +247,7 @@ public:
 
     // void ERFilter::er_grouping(ERs &all_er, vector<Text> &text, bool overlap_sup, bool inner_sup) (src/ER.cpp:612-692).
     // all_er comes back sorted by center.x (and inner-suppressed); bound / center of ERs that overlap_suppression merged
-    // into are updated in place as in the reference.  overlap_sup = true is not built.
+    // into are updated in place as in the reference, and the ERs it merged away are erased.
     void er_grouping(ERs &all_er, std::vector<Text> &text, bool overlap_sup = false, bool inner_sup = false)
     {
         // ties in center.x are broken by candidate order = (channel, key), whatever order all_er arrives in

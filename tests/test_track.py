@@ -214,7 +214,7 @@ def test_oracle_er_grouping_lines(oracle):
     assert list(oracle.er_grouping(e, inner_sup=False)[0]) == [0, 1, 2]
 
 
-def _expected_lines(oracle, res, sel, inner_sup):
+def _expected_lines(oracle, res, sel, inner_sup, overlap_sup=False):
     """Oracle er_grouping on the tracked candidates `sel` (indices into res.cands, candidate order)."""
     tr = res.tracks[sel]
     keep = sel[tr["tracked"] != 0]
@@ -225,17 +225,17 @@ def _expected_lines(oracle, res, sel, inner_sup):
         e[k]["cx"], e[k]["cy"] = t["cx"], t["cy"]
         e[k]["color1"], e[k]["color2"], e[k]["color3"] = t["color1"], t["color2"], t["color3"]
         e[k]["id"] = i
-    all_idx, lines, after = oracle.er_grouping(e, inner_sup=inner_sup)
+    all_idx, lines, after = oracle.er_grouping(e, overlap_sup=overlap_sup, inner_sup=inner_sup)
     return keep, lines, after, keep[all_idx]
 
 
-def _check_lines(res, groups, oracle, inner_sup):
+def _check_lines(res, groups, oracle, inner_sup, overlap_sup=False):
     """groups: list of candidate-index arrays, one per image, in image order."""
     li = 0
     n_lines = 0
     all_er = []
     for sel in groups:
-        keep, lines, after, ga = _expected_lines(oracle, res, sel, inner_sup)
+        keep, lines, after, ga = _expected_lines(oracle, res, sel, inner_sup, overlap_sup)
         all_er += [int(v) for v in ga]
         for members, slope, box in lines:
             t = res.texts[li]
@@ -278,9 +278,17 @@ def test_gpu_group_stage_matches_oracle(S, cascade_paths, oracle, inner_sup):
         assert list(res.text_ers[a["first"]:a["first"] + a["count"]] - sel[0]) == list(r1.text_ers[b["first"]:b["first"] + b["count"]])
         assert a["slope"] == b["slope"] or (np.isnan(a["slope"]) and np.isnan(b["slope"]))
     with pytest.raises(S.StrErError):
-        f.er_grouping(res.cands[sel], res.tracks[sel], overlap_sup=True)
-    with pytest.raises(S.StrErError):
         f.text_detect(frames, S.STAGE_ALL | S.STAGE_GROUP)
+    with pytest.raises(S.StrErError):
+        f.text_detect(frames, S.STAGE_ALL | S.STAGE_TRACK | S.GROUP_OVERLAP_SUP)
+    # er_grouping(tracked, text, overlap_sup = true, inner_sup) -- video_mode's call (src/utils.cpp:196) -- fused and single-stage
+    res2 = f.text_detect(frames, st | S.GROUP_OVERLAP_SUP)
+    assert res2.cands.tobytes() == res.cands.tobytes()
+    _check_lines(res2, groups, oracle, inner_sup, overlap_sup=True)
+    assert len(res2.group_all) <= len(res.group_all)
+    r2 = f.er_grouping(res.cands[sel], res.tracks[sel], overlap_sup=True, inner_sup=inner_sup)
+    r2.cands, r2.tracks = res.cands[sel], res.tracks[sel]
+    _check_lines(r2, [np.arange(len(sel))], oracle, inner_sup, overlap_sup=True)
     f.close()
 
 
@@ -288,6 +296,7 @@ def test_gpu_group_stage_matches_oracle(S, cascade_paths, oracle, inner_sup):
 def test_gpu_group_random_boxes(erf, oracle, S):
     """er_grouping on made-up ERs: dense clusters with many equal centres, shared members, merges and NaN colours."""
     rng = np.random.default_rng(11)
+    merged = 0
     for trial in range(6):
         n = int(rng.integers(1, 260))
         cd = np.zeros(n, S.CAND_DTYPE)
@@ -301,10 +310,13 @@ def test_gpu_group_random_boxes(erf, oracle, S):
             tr[k] = rng.integers(90, 130, n)
         tr["color2"][rng.random(n) < 0.03] = np.nan
         tr["tracked"] = (rng.random(n) < 0.8) & (cd["cls"] != 0)
-        for inner in (False, True):
-            res = erf.er_grouping(cd, tr, inner_sup=inner)
+        for inner, overlap in ((False, False), (True, False), (False, True), (True, True)):
+            res = erf.er_grouping(cd, tr, overlap_sup=overlap, inner_sup=inner)
             res.cands, res.tracks = cd, tr
-            _check_lines(res, [np.arange(n)], oracle, inner)
+            _check_lines(res, [np.arange(n)], oracle, inner, overlap)
+            if overlap and not inner:
+                merged += int(tr["tracked"].sum()) - len(res.group_all)
+    assert merged > 5                       # overlap_suppression did merge boxes away
 
 
 @pytest.mark.gpu
