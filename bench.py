@@ -37,6 +37,11 @@ import time
 
 import numpy as np
 
+# Several contexts in flight use three HIP streams each (main, alt NMS pass, tie pass); with the runtime's default of 4 hardware queues
+# the long single-workgroup kernels of one context's tie pass sit in front of another context's tile kernel (measured: 4940 -> 5330
+# frames/s with 16).  The runtime reads this when it starts, i.e. before torch's first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

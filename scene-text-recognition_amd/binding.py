@@ -16,6 +16,9 @@ from typing import List, Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# (see str_er_api.cpp: three streams per context, several contexts in flight -- effective when nothing in the process has
+# initialised the HIP runtime yet)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES, STAGE_TRACK = 1, 2, 4, 7, 8, 16, 32
 STAGE_GROUP, GROUP_INNER_SUP, STAGE_OCR_LINES, GROUP_OVERLAP_SUP = 64, 128, 256, 512

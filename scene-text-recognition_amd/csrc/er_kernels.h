@@ -69,7 +69,10 @@ void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p,
 void launch_cand_prefix(hipStream_t s, const BatchDev &b);
 // classify (src/ER.cpp:507-528) over the packed pool of the batch.
 void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong,
-                     CascadeDev weak, int run_cascades);
+                     CascadeDev weak, int run_cascades, const uint32_t *list = nullptr, const uint32_t *n_list = nullptr);
+// after the NMS tie pass: new candidate offsets (b.cands / b.cand_plane = the second set of buffers), the records of unchanged planes
+// moved over from `from`, the candidates of the changed planes listed in redo[0 .. *n_redo) for launch_classify
+void launch_cand_reprefix(hipStream_t s, const BatchDev &b, const CandRec *from, uint32_t *redo, uint32_t *n_redo);
 
 // Stand-alone classify chain on explicit boxes of one device plane (single-stage API).
 void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int stride, const int32_t *boxes,

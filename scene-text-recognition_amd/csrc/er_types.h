@@ -66,7 +66,8 @@ struct PlaneCtr {
     uint32_t n_rel;         // NMS: ties that can change the pool (n_amb counts all ties); > 0 -> the plane's flood is replayed
     uint32_t tie_node;      // NMS: kept slot of a node with a tie and the number of its contenders (meaningful when n_amb == 1)
     uint32_t tie_nc;
-    uint32_t pad_[2];
+    uint32_t pool_changed;  // NMS tie pass: the plane's pool is not the first pass's pool (its candidates have to be classified again)
+    uint32_t cand_base_old; // candidate offset of the plane before the tie pass (k_cand_reprefix)
 };
 static_assert(sizeof(PlaneCtr) == 80, "PlaneCtr is mirrored in pinned host memory");
 

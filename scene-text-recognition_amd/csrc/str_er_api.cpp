@@ -31,6 +31,12 @@ using namespace str_er;
 
 namespace {
 
+// A context uses three HIP streams (main, alt NMS pass, tie pass) and applications keep several contexts in flight; on the runtime's
+// default of 4 hardware queues the long single-workgroup kernels of one context's tie pass end up in front of another context's
+// tile kernel (bench.py: 4940 -> 5330 frames/s with 16).  The HIP runtime reads the variable when it initialises, so this helps
+// when the library is loaded before the process's first HIP call (a C++ host linked against it); otherwise export it.
+__attribute__((constructor)) void str_er_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+
 thread_local std::string g_create_error;
 constexpr int TIE_SLOTS = 4;       // planes per batch the device hands to the host for the flood order walk without a round trip
 
@@ -110,7 +116,8 @@ struct str_er_ctx {
     std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
     uint32_t *d_tile_nbase = nullptr; size_t tile_slots = 0;
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
-    CandRec *d_cands = nullptr;
+    CandRec *d_cands = nullptr, *d_cands2 = nullptr;      // (second set: the layout after an NMS tie pass changed pools, then swapped)
+    uint32_t *d_redo = nullptr;                          // candidates to classify again + their count (last word)
     TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
     uint32_t *d_group = nullptr, *d_group_pairs = nullptr; size_t group_words = 0, group_pair_cap = 0;   // STR_ER_STAGE_GROUP, grown on demand
     uint32_t *d_total = nullptr;
@@ -125,7 +132,7 @@ struct str_er_ctx {
     uint32_t last_total = 0; bool last_valid = false;   // candidates of the last detect call, still in d_cands (str_er_gather_last)
     uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
     bool replay_on_gpu = false;                       // STR_ER_REPLAY=gpu: walk the flood with k_flood_order instead of a host core
-    uint16_t *d_cand_plane = nullptr;
+    uint16_t *d_cand_plane = nullptr, *d_cand_plane2 = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
     std::vector<void *> allocs;
 
@@ -881,7 +888,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     const DetectParams dp = make_dp(c);
     hipStream_t s = c->stream;
     { const int rcu = upload_layout(c, b); if (rcu != STR_ER_OK) return rcu; }
-    const BatchDev bd = make_batchdev(c, b);
+    BatchDev bd = make_batchdev(c, b);
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
 
     if (import_trees) {
@@ -919,21 +926,23 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
     }
     // everything after NMS reads the pools: enqueued once, and once more if sibling ties had to be decided by a flood replay
-    auto after_nms = [&](bool record, hipStream_t st) {
-        if (stages & STR_ER_STAGE_NMS) {
-            launch_cand_prefix(st, bd);
-            launch_classify(st, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
-        }
-        if (record) rec(c, "classify");
+    // everything after NMS reads the pools: enqueued once; if sibling ties had to be decided by a flood order walk, the planes whose
+    // pool that changed are classified again (the others keep their records) and the stages behind classify run once more
+    auto track_stage = [&](bool record, hipStream_t st, const BatchDev &d) {
         if (stages & STR_ER_STAGE_TRACK) {
             const int n_img = np / b.planes_per_image;
-            launch_calc_color_batch(st, bd, c->d_track);
-            launch_group_ranges(st, bd, b.planes_per_image, n_img, c->d_ranges);
-            launch_er_track(st, c->d_cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
+            launch_calc_color_batch(st, d, c->d_track);
+            launch_group_ranges(st, d, b.planes_per_image, n_img, c->d_ranges);
+            launch_er_track(st, d.cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
             if (record) rec(c, "track");
         }
     };
-    after_nms(true, s);
+    if (stages & STR_ER_STAGE_NMS) {
+        launch_cand_prefix(s, bd);
+        launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
+    }
+    rec(c, "classify");
+    track_stage(true, s, bd);
     const int i_cls = (stages & STR_ER_STAGE_TRACK) ? c->n_ev - 2 : c->n_ev - 1;
     const int i_trk = c->n_ev - 1;
     if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -967,8 +976,14 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         if (replayed && c->dbg_stats) std::fprintf(stderr, "[str_er] tie resolution (copies + walk + NMS pass): %.1f ms\n", std::chrono::duration<double, std::milli>(tr1 - tr0).count());
         if (replayed) {
             hipStream_t sp = c->prio ? c->prio : s;         // same stream as the tie pass: ordered behind it
-            HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), sp));
-            after_nms(false, sp);
+            const CandRec *first = c->d_cands;
+            std::swap(c->d_cands, c->d_cands2);
+            std::swap(c->d_cand_plane, c->d_cand_plane2);
+            bd = make_batchdev(c, b);
+            uint32_t *n_redo = c->d_redo + (size_t)c->max_planes * c->pool_cap;
+            launch_cand_reprefix(sp, bd, first, c->d_redo, n_redo);
+            launch_classify(sp, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, c->d_redo, n_redo);
+            track_stage(false, sp, bd);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
             HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
@@ -1345,6 +1360,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
     A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
     A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
+    A(dev_alloc(c, c->d_cands2, PP)); A(dev_alloc(c, c->d_cand_plane2, PP)); A(dev_alloc(c, c->d_redo, PP + 1));
     A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));

@@ -6,15 +6,16 @@ set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/scene-text-recognition_amd/lib/stop
 PHASES="0 1 2 3 4 5 7 13 6"
+# EXTRA="-DSTR_ER_TILE_V2" tools/dev_stop_all.sh build: the same for another build of the kernel
 if [ "${1:-build}" = "build" ]; then
-    mkdir -p $OUT
+    mkdir -p $OUT; rm -f $OUT/*
     for n in $PHASES; do
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DSTR_ER_STOP_AFTER=$n -x hip \
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DSTR_ER_STOP_AFTER=$n ${EXTRA:-} -x hip \
             -c $ROOT/scene-text-recognition_amd/csrc/er_kernels.hip -o $OUT/er_kernels_$n.o &
     done
     wait
     for n in $PHASES; do
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libstop_$n.so $OUT/er_kernels_$n.o $ROOT/scene-text-recognition_amd/lib/{svm_kernels,track_kernels,er_group,flood_order,str_er_api,stream_api}.o
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libstop_$n.so $OUT/er_kernels_$n.o $ROOT/scene-text-recognition_amd/lib/{svm_kernels,track_kernels,er_group,flood_order,gather,str_er_api,stream_api}.o -ldl -lpthread
         rm -f $OUT/er_kernels_$n.o
     done
     ls -la $OUT
