@@ -251,7 +251,9 @@ def main():
             t.join()
         return prof, last
 
-    run(args.warmup)
+    # W untimed warm-up steps -- on EVERY context: a context's first batch sizes its node records for the frames' content (and on
+    # noise-like frames picks the large tile kernel), which must not happen inside the timed region of whichever contexts W did not reach
+    run(args.warmup * P)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -385,19 +385,17 @@ __device__ unsigned long long g_tile_phase[16];
 #define PHASE_INIT() do { } while (0)
 #endif
 
-// Join pixels a and b (4-neighbours, both not walls): afterwards the root paths of a
-// and b are merged into one path sorted by level.  Lock-free; every change is one CAS
-// on the parent word of a level root, conditional on the value that was read.
 // Level root of pixel a (level la), with path halving: every same-level hop re-points the
 // pixel at its grandparent.  Only non-roots are rewritten, and only with another pixel of
-// the same node, so racing with the CAS in tile_connect (which targets level roots) is benign.
+// the same node, so racing with the CAS in connect_pass (which targets level roots) is benign.
 __device__ __forceinline__ uint32_t tile_find(uint32_t *s_par, uint32_t &a, uint32_t la)
 {
     uint32_t wa = LD_WG(&s_par[LX(a)]);
-    while (wa != NONE && (wa >> 16) == la) {
+    // (NONE reads as level 0xFFFF, which no pixel has: the level test covers it)
+    while ((wa >> 16) == la) {
         const uint32_t nx = wa & 0xFFFFu;
         const uint32_t w2 = LD_WG(&s_par[LX(nx)]);
-        if (w2 != NONE && (w2 >> 16) == la) s_par[LX(a)] = w2;
+        if ((w2 >> 16) == la) s_par[LX(a)] = w2;
         a = nx;
         wa = w2;
         CNT(2, 1);
@@ -405,155 +403,65 @@ __device__ __forceinline__ uint32_t tile_find(uint32_t *s_par, uint32_t &a, uint
     return wa;
 }
 
-__device__ __forceinline__ void tile_connect(uint32_t *s_par, const uint16_t *s_lev, uint32_t a, uint32_t b)
+// Join pixels a and b (4-neighbours, both not walls): when the edge is done, the root paths of a and b are merged into one path
+// sorted by level.  Lock-free; every change is one CAS on the parent word of a level root, conditional on the value that was read.
+// This is ONE pass -- find both level roots, then link the lower one under the other, or climb -- written with a single branch
+// (around the CAS) besides the finds, everything else is selects: the kernel is bound by instruction issue, scalar
+// bookkeeping of divergent branches included (round 2: 3.19 -> 3.11 ms per 32 text frames, 9.8 -> 8.5 on noise, against the same
+// pass as nested ifs).  Returns whether the edge still needs passes.
+__device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint32_t &b, uint32_t &la, uint32_t &lb)
 {
-    uint32_t la = s_lev[LX(a)], lb = s_lev[LX(b)];
-    CNT(0, 1);
-    for (;;) {
-        CNT(1, 1);
-        uint32_t wa = tile_find(s_par, a, la);
-        uint32_t wb = tile_find(s_par, b, lb);
-        if (a == b) return;
-        if (la > lb || (la == lb && a < b)) {
-            uint32_t t;
-            t = a; a = b; b = t;
-            t = la; la = lb; lb = t;
-            t = wa; wa = wb; wb = t;
-        }
-        // now a must end up below b: either in the same node (equal levels, a > b) or
-        // as a descendant.  If a's current parent is higher than b, b slots in between.
-        if (la == lb || wa == NONE || (wa >> 16) > lb) {
-            const uint32_t old = atomicCAS(&s_par[LX(a)], wa, (lb << 16) | b);
-            CNT(3, 1);
-            if (old != wa) { CNT(4, 1); continue; }   // somebody else moved a: re-read
-            if (wa == NONE) return;    // a was a tree root: nothing left to merge
-            a = wa & 0xFFFFu;          // a's former parent still has to be merged with b
-            la = wa >> 16;
-        } else {
-            a = wa & 0xFFFFu;          // climb
-            la = wa >> 16;
-        }
+    CNT(1, 1);
+    uint32_t       wa = tile_find(s_par, a, la);
+    const uint32_t wb = tile_find(s_par, b, lb);
+    const bool     same = a == b;
+    if (la > lb || (la == lb && a < b)) {
+        uint32_t t;
+        t = a; a = b; b = t;
+        t = la; la = lb; lb = t;
+        wa = wb;
     }
+    // now a must end up below b: either in the same node (equal levels, a > b) or as a descendant.  If a's current parent is
+    // higher than b (or there is none: NONE reads as level 0xFFFF), b slots in between; otherwise climb
+    const bool link = !same && (la == lb || (wa >> 16) > lb);
+    uint32_t   old = wa;
+    if (link) { old = atomicCAS(&s_par[LX(a)], wa, (lb << 16) | b); CNT(3, 1); }
+    const bool ok = old == wa;                  // (a lane that climbs has ok = true as well)
+    // linked under b, or climbing: carry on with a's (former) parent; a lost CAS repeats the pass with the same pair
+    if (!same && ok) { a = wa & 0xFFFFu; la = wa >> 16; }
+    return !(same || (link && ok && wa == NONE));
 }
 
-// (Measured and not adopted, round 2: restricting this loop to fewer waves so that every iteration is fuller -- 1 / 2 / 3 / 4 waves:
-// 5.06 / 4.13 / 3.84 / 3.71 ms per 32 frames, the loop is bound by LDS latency, not by issue; and a flat form with two edges per lane
-// in flight, every step "load both parent words of both edges, then hop or CAS" -- 4.87 ms: the hops become steps of their own and
-// every step pays the refill logic.)
-// All edges of a worklist, with the lanes kept busy: a connect takes anything from one to a dozen passes of its loop,
-// so "lane i does edge i, then everybody waits for the slowest lane" leaves most lanes idle most of the time.  Here a
-// lane that finishes its edge takes the next one from a workgroup-wide cursor straight away (one LDS atomic per wave and
-// pass for all its idle lanes); a wave leaves when the list is empty and its lanes are done.
-__device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges,
-                                                 uint32_t *s_cursor, int round)
+// All edges of a worklist.  A connect takes anything from one to a dozen passes, so a lane moves on to its next edge as soon as it is
+// done with one; a wave leaves when its lanes have nothing left.  Every lane walks its own contiguous part of the list: at any moment
+// the 256 lanes work in 256 different places of the tile (fewer lost CASes) and a lane's next edge touches the nodes it has just
+// compressed.
+// (Measured, 32 frames text / noise, and not adopted: a workgroup-wide cursor that hands the next entries to whichever lanes are idle
+// -- round 1's form -- 3.19 / 9.8 ms against 3.11 / 8.5: the ballots and the LDS atomic per refill cost more than the balance gains;
+// lane i takes entries i, i + 256, ...: 3.28 / 10.2; both finds of a pass in one loop so that their loads are in flight together:
+// 3.62 / 11.5, the loop runs as long as the longer chain with both halves' instructions; walking up a's chain to b's level in a loop of
+// finds inside the pass: 3.67 / 12.3; the vertical round first: 3.21 / 10.8; round 1's attempts -- fewer waves in the loop, two edges
+// per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
+__device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges, int round)
 {
-    const int lane = threadIdx.x & 63;
-    bool      active = false, more = true;
-    uint32_t  a = 0, b = 0, la = 0, lb = 0;
+    bool           active = false;
+    const uint32_t chunk = (n_edges + TILE_THREADS - 1) / TILE_THREADS;
+    uint32_t       next = threadIdx.x * chunk;
+    const uint32_t n_end = min(n_edges, next + chunk);
+    uint32_t       a = 0, b = 0, la = 0, lb = 0;
     for (;;) {
-        if (more) {
-            const unsigned long long idle = __ballot(!active);
-            if (idle) {
-                const int leader = __ffsll((long long)idle) - 1;
-                uint32_t  base = 0;
-                if (lane == leader) base = atomicAdd(s_cursor, (uint32_t)__popcll(idle));
-                base = __shfl(base, leader);
-                if (base >= n_edges) more = false;
-                else if (!active) {
-                    const uint32_t e = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (e < n_edges) {
-                        // an entry is the slot p of the edge's second (round 0) or first (round 1) pixel: the edge is (left of p, p) --
-                        // one slot back, two across the unused word after every 32 pixels -- or (p, pixel below p)
-                        const uint32_t p = s_elist[e];
-                        if (round == 0) { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
-                        else { a = p; b = p + (uint32_t)TILE_WS; }
-                        la = s_lev[LX(a)]; lb = s_lev[LX(b)];
-                        active = true;
-                        CNT(0, 1);
-                    }
-                }
-            }
-        }
-        if (!__any(active)) break;
-        if (active) {      // one pass of tile_connect's loop
-            CNT(1, 1);
-            uint32_t wa = tile_find(s_par, a, la);
-            uint32_t wb = tile_find(s_par, b, lb);
-            if (a == b) active = false;
-            else {
-                if (la > lb || (la == lb && a < b)) {
-                    uint32_t t;
-                    t = a; a = b; b = t;
-                    t = la; la = lb; lb = t;
-                    t = wa; wa = wb; wb = t;
-                }
-                if (la == lb || wa == NONE || (wa >> 16) > lb) {
-                    const uint32_t old = atomicCAS(&s_par[LX(a)], wa, (lb << 16) | b);
-                    CNT(3, 1);
-                    if (old == wa) {
-                        if (wa == NONE) active = false;     // a was a tree root: nothing left to merge
-                        else { a = wa & 0xFFFFu; la = wa >> 16; }
-                    } else CNT(4, 1);                       // somebody else moved a: same edge again
-                } else {
-                    a = wa & 0xFFFFu;                       // climb
-                    la = wa >> 16;
-                }
-            }
-        }
-    }
-}
-
-// (k_tile_tree2) The same, with the edges dealt out statically -- lane i takes edges i, i + 256, ... -- and a lane moves on to its next
-// edge as soon as it is done with one: the list is compact, so every lane gets the same number of edges (+-1) and what is left to balance
-// is the number of passes an edge takes; no cursor, no ballots.  STR_ER_CLIMB: walking up a's chain to b's level is a loop of finds
-// inside the pass instead of one pass per step.
-__device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges, int round)
-{
-    bool     active = false;
-    uint32_t next = threadIdx.x;
-    uint32_t a = 0, b = 0, la = 0, lb = 0;
-    for (;;) {
-        if (!active && next < n_edges) {
+        if (!active && next < n_end) {
             // an entry is the slot p of the edge's second (round 0) or first (round 1) pixel: the edge is (left of p, p) --
             // one slot back, two across the unused word after every 32 pixels -- or (p, pixel below p)
-            const uint32_t p = s_elist[next];
-            next += TILE_THREADS;
+            const uint32_t p = s_elist[next++];
             if (round == 0) { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
             else { a = p; b = p + (uint32_t)TILE_WS; }
             la = s_lev[LX(a)]; lb = s_lev[LX(b)];
             active = true;
+            CNT(0, 1);
         }
         if (!__any(active)) break;
-        if (active) {      // one pass of tile_connect's loop
-            uint32_t wa = tile_find(s_par, a, la);
-            uint32_t wb = tile_find(s_par, b, lb);
-            if (a == b) active = false;
-            else {
-                if (la > lb || (la == lb && a < b)) {
-                    uint32_t t;
-                    t = a; a = b; b = t;
-                    t = la; la = lb; lb = t;
-                    t = wa; wa = wb; wb = t;
-                }
-#ifdef STR_ER_CLIMB
-                // a is below b: walk up a's chain while its parent is still below b's level
-                while (wa != NONE && (wa >> 16) < lb) {
-                    a = wa & 0xFFFFu; la = wa >> 16;
-                    wa = tile_find(s_par, a, la);
-                }
-#endif
-                if (la == lb || wa == NONE || (wa >> 16) > lb) {
-                    const uint32_t old = atomicCAS(&s_par[LX(a)], wa, (lb << 16) | b);
-                    if (old == wa) {
-                        if (wa == NONE) active = false;     // a was a tree root: nothing left to merge
-                        else { a = wa & 0xFFFFu; la = wa >> 16; }
-                    }                                       // else somebody else moved a: same edge again
-                } else {
-                    a = wa & 0xFFFFu;                       // climb
-                    la = wa >> 16;
-                }
-            }
-        }
+        if (active) active = connect_pass(s_par, a, b, la, lb);
     }
 }
 
@@ -601,530 +509,38 @@ __device__ __forceinline__ int row_lo(unsigned long long m) { return __ffsll((lo
 __device__ __forceinline__ int row_hi(unsigned long long m) { return 63 - __clzll((long long)m); }
 // The tile kernel exists in two sizes.  FOLD_CAP = how many nodes a tile may have and still fold its closed nodes in LDS
 // (more: every node is exported and the global passes do the folding); it sets the size of s_work and with it how many
-// workgroups fit a CU.  The kernel waits on LDS round trips most of the time, so occupancy pays: measured on text-like frames
-// 4.50 ms (880 nodes, 6 workgroups per CU) -> 4.0 ms (480 nodes, 8 per CU, a few spilled registers).  Frames that are mostly
-// noise have ~860 nodes per tile and need the big one (with 480 the global accumulate pass quadruples).  The host picks per
-// batch from the node density of the previous batch (str_er_api.cpp).
+// workgroups fit a CU: 880 nodes = 26.2 KB of LDS = 21 of the 1280-byte granules LDS is handed out in -> 6 workgroups (24 waves) per
+// CU; 480 nodes = 19.9 KB = 16 granules -> 8 per CU, 13 % faster on text-like frames.  Frames that are mostly noise have ~860 nodes
+// per tile and need the big one (with 480 the global accumulate pass quadruples).  The host picks per batch from the node density of
+// the previous batch (str_er_api.cpp).
 constexpr int FOLD_CAP_DENSE = TILE_H > 32 ? 1408 : 880;    // 21 (42) LDS granules of 1280 B: 6 (3) workgroups per CU
 constexpr int FOLD_CAP_SPARSE = TILE_H > 32 ? 1024 : 480;   // 16 (32) granules: 8 (4) workgroups per CU
 
-// (waves per SIMD = what the LDS allows: 6 with 80 VGPRs for the dense size, 8 with 64 VGPRs for the sparse one)
-template <int FOLD_CAP>
-#ifndef STR_ER_DEV_OCC
-#define STR_ER_DEV_OCC (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
-#endif
-__global__ __launch_bounds__(TILE_THREADS, STR_ER_DEV_OCC) void k_tile_tree(BatchDev b, DetectParams prm)
-{
-    // dense size: 26.2 KB of LDS -> 6 workgroups (24 waves) per CU: LDS is handed out in 1280-byte granules, 21 of them (26880 B) is the
-    // most that still fits six times into 160 KB; sparse size: 19.9 KB = 16 granules, eight times
-    constexpr int STAT_CHUNK = FOLD_CAP < 512 ? FOLD_CAP : 512;   // dense tiles: nodes whose statistics are accumulated per pass
-    static_assert(2 * NODE_WORDS * FOLD_CAP >= TILE_PX, "the 16-bit edge list of a round (one entry per pixel at most) must fit s_work");
-    __shared__ uint32_t s_par[TILE_SLOTS];
-    __shared__ __attribute__((aligned(8))) uint32_t s_work[NODE_WORDS * FOLD_CAP]; // edge worklist, later the per-node statistics
-    __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
-    uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
-    __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_walls, s_start, s_cursor, s_nbase;
-    __shared__ uint32_t s_present[8];        // which levels have a node in this tile
-
-    const int       tid = threadIdx.x;
-    const int       pi = b.tile_plane[blockIdx.x];
-    const PlaneDesc pd = b.planes[pi];
-    const uint32_t  tl = blockIdx.x - pd.tile_base;
-    const int       tx = tl % pd.tiles_x, ty = tl / pd.tiles_x;
-    const int       ox = tx * TILE_W, oy = ty * TILE_H;
-    const int       ly = tid >> 3, lx = (tid & 7) * TILE_PPT;
-    const uint32_t  p0 = (uint32_t)tid * TILE_PPT + ((uint32_t)tid >> 2);   // slot of the lane's first pixel
-    const uint32_t  pl = p0 - 1u - ((tid & 3) == 0 ? 1u : 0u);             // slot of the pixel to its left (lx > 0)
-    const int       gx = ox + lx, gy = oy + ly;
-
-    if (tid == 0) s_walls = 0;
-    if (tid < 8) s_present[tid] = 0;
-    PHASE_INIT();
-
-    // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
-    uint32_t lev[TILE_PPT];
-    uint32_t left_lev;          // level of the pixel left of the lane's first one (WALL at the tile edge)
-#ifdef STR_ER_E1
-    // the lane's 8 pixels as two bit sets: walls, and starts of runs of equal level (the first pixel of the lane starts one unless it
-    // continues the run of the pixel to its left).  The edges that need a connect follow from these sets of the lane and of the lane below.
-    uint32_t wallm = 0, startm = 0;
-    uint16_t *const s_msk = reinterpret_cast<uint16_t *>(s_work) + TILE_PX;     // behind the edge list (<= TILE_PX 16-bit entries)
-    static_assert(NODE_WORDS * FOLD_CAP * 4 >= 2 * TILE_PX + 2 * TILE_THREADS, "edge list and lane masks must fit s_work");
-#endif
-    {
-        uint8_t px[TILE_PPT];
-        int     nvalid = 0;
-        // (rows above y_lo are not part of the image either: the phantom tile row on top of a strip of a plane)
-#ifdef STR_ER_DEV_EDIT
-        if (gy < pd.h && gx < pd.w && gy >= (int)pd.pad0) {
-#else
-        if (gy < pd.h && gx < pd.w) {
-#endif
-            const uint8_t *row = pd.pix + (size_t)gy * pd.stride + gx;
-            nvalid = min(TILE_PPT, pd.w - gx);
-            if (nvalid == TILE_PPT && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(row);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { px[k] = (v.x >> (8 * k)) & 255; px[4 + k] = (v.y >> (8 * k)) & 255; }
-            } else {
-                for (int k = 0; k < nvalid; ++k) px[k] = row[k];
-            }
-        }
-        uint32_t walls = 0;
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            uint32_t q = WALL;
-            if (k < nvalid) {
-                q = (uint32_t)__float2int_rn((float)(px[k] ^ pd.invert) * prm.qscale);
-                if (q >= (uint32_t)prm.hi) { q = WALL; ++walls; }
-            }
-            lev[k] = q;
-            s_lev[OWN(k)] = (uint16_t)q;
-#ifdef STR_ER_E1
-            if (q == WALL) wallm |= 1u << k;
-            else if (k > 0 && lev[k > 0 ? k - 1 : 0] != q) startm |= 1u << k;
-#endif
-        }
-        // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; point every
-        // pixel of a run at the run's first pixel
-        uint32_t head = p0;
-#pragma unroll
-        for (int k = 1; k < TILE_PPT; ++k) {
-            if (lev[k] != WALL && lev[k] == lev[k - 1]) s_par[OWN(k)] = (lev[k] << 16) | head;
-            else { head = p0 + k; s_par[OWN(k)] = NONE; }
-        }
-        // ... and across the lane boundary: if the lane's first pixel continues the run of the pixel to
-        // its left, it points at the head of that run.  The 8 lanes of a tile row are neighbours in the
-        // wave; a lane that is one single run and itself continues leftwards forwards the head it got.
-        left_lev = __shfl_up(lev[TILE_PPT - 1], 1);
-        if (lx == 0) left_lev = WALL;
-        const bool joins = lev[0] != WALL && lev[0] == left_lev;
-#ifdef STR_ER_E1
-        if (lev[0] != WALL && !joins) startm |= 1u;
-        s_msk[tid] = (uint16_t)(wallm | (startm << 8));
-#endif
-        {
-            uint32_t val = head;                       // head of the lane's last run
-            bool     pass = joins && head == p0;
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                const uint32_t lv = __shfl_up(val, o);
-                const int      lp = __shfl_up((int)pass, o);
-                if (pass) { val = lv; pass = lp != 0; }
-            }
-            const uint32_t t = __shfl_up(val, 1);
-            s_par[OWN(0)] = joins ? ((lev[0] << 16) | t) : NONE;
-        }
-        __syncthreads();
-        if (walls) atomicAdd(&s_walls, walls);
-    }
-    PHASE_MARK(0);
-
-    // ---- connect the in-tile edges, in two balanced rounds -------------------------------------
-    // Each lane lists the edges that still need a connect (horizontal: level changes and lane
-    // boundaries; vertical: the first column of a pair of runs -- the other columns join the same
-    // two nodes); the list is compacted into LDS and dealt out evenly, so a lane whose pixels
-    // happen to need many connects does not hold its whole wave back.
-    uint16_t *const s_elist = reinterpret_cast<uint16_t *>(s_work);     // one 16-bit slot per edge
-    for (int round = 0; round < 2; ++round) {
-        uint32_t emask = 0;
-#ifdef STR_ER_E1
-        // horizontal: a run starts here and the pixel to its left is no wall (an equal-level left neighbour is already linked: by the run
-        // pointers above); vertical: neither this pixel nor the one below is a wall, and a run starts in either row -- in the other
-        // columns the column to the left joins the same two nodes
-        if (round == 0) emask = startm & ~((wallm << 1) | (left_lev == WALL ? 1u : 0u)) & 0xFFu;
-        else if (ly + 1 < TILE_H) {
-            const uint32_t mb = s_msk[tid + TILE_W / TILE_PPT];
-            emask = (startm | (mb >> 8)) & ~(wallm | mb) & 0xFFu;
-        }
-#else
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            if (lev[k] == WALL) continue;
-            const uint32_t p = p0 + k;
-            if (round == 0) {
-                // (an equal-level left neighbour is already linked: by the run pointers above)
-                const uint32_t ll = k == 0 ? left_lev : lev[k > 0 ? k - 1 : 0];
-                if (ll != WALL && ll != lev[k]) emask |= 1u << k;
-            } else if (ly + 1 < TILE_H) {
-                const uint32_t lq = s_lev[LX(p + TILE_WS)];
-                if (lq != WALL) {
-                    // covered: the column to the left joins the same two nodes
-                    bool covered;
-                    if (k > 0) covered = lev[k - 1] == lev[k] && s_lev[LX(p + TILE_WS - 1)] == lq;
-                    else       covered = left_lev == lev[0] && s_lev[LX(lx > 0 ? pl + TILE_WS : p + TILE_WS)] == lq;
-                    if (!covered) emask |= 1u << k;
-                }
-            }
-        }
-#endif
-        uint32_t n_edges;
-        uint32_t off = block_excl_scan(__popc(emask), s_wsum, &n_edges);
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k)
-            if ((emask >> k) & 1) {
-                const uint32_t p = p0 + k;
-                s_elist[off++] = (uint16_t)p;          // the other end follows from the round: left neighbour / pixel below
-            }
-        if (tid == 0) s_cursor = 0;
-        __syncthreads();
-        tile_connect_all(s_par, s_lev, s_elist, n_edges, &s_cursor, round);
-        __syncthreads();
-        PHASE_MARK(1 + round);
-    }
-
-    // ---- flatten: every pixel points straight at its level root ----------------------------
-    // (the pixels of one run share their node: only the run's first pixel walks)
-    uint32_t rootmask = 0;
-    uint32_t rk[TILE_PPT];          // slot of the level root of each of the lane's pixels
-    {
-        uint32_t r_run = NONE;
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            rk[k] = NONE;
-            if (lev[k] == WALL) continue;
-            const uint32_t p = p0 + k, l = lev[k];
-            if (k > 0 && lev[k > 0 ? k - 1 : 0] == l) { s_par[LX(p)] = (l << 16) | r_run; rk[k] = r_run; continue; }
-            uint32_t w = LD_WG(&s_par[LX(p)]);
-            if (w != NONE && (w >> 16) == l) {
-                uint32_t r = w & 0xFFFFu;
-                for (;;) {
-                    const uint32_t w2 = LD_WG(&s_par[LX(r)]);
-                    if (w2 == NONE || (w2 >> 16) != l) break;
-                    r = w2 & 0xFFFFu;
-                }
-                s_par[LX(p)] = (l << 16) | r;
-                r_run = r;
-            } else {
-                rootmask |= 1u << k;
-                r_run = p;
-            }
-            rk[k] = r_run;
-        }
-    }
-    __syncthreads();
-    // level roots: make the parent word point at the parent node's level root
-    {
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            if (!((rootmask >> k) & 1)) continue;
-            if (!(k > 0 && ((rootmask >> (k > 0 ? k - 1 : 0)) & 1) && lev[k > 0 ? k - 1 : 0] == lev[k]))
-                atomicOr(&s_present[(lev[k] >> 5) & 7u], 1u << (lev[k] & 31u));
-            const uint32_t p = p0 + k;
-            const uint32_t w = s_par[LX(p)];
-            if (w == NONE) continue;
-            uint32_t       q = w & 0xFFFFu;
-            const uint32_t wq = LD_WG(&s_par[LX(q)]);
-            if (wq != NONE && (wq >> 16) == (w >> 16)) q = wq & 0xFFFFu;
-            s_par[LX(p)] = (w & 0xFFFF0000u) | q;
-        }
-    }
-    PHASE_MARK(3);
-
-    // ---- the flood's start pixel: pixel 0, else pixel 1, else pixel w (read the
-    // levels now: s_lev is about to be reused for node ids) -----------------------------------------
-    if (tid == 0) {
-        if (s_walls) atomicAdd(&b.ctr[pi].n_walls, s_walls);
-        uint32_t sr = NONE;
-        if (tl == 0) {
-            int sp = -1;
-            if (s_lev[LX(0)] != WALL) sp = 0;
-            else if (pd.w > 1 && s_lev[LX(1)] != WALL) sp = 1;
-            else if (pd.h > 1 && s_lev[LX(TILE_WS)] != WALL) sp = TILE_WS;
-            if (sp >= 0) {
-                const uint32_t l = s_lev[LX(sp)], w = s_par[LX(sp)];
-                sr = (w != NONE && (w >> 16) == l) ? (w & 0xFFFFu) : (uint32_t)sp;
-            }
-        }
-        s_start = sr;
-    }
-    // ---- dense ids for ALL level roots of the tile, in pixel order ---------------------------------
-    uint32_t total_all;
-    const uint32_t aid0 = block_excl_scan(__popc(rootmask), s_wsum, &total_all);
-    {
-        uint32_t id = aid0;
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k)
-            if ((rootmask >> k) & 1) s_nid[OWN(k)] = (uint16_t)id++;
-    }
-    __syncthreads();
-    PHASE_MARK(4);
-
-    NodeRec *const nrec = b.na.rec + pd.node_base;
-    uint32_t total = 0;     // nodes exported by this tile
-    // The exported nodes of a tile are consecutive records of the plane, handed out with one atomic per tile (the ids depend on
-    // the order in which tiles finish; nothing downstream does -- results are ordered by key).  A plane that runs out of records
-    // flags it and exports nothing from this tile: the host grows the share and repeats the batch.
-    auto take_records = [&](uint32_t n) {
-        uint32_t at = atomicAdd(&b.ctr[pi].n_nodes, n);
-        if (at + n > pd.node_cap) { atomicOr(&b.ctr[pi].overflow, 8u); at = NONE; }
-        s_nbase = at;
-    };
-    auto put_record = [&](uint32_t id, uint32_t par, uint32_t cnt, uint32_t nod_flags, uint32_t key_lvl, uint32_t x0, uint32_t y0,
-                          uint32_t x1, uint32_t y1) {
-        uint4 *dst = reinterpret_cast<uint4 *>(nrec + id);
-        dst[0] = make_uint4(par, cnt, nod_flags, key_lvl);
-        dst[1] = make_uint4(x0, y0, x1, y1);
-        b.na.aux[pd.node_base + id] = 0;           // dependency counter of k_resolve / k_reduce
-    };
-
-    if (total_all <= (uint32_t)FOLD_CAP) {
-        // ---- fold path.  Statistics of every node of the tile live in LDS:
-        //   s_w0[a]  = pixels (CNT_BITS bits) | nodes (CNT_BITS bits) | open (bit 31)
-        //   s_row[a] = set of tile rows, s_col[a] = set of tile columns the component touches.
-        // "open" = the component reaches a pixel that has a neighbour in another tile, so seam
-        // merging may still change it.  Everything else ("closed") is final inside this tile: a
-        // closed node adds its totals to its parent here in LDS and is exported only if the
-        // reference would keep it (area > MIN_AREA); the thousands of small speckle nodes never
-        // reach global memory, yet they are counted (ER::area includes the node count).
-        // The three arrays are packed for the tile's own node count n (not FOLD_CAP): what is left
-        // of s_work behind them holds the export list further down.
-        const uint32_t      n_even = (total_all + 1u) & ~1u;
-        uint32_t           *s_w0 = s_work;                                   // [n_even]
-        rowmask_t          *s_row = reinterpret_cast<rowmask_t *>(s_work + n_even);                  // [n_even]
-        unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * n_even); // [n_even]
-        uint32_t           *s_exp = s_work + NODE_WORDS * n_even;            // [NODE_WORDS * (FOLD_CAP - n_even)]
-        for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
-        __syncthreads();
-        {
-            // the lane's pixels form runs with a common node: one set of atomics per run.  The run
-            // that holds the node's level root also carries the node itself (+1 in bits 12..), a run
-            // with a pixel on a seam carries the open bit (OR-ed separately: an add could carry).
-            uint32_t cur = NONE, cnt = 0, open = 0;
-            unsigned long long col = 0;
-            const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
-#pragma unroll
-            for (int k = 0; k <= TILE_PPT; ++k) {
-                uint32_t id = NONE;
-                if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL)
-                    id = (k > 0 && lev[k > 0 ? k - 1 : 0] == lev[k < TILE_PPT ? k : 0]) ? cur : (uint32_t)s_nid[LX(rk[k < TILE_PPT ? k : 0])];
-                if (id != cur) {
-                    if (cur != NONE) {
-                        atomicAdd(&s_w0[cur], cnt);
-                        atomicOr(&s_row[cur], (rowmask_t)1 << ly);
-                        atomicOr(&s_col[cur], col);
-                        if (open) atomicOr(&s_w0[cur], 0x80000000u);
-                    }
-                    cur = id; cnt = 0; col = 0; open = 0;
-                }
-                if (id != NONE) {
-                    const int xx = lx + k;
-                    cnt += 1u + (((rootmask >> k) & 1u) << CNT_BITS);
-                    col |= 1ull << xx;
-                    open |= (uint32_t)(top || bot || (xx == 0 && tx > 0) || (xx == TILE_W - 1 && tx + 1 < pd.tiles_x));
-                }
-            }
-        }
-        __syncthreads();
-        PHASE_MARK(5);
-        // bottom-up over the levels present in the tile: children are at lower levels than parents
-        // (only the levels that occur: one barrier per level)
-        for (int wd = 0; wd < 8; ++wd) {
-          uint32_t pm = s_present[wd];
-          while (pm) {
-            const uint32_t t = (uint32_t)wd * 32u + (uint32_t)__ffs((int)pm) - 1u;
-            pm &= pm - 1u;
-            uint32_t id = aid0;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
-                const uint32_t a = id++;
-                if (lev[k] != t) continue;
-                const uint32_t w = s_par[OWN(k)];
-                if (w == NONE) continue;
-                const uint32_t pa = s_nid[LX(w & 0xFFFFu)];
-                const uint32_t v = s_w0[a];
-                if (v >> 31) atomicOr(&s_w0[pa], 0x80000000u);
-                else {
-                    atomicAdd(&s_w0[pa], v & ((1u << (2 * CNT_BITS)) - 1u));
-                    atomicOr(&s_row[pa], s_row[a]);
-                    atomicOr(&s_col[pa], s_col[a]);
-                }
-            }
-            __syncthreads();
-          }
-        }
-        PHASE_MARK(7);
-        // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
-        // node of the flood's start pixel
-        uint32_t expmask = 0, openmask = 0;
-        {
-            uint32_t id = aid0;
-            const uint32_t sroot = s_start;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
-                const uint32_t v = s_w0[id++];
-                const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
-                const bool     open = (v >> 31) != 0;
-                if (open) openmask |= 1u << k;
-                if (open || (int64_t)area > (int64_t)prm.min_area || s_par[OWN(k)] == NONE || p0 + k == sroot) expmask |= 1u << k;
-            }
-        }
-        const uint32_t eid0 = block_excl_scan(__popc(expmask), s_wsum, &total);
-        if (tid == 0) take_records(total);
-        // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
-        // One exported node: everything it needs is in LDS except its own level and whether it is open.
-        auto export_node = [&](uint32_t nbase, uint32_t p, uint32_t a, uint32_t l, bool open) {
-            uint32_t q = s_par[LX(p)], ql = 0;
-            if (q != NONE) { ql = (q >> 16) & 0xFFu; q &= 0xFFFFu; }
-            while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
-                const uint32_t w2 = s_par[LX(q)];
-                if (w2 == NONE) q = NONE;
-                else { ql = (w2 >> 16) & 0xFFu; q = w2 & 0xFFFFu; }
-            }
-            const uint32_t v = s_w0[a];
-            const unsigned long long cm = s_col[a];
-            const rowmask_t          rm = s_row[a];
-            const uint32_t px = SLOT_PIXEL(p);
-            put_record(nbase + s_nid[LX(p)], (q == NONE) ? NONE : PAR_MAKE(ql, nbase + s_nid[LX(q)]), v & CNT_MASK,
-                       ((v >> CNT_BITS) & CNT_MASK) | (open ? 0u : NODE_CLOSED),
-                       (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u)) | (l << 24),
-                       ox + __ffsll((long long)cm) - 1, oy + row_lo(rm), ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
-        };
-        // The exported nodes are listed behind the statistics (slot | a << SLOT_BITS | level << (SLOT_BITS + A_BITS))
-        // and written out one per lane; a tile too full for the list writes them from the owners.
-        const bool listed = (uint32_t)NODE_WORDS * n_even + total <= (uint32_t)NODE_WORDS * (uint32_t)FOLD_CAP;
-        {
-            uint32_t id = eid0, aid = aid0;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
-                const uint32_t a = aid++;
-                if ((expmask >> k) & 1) {
-                    if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (lev[k] << (SLOT_BITS + A_BITS));
-                    s_nid[OWN(k)] = (uint16_t)id++;
-                } else {
-                    s_nid[OWN(k)] = (uint16_t)0xFFFFu;
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t nbase = s_nbase;
-        if (nbase == NONE) {
-            // no records: nothing leaves this tile
-        } else if (listed) {
-            for (uint32_t e = tid; e < total; e += TILE_THREADS) {
-                const uint32_t w = s_exp[e];
-                export_node(nbase, w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu,
-                            (s_w0[(w >> SLOT_BITS) & ((1u << A_BITS) - 1u)] >> 31) != 0);
-            }
-        } else {
-            uint32_t aid = aid0;
-#pragma unroll 1
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
-                const uint32_t a = aid++;
-                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev[k], (openmask >> k) & 1);
-            }
-        }
-    } else {
-        // ---- dense tile (more than FOLD_CAP nodes): export every node with its own statistics,
-        // STAT_CHUNK nodes per pass; the global passes do all the accumulation.
-        total = total_all;
-        if (tid == 0) take_records(total);
-        uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
-        rowmask_t           *s_row = reinterpret_cast<rowmask_t *>(s_work + STAT_CHUNK);          // [STAT_CHUNK]
-        unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * STAT_CHUNK); // [STAT_CHUNK]
-        for (uint32_t c0 = 0; c0 < total; c0 += STAT_CHUNK) {
-            for (int i = tid; i < NODE_WORDS * STAT_CHUNK; i += TILE_THREADS) s_work[i] = 0;
-            __syncthreads();
-            {   // the lane's pixels form runs with a common root: one set of atomics per run
-                uint32_t cur = NONE, cnt = 0;
-                unsigned long long col = 0;
-#pragma unroll
-                for (int k = 0; k <= TILE_PPT; ++k) {
-                    uint32_t id = NONE;
-                    if (k < TILE_PPT && lev[k < TILE_PPT ? k : 0] != WALL) {
-                        id = (uint32_t)s_nid[LX(rk[k < TILE_PPT ? k : 0])] - c0;
-                        if (id >= (uint32_t)STAT_CHUNK) id = NONE;
-                    }
-                    if (id != cur) {
-                        if (cur != NONE) {
-                            atomicAdd(&s_cnt[cur], cnt);
-                            atomicOr(&s_row[cur], (rowmask_t)1 << ly);
-                            atomicOr(&s_col[cur], col);
-                        }
-                        cur = id; cnt = 0; col = 0;
-                    }
-                    if (id != NONE) { ++cnt; col |= 1ull << (lx + k); }
-                }
-            }
-            __syncthreads();
-            const uint32_t nbase = s_nbase;
-#pragma unroll 1
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1) || nbase == NONE) continue;
-                const uint32_t p = p0 + k;
-                const uint32_t li = (uint32_t)s_nid[LX(p)] - c0;
-                if (li >= (uint32_t)STAT_CHUNK) continue;
-                const uint32_t w = s_par[LX(p)];
-                const unsigned long long cm = s_col[li];
-                const rowmask_t          rm = s_row[li];
-                put_record(nbase + s_nid[LX(p)], (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, nbase + s_nid[LX(w & 0xFFFFu)]), s_cnt[li], 1u,
-                           (uint32_t)(gy * pd.w + gx + k) | (lev[k] << 24), ox + __ffsll((long long)cm) - 1, oy + row_lo(rm),
-                           ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    const uint32_t nbase = s_nbase;
-    if (tid == 0) {
-        b.tile_nbase[blockIdx.x] = nbase;
-        if (tl == 0) b.ctr[pi].start_node = (s_start == NONE || nbase == NONE) ? NONE : nbase + s_nid[LX(s_start)];
-    }
-    PHASE_MARK(13);
-
-    // ---- node of every tile-border pixel, for the seam pass: its index inside this tile's records (16 bits; the seam
-    // kernel adds tile_nbase) ---------------------------------------------------------------
-    // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
-    // of w entries (pixel row j*TH-1, then j*TH); then for every vertical boundary i two
-    // columns of h entries (pixel column i*TW-1, then i*TW).  Each lane writes its own pixels.
-    {
-        uint16_t *seam = b.seam + pd.seam_base;
-        const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
-        const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            const int  xx = lx + k;
-            const bool lef = xx == 0 && tx > 0, rig = xx == TILE_W - 1 && tx + 1 < pd.tiles_x;
-            if (!(top || bot || lef || rig)) continue;
-            if (gx + k >= pd.w || gy >= pd.h) continue;
-            uint16_t id = 0xFFFFu;
-            if (lev[k] != WALL && nbase != NONE) id = s_nid[LX(rk[k])];
-            if (top) seam[((size_t)(ty - 1) * 2 + 1) * pd.w + gx + k] = id;
-            if (bot) seam[((size_t)ty * 2) * pd.w + gx + k] = id;
-            if (lef) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = id;
-            if (rig) seam[voff + ((size_t)tx * 2) * pd.h + gy] = id;
-        }
-    }
-    PHASE_MARK(6);
-
-}
-
-
 // ------------------------------------------------------------------------------------
-// k_tile_tree2: the same tree, built from PIECES.  A piece is a maximal run of equal-level pixels inside a lane's 8 pixels; its
-// first pixel is its head.  A lane knows its pieces as two bit sets (walls, run starts); everything after the load phase works on
-// pieces instead of pixels: the edges that need a connect follow from the bit sets of the lane and of the lane below, and the phases
-// after the connects (flatten, statistics) run over a compacted list of all pieces of the tile -- on text-like frames a lane holds
-// 1.8 pieces on average but the fullest lane of a wave 4.4, so "every lane walks its own 8 pixels" leaves most lanes idle.
+// k_tile_tree: the component tree of one 64x32 tile, built from PIECES.  A piece is a maximal run of equal-level pixels inside a
+// lane's 8 pixels; its first pixel is its head.  A lane knows its pieces as two bit sets (walls, run starts); everything after the load
+// phase works on pieces instead of pixels: the edges that need a connect follow from the bit sets of the lane and of the lane below, and
+// the phases after the connects (flatten, statistics) loop over the lane's pieces -- on text-like frames a lane holds 1.8 pieces on
+// average and the fullest lane of a wave 4.4, where a loop over the lane's 8 pixels always costs 8 rounds.
+// The kernel is bound by instruction issue (vector AND scalar: every divergent branch is scalar bookkeeping), not by HBM (1 byte per
+// pixel) nor by LDS bandwidth: what made it faster in round 2 was fewer instructions per wave, 4435 -> 3270 (vector 2105 -> 1749, scalar
+// 1960 -> 1213, LDS 370 -> 308), for 3.73 -> 3.03 ms per 32 text frames.
+// (Measured and not adopted: one compacted list of all pieces of the tile, processed by all lanes evenly -- fewer instructions, but the
+// two extra barriers and the dependent LDS reads of the list cost what they save.)
 // ------------------------------------------------------------------------------------
 #define LEVK(k) ((((k) < 4 ? lev_lo : lev_hi) >> (8 * ((k) & 3))) & 0xFFu)
 template <int FOLD_CAP>
-__global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)) void k_tile_tree2(BatchDev b, DetectParams prm)
+__global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)) void k_tile_tree(BatchDev b, DetectParams prm)
 {
     constexpr int WORK_WORDS = NODE_WORDS * FOLD_CAP;
     constexpr int STAT_CHUNK = FOLD_CAP < 512 ? FOLD_CAP : 512;   // dense tiles: nodes whose statistics are accumulated per pass
     static_assert(WORK_WORDS * 4 >= 2 * TILE_PX + 2 * TILE_THREADS, "the 16-bit edge list of a round (one entry per pixel at most) and the lane masks must fit s_work");
     __shared__ uint32_t s_par[TILE_SLOTS];
-    __shared__ __attribute__((aligned(8))) uint32_t s_work[WORK_WORDS];    // edge worklist + lane masks, later the piece list and the per-node statistics
+    __shared__ __attribute__((aligned(8))) uint32_t s_work[WORK_WORDS];    // edge worklist + lane masks, later the per-node statistics
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_walls, s_start, s_cursor, s_nbase;
+    __shared__ uint32_t s_walls, s_start, s_nbase;
     __shared__ uint32_t s_present[8];        // which levels have a node in this tile
 
     const int       tid = threadIdx.x;
@@ -1231,54 +647,18 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             emask &= emask - 1u;
             s_elist[off++] = (uint16_t)(p0 + k);       // the other end follows from the round: left neighbour / pixel below
         }
-#ifdef STR_ER_STATIC
         __syncthreads();
-        tile_connect_list(s_par, s_lev, s_elist, n_edges, round);
-#else
-        if (tid == 0) s_cursor = 0;
-        __syncthreads();
-        tile_connect_all(s_par, s_lev, s_elist, n_edges, &s_cursor, round);
-#endif
+        tile_connect_all(s_par, s_lev, s_elist, n_edges, round);
         __syncthreads();
         PHASE_MARK(1 + round);
     }
 
-    // ---- the pieces of the tile, as a list at the top end of s_work: slot of the head | (length - 1) << 12 -----------
+    // ---- flatten + level roots, one pass over the lane's pieces.  The head of a piece that is not a level root is pointed straight at
+    // its level root (the other pixels of a piece point at the head or, where a find halved a path, at some pixel further up in the same
+    // node); the parent word of a level root is made to point at the parent node's level root.  No barrier in between: a walk follows
+    // same-level words and stops at a word of another level, and neither kind of rewrite changes the level in a word.
     const uint32_t headm = (startm | (~wallm & 1u)) & 0xFFu;      // (a lane's first pixel heads a piece also when it continues a run)
     const uint32_t stopm = headm | wallm | 0x100u;
-    uint32_t       n_pieces;
-    const uint32_t poff = block_excl_scan(__popc(headm), s_wsum, &n_pieces);
-    uint16_t *const s_pl = reinterpret_cast<uint16_t *>(s_work) + (2 * WORK_WORDS - n_pieces);
-    {
-        uint32_t m = headm, i = poff;
-        while (m) {
-            const int k = __ffs((int)m) - 1;
-            m &= m - 1u;
-            const uint32_t len = (uint32_t)__ffs((int)(stopm >> (k + 1)));      // distance to the next head, wall or the lane's end
-            s_pl[i++] = (uint16_t)((p0 + k) | ((len - 1u) << 12));
-        }
-    }
-    __syncthreads();
-    // ---- flatten: the head of every piece points straight at its level root (the other pixels of a piece point at the head, or,
-    // where a find halved a path, at some pixel further up in the same node).  A head that IS a level root is flagged in the list.
-    for (uint32_t i = tid; i < n_pieces; i += TILE_THREADS) {
-        const uint32_t e = s_pl[i], p = e & 0xFFFu;
-        const uint32_t l = s_lev[LX(p)];
-        const uint32_t w = LD_WG(&s_par[LX(p)]);
-        if (w != NONE && (w >> 16) == l) {
-            uint32_t r = w & 0xFFFFu;
-            for (;;) {
-                const uint32_t w2 = LD_WG(&s_par[LX(r)]);
-                if (w2 == NONE || (w2 >> 16) != l) break;
-                r = w2 & 0xFFFFu;
-            }
-            s_par[LX(p)] = (l << 16) | r;
-        } else {
-            s_pl[i] = (uint16_t)(e | 0x8000u);
-        }
-    }
-    __syncthreads();
-    // ---- the lane's level roots; their parent words are made to point at the parent node's level root
     uint32_t rootmask = 0;
     {
         uint32_t m = headm;
@@ -1287,18 +667,27 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             m &= m - 1u;
             const uint32_t p = p0 + k;
             const uint32_t l = s_lev[LX(p)];
-            const uint32_t w = s_par[LX(p)];
-            if (w != NONE && (w >> 16) == l) continue;
-            rootmask |= 1u << k;
-            atomicOr(&s_present[(l >> 5) & 7u], 1u << (l & 31u));
-            if (w == NONE) continue;
-            uint32_t q = w & 0xFFFFu;
-            for (;;) {     // (roots that are rewritten meanwhile keep their level: the test reads the same either way)
-                const uint32_t wq = LD_WG(&s_par[LX(q)]);
-                if (wq == NONE || (wq >> 16) != (w >> 16)) break;
-                q = wq & 0xFFFFu;
+            const uint32_t w = LD_WG(&s_par[LX(p)]);
+            if ((w >> 16) == l) {           // (NONE reads as level 0xFFFF: never a pixel's level)
+                uint32_t r = w & 0xFFFFu;
+                for (;;) {
+                    const uint32_t w2 = LD_WG(&s_par[LX(r)]);
+                    if ((w2 >> 16) != l) break;
+                    r = w2 & 0xFFFFu;
+                }
+                s_par[LX(p)] = (l << 16) | r;
+            } else {
+                rootmask |= 1u << k;
+                atomicOr(&s_present[(l >> 5) & 7u], 1u << (l & 31u));
+                if (w == NONE) continue;
+                uint32_t q = w & 0xFFFFu;
+                for (;;) {
+                    const uint32_t wq = LD_WG(&s_par[LX(q)]);
+                    if ((wq >> 16) != (w >> 16)) break;
+                    q = wq & 0xFFFFu;
+                }
+                s_par[LX(p)] = (w & 0xFFFF0000u) | q;
             }
-            s_par[LX(p)] = (w & 0xFFFF0000u) | q;
         }
     }
     PHASE_MARK(3);
@@ -1328,11 +717,15 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     // ---- dense ids for ALL level roots of the tile, in pixel order ---------------------------------
     uint32_t total_all;
     const uint32_t aid0 = block_excl_scan(__popc(rootmask), s_wsum, &total_all);
+    // (a lane holds half a level root on average on text-like frames: the loops over "the lane's roots" below run over the set bits)
+    auto lev_of = [&](int k) -> uint32_t { return ((k < 4 ? lev_lo : lev_hi) >> (8 * (k & 3))) & 0xFFu; };
     {
-        uint32_t id = aid0;
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k)
-            if ((rootmask >> k) & 1) s_nid[OWN(k)] = (uint16_t)id++;
+        uint32_t m = rootmask, id = aid0;
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1u;
+            s_nid[OWN(k)] = (uint16_t)id++;
+        }
     }
     __syncthreads();
     PHASE_MARK(4);
@@ -1367,42 +760,38 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // reference would keep it (area > MIN_AREA); the thousands of small speckle nodes never
         // reach global memory, yet they are counted (ER::area includes the node count).
         // The three arrays are packed for the tile's own node count n (not FOLD_CAP): what is left
-        // of s_work behind them holds the piece list (at the top end) and later the export list.
+        // of s_work behind them holds the export list further down.
         const uint32_t      n_even = (total_all + 1u) & ~1u;
         uint32_t           *s_w0 = s_work;                                   // [n_even]
         rowmask_t          *s_row = reinterpret_cast<rowmask_t *>(s_work + n_even);                  // [n_even]
         unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * n_even); // [n_even]
         uint32_t           *s_exp = s_work + NODE_WORDS * n_even;            // [NODE_WORDS * (FOLD_CAP - n_even)]
-        const bool          list_ok = 2u * NODE_WORDS * n_even + n_pieces <= 2u * (uint32_t)WORK_WORDS;     // the arrays leave the piece list alone
         for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
         __syncthreads();
         // one set of atomics per piece.  The piece headed by the node's level root also carries the node itself (+1 in the
         // node field), a piece with a pixel on a seam carries the open bit (OR-ed separately: an add could carry).
-        auto piece_stats = [&](uint32_t p, uint32_t len, bool isroot) {
-            const uint32_t id = piece_node(p, isroot);
-            const uint32_t px = SLOT_PIXEL(p), x = px & 63u, y = px >> 6;
-            const bool     open = (y == 0 && ty > 0) || (y == TILE_H - 1 && ty + 1 < pd.tiles_y) || (x == 0 && tx > 0) ||
-                                  (x + len == TILE_W && tx + 1 < pd.tiles_x);
-            atomicAdd(&s_w0[id], len + (isroot ? 1u << CNT_BITS : 0u));
-            atomicOr(&s_row[id], (rowmask_t)1 << y);
-            atomicOr(&s_col[id], ((1ull << len) - 1ull) << x);
-            if (open) atomicOr(&s_w0[id], 0x80000000u);
-        };
-        if (list_ok) {
-            for (uint32_t i = tid; i < n_pieces; i += TILE_THREADS) {
-                const uint32_t e = s_pl[i];
-                piece_stats(e & 0xFFFu, ((e >> 12) & 7u) + 1u, (e >> 15) != 0);
-            }
-        } else {     // (a tile with so many nodes has about as many pieces as pixels: every lane is busy with its own)
+        {
+            const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
+            const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
             uint32_t m = headm;
             while (m) {
                 const int k = __ffs((int)m) - 1;
                 m &= m - 1u;
-                piece_stats(p0 + k, (uint32_t)__ffs((int)(stopm >> (k + 1))), ((rootmask >> k) & 1u) != 0);
+                const uint32_t len = (uint32_t)__ffs((int)(stopm >> (k + 1)));      // distance to the next head, wall or the lane's end
+                const bool     isroot = ((rootmask >> k) & 1u) != 0;
+                const uint32_t id = piece_node(p0 + k, isroot);
+                atomicAdd(&s_w0[id], len + (isroot ? 1u << CNT_BITS : 0u));
+                atomicOr(&s_row[id], (rowmask_t)1 << ly);
+                // (the lane's 8 columns lie in one half of the 64-bit column set)
+                atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + (lx >> 5), ((1u << len) - 1u) << ((lx & 31) + k));
+                if (top || bot || (lef && k == 0) || (rig && k + (int)len == TILE_PPT)) atomicOr(&s_w0[id], 0x80000000u);
             }
         }
         __syncthreads();
         PHASE_MARK(5);
+        uint32_t rootspread = 0;        // rootmask with pixel k at bit 8 (k & 3) + 4 (k >> 2)
+#pragma unroll
+        for (int k = 0; k < TILE_PPT; ++k) rootspread |= ((rootmask >> k) & 1u) << (8 * (k & 3) + 4 * (k >> 2));
         // bottom-up over the levels present in the tile: children are at lower levels than parents
         // (only the levels that occur: one barrier per level)
         for (int wd = 0; wd < 8; ++wd) {
@@ -1410,12 +799,17 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
           while (pm) {
             const uint32_t t = (uint32_t)wd * 32u + (uint32_t)__ffs((int)pm) - 1u;
             pm &= pm - 1u;
-            uint32_t id = aid0;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
-                const uint32_t a = id++;
-                if (LEVK(k) != t) continue;
+            // the lane's roots at level t: compare all 8 level bytes at once (0x80 in every byte of x that is zero), then keep the roots --
+            // a tile has a few hundred nodes on six levels, so most lanes have nothing to do at a given level
+            const uint32_t tt = t * 0x01010101u;
+            const uint32_t x0 = lev_lo ^ tt, x1 = lev_hi ^ tt;
+            const uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0 | 0x7F7F7F7Fu), z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1 | 0x7F7F7F7Fu);
+            uint32_t       hit = ((z0 >> 7) | (z1 >> 3)) & rootspread;       // bit 8 j (pixel j < 4), bit 8 j + 4 (pixel 4 + j)
+            while (hit) {
+                const int pos = __ffs((int)hit) - 1;
+                hit &= hit - 1u;
+                const int k = (pos >> 3) | (pos & 4);
+                const uint32_t a = aid0 + (uint32_t)__popc(rootmask & ((1u << k) - 1u));
                 const uint32_t w = s_par[OWN(k)];
                 if (w == NONE) continue;
                 const uint32_t pa = s_nid[LX(w & 0xFFFFu)];
@@ -1435,11 +829,11 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // node of the flood's start pixel
         uint32_t expmask = 0, openmask = 0;
         {
-            uint32_t id = aid0;
+            uint32_t m = rootmask, id = aid0;
             const uint32_t sroot = s_start;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
+            while (m) {
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1u;
                 const uint32_t v = s_w0[id++];
                 const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
                 const bool     open = (v >> 31) != 0;
@@ -1472,13 +866,13 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // and written out one per lane; a tile too full for the list writes them from the owners.
         const bool listed = (uint32_t)NODE_WORDS * n_even + total <= (uint32_t)NODE_WORDS * (uint32_t)FOLD_CAP;
         {
-            uint32_t id = eid0, aid = aid0;
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
+            uint32_t m = rootmask, id = eid0, aid = aid0;
+            while (m) {
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1u;
                 const uint32_t a = aid++;
                 if ((expmask >> k) & 1) {
-                    if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (LEVK(k) << (SLOT_BITS + A_BITS));
+                    if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (lev_of(k) << (SLOT_BITS + A_BITS));
                     s_nid[OWN(k)] = (uint16_t)id++;
                 } else {
                     s_nid[OWN(k)] = (uint16_t)0xFFFFu;
@@ -1501,7 +895,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (!((rootmask >> k) & 1)) continue;
                 const uint32_t a = aid++;
-                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, (k < 4 ? lev_lo : lev_hi) >> (8 * (k & 3)) & 0xFFu, (openmask >> k) & 1);
+                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev_of(k), (openmask >> k) & 1);
             }
         }
     } else {
@@ -1525,7 +919,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                     const uint32_t len = (uint32_t)__ffs((int)(stopm >> (k + 1)));
                     atomicAdd(&s_cnt[id], len);
                     atomicOr(&s_row[id], (rowmask_t)1 << ly);
-                    atomicOr(&s_col[id], ((1ull << len) - 1ull) << (lx + k));
+                    atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + (lx >> 5), ((1u << len) - 1u) << ((lx & 31) + k));
                 }
             }
             __syncthreads();
@@ -1540,7 +934,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 const unsigned long long cm = s_col[li];
                 const rowmask_t          rm = s_row[li];
                 put_record(nbase + s_nid[LX(p)], (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, nbase + s_nid[LX(w & 0xFFFFu)]), s_cnt[li], 1u,
-                           (uint32_t)(gy * pd.w + gx + k) | (((k < 4 ? lev_lo : lev_hi) >> (8 * (k & 3)) & 0xFFu) << 24),
+                           (uint32_t)(gy * pd.w + gx + k) | (lev_of(k) << 24),
                            ox + __ffsll((long long)cm) - 1, oy + row_lo(rm), ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
             }
             __syncthreads();
@@ -1564,29 +958,23 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
         const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
         const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
-        // record (inside the tile) of the node of the lane's pixel k
-        auto pixel_node = [&](int k, uint32_t l) -> uint16_t {
+        // record (inside the tile) of the node of the lane's pixel k: the level root of the piece it lies in
+        auto pixel_node = [&](int k) -> uint16_t {
             if (((wallm >> k) & 1u) || nbase == NONE) return (uint16_t)0xFFFFu;
-            uint32_t q = p0 + (uint32_t)k;
-            if (!((rootmask >> k) & 1u))
-                for (;;) {
-                    const uint32_t w = s_par[LX(q)];
-                    if (w == NONE || (w >> 16) != l) break;
-                    q = w & 0xFFFFu;
-                }
-            return s_nid[LX(q)];
+            const int hk = 31 - __clz((int)(headm & ((2u << k) - 1u)));       // head of the piece
+            return s_nid[LX(((rootmask >> hk) & 1u) ? p0 + (uint32_t)hk : (s_par[LX(p0 + (uint32_t)hk)] & 0xFFFFu))];
         };
         if ((top || bot) && gy < pd.h) {
 #pragma unroll
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (gx + k >= pd.w) continue;
-                const uint16_t id = pixel_node(k, LEVK(k));
+                const uint16_t id = pixel_node(k);
                 if (top) seam[((size_t)(ty - 1) * 2 + 1) * pd.w + gx + k] = id;
                 if (bot) seam[((size_t)ty * 2) * pd.w + gx + k] = id;
             }
         }
-        if (lef && gy < pd.h && gx < pd.w) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = pixel_node(0, LEVK(0));
-        if (rig && gy < pd.h && gx + TILE_PPT - 1 < pd.w) seam[voff + ((size_t)tx * 2) * pd.h + gy] = pixel_node(TILE_PPT - 1, LEVK(TILE_PPT - 1));
+        if (lef && gy < pd.h && gx < pd.w) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = pixel_node(0);
+        if (rig && gy < pd.h && gx + TILE_PPT - 1 < pd.w) seam[voff + ((size_t)tx * 2) * pd.h + gy] = pixel_node(TILE_PPT - 1);
     }
     PHASE_MARK(6);
 }
@@ -1605,13 +993,8 @@ extern "C" void str_er_debug_phase_cycles(unsigned long long *out16, int reset)
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse)
 {
     if (!b.n_tiles) return;
-#ifdef STR_ER_TILE_V2
-    if (sparse) hipLaunchKernelGGL(k_tile_tree2<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
-    else        hipLaunchKernelGGL(k_tile_tree2<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
-#else
     if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
     else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
-#endif
 }
 
 // ------------------------------------------------------------------------------------
