@@ -564,41 +564,45 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     uint16_t *const s_msk = reinterpret_cast<uint16_t *>(s_work) + TILE_PX;     // the lanes' bit sets, behind the edge list
     {
         uint32_t lev[TILE_PPT];
-        uint8_t  px[TILE_PPT];
         int      nvalid = 0;
+        // (written without branches per pixel: selects and bit operations only -- a branch costs scalar instructions whether or not a
+        // lane takes it, and this kernel is bound by instruction issue)
+        uint32_t vx = 0, vy = 0;            // the 8 pixels, bytes 0-3 and 4-7
         if (gy < pd.h && gx < pd.w) {
             const uint8_t *row = pd.pix + (size_t)gy * pd.stride + gx;
             nvalid = min(TILE_PPT, pd.w - gx);
             if (nvalid == TILE_PPT && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(row);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { px[k] = (v.x >> (8 * k)) & 255; px[4 + k] = (v.y >> (8 * k)) & 255; }
+                vx = v.x; vy = v.y;
             } else {
-                for (int k = 0; k < nvalid; ++k) px[k] = row[k];
+#pragma unroll 1
+                for (int k = 0; k < nvalid; ++k) {
+                    const uint32_t bv = row[k];
+                    if (k < 4) vx |= bv << (8 * k); else vy |= bv << (8 * (k - 4));
+                }
             }
         }
-#pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            uint32_t q = WALL;
-            if (k < nvalid) {
-                q = (uint32_t)__float2int_rn((float)(px[k] ^ pd.invert) * prm.qscale);
-                if (q >= (uint32_t)prm.hi) q = WALL;
-            }
-            lev[k] = q;
-            s_lev[OWN(k)] = (uint16_t)q;
-            if (q == WALL) wallm |= 1u << k;
-            else {
-                if (k > 0 && lev[k > 0 ? k - 1 : 0] != q) startm |= 1u << k;
-                if (k < 4) lev_lo |= q << (8 * (k & 3)); else lev_hi |= q << (8 * (k & 3));
-            }
-        }
-        // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; point every
-        // pixel of a run at the run's first pixel
+        const uint32_t inv = (uint32_t)pd.invert * 0x01010101u;
+        vx ^= inv; vy ^= inv;
+        const uint32_t invalidm = ~((1u << nvalid) - 1u);
         uint32_t head = p0;
 #pragma unroll
-        for (int k = 1; k < TILE_PPT; ++k) {
-            if (lev[k] != WALL && lev[k] == lev[k - 1]) s_par[OWN(k)] = (lev[k] << 16) | head;
-            else { head = p0 + k; s_par[OWN(k)] = NONE; }
+        for (int k = 0; k < TILE_PPT; ++k) {
+            const uint32_t q0 = (uint32_t)__float2int_rn((float)(((k < 4 ? vx : vy) >> (8 * (k & 3))) & 0xFFu) * prm.qscale);
+            const bool     wall = q0 >= (uint32_t)prm.hi || ((invalidm >> k) & 1u);
+            const uint32_t q = wall ? WALL : q0;
+            lev[k] = q;
+            s_lev[OWN(k)] = (uint16_t)q;
+            wallm |= (wall ? 1u : 0u) << k;
+            if (k < 4) lev_lo |= (wall ? 0u : q0) << (8 * (k & 3)); else lev_hi |= (wall ? 0u : q0) << (8 * (k & 3));
+            if (k > 0) {
+                // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; every pixel of a run points at the
+                // run's first pixel
+                const bool same = !wall && q == lev[k > 0 ? k - 1 : 0];
+                startm |= ((wall || same) ? 0u : 1u) << k;
+                s_par[OWN(k)] = same ? ((q << 16) | head) : NONE;
+                head = same ? head : p0 + k;
+            }
         }
         // ... and across the lane boundary: if the lane's first pixel continues the run of the pixel to
         // its left, it points at the head of that run.  The 8 lanes of a tile row are neighbours in the

@@ -1578,8 +1578,7 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
     if (rows > 0) {
         // A strip is laid out as a plane with a PHANTOM tile row above and / or below wherever the plane goes on: the strip's first /
         // last row is then an ordinary tile seam -- its nodes stay open and their ids are in the seam map -- and the tile kernel needs to
-        // know nothing about strips (it is not touched: with ~100 spilled SGPRs it sits on a code-generation cliff -- one more compare in
-        // its load phase made this toolchain emit a kernel that loses seam entries on ordinary planes).  Below, the phantom row is simply
+        // know nothing about strips (no strip flags, no second code path in the kernel that is 58 % of the step).  Below, the phantom row is simply
         // past the image (one tile row more than the height needs).  Above, the strip is copied behind TILE_H rows of pixels at the
         // sentinel level, which the flood never enters -- hence the restriction to thresh_steps that have such a level.
         const bool ptop = r0 > 0, pbot = r1 < h;

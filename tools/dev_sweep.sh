@@ -1,5 +1,4 @@
-export GPU_MAX_HW_QUEUES=16
-for so in 2 0; do
-echo -n "noise native6 sibling $so: "; STR_ER_DEBUG_STATS=0 python bench.py --kind noise --workload native6 --no-cpu-baseline --no-latency --no-host-frames --sibling-order $so --steps 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['gpu_ms_per_step_by_kernel_group_serial'])"
-done
-STR_ER_DEBUG_STATS=1 python bench.py --kind noise --workload native6 --no-cpu-baseline --no-latency --no-host-frames --steps 2 --warmup 1 --pipelines 1 2>&1 | grep "str_er\]" | grep -v "tie plane" | tail -12
+# Developer aid (GPU box): S-noise native6 over pipelines x batch size
+for f in 16 48; do for p in 1 2 3 6; do
+echo -n "noise native6 frames $f pipelines $p: "; python bench.py --kind noise --workload native6 --no-cpu-baseline --no-latency --no-host-frames --frames-per-gpu $f --pipelines $p --steps 12 --warmup 2 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done; done
