@@ -433,7 +433,8 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 }
 
 // All edges of a worklist.  A connect takes anything from one to a dozen passes, so a lane moves on to its next edge as soon as it is
-// done with one; a wave leaves when its lanes have nothing left.  Every lane walks its own contiguous part of the list: at any moment
+// done with one; a wave leaves when its lanes have nothing left.  Every lane walks its own contiguous part of the list (lane i: entries
+// [i n / 256, (i + 1) n / 256), so that all lanes and all four waves get their share also when n is no multiple of 256): at any moment
 // the 256 lanes work in 256 different places of the tile (fewer lost CASes) and a lane's next edge touches the nodes it has just
 // compressed.
 // (Measured, 32 frames text / noise, and not adopted: a workgroup-wide cursor that hands the next entries to whichever lanes are idle
@@ -445,9 +446,9 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 __device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges, int round)
 {
     bool           active = false;
-    const uint32_t chunk = (n_edges + TILE_THREADS - 1) / TILE_THREADS;
-    uint32_t       next = threadIdx.x * chunk;
-    const uint32_t n_end = min(n_edges, next + chunk);
+    // lane i takes entries [i n / 256, (i + 1) n / 256): all lanes and all four waves get their share also when n is not a multiple of 256
+    uint32_t       next = (threadIdx.x * n_edges) / TILE_THREADS;
+    const uint32_t n_end = ((threadIdx.x + 1u) * n_edges) / TILE_THREADS;
     uint32_t       a = 0, b = 0, la = 0, lb = 0;
     for (;;) {
         if (!active && next < n_end) {

@@ -1,16 +1,17 @@
 #!/bin/bash
 # Run on a GPU box (via gpurun) from the repo root: bench lines + rocprofv3 summaries for profiles/.
-# Usage: tools/collect_profiles.sh r01
+# Usage: tools/collect_profiles.sh r02
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py > $OUT/bench_${TAG}_pyr3x8_text.json 2> $OUT/bench_err.log
 python $ROOT/bench.py --workload native6 > $OUT/bench_${TAG}_native6_text.json 2>> $OUT/bench_err.log
-python $ROOT/bench.py --workload native6 --kind noise --frames-per-gpu 16 --no-cpu-baseline > $OUT/bench_${TAG}_native6_noise.json 2>> $OUT/bench_err.log
-B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+python $ROOT/bench.py --workload native6 --kind noise --no-cpu-baseline > $OUT/bench_${TAG}_native6_noise.json 2>> $OUT/bench_err.log
+# (the profiled runs keep ONE batch in flight: a kernel's average duration is then its isolated launch duration, the quantity roofline.avg_launch_ms reports)
+B="python $ROOT/bench.py --steps 6 --warmup 2 --pipelines 1 --no-cpu-baseline --no-latency --no-host-frames"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $B > $OUT/pmc_write.log 2>&1
