@@ -93,9 +93,12 @@ typedef struct str_er_params {
     int32_t  max_frames;      /* capacity: frames per str_er_detect_bgr call; the
                                  per-plane entry points accept up to
                                  max_frames * popcount(channel_mask) * n_pyr_levels   */
-    int32_t  kept_cap;        /* per-plane capacity of the kept-node table,
-                                 0 = default max(4096, w*h/64)                        */
-    int32_t  pool_cap;        /* per-plane capacity of the NMS pool, 0 = kept_cap/4   */
+    int32_t  kept_cap;        /* per-plane capacity of the kept-node table.  0 (both
+                                 this and pool_cap) = by the plane's size: padded
+                                 pixels / 64 + 512, at most max(4096, w*h/64)         */
+    int32_t  pool_cap;        /* per-plane capacity of the NMS pool, 0 = kept_cap/4
+                                 (at least 256); a plane that needs more fails with
+                                 STR_ER_ECAPACITY, the message names the plane        */
     int32_t  sibling_order;   /* what decides NMS where two or more child chains
                                  compete for a parent:
                                  0 = the reference's own order -- the child whose

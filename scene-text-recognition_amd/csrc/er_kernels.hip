@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
             }
         }
         const uint32_t slot = atomicAdd(&c.n_kept, 1u);
-        if (slot < (uint32_t)prm.kept_cap) {
+        if (slot < pd.kept_cap) {
             b.ka.node[pd.kept_base + slot] = x;
             aux[x] = slot;
         } else {
@@ -1480,8 +1480,9 @@ __global__ __launch_bounds__(256) void k_kept(BatchDev b, DetectParams prm)
     const int       pi = blockIdx.y;
     PlaneCtr       &c = b.ctr[pi];
     if (c.root_node == NONE) return;
-    const uint32_t  n = min(c.n_kept, (uint32_t)prm.kept_cap);
     const PlaneDesc &pd = b.planes[pi];
+    if (c.n_kept > pd.kept_cap) return;         // table overflow (flagged by k_select): parents may be missing -- the host grows the table or fails
+    const uint32_t  n = c.n_kept;
     const size_t    kb = pd.kept_base;
     const NodeRec  *nr = b.na.rec + pd.node_base;
     const uint32_t *aux = b.na.aux + pd.node_base;
@@ -1557,7 +1558,8 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     if (alt && !(c.n_rel != 0 && c.n_amb == 1 && c.tie_nc == 2)) return;
     const PlaneDesc &pd = b.planes[pi];
     const size_t     kb = pd.kept_base, pb = pd.pool_base;
-    const uint32_t   K = min(c.n_kept, (uint32_t)prm.kept_cap);
+    if (c.n_kept > pd.kept_cap) return;         // (see k_kept)
+    const uint32_t   K = c.n_kept;
     const int        tid = threadIdx.x;
     const uint8_t   *klev = b.ka.level + kb;
     const int32_t   *kpar = b.ka.parent + kb;
@@ -1687,14 +1689,14 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         const int    area = (int)b.ka.area[kb + best];
         if (ar < 2.0 && ar > 0.10 && area < prm.max_area && area > prm.min_area && bh < pd.h * 0.8 && bw < pd.w * 0.8) {
             const uint32_t slot = atomicAdd(&s_npool, 1u);
-            if (slot < (uint32_t)prm.pool_cap) b.pool_tmp[pb + slot] = best;
+            if (slot < pd.pool_cap) b.pool_tmp[pb + slot] = best;
         }
     }
     __syncthreads();
     uint32_t np = s_npool;
-    if (np > (uint32_t)prm.pool_cap) {
+    if (np > pd.pool_cap) {
         if (tid == 0) atomicOr(&c.overflow, 2u);
-        np = prm.pool_cap;
+        np = pd.pool_cap;
     }
     // order the pool by key (keys are unique inside a plane): rank = number of smaller keys.  The keys are staged in LDS
     // first -- ranking straight from the tables is two dependent global loads per comparison, the longest part of the kernel

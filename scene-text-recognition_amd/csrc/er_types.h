@@ -43,8 +43,11 @@ struct PlaneDesc {
     uint8_t  pad0, pad1;
     uint32_t color_pitch;   // BGR frames: bytes between the Y, Cr, Cb planes of this level (pix - (ch % 3) * color_pitch is Y); 0 = no colour image
     uint32_t node_cap;      // node records this plane may use (a share of its pixel count; overflow -> the host grows the share and repeats)
+    uint32_t kept_cap;      // entries of the kept-node arrays / of the pool arrays that belong to this plane (by default a share of its pixel
+    uint32_t pool_cap;      // count: a 240 x 135 pyramid level does not need the table of a 1920 x 1080 plane)
+    uint32_t pad2_[2];
 };
-static_assert(sizeof(PlaneDesc) == 80 && offsetof(PlaneDesc, node_cap) == 76, "PlaneDesc layout (host and device)");
+static_assert(sizeof(PlaneDesc) == 96 && offsetof(PlaneDesc, node_cap) == 76, "PlaneDesc layout (host and device)");
 
 // Per-plane device counters, zeroed before every batch.
 struct PlaneCtr {

@@ -92,7 +92,11 @@ struct str_er_ctx {
     std::vector<int> chans;          // channel indices selected by the mask
     size_t slots = 0;                // node slots (== plane pixels) the workspace can hold
     int max_planes = 0;
-    int kept_cap = 0, pool_cap = 0;
+    int kept_cap = 0, pool_cap = 0;   // per plane: the most a plane may get
+    bool auto_caps = true;            // (neither was given: every plane gets a share of the tables by its pixel count)
+    double kept_share = 1.0 / 64, pool_share = 1.0 / 256;   // ... kept nodes / pooled ERs per padded pixel; grown -- and the batch repeated -- on overflow
+    size_t kept_total = 0, pool_total = 0;      // entries of the kept-node / pool arrays
+    int64_t table_bytes = 0;
     double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
     bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
     bool   dbg_tile_only = false, dbg_stats = false;   // developer aids (STR_ER_DEBUG_TILE_ONLY / _STATS), read once at create
@@ -110,7 +114,7 @@ struct str_er_ctx {
     size_t node_slots = 0;            // node records allocated (NodeArrays::rec / aux)
     uint32_t node_blocks_cap = 12;
     uint32_t node_blocks = 12;        // workgroups per plane of the per-record kernels: from the record counts of the previous batch
-    double node_share = 0.25;         // records per padded plane pixel; grown (and the batch repeated) when a plane runs out
+    double node_share = 0.06;         // records per padded plane pixel (S-text needs 0.006, S-noise 0.09); grown -- and the batch repeated -- when a plane runs out
     uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
     std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
     std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
@@ -350,11 +354,12 @@ struct Batch {
     std::vector<PlaneDesc> planes;
     uint32_t n_tiles = 0, n_pairs = 0;
     size_t slots = 0, seam = 0, nodes = 0;      // padded pixels, seam entries, node records
+    size_t kept = 0, pool = 0;                  // entries of the kept-node / pool arrays handed to the planes
+    uint32_t kept_floor = 0, pool_floor = 0;    // str_er_nms_tree: the plane's tables must hold the imported tree
     int planes_per_image = 0;       // BGR frames: planes of one (frame, pyramid level), consecutive in `planes`; 0 = no colour image
 };
 
-void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int invert, uint32_t frame, int ch, int pyr,
-               int kept_cap, int pool_cap)
+void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int invert, uint32_t frame, int ch, int pyr)
 {
     PlaneDesc d{};
     d.pix = pix; d.w = w; d.h = h; d.stride = stride; d.invert = invert ? 0xFF : 0;
@@ -365,8 +370,6 @@ void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int inver
     d.pair_base = b.n_pairs; b.n_pairs += d.n_pairs;
     b.slots += (size_t)d.tiles_x * d.tiles_y * TILE_PX;      // (node records are laid out by assign_node_records)
     d.seam_base = (uint32_t)b.seam; b.seam += 2 * (size_t)d.n_pairs;
-    d.kept_base = (uint32_t)(b.planes.size() * (size_t)kept_cap);
-    d.pool_base = (uint32_t)(b.planes.size() * (size_t)pool_cap);
     d.frame = frame; d.ch = (uint8_t)ch; d.pyr = (uint8_t)pyr;
     b.planes.push_back(d);
 }
@@ -385,6 +388,56 @@ void assign_node_records(Batch &b, double share)
         d.node_cap = (uint32_t)plane_node_cap(d.tiles_x * d.tiles_y, share);
         b.nodes += d.node_cap;
     }
+}
+
+// Kept-node and pool tables.  Explicit caps (str_er_params) are given to every plane; by default a plane's share follows its padded
+// pixel count -- a 240 x 135 pyramid level does not need the table of a 1920 x 1080 plane -- and grows with the context's shares.
+void assign_tables(Batch &b, const str_er_ctx *c)
+{
+    b.kept = b.pool = 0;
+    for (PlaneDesc &d : b.planes) {
+        const size_t px = (size_t)d.tiles_x * d.tiles_y * TILE_PX;
+        if (c->auto_caps) {
+            d.kept_cap = (uint32_t)std::min<size_t>(px + 1, (size_t)std::ceil((double)px * c->kept_share) + 512);
+            d.kept_cap = std::max(d.kept_cap, b.kept_floor);
+            d.pool_cap = (uint32_t)std::min<size_t>(px + 1, (size_t)std::ceil((double)px * c->pool_share) + 256);
+            d.pool_cap = std::max(d.pool_cap, b.pool_floor);
+        } else {
+            d.kept_cap = (uint32_t)c->kept_cap;
+            d.pool_cap = (uint32_t)c->pool_cap;
+        }
+        d.kept_base = (uint32_t)b.kept; b.kept += d.kept_cap;
+        d.pool_base = (uint32_t)b.pool; b.pool += d.pool_cap;
+    }
+}
+
+// (Re)allocate the tables for KP kept nodes and PP pooled ERs in all.
+int alloc_tables(str_er_ctx *c, size_t KP, size_t PP)
+{
+    auto re = [&](auto *&p, size_t n) -> int {
+        using T = std::remove_reference_t<decltype(*p)>;
+        if (p) { (void)hipFree(p); p = nullptr; }
+        void *v = nullptr;
+        const size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+        if (hipMalloc(&v, bytes) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (kept-node / pool tables, " + std::to_string(bytes) + " bytes)");
+        p = static_cast<T *>(v);
+        c->ws_bytes += (int64_t)bytes;
+        return STR_ER_OK;
+    };
+    c->ws_bytes -= c->table_bytes;
+    const int64_t before = c->ws_bytes;
+    c->kept_total = c->pool_total = 0; c->table_bytes = 0;
+    int rc = STR_ER_OK;
+#define T_(p, n) if (rc == STR_ER_OK) rc = re(p, n)
+    T_(c->ka.node, KP); T_(c->ka.key, KP); T_(c->ka.area, KP); T_(c->ka.parent, KP); T_(c->ka.box, 4 * KP); T_(c->ka.level, KP);
+    T_(c->ka.start, KP); T_(c->ka.ncand, KP); T_(c->ka.best, KP);
+    T_(c->d_pool, PP); T_(c->d_pool_tmp, PP); T_(c->d_cands, PP); T_(c->d_cand_plane, PP); T_(c->d_cands2, PP); T_(c->d_cand_plane2, PP);
+    T_(c->d_redo, PP + 1); T_(c->d_track, PP); T_(c->d_track_list, PP);
+#undef T_
+    c->table_bytes = c->ws_bytes - before;
+    if (rc != STR_ER_OK) return rc;
+    c->kept_total = KP; c->pool_total = PP;
+    return STR_ER_OK;
 }
 
 BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
@@ -856,12 +909,17 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
 {
     Batch b = b_in;
     assign_node_records(b, c->node_share);
+    assign_tables(b, c);
     const int ev_entry = pre_recorded ? c->n_ev : -1;
     const int np = (int)b.planes.size();
     if (np == 0) return fail(c, STR_ER_EINVAL, "no planes");
     if (np > c->max_planes) return fail(c, STR_ER_ECAPACITY, "more planes than the context was created for");
     if (b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "planes exceed the pixel capacity of the context");
     if (b.seam > c->seam_slots) return fail(c, STR_ER_ECAPACITY, "seam map capacity exceeded");
+    if (b.kept > c->kept_total || b.pool > c->pool_total) {     // (many tiny planes: the per-plane floors add up; or the shares have grown)
+        const int rct = alloc_tables(c, std::max(c->kept_total, b.kept + b.kept / 8), std::max(c->pool_total, b.pool + b.pool / 8));
+        if (rct != STR_ER_OK) return rct;
+    }
     if (b.n_tiles > c->tile_slots) return fail(c, STR_ER_ECAPACITY, "tile table capacity exceeded");
     if (b.nodes > c->node_slots) {       // (a layout with many tiny planes: the per-plane floor adds up)
         const int rcn = alloc_node_records(c, b.nodes + b.nodes / 8);
@@ -967,6 +1025,24 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees);
         }
     }
+    if (c->auto_caps) {     // the same for the kept-node table (the counter says how many nodes the plane has) and the pool (it does not: double)
+        double need_k = 0;
+        bool   more_pool = false;
+        for (int i = 0; i < np; ++i) {
+            const double px = (double)((size_t)b.planes[i].tiles_x * b.planes[i].tiles_y * TILE_PX);
+            if (c->h_ctr[i].overflow & 1u) need_k = std::max(need_k, (double)c->h_ctr[i].n_kept / px);
+            else if (c->h_ctr[i].overflow & 2u) more_pool = true;
+        }
+        if (need_k > 0 || more_pool) {
+            if ((need_k > 0 && c->kept_share >= 1.0) || (more_pool && c->pool_share >= 1.0))
+                return fail(c, STR_ER_ECAPACITY, "kept-node / pool tables exhausted at one entry per pixel (internal error)");
+            if (need_k > 0) c->kept_share = std::min(1.0, std::max(c->kept_share * 1.5, need_k * 1.25));
+            if (more_pool) c->pool_share = std::min(1.0, c->pool_share * 2.0);
+            c->pool_share = std::min(c->pool_share, std::max(c->kept_share, 1.0 / 256));      // (the pool is a subset of the kept nodes)
+            if (ev_entry >= 0) { c->n_ev = ev_entry; c->profile.resize((size_t)ev_entry); }
+            return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees);      // (re-laid out, tables re-allocated on entry)
+        }
+    }
     if ((stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0) {
         bool replayed = false;
         const auto tr0 = std::chrono::steady_clock::now();
@@ -980,7 +1056,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             std::swap(c->d_cands, c->d_cands2);
             std::swap(c->d_cand_plane, c->d_cand_plane2);
             bd = make_batchdev(c, b);
-            uint32_t *n_redo = c->d_redo + (size_t)c->max_planes * c->pool_cap;
+            uint32_t *n_redo = c->d_redo + c->pool_total;
             launch_cand_reprefix(sp, bd, first, c->d_redo, n_redo);
             launch_classify(sp, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, c->d_redo, n_redo);
             track_stage(false, sp, bd);
@@ -1008,7 +1084,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     for (int i = 0; i < np; ++i) {
         if (c->h_ctr[i].overflow & 1u)
             return fail(c, STR_ER_ECAPACITY, "kept-node table overflow: plane " + std::to_string(i) + " has " +
-                        std::to_string(c->h_ctr[i].n_kept) + " kept nodes, kept_cap = " + std::to_string(c->kept_cap));
+                        std::to_string(c->h_ctr[i].n_kept) + " kept nodes, its share of the table is " + std::to_string(b.planes[i].kept_cap) + " (set kept_cap)");
         if (c->h_ctr[i].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
     }
     {
@@ -1253,6 +1329,10 @@ void str_er_destroy(str_er_ctx *c)
     if (c->h_tie) (void)hipHostFree(c->h_tie);
     if (c->na.rec) (void)hipFree(c->na.rec);
     if (c->na.aux) (void)hipFree(c->na.aux);
+    for (void *p : {(void *)c->ka.node, (void *)c->ka.key, (void *)c->ka.area, (void *)c->ka.parent, (void *)c->ka.box, (void *)c->ka.level, (void *)c->ka.start,
+                    (void *)c->ka.ncand, (void *)c->ka.best, (void *)c->d_pool, (void *)c->d_pool_tmp, (void *)c->d_cands, (void *)c->d_cand_plane, (void *)c->d_cands2,
+                    (void *)c->d_cand_plane2, (void *)c->d_redo, (void *)c->d_track, (void *)c->d_track_list})
+        if (p) (void)hipFree(p);
     if (c->d_group) (void)hipFree(c->d_group);
     if (c->d_group_pairs) (void)hipFree(c->d_group_pairs);
     for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
@@ -1315,6 +1395,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     const size_t plane_px = (size_t)p->max_width * p->max_height;
     c->kept_cap = p->kept_cap > 0 ? p->kept_cap : (int)std::max<size_t>(4096, plane_px / 64);
     c->pool_cap = p->pool_cap > 0 ? p->pool_cap : std::max(256, c->kept_cap / 4);
+    c->auto_caps = p->kept_cap <= 0 && p->pool_cap <= 0;
     c->seam_slots = c->slots / 8 + 4096;
 
     int rc = STR_ER_OK;
@@ -1344,24 +1425,23 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         A(fail(nullptr, STR_ER_EHIP, "side stream creation failed"));
     c->in_bytes = std::max((size_t)p->max_frames * plane_px * 3, c->slots);
     c->pix_bytes = std::max(phys_frame * p->max_frames, c->slots + 4096);
-    const size_t S = c->slots, KP = (size_t)c->max_planes * c->kept_cap, PP = (size_t)c->max_planes * c->pool_cap;
+    // kept-node and pool tables: by default a plane's share follows its (padded) pixel count (assign_tables); explicit caps are given to
+    // every plane
+    const size_t S = c->slots;
+    const size_t KP = c->auto_caps ? (size_t)std::ceil((double)S * c->kept_share) + 512 * (size_t)c->max_planes : (size_t)c->max_planes * c->kept_cap;
+    const size_t PP = c->auto_caps ? (size_t)std::ceil((double)S * c->pool_share) + 256 * (size_t)c->max_planes : (size_t)c->max_planes * c->pool_cap;
     A(dev_alloc(c, c->d_in, c->in_bytes));
     A(dev_alloc(c, c->d_pix, c->pix_bytes));
     A(dev_alloc(c, c->d_planes, (size_t)c->max_planes));
     A(dev_alloc(c, c->d_ctr, (size_t)c->max_planes));
     A(alloc_node_records(c, (size_t)std::ceil((double)S * c->node_share) + 256 * (size_t)c->max_planes));
-    A(dev_alloc(c, c->ka.node, KP)); A(dev_alloc(c, c->ka.key, KP)); A(dev_alloc(c, c->ka.area, KP));
-    A(dev_alloc(c, c->ka.parent, KP)); A(dev_alloc(c, c->ka.box, 4 * KP)); A(dev_alloc(c, c->ka.level, KP));
-    A(dev_alloc(c, c->ka.start, KP)); A(dev_alloc(c, c->ka.ncand, KP)); A(dev_alloc(c, c->ka.best, KP));
+    A(alloc_tables(c, KP, PP));
     A(dev_alloc(c, c->d_seam, c->seam_slots));
     c->tile_slots = c->slots / TILE_PX + 16;
     c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
-    A(dev_alloc(c, c->d_pool, PP)); A(dev_alloc(c, c->d_pool_tmp, PP));
-    A(dev_alloc(c, c->d_cands, PP)); A(dev_alloc(c, c->d_cand_plane, PP));
-    A(dev_alloc(c, c->d_cands2, PP)); A(dev_alloc(c, c->d_cand_plane2, PP)); A(dev_alloc(c, c->d_redo, PP + 1));
-    A(dev_alloc(c, c->d_track, PP)); A(dev_alloc(c, c->d_track_list, PP)); A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
+    A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
     A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
@@ -1507,7 +1587,7 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
                 if (plane_select && !plane_select[(size_t)l * c->chans.size() + k]) continue;
                 const int ch = c->chans[k];
                 const uint8_t *pix = c->d_pix + (size_t)f * frame_bytes + geo[l].off + (size_t)(ch % 3) * plane_sz(l);
-                add_plane(b, pix, geo[l].w, geo[l].h, geo[l].stride, ch >= 3, (uint32_t)f, ch, l, c->kept_cap, c->pool_cap);
+                add_plane(b, pix, geo[l].w, geo[l].h, geo[l].stride, ch >= 3, (uint32_t)f, ch, l);
                 b.planes.back().color_pitch = (uint32_t)plane_sz(l);
             }
     b.planes_per_image = plane_select ? 0 : (int)c->chans.size();
@@ -1600,7 +1680,7 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
                 HIP_TRY(c, hipMemcpyAsync(dst + (size_t)TILE_H * pstride, src, (size_t)rows * pstride, hipMemcpyDeviceToDevice, c->stream));
                 lay = dst;
             }
-            add_plane(b, lay, w, rows + (ptop ? TILE_H : 0) + (pbot ? TILE_H : 0), pstride, ch >= 3, 0, ch, 0, c->kept_cap, c->pool_cap);
+            add_plane(b, lay, w, rows + (ptop ? TILE_H : 0) + (pbot ? TILE_H : 0), pstride, ch >= 3, 0, ch, 0);
             PlaneDesc &pd = b.planes.back();
             pd.h = rows + (ptop ? TILE_H : 0);                   // (the phantom row below is simply past the image)
             pd.n_pairs = pd.n_hpairs + (uint32_t)pd.h * (uint32_t)(pd.tiles_x - 1);
@@ -1726,7 +1806,7 @@ int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, 
     rec(c, "channels");
     Batch b;
     for (int ch : c->chans) {
-        add_plane(b, c->d_pix + (size_t)(ch % 3) * psize, w, h, pstride, ch >= 3, 0, ch, 0, c->kept_cap, c->pool_cap);
+        add_plane(b, c->d_pix + (size_t)(ch % 3) * psize, w, h, pstride, ch >= 3, 0, ch, 0);
         b.planes.back().color_pitch = (uint32_t)psize;
     }
     b.planes_per_image = (int)npl;
@@ -1822,7 +1902,7 @@ int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_
     else return fail(c, STR_ER_EINVAL, "bad mem_kind");
     Batch b;
     for (int i = 0; i < n_planes; ++i)
-        add_plane(b, dp + (size_t)i * dpitch, w, h, dstride, 0, 0, i & 255, 0, c->kept_cap, c->pool_cap);
+        add_plane(b, dp + (size_t)i * dpitch, w, h, dstride, 0, 0, i & 255, 0);
     return run_batch(c, b, stages, out, t0, false);
 }
 
@@ -2159,7 +2239,7 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     if (!nodes || n_nodes < 1 || rows < 1 || cols < 1 || !n_pool || (cap > 0 && !pool_idx) || cap < 0 || (plane && stride < cols))
         return fail(c, STR_ER_EINVAL, "bad arguments");
     if (plane && (size_t)rows * (size_t)cols > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
-    if (n_nodes > c->kept_cap) return fail(c, STR_ER_ECAPACITY, "tree larger than kept_cap");
+    if (!c->auto_caps && n_nodes > c->kept_cap) return fail(c, STR_ER_ECAPACITY, "tree larger than kept_cap");
     HIP_TRY(c, hipSetDevice(c->prm.device));
     std::vector<uint32_t> key(n_nodes), area(n_nodes); std::vector<int32_t> par(n_nodes);
     std::vector<uint16_t> box(4 * (size_t)n_nodes); std::vector<uint8_t> lev(n_nodes);
@@ -2180,7 +2260,13 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
         if (i != root && lev[par[i]] <= lev[i]) return fail(c, STR_ER_EINVAL, "parent level must exceed child level");
     hipStream_t s = c->stream;
     Batch b;
-    add_plane(b, c->d_pix, cols, rows, cols, 0, 0, 0, 0, c->kept_cap, c->pool_cap);
+    add_plane(b, c->d_pix, cols, rows, cols, 0, 0, 0, 0);
+    b.kept_floor = b.pool_floor = (uint32_t)n_nodes;        // (the imported tree is the plane's kept-node table)
+    assign_tables(b, c);
+    if (b.kept > c->kept_total || b.pool > c->pool_total) {
+        const int rct = alloc_tables(c, std::max(c->kept_total, b.kept), std::max(c->pool_total, b.pool));
+        if (rct != STR_ER_OK) return rct;
+    }
     std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc));
     PlaneCtr pc{};
     pc.n_kept = (uint32_t)n_nodes; pc.root_slot = (uint32_t)root; pc.max_level = (uint32_t)maxl;

@@ -401,6 +401,22 @@ def test_kept_table_overflow_is_reported(S):
     f.close()
 
 
+def test_default_tables_grow_with_the_content(S, oracle):
+    """Default capacities follow the planes' pixel counts (a share of a record / kept node / pooled ER per pixel) and are grown, the
+    batch repeated, when the content needs more: MIN_AREA 1 on noise keeps nearly every node, far beyond the default shares."""
+    f = S.ERFilter(8, 1, 900000, 2, 0.7, max_width=400, max_height=300, max_frames=2)
+    ws0 = f.workspace_bytes()
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (300, 400), dtype=np.uint8), S.synth.gray(S.synth.stext_bgr(5, 400, 300))]
+    for _ in range(2):          # (the second round runs on the grown tables: no retry, same answer)
+        for img in imgs:
+            p = f.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS, want_nodes=True).planes[0]
+            check_plane_against_oracle(oracle, p, img, None, min_area=1)
+            assert p.n_kept > 400 * 300 // 64 + 512 or img is imgs[1]
+    assert f.workspace_bytes() > ws0
+    f.close()
+
+
 # ---- config 5 geometry: 3840x2160, 12-level pyramid ------------------------------------------------------
 def test_4k_plane_and_pyramid_dims(S, cascade_paths, oracle, oracle_cascades):
     f = S.ERFilter(params=S.Params(max_width=3840, max_height=2160, max_frames=1, n_pyr_levels=12, channel_mask=0x01))
