@@ -107,7 +107,7 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40, help="timed batches (one step = one batch of --frames-per-gpu frames per GPU; 40 steps = about a third of a second)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=48,
                     help="frames per batch (= per step) and GPU; 48-64 amortise the per-batch launch latencies best (32 or 96: about 7 %% slower)")

@@ -1136,7 +1136,10 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
     // The survivors (typically a tenth of the lanes, scattered over all 16 waves) are packed into the first waves: the other
     // waves retire at once and make room for the next workgroups, so more connects -- chains of dependent fabric round
     // trips -- are in flight per CU.
-    __shared__ uint32_t s_pa[SEAM_BLOCK], s_pb[SEAM_BLOCK];
+    // (the list lives in the set's memory -- the set is done with after a barrier: 16 KB of LDS per workgroup instead of 24, and it
+    // is the LDS that limits how many workgroups, each down to a wave or two by now, share a CU)
+    __syncthreads();
+    uint32_t *const s_pa = reinterpret_cast<uint32_t *>(s_seen), *const s_pb = s_pa + SEAM_BLOCK;
     if (mine) { const uint32_t at = atomicAdd(&s_n, 1u); s_pa[at] = na; s_pb[at] = nbn; }
     __syncthreads();
     if (threadIdx.x >= s_n) return;
