@@ -443,7 +443,8 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 // 3.62 / 11.5, the loop runs as long as the longer chain with both halves' instructions; walking up a's chain to b's level in a loop of
 // finds inside the pass: 3.67 / 12.3; the vertical round first: 3.21 / 10.8; three rounds with the vertical edges between equal levels first
 // (plain unions while no node has a parent): 3.27 / 9.4 against 2.98 / 8.0; runs that start right below a pixel of their own level linked
-// upwards in the load phase (a fifth of the vertical edges gone, but long same-level chains): 3.03 / 8.8 against 2.99 / 8.1; round 1's attempts -- fewer waves in the loop, two edges
+// upwards in the load phase (a fifth of the vertical edges gone, but long same-level chains): 3.03 / 8.8 against 2.99 / 8.1; a lost CAS judged
+// again on the spot with the word it returned instead of in the next pass: 3.22 / 9.9 against 2.98 / 8.05; round 1's attempts -- fewer waves in the loop, two edges
 // per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
 __device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges, int round)
 {
