@@ -112,7 +112,7 @@ struct str_er_ctx {
     KeptArrays ka{};
     uint16_t *d_seam = nullptr; size_t seam_slots = 0;
     size_t node_slots = 0;            // node records allocated (NodeArrays::rec / aux)
-    uint32_t node_blocks_cap = 12;
+    uint32_t node_blocks_cap = 0;     // workgroups per plane in k_resolve / k_reduce; 0 = by the frames' content (STR_ER_NODE_BLOCKS sets it)
     uint32_t node_blocks = 12;        // workgroups per plane of the per-record kernels: from the record counts of the previous batch
     double node_share = 0.06;         // records per padded plane pixel (S-text needs 0.006, S-noise 0.09); grown -- and the batch repeated -- when a plane runs out
     uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
@@ -1091,8 +1091,10 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         uint32_t most = 0;
         for (int i = 0; i < np; ++i) most = std::max(most, c->h_ctr[i].n_nodes);
         // (more lanes than this in flight only queue up behind the same hot parent words: measured on noise, 256 workgroups per
-        // plane made k_resolve 4x slower than 12)
-        c->node_blocks = std::min<uint32_t>(c->node_blocks_cap, std::max<uint32_t>(4, (most + 255) / 256));
+        // plane made k_resolve 4x slower than 12, 32 10 % slower; text-like batches -- the ones the small tile kernel runs on -- are
+        // fastest with 24: resolve + accumulate 1.42 -> 1.26 ms per 48 frames against 12, and slower again with 48)
+        const uint32_t cap = c->node_blocks_cap ? c->node_blocks_cap : (c->tile_sparse ? 24u : 12u);
+        c->node_blocks = std::min<uint32_t>(cap, std::max<uint32_t>(4, (most + 255) / 256));
     }
     if (c->tile_mode == 0 && b.n_tiles) {      // text-like frames make a few dozen nodes per tile, noise several hundred
         unsigned long long created = 0;

@@ -1,4 +1,7 @@
-# Developer aid (GPU box): the PCIe-inclusive leg with and without SDMA copies
-for sd in 1 0; do
-echo -n "HSA_ENABLE_SDMA=$sd: "; HSA_ENABLE_SDMA=$sd python bench.py --no-cpu-baseline --no-latency --steps 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['pcie_inclusive']['value'], d['pcie_inclusive']['ms_per_step'])"
+# Developer aid (GPU box): workgroups per plane in k_resolve / k_reduce (STR_ER_NODE_BLOCKS)
+for nb in 6 12 24 48; do
+echo -n "STR_ER_NODE_BLOCKS=$nb text: "; STR_ER_NODE_BLOCKS=$nb python bench.py --no-cpu-baseline --no-latency --no-host-frames --steps 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); g=d['gpu_ms_per_step_by_kernel_group_serial']; print(d['value'], d['ms_per_step'], g['resolve'], g['accumulate'], g['select'])"
+done
+for nb in 12 32; do
+echo -n "STR_ER_NODE_BLOCKS=$nb noise: "; STR_ER_NODE_BLOCKS=$nb python bench.py --kind noise --workload native6 --no-cpu-baseline --no-latency --no-host-frames --steps 8 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); g=d['gpu_ms_per_step_by_kernel_group_serial']; print(d['value'], d['ms_per_step'], g['resolve'], g['accumulate'], g['select'])"
 done
