@@ -111,8 +111,9 @@ def test_soak_random_planes(S, oracle, monkeypatch, mode):
     """Bounded soak of the lock-free tree kernels (was tools/soak.py): random planes -- sizes up to 400x300, five value
     distributions, thresh steps 1-16, MIN_AREA 1/20/120 -- node for node against the oracle, for 25 s per tile-kernel size."""
     monkeypatch.setenv("STR_ER_TILE_KERNEL", mode)
-    rng = np.random.default_rng(11 if mode == "sparse" else 12)
-    budget, t0, n = 25.0, time.time(), 0
+    # (STR_ER_SOAK_SECONDS / STR_ER_SOAK_SEED: a longer or different soak by hand)
+    rng = np.random.default_rng((11 if mode == "sparse" else 12) + int(os.environ.get("STR_ER_SOAK_SEED", "0")))
+    budget, t0, n = float(os.environ.get("STR_ER_SOAK_SECONDS", "25")), time.time(), 0
     filters = {}
     try:
         while time.time() - t0 < budget:
