@@ -1548,6 +1548,7 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // ------------------------------------------------------------------------------------
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_SORT_CAP = 4096;       // pooled ERs of a plane whose keys are ranked out of LDS
+constexpr int NMS_LDS_CAP = 4096;        // kept nodes of a plane whose NMS scratch lives in LDS (16 bytes each)
 
 // order word of a child in a tie: the smallest one wins
 enum { NMS_ORD_KEY_MAX = 0, NMS_ORD_KEY_MIN = 1, NMS_ORD_INDEX = 2, NMS_ORD_STAMP = 3 };
@@ -1570,9 +1571,14 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     const uint8_t   *klev = b.ka.level + kb;
     const int32_t   *kpar = b.ka.parent + kb;
     const uint16_t  *kbox = b.ka.box + 4 * kb;
-    uint32_t        *kstart = b.ka.start + kb;
-    uint32_t        *kncand = b.ka.ncand + kb;
-    unsigned long long *kbest = b.ka.best + kb;
+    // chain starts, proposal counts and best proposals: in LDS when the plane's kept nodes fit (they do on everything but noise-like
+    // full-size planes) -- the level loop below is one dependent atomic / load round trip after another on these three
+    __shared__ uint32_t s_nstart[NMS_LDS_CAP], s_nncand[NMS_LDS_CAP];
+    __shared__ unsigned long long s_nbest[NMS_LDS_CAP];
+    const bool       in_lds = c.n_kept <= (uint32_t)NMS_LDS_CAP;
+    uint32_t        *kstart = in_lds ? s_nstart : b.ka.start + kb;
+    uint32_t        *kncand = in_lds ? s_nncand : b.ka.ncand + kb;
+    unsigned long long *kbest = in_lds ? s_nbest : b.ka.best + kb;
     const uint32_t  *kkey = b.ka.key + kb;
     const int        maxl = (int)c.max_level;
     const uint32_t   root = c.root_slot;
