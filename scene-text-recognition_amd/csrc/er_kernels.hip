@@ -1569,7 +1569,6 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     const uint32_t   K = c.n_kept;
     const int        tid = threadIdx.x;
     const uint8_t   *klev = b.ka.level + kb;
-    const int32_t   *kpar = b.ka.parent + kb;
     const uint16_t  *kbox = b.ka.box + 4 * kb;
     // chain starts, proposal counts and best proposals: in LDS when the plane's kept nodes fit (they do on everything but noise-like
     // full-size planes) -- the level loop below is one dependent atomic / load round trip after another on these three
@@ -1579,6 +1578,10 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     uint32_t        *kstart = in_lds ? s_nstart : b.ka.start + kb;
     uint32_t        *kncand = in_lds ? s_nncand : b.ka.ncand + kb;
     unsigned long long *kbest = in_lds ? s_nbest : b.ka.best + kb;
+    // ... and, for the chain walks, the parents and the box areas (w * h) beside them
+    __shared__ int32_t s_npar[NMS_LDS_CAP], s_narea[NMS_LDS_CAP];
+    const int32_t   *kpar = in_lds ? s_npar : b.ka.parent + kb;
+    auto barea = [&](uint32_t i) -> int { return in_lds ? s_narea[i] : (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]; };
     const uint32_t  *kkey = b.ka.key + kb;
     const int        maxl = (int)c.max_level;
     const uint32_t   root = c.root_slot;
@@ -1600,6 +1603,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     __syncthreads();
     for (uint32_t i = tid; i < K; i += NMS_THREADS) {
         kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull;
+        if (in_lds) { s_npar[i] = b.ka.parent[kb + i]; s_narea[i] = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]; }
         atomicOr(&s_levels[klev[i] >> 5], 1u << (klev[i] & 31));
     }
     __syncthreads();
@@ -1620,21 +1624,21 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
                 if (nc > 1 && !pass1) {
                     atomicAdd(&c.n_amb, 1u);
                     c.tie_node = i; c.tie_nc = nc;
-                    if ((double)((int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]) * prm.overlap_coef < rel_area) atomicAdd(&c.n_rel, 1u);
+                    if ((double)(barea(i)) * prm.overlap_coef < rel_area) atomicAdd(&c.n_rel, 1u);
                 }
                 if (nc > 1 && alt) { atomicAdd(&s_alt_amb, 1u); s_alt_node = i; s_alt_nc = nc; }
             }
             if (i == root) continue;
             const uint32_t P = (uint32_t)kpar[i];
-            const int as = (int)kbox[4 * s + 2] * (int)kbox[4 * s + 3];
-            const int ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
+            const int as = barea(s);
+            const int ap = barea(P);
             if ((double)as / (double)ap > prm.overlap_coef) {
                 atomicAdd(&kncand[P], 1u);
                 uint32_t ord;
                 if (ord_mode == NMS_ORD_STAMP) {                             // entered last = first in the child list
                     uint32_t st = 0;
                     if (!sparse) st = stamp[kkey[i]];
-                    else if ((double)((int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]) / (double)ap > prm.overlap_coef) {   // (only such children are watched)
+                    else if ((double)(barea(i)) / (double)ap > prm.overlap_coef) {   // (only such children are watched)
                         const uint32_t key = kkey[i];
                         for (uint32_t j = 0; j < n_watch; ++j) if (s_wkey[j] == key) { st = s_wstamp[j]; break; }
                     }
@@ -1658,14 +1662,14 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         for (uint32_t i = tid; i < K; i += NMS_THREADS) {
             if (i == root) continue;
             const uint32_t P = (uint32_t)kpar[i];
-            const int ai = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3], ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
+            const int ai = barea(i), ap = barea(P);
             if ((double)ai / (double)ap > prm.overlap_coef) atomicAdd(&kncand[P], 1u);
         }
         __syncthreads();
         for (uint32_t i = tid; i < K; i += NMS_THREADS) {
             if (i == root) continue;
             const uint32_t P = (uint32_t)kpar[i];
-            const int ai = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3], ap = (int)kbox[4 * P + 2] * (int)kbox[4 * P + 3];
+            const int ai = barea(i), ap = barea(P);
             if ((double)ai / (double)ap > prm.overlap_coef && kncand[P] > 1 && (double)ap * prm.overlap_coef < rel_area) {
                 const uint32_t at = atomicAdd(&c.n_watch, 1u);
                 if (at < (uint32_t)NMS_WATCH_CAP) { b.watch[(size_t)pi * NMS_WATCH_CAP + at] = kkey[i]; b.wparent[(size_t)pi * NMS_WATCH_CAP + at] = P; }
@@ -1688,8 +1692,8 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         double   best_st = 0;
         int      best_a = 0;
         for (int i = 0; i < len - T; ++i) {
-            const int a = (int)kbox[4 * trail + 2] * (int)kbox[4 * trail + 3];
-            const int bb = (int)kbox[4 * lead + 2] * (int)kbox[4 * lead + 3];
+            const int a = barea(trail);
+            const int bb = barea(lead);
             const double st = (double)a / (double)(bb - a);   // 0 denominator -> +inf, as in the reference
             if (i == 0 || st > best_st) { best = trail; best_st = st; best_a = a; }
             else if (st == best_st && a < best_a) { best = trail; best_a = a; }
