@@ -1956,14 +1956,18 @@ __global__ __launch_bounds__(1024) void k_cand_prefix(BatchDev b)
         const uint32_t mine = off + incl - n;
         if (i < b.n_planes) {
             b.ctr[i].cand_base = mine;
-            b.ctr[i].n_strong = 0; b.ctr[i].n_weak = 0;     // k_classify counts into these (it may run twice: flood-replay path)
-            for (uint32_t k = 0; k < n; ++k) b.cand_plane[mine + k] = (uint16_t)i;
+            b.ctr[i].n_strong = 0; b.ctr[i].n_weak = 0;     // k_classify counts into these
         }
         __syncthreads();
         if (tid == 0) s_carry += tot;
         __syncthreads();
     }
     if (tid == 0) *b.total_cands = s_carry;
+    // candidate -> plane, a wave per plane (one lane writing a plane's few hundred entries one after the other was most of this kernel)
+    for (int i = wv; i < b.n_planes; i += 16) {
+        const uint32_t n = b.ctr[i].n_pool, base = b.ctr[i].cand_base;
+        for (uint32_t k = lane; k < n; k += 64) b.cand_plane[base + k] = (uint16_t)i;
+    }
 }
 
 void launch_cand_prefix(hipStream_t s, const BatchDev &b)
@@ -1994,7 +1998,6 @@ __global__ __launch_bounds__(1024) void k_cand_reprefix(BatchDev b, uint32_t *re
             PlaneCtr &c = b.ctr[i];
             c.cand_base_old = c.cand_base;
             c.cand_base = mine;
-            for (uint32_t k = 0; k < n; ++k) b.cand_plane[mine + k] = (uint16_t)i;
             if (c.pool_changed) {
                 c.n_strong = 0; c.n_weak = 0;
                 const uint32_t at = atomicAdd(n_redo, n);
@@ -2006,6 +2009,10 @@ __global__ __launch_bounds__(1024) void k_cand_reprefix(BatchDev b, uint32_t *re
         __syncthreads();
     }
     if (tid == 0) *b.total_cands = s_carry;
+    for (int i = wv; i < b.n_planes; i += 16) {         // candidate -> plane, a wave per plane
+        const uint32_t n = b.ctr[i].n_pool, base = b.ctr[i].cand_base;
+        for (uint32_t k = lane; k < n; k += 64) b.cand_plane[base + k] = (uint16_t)i;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cand_move(BatchDev b, const CandRec *__restrict__ from)
