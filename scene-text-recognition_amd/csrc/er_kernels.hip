@@ -444,7 +444,9 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 // finds inside the pass: 3.67 / 12.3; the vertical round first: 3.21 / 10.8; three rounds with the vertical edges between equal levels first
 // (plain unions while no node has a parent): 3.27 / 9.4 against 2.98 / 8.0; runs that start right below a pixel of their own level linked
 // upwards in the load phase (a fifth of the vertical edges gone, but long same-level chains): 3.03 / 8.8 against 2.99 / 8.1; a lost CAS judged
-// again on the spot with the word it returned instead of in the next pass: 3.22 / 9.9 against 2.98 / 8.05; round 1's attempts -- fewer waves in the loop, two edges
+// again on the spot with the word it returned instead of in the next pass: 3.22 / 9.9 against 2.98 / 8.05; every wave joining the horizontal
+// and inner vertical edges of its own 8-row band by itself (wave-wide scans, no workgroup barriers, nobody else on its words), the three row
+// pairs between bands in a workgroup-wide round afterwards: 3.22 / 8.4 against 2.99 / 8.07 -- the bands' edge counts differ; round 1's attempts -- fewer waves in the loop, two edges
 // per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
 __device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges, int round)
 {
