@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define STR_ER_ABI_VERSION 1
+/* 2: str_er_params::sibling_order 0 means the reference's exact flood order (it was the largest-key rule, now 2);
+ *    the library no longer edits the process environment when it is loaded (str_er_runtime_hint).                  */
+#define STR_ER_ABI_VERSION 2
 
 /* ---- error codes (reference: loaders print+return false, src/adaboost.cpp:877-881;
  *      CV_Assert throws on non-8UC1, src/ER.cpp:242) ------------------------------ */
@@ -184,6 +186,13 @@ void str_er_destroy(str_er_ctx *ctx);
 const char *str_er_last_error(const str_er_ctx *ctx);
 const char *str_er_strerror(int code);
 int  str_er_abi_version(void);
+/* Settings of the HIP runtime this library works best with, as "NAME=value" (space separated if several): a context uses
+ * three HIP streams and hosts keep several contexts in flight, which the runtime's default of 4 hardware queues serialises
+ * (about 8 % in bench.py).  The runtime reads them when it initialises, so they must be in the environment before the
+ * process's first HIP call.  The library never sets them by itself; str_er_apply_runtime_hint() does, for a host that
+ * opts in: returns 1 if it set something, 0 if the host's environment already decides, < 0 on error.                  */
+const char *str_er_runtime_hint(void);
+int  str_er_apply_runtime_hint(void);
 
 /* ERFilter::set_thresh_step / set_min_area (src/ER.cpp:21-30) */
 int str_er_set_thresh_step(str_er_ctx *ctx, int32_t t);
@@ -240,6 +249,13 @@ int str_er_classify_boxes(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int3
 int str_er_lbp_hist(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h,
                     int64_t stride, const int32_t *boxes_xywh, int32_t n,
                     double *hist, uint8_t *tiles26);
+
+/* ERFilter::calc_LBP(input, 24) (inc/ER.h:134, src/ER.cpp:819-845; caller OCR::lbp_run,
+ * src/OCR.cpp:37-39) for n boxes of one host plane: lbp24 receives the n 24x24 Mean-LBP
+ * code maps, 576 bytes each, row-major -- the Mat the reference returns, stride-24-on-26
+ * addressing included.                                                                */
+int str_er_calc_lbp(str_er_ctx *ctx, const uint8_t *plane, int32_t w, int32_t h,
+                    int64_t stride, const int32_t *boxes_xywh, int32_t n, uint8_t *lbp24);
 
 /* AdaBoost::predict(vector<double> fv) (inc/adaboost.h:131; CascadeBoost::predict,
  * src/adaboost.cpp:507-542) for n caller-supplied 1024-element feature vectors:

@@ -16,9 +16,6 @@ from typing import List, Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# (see str_er_api.cpp: three streams per context, several contexts in flight -- effective when nothing in the process has
-# initialised the HIP runtime yet)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 STAGE_EXTRACT, STAGE_NMS, STAGE_CLASSIFY, STAGE_ALL, STAGE_OCR, WANT_NODES, STAGE_TRACK = 1, 2, 4, 7, 8, 16, 32
 STAGE_GROUP, GROUP_INNER_SUP, STAGE_OCR_LINES, GROUP_OVERLAP_SUP = 64, 128, 256, 512
@@ -129,6 +126,7 @@ def load_library():
     L.str_er_compute_channels.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]
     L.str_er_classify_boxes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
     L.str_er_lbp_hist.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp]
+    L.str_er_calc_lbp.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp]
     L.str_er_cascade_predict.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
     L.str_er_load_svm_model.argtypes = [vp, C.c_char_p, C.c_int32]
     L.str_er_load_svm_model_mem.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int32]
@@ -201,10 +199,18 @@ def load_library():
     L.str_er_set_profiling.argtypes = [vp, C.c_int]
     L.str_er_workspace_bytes.argtypes = [vp]
     L.str_er_workspace_bytes.restype = C.c_int64
-    if L.str_er_abi_version() != 1:
+    L.str_er_runtime_hint.restype = C.c_char_p
+    if L.str_er_abi_version() != 2:
         raise RuntimeError("libstr_er_hip.so ABI version mismatch")
     _LIB = L
     return L
+
+
+def apply_runtime_hint() -> int:
+    """Opt in to the HIP runtime settings the library recommends (str_er_runtime_hint(): more hardware queues).  Only
+    effective before the process's first HIP call (e.g. before torch.cuda is initialised); importing the package does
+    not touch the environment."""
+    return int(load_library().str_er_apply_runtime_hint())
 
 
 @dataclass
@@ -637,6 +643,17 @@ class ERFilter:
         self._check(self.L.str_er_lbp_hist(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), n,
                                            _np_ptr(hist), _np_ptr(tiles) if return_tiles else None))
         return (hist, tiles) if return_tiles else hist
+
+    def calc_LBP(self, plane: np.ndarray, boxes_xywh: Optional[np.ndarray] = None) -> np.ndarray:
+        """ERFilter::calc_LBP(input, 24) (inc/ER.h:134, src/ER.cpp:819-845): the 24x24 Mean-LBP code map of every box
+        (of the whole plane with no boxes, which is how OCR::lbp_run calls it, src/OCR.cpp:37-39)."""
+        a = np.ascontiguousarray(plane, dtype=np.uint8)
+        if boxes_xywh is None:
+            boxes_xywh = np.array([[0, 0, a.shape[1], a.shape[0]]], np.int32)
+        b = np.ascontiguousarray(boxes_xywh, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((len(b), 24, 24), np.uint8)
+        self._check(self.L.str_er_calc_lbp(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(b), len(b), _np_ptr(out)))
+        return out
 
     def resize_plane(self, src: np.ndarray, dw: int, dh: int) -> np.ndarray:
         a = np.ascontiguousarray(src, dtype=np.uint8)

@@ -76,7 +76,7 @@ void launch_cand_reprefix(hipStream_t s, const BatchDev &b, const CandRec *from,
 
 // Stand-alone classify chain on explicit boxes of one device plane (single-stage API).
 void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int stride, const int32_t *boxes,
-                      int n, double *hist /*n*1024 or null*/, uint8_t *tiles /*n*676 or null*/, uint8_t *cls,
+                      int n, double *hist /*n*1024 or null*/, uint8_t *tiles /*n*676 or null*/, uint8_t *codes /*n*576 or null*/, uint8_t *cls,
                       double *s_strong, double *s_weak, CascadeDev strong, CascadeDev weak, int run_cascades);
 
 // CascadeBoost::predict on explicit feature vectors (n x 1024 doubles).

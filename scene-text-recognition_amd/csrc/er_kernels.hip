@@ -471,6 +471,68 @@ __device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t
     }
 }
 
+// The edge list of the single connect round (see k_tile_tree): entry = slot of the edge's second (horizontal: the edge is (left of p, p),
+// one slot back, two across the unused word after every 32 pixels) or first (vertical, bit 15 set: (p, pixel below p)) pixel.  A connect
+// takes anything from one to a dozen passes, so a lane takes its next edge as soon as it is done with one.  Every WAVE owns a contiguous
+// quarter of the list and hands its entries to whichever of its lanes are idle (ballot + mbcnt: no LDS traffic, no barrier): a wave
+// leaves after ~(passes of its quarter) / 64 iterations instead of after the passes of its unluckiest lane.
+// STR_ER_DYN: 1 = idle lanes take the next entries in list order, 2 = the k-th batch of 64 is spread over the wave's whole share
+// (entry c -> (c % 64) * ceil(m / 64) + c / 64), 0 = static contiguous deal per lane (round 2's form).
+#ifndef STR_ER_DYN
+#define STR_ER_DYN 1
+#endif
+__device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges_)
+{
+    constexpr uint32_t NW = TILE_THREADS / 64;
+    const uint32_t n_edges = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_edges_);
+    bool           active = false;
+    uint32_t       a = 0, b = 0, la = 0, lb = 0;
+    auto take = [&](uint32_t idx) {
+        const uint32_t e = s_elist[idx];
+        const uint32_t p = e & 0x7FFFu;
+        if (e & 0x8000u) { a = p; b = p + (uint32_t)TILE_WS; }
+        else { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
+        la = s_lev[LX(a)]; lb = s_lev[LX(b)];
+        active = true;
+        CNT(0, 1);
+    };
+#if STR_ER_DYN == 0
+    uint32_t       next = (threadIdx.x * n_edges) / TILE_THREADS;
+    const uint32_t n_end = ((threadIdx.x + 1u) * n_edges) / TILE_THREADS;
+    for (;;) {
+        if (!active && next < n_end) take(next++);
+        if (!__any(active)) break;
+        if (active) active = connect_pass(s_par, a, b, la, lb);
+    }
+#else
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t w0 = (wv * n_edges) / NW, m = ((wv + 1u) * n_edges) / NW - w0;     // the wave's share: entries [w0, w0 + m)
+#if STR_ER_DYN == 2
+    const uint32_t per = (m + 63u) / 64u, c_end = per * 64u;
+#else
+    const uint32_t c_end = m;
+#endif
+    uint32_t       cur = 0;                                                           // wave-uniform cursor
+    for (;;) {
+        if (cur < c_end) {
+            const unsigned long long idle = __ballot(!active);
+            if (idle) {
+                const uint32_t c = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+#if STR_ER_DYN == 2
+                const uint32_t e = (c & 63u) * per + (c >> 6);
+                if (!active && c < c_end && e < m) take(w0 + e);
+#else
+                if (!active && c < c_end) take(w0 + c);
+#endif
+                cur += (uint32_t)__popcll(idle);
+            }
+        }
+        if (!__any(active)) break;
+        if (active) active = connect_pass(s_par, a, b, la, lb);
+    }
+#endif
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
     const int lane = threadIdx.x & 63;
@@ -540,7 +602,15 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
 {
     constexpr int WORK_WORDS = NODE_WORDS * FOLD_CAP;
     constexpr int STAT_CHUNK = FOLD_CAP < 512 ? FOLD_CAP : 512;   // dense tiles: nodes whose statistics are accumulated per pass
+#ifdef STR_ER_OLD_ROUNDS
     static_assert(WORK_WORDS * 4 >= 2 * TILE_PX + 2 * TILE_THREADS, "the 16-bit edge list of a round (one entry per pixel at most) and the lane masks must fit s_work");
+#else
+    // the edge list: at most 63 horizontal edges per row and 32 vertical ones per pair of rows (local minima, see below); behind it the levels of
+    // every wave's first row (3 words per lane), which the wave above needs
+    constexpr int ELIST_CAP = TILE_H * (TILE_W - 1) + (TILE_H - 1) * (TILE_W / 2);
+    constexpr int ROWLV_AT = (ELIST_CAP + 1) / 2;                 // word offset in s_work
+    static_assert(ROWLV_AT + 3 * 8 * (TILE_THREADS / 64) <= WORK_WORDS, "edge list + first-row levels must fit s_work");
+#endif
     __shared__ uint32_t s_par[TILE_SLOTS];
     __shared__ __attribute__((aligned(8))) uint32_t s_work[WORK_WORDS];    // edge worklist + lane masks, later the per-node statistics
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
@@ -567,7 +637,11 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     uint32_t lev_lo = 0, lev_hi = 0;    // the 8 levels, one byte each (walls: 0, see wallm)
     uint32_t wallm = 0, startm = 0;     // bit k: pixel k is a wall / starts a run of equal level (bit 0: unless it continues the run of the pixel to its left)
     bool     left_wall;                 // the pixel left of the lane's first one is a wall (or the tile's edge)
+#ifdef STR_ER_OLD_ROUNDS
     uint16_t *const s_msk = reinterpret_cast<uint16_t *>(s_work) + TILE_PX;     // the lanes' bit sets, behind the edge list
+#else
+    uint32_t *const s_rowlv = s_work + ROWLV_AT;
+#endif
     {
         uint32_t lev[TILE_PPT];
         int      nvalid = 0;
@@ -618,7 +692,14 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         left_wall = left_lev == WALL;
         const bool joins = lev[0] != WALL && lev[0] == left_lev;
         if (lev[0] != WALL && !joins) startm |= 1u;
+#ifdef STR_ER_OLD_ROUNDS
         s_msk[tid] = (uint16_t)(wallm | (startm << 8));
+#else
+        if ((ly & 7) == 0) {        // a wave's first row: the last row of the wave above reads it from LDS (the other rows are exchanged by shuffles)
+            uint32_t *d = s_rowlv + 3 * ((tid >> 6) * 8 + (tid & 7));
+            d[0] = lev_lo; d[1] = lev_hi; d[2] = wallm;
+        }
+#endif
         {
             uint32_t val = head;                       // head of the lane's last run
             bool     pass = joins && head == p0;
@@ -637,6 +718,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     }
     PHASE_MARK(0);
 
+#ifdef STR_ER_OLD_ROUNDS
     // ---- connect the in-tile edges, in two balanced rounds -------------------------------------
     // horizontal: a run starts here and the pixel to its left is no wall (an equal-level left neighbour is already linked: by the
     // run pointers above); vertical: neither this pixel nor the one below is a wall and a run starts in either row -- in the other
@@ -663,6 +745,85 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         PHASE_MARK(1 + round);
     }
 
+#else
+    // ---- connect the in-tile edges: one list, one round -----------------------------------------------------------------------
+    // Which pixel pairs need a connect.  The component tree of the tile is the tree of ANY spanning subgraph of its pixel grid that holds a
+    // minimum spanning forest for the edge weight max(level, level): the components of {level <= t} are those of the edges of weight <= t, and
+    // an edge that is the largest of a cycle (under any fixed total order refining the weight) is in no minimum spanning forest.  The cycles
+    // used here are the 2 x 2 pixel blocks, the order is (weight, then equal-level horizontal < other horizontal < vertical, then position):
+    //   * horizontal edges inside a run of equal level are never dropped -- they cost nothing, the run pointers of the load phase are them;
+    //   * the other horizontal edges are never the largest of a block (a vertical edge of the block weighs at least as much and ranks higher);
+    //   * the vertical edge of column x, weight w(x) = max(level above, level below), is the largest of the block to its left iff
+    //     w(x) >= w(x-1) and of the block to its right iff w(x) > w(x+1) (blocks with a wall in them are no cycles: w = infinity there).
+    // So a pair of rows is joined at the LOCAL MINIMA of w -- the leftmost column of a plateau -- and nowhere else: 29 % of the vertical
+    // edges the rule "wherever a run starts in either row" (round 2) listed on text-like planes, 34 % on noise, and what is left is within
+    // a few percent of a spanning forest (text-like Y plane: 823 edges for 762 pieces).  Checked in tools/sim_tile.cpp (same trees).
+    uint16_t *const s_elist = reinterpret_cast<uint16_t *>(s_work);     // one 16-bit entry per edge
+    {
+        const uint32_t hmask = startm & ~((wallm << 1) | (left_wall ? 1u : 0u)) & 0xFFu;
+        uint32_t       vmask = 0;
+        // the row below: lane + 8 of the wave, or -- for a wave's last row -- the first row of the next wave, from LDS
+        uint32_t b_lo = __shfl_down(lev_lo, 8), b_hi = __shfl_down(lev_hi, 8), b_wall = __shfl_down(wallm, 8);
+        if ((ly & 7) == 7 && ly + 1 < TILE_H) {
+            const uint32_t *d = s_rowlv + 3 * (((tid >> 6) + 1) * 8 + (tid & 7));
+            b_lo = d[0]; b_hi = d[1]; b_wall = d[2];
+        }
+        if (ly + 1 >= TILE_H) b_wall = 0xFFu;
+        const uint32_t nowall = ~(wallm | b_wall) & 0xFFu;
+        if (prm.hi <= 0x7F) {
+            // levels are < 0x7F: eight columns at a time, one byte each, 0x7F = infinity (a wall in either row)
+            constexpr uint32_t H = 0x80808080u;
+            const uint32_t wm = wallm | b_wall;
+            const uint32_t inf_lo = (((wm & 0xFu) * 0x00204081u) & 0x01010101u) * 0x7Fu, inf_hi = ((((wm >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) * 0x7Fu;
+            auto bmax = [](uint32_t x, uint32_t y) {
+                const uint32_t m = ((((x | 0x80808080u) - y) & 0x80808080u) >> 7) * 0xFFu;      // 0xFF in the bytes where x >= y
+                return (x & m) | (y & ~m);
+            };
+            const uint32_t w_lo = bmax(lev_lo, b_lo) | inf_lo, w_hi = bmax(lev_hi, b_hi) | inf_hi;
+            uint32_t lw = __shfl_up(w_hi, 1), rw = __shfl_down(w_lo, 1);
+            if (lx == 0) lw = 0x7F7F7F7Fu;
+            if (lx == TILE_W - TILE_PPT) rw = 0x7F7F7F7Fu;
+            const uint32_t prev_lo = (w_lo << 8) | (lw >> 24), prev_hi = (w_hi << 8) | (w_lo >> 24);
+            const uint32_t next_lo = (w_lo >> 8) | (w_hi << 24), next_hi = (w_hi >> 8) | (rw << 24);
+            // w < prev and w <= next (bit 7 of (x | H) - y is set iff x >= y)
+            const uint32_t k_lo = ~((w_lo | H) - prev_lo) & ((next_lo | H) - w_lo) & H;
+            const uint32_t k_hi = ~((w_hi | H) - prev_hi) & ((next_hi | H) - w_hi) & H;
+            vmask = ((((k_lo >> 7) * 0x01020408u) >> 24) & 0xFu) | ((((k_hi >> 7) * 0x01020408u) >> 20) & 0xF0u);
+            vmask &= nowall;
+        } else {
+            // thresh_step 1 and 2: levels up to 255, column by column
+            constexpr uint32_t INF = 0x1FFu;
+            uint32_t w[TILE_PPT];
+#pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k) {
+                const uint32_t bl = ((k < 4 ? b_lo : b_hi) >> (8 * (k & 3))) & 0xFFu;
+                w[k] = ((nowall >> k) & 1u) ? max(LEVK(k), bl) : INF;
+            }
+            uint32_t lw = __shfl_up(w[TILE_PPT - 1], 1), rw = __shfl_down(w[0], 1);
+            if (lx == 0) lw = INF;
+            if (lx == TILE_W - TILE_PPT) rw = INF;
+#pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k) {
+                const uint32_t pv = k > 0 ? w[k > 0 ? k - 1 : 0] : lw, nx = k < TILE_PPT - 1 ? w[k < TILE_PPT - 1 ? k + 1 : 0] : rw;
+                vmask |= (w[k] != INF && w[k] < pv && w[k] <= nx ? 1u : 0u) << k;
+            }
+        }
+        uint32_t n_edges;
+        uint32_t off = block_excl_scan(__popc(hmask) + __popc(vmask), s_wsum, &n_edges);
+        uint32_t em = hmask | (vmask << 8);
+        while (em) {
+            const int k = __ffs((int)em) - 1;
+            em &= em - 1u;
+            s_elist[off++] = (uint16_t)(k < 8 ? p0 + k : (p0 + k - 8) | 0x8000u);
+        }
+        __syncthreads();
+        tile_connect_list(s_par, s_lev, s_elist, n_edges);
+        __syncthreads();
+        PHASE_MARK(1);
+        PHASE_MARK(2);
+    }
+
+#endif
     // ---- flatten + level roots, one pass over the lane's pieces.  The head of a piece that is not a level root is pointed straight at
     // its level root (the other pixels of a piece point at the head or, where a find halved a path, at some pixel further up in the same
     // node); the parent word of a level root is made to point at the parent node's level root.  No barrier in between: a walk follows
@@ -2052,7 +2213,7 @@ struct ClsShared {
 
 // make_LBP_hist (src/ER.cpp:789-816) + calc_LBP (:819-845) + OCR::ARAN (src/OCR.cpp:394-430)
 __device__ void block_lbp_hist(ClsShared &sh, const uint8_t *__restrict__ pix, int stride, int inv, int bx, int by,
-                               int bw, int bh)
+                               int bw, int bh, uint8_t *__restrict__ codes = nullptr)
 {
     const int tid = threadIdx.x;
     for (int i = tid; i < 1024; i += CLS_THREADS) sh.hist[i] = 0;
@@ -2082,6 +2243,7 @@ __device__ void block_lbp_hist(ClsShared &sh, const uint8_t *__restrict__ pix, i
         const int code = (8 * v0 > sum) | ((8 * v1 > sum) << 1) | ((8 * v2 > sum) << 2) | ((8 * v3 > sum) << 3) |
                          ((8 * v4 > sum) << 4) | ((8 * v5 > sum) << 5) | ((8 * v6 > sum) << 6) | ((8 * v7 > sum) << 7);
         atomicAdd(&sh.hist[(i / 12) * 512 + (j / 12) * 256 + code], 1u);
+        if (codes) codes[idx] = (uint8_t)code;          // the Mat calc_LBP returns (src/ER.cpp:819-845)
     }
     __syncthreads();
 }
@@ -2460,14 +2622,14 @@ void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, Ca
 // Single-stage entry points (str_er_classify_boxes / str_er_lbp_hist): explicit boxes.
 __global__ __launch_bounds__(CLS_THREADS) void k_lbp_boxes(const uint8_t *__restrict__ plane, int w, int h, int stride,
                                                            const int32_t *__restrict__ boxes, int n, double *hist,
-                                                           uint8_t *tiles, uint8_t *cls_out, double *s_strong,
+                                                           uint8_t *tiles, uint8_t *codes, uint8_t *cls_out, double *s_strong,
                                                            double *s_weak, CascadeDev strong, CascadeDev weak,
                                                            int run_cascades)
 {
     __shared__ ClsShared sh;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int bx = boxes[4 * i], by = boxes[4 * i + 1], bw = boxes[4 * i + 2], bh = boxes[4 * i + 3];
-        block_lbp_hist(sh, plane, stride, 0, bx, by, bw, bh);
+        block_lbp_hist(sh, plane, stride, 0, bx, by, bw, bh, codes ? codes + (size_t)i * 576 : nullptr);
         if (hist)
             for (int k = threadIdx.x; k < 1024; k += CLS_THREADS) hist[(size_t)i * 1024 + k] = (double)sh.hist[k];
         if (tiles)
@@ -2487,12 +2649,12 @@ __global__ __launch_bounds__(CLS_THREADS) void k_lbp_boxes(const uint8_t *__rest
 }
 
 void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int stride, const int32_t *boxes, int n,
-                      double *hist, uint8_t *tiles, uint8_t *cls, double *s_strong, double *s_weak, CascadeDev strong,
+                      double *hist, uint8_t *tiles, uint8_t *codes, uint8_t *cls, double *s_strong, double *s_weak, CascadeDev strong,
                       CascadeDev weak, int run_cascades)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lbp_boxes, dim3(n < 2048 ? n : 2048), dim3(CLS_THREADS), 0, s, plane, w, h, stride, boxes, n,
-                       hist, tiles, cls, s_strong, s_weak, strong, weak, run_cascades);
+                       hist, tiles, codes, cls, s_strong, s_weak, strong, weak, run_cascades);
 }
 
 // CascadeBoost::predict (src/adaboost.cpp:507-542) on caller-supplied feature vectors.

@@ -31,12 +31,6 @@ using namespace str_er;
 
 namespace {
 
-// A context uses three HIP streams (main, alt NMS pass, tie pass) and applications keep several contexts in flight; on the runtime's
-// default of 4 hardware queues the long single-workgroup kernels of one context's tie pass end up in front of another context's
-// tile kernel (bench.py: 4940 -> 5330 frames/s with 16).  The HIP runtime reads the variable when it initialises, so this helps
-// when the library is loaded before the process's first HIP call (a C++ host linked against it); otherwise export it.
-__attribute__((constructor)) void str_er_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
-
 thread_local std::string g_create_error;
 constexpr int TIE_SLOTS = 4;       // planes per batch the device hands to the host for the flood order walk without a round trip
 
@@ -1292,6 +1286,18 @@ extern "C" {
 
 int str_er_abi_version(void) { return STR_ER_ABI_VERSION; }
 
+// A context uses three HIP streams (main, alt NMS pass, tie pass) and applications keep several contexts in flight; on the runtime's
+// default of 4 hardware queues the long single-workgroup kernels of one context's tie pass end up in front of another context's
+// tile kernel (bench.py: 4940 -> 5330 frames/s with 16).  The HIP runtime reads the variable when it initialises, so it has to be
+// in the environment before the process's first HIP call.  The library never touches the environment by itself: the host either
+// exports what str_er_runtime_hint() names or calls str_er_apply_runtime_hint() -- an explicit opt-in -- before it initialises HIP.
+const char *str_er_runtime_hint(void) { return "GPU_MAX_HW_QUEUES=16"; }
+int str_er_apply_runtime_hint(void)
+{
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+    return setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0) == 0 ? 1 : STR_ER_EINVAL;
+}
+
 const char *str_er_strerror(int code)
 {
     switch (code) {
@@ -1926,7 +1932,7 @@ int str_er_compute_channels(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_
 }
 
 static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
-                      double *hist, uint8_t *tiles, uint8_t *cls, double *ss, double *sw, bool cascades)
+                      double *hist, uint8_t *tiles, uint8_t *cls, double *ss, double *sw, bool cascades, uint8_t *codes = nullptr)
 {
     if (!c) return STR_ER_EINVAL;
     if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
@@ -1944,18 +1950,19 @@ static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h,
     HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
     const size_t o_box = 0, o_hist = align_up(16 * (size_t)n, 256), o_tile = o_hist + 8192 * (size_t)n,
                  o_cls = align_up(o_tile + 676 * (size_t)n, 256), o_ss = align_up(o_cls + (size_t)n, 256), o_sw = o_ss + 8 * (size_t)n,
-                 total = o_sw + 8 * (size_t)n;
+                 o_code = align_up(o_sw + 8 * (size_t)n, 256), total = o_code + 576 * (size_t)n;
     int rc = ensure_scratch(c, total);
     if (rc != STR_ER_OK) return rc;
     uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     launch_lbp_boxes(c->stream, c->d_pix, w, h, w, reinterpret_cast<const int32_t *>(s + o_box), n,
-                     hist ? reinterpret_cast<double *>(s + o_hist) : nullptr, tiles ? s + o_tile : nullptr, s + o_cls,
+                     hist ? reinterpret_cast<double *>(s + o_hist) : nullptr, tiles ? s + o_tile : nullptr, codes ? s + o_code : nullptr, s + o_cls,
                      reinterpret_cast<double *>(s + o_ss), reinterpret_cast<double *>(s + o_sw), c->casc[0].dev, c->casc[1].dev,
                      cascades ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     if (hist) HIP_TRY(c, hipMemcpyAsync(hist, s + o_hist, 8192 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (tiles) HIP_TRY(c, hipMemcpyAsync(tiles, s + o_tile, 676 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (codes) HIP_TRY(c, hipMemcpyAsync(codes, s + o_code, 576 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (cascades) {
         HIP_TRY(c, hipMemcpyAsync(cls, s + o_cls, (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(ss, s + o_ss, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -1976,6 +1983,12 @@ int str_er_lbp_hist(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, i
 {
     if (c && !hist) return fail(c, STR_ER_EINVAL, "null hist");
     return boxes_call(c, plane, w, h, stride, boxes, n, hist, tiles26, nullptr, nullptr, nullptr, false);
+}
+
+int str_er_calc_lbp(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n, uint8_t *lbp24)
+{
+    if (c && !lbp24) return fail(c, STR_ER_EINVAL, "null lbp24");
+    return boxes_call(c, plane, w, h, stride, boxes, n, nullptr, nullptr, nullptr, nullptr, nullptr, false, lbp24);
 }
 
 int str_er_cascade_predict(str_er_ctx *c, int which, const double *fv, int32_t n, double *out)

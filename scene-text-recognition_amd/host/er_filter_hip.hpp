@@ -207,6 +207,15 @@ public:
         return h;
     }
 
+    // Mat ERFilter::calc_LBP(Mat input, const int size = 24) (inc/ER.h:134, src/ER.cpp:819-845): the 24 x 24 code map, row-major
+    std::vector<uint8_t> calc_LBP(const Image8 &input)
+    {
+        const int32_t box[4] = {0, 0, input.cols, input.rows};
+        std::vector<uint8_t> lbp(24 * 24);
+        check(str_er_calc_lbp(ctx_.get(), input.data, input.cols, input.rows, input.step, box, 1, lbp.data()));
+        return lbp;
+    }
+
     // void ERFilter::er_track(vector<ERs> &strong, vector<ERs> &weak, ERs &all_er, vector<Mat> &channel, Mat Ycrcb)
     // (src/ER.cpp:530-590).  channel[i] is the plane strong[i] / weak[i] came from, Ycrcb the 8UC3 image
     // compute_channels made.  all_er = the strong ERs (channel order), then the tracked weak ones in channel / list

@@ -200,6 +200,12 @@ def test_lbp_hist_and_tiles(erf, oracle):
         assert (h == oracle.lbp_hist(roi)).all(), b
     whole = erf.make_LBP_hist(plane)
     assert (whole[0] == oracle.lbp_hist(plane)).all()
+    # Mat ERFilter::calc_LBP (inc/ER.h:134): the 24x24 code maps themselves, same ROIs
+    codes = erf.calc_LBP(plane, boxes)
+    for b, c in zip(boxes, codes):
+        roi = plane[b[1]:b[1] + b[3], b[0]:b[0] + b[2]]
+        assert (c == oracle.lbp24(oracle.aran26(roi))).all(), b
+    assert (erf.calc_LBP(plane)[0] == oracle.lbp24(oracle.aran26(plane))).all()
 
 
 def test_classify_boxes(erf, oracle, oracle_cascades, S):

@@ -25,7 +25,7 @@ def test_host_mirror_compiles(S, tmp_path):
 def test_host_mirror_has_the_reference_surface():
     txt = open(os.path.join(HOST, "er_filter_hip.hpp")).read()
     for name in ("text_detect", "compute_channels", "er_tree_extract", "non_maximum_supression", "classify", "er_delete",
-                 "make_LBP_hist", "set_thresh_step", "set_min_area", "stc", "wtc", "er_track", "er_grouping", "chain_run"):
+                 "make_LBP_hist", "calc_LBP", "set_thresh_step", "set_min_area", "stc", "wtc", "er_track", "er_grouping", "chain_run"):
         assert name in txt, name
 
 
