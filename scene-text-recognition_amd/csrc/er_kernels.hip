@@ -533,14 +533,40 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
 #endif
 }
 
+// Data-parallel-primitive moves: the source lane is named in the instruction (no LDS-pipe bpermute, no address register).  A "row" is
+// 16 lanes = two tile rows of 8 lanes; a lane whose source lies outside its row keeps `v` (the callers ignore those lanes).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t keep, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)keep, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+#define LANE_M1(v) dpp_mov<0x111>((v), (v))      // row_shr:1 -- the value of lane - 1
+#define LANE_M2(v) dpp_mov<0x112>((v), (v))
+#define LANE_M4(v) dpp_mov<0x114>((v), (v))
+#define LANE_P1(v) dpp_mov<0x101>((v), (v))      // row_shl:1 -- the value of lane + 1
+
+// All-reduce over the 8 lanes of a tile row (butterfly: lane ^ 1, lane ^ 2, then lane <-> 7 - lane): every lane ends up with the result.
+#define ROW8_ALLREDUCE(v, OP)                                  \
+    do {                                                       \
+        v = OP(v, dpp_mov<0xB1>((v), (v)));   /* quad_perm:[1,0,3,2] */ \
+        v = OP(v, dpp_mov<0x4E>((v), (v)));   /* quad_perm:[2,3,0,1] */ \
+        v = OP(v, dpp_mov<0x141>((v), (v)));  /* row_half_mirror */     \
+    } while (0)
+#define OP_ADD(a, b) ((a) + (b))
+#define OP_OR(a, b)  ((a) | (b))
+#define OP_MIN(a, b) min((a), (b))
+
+// Inclusive prefix sum over the wave in six DPP adds: shifts by 1, 2, 4, 8 inside every row of 16 lanes (a lane whose source is outside the
+// row adds 0), then lane 15 of rows 0 and 2 is added to rows 1 and 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).
+// (Round 2 used six ds_bpermute shuffles, each with a select: 3 scans per tile.)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t n = __shfl_up(v, o);
-        if (lane >= o) v += n;
-    }
+    v += dpp_mov<0x111>(0u, v);
+    v += dpp_mov<0x112>(0u, v);
+    v += dpp_mov<0x114>(0u, v);
+    v += dpp_mov<0x118>(0u, v);
+    v += dpp_mov<0x142, 0xA>(0u, v);
+    v += dpp_mov<0x143, 0xC>(0u, v);
     return v;
 }
 
@@ -687,7 +713,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // ... and across the lane boundary: if the lane's first pixel continues the run of the pixel to
         // its left, it points at the head of that run.  The 8 lanes of a tile row are neighbours in the
         // wave; a lane that is one single run and itself continues leftwards forwards the head it got.
-        uint32_t left_lev = __shfl_up(lev[TILE_PPT - 1], 1);
+        uint32_t left_lev = LANE_M1(lev[TILE_PPT - 1]);
         if (lx == 0) left_lev = WALL;
         left_wall = left_lev == WALL;
         const bool joins = lev[0] != WALL && lev[0] == left_lev;
@@ -703,13 +729,11 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         {
             uint32_t val = head;                       // head of the lane's last run
             bool     pass = joins && head == p0;
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                const uint32_t lv = __shfl_up(val, o);
-                const int      lp = __shfl_up((int)pass, o);
-                if (pass) { val = lv; pass = lp != 0; }
-            }
-            const uint32_t t = __shfl_up(val, 1);
+            // (lane - o by DPP; where that lane is in another tile row -- or outside the 16-lane DPP row -- `pass` is already false)
+            { const uint32_t lv = LANE_M1(val), lp = LANE_M1((uint32_t)pass); if (pass) { val = lv; pass = lp != 0; } }
+            { const uint32_t lv = LANE_M2(val), lp = LANE_M2((uint32_t)pass); if (pass) { val = lv; pass = lp != 0; } }
+            { const uint32_t lv = LANE_M4(val), lp = LANE_M4((uint32_t)pass); if (pass) { val = lv; pass = lp != 0; } }
+            const uint32_t t = LANE_M1(val);
             s_par[OWN(0)] = joins ? ((lev[0] << 16) | t) : NONE;
         }
         const uint32_t walls = (uint32_t)__popc(wallm & ((1u << nvalid) - 1u));    // pixels of the image at the sentinel level
@@ -780,7 +804,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 return (x & m) | (y & ~m);
             };
             const uint32_t w_lo = bmax(lev_lo, b_lo) | inf_lo, w_hi = bmax(lev_hi, b_hi) | inf_hi;
-            uint32_t lw = __shfl_up(w_hi, 1), rw = __shfl_down(w_lo, 1);
+            uint32_t lw = LANE_M1(w_hi), rw = LANE_P1(w_lo);
             if (lx == 0) lw = 0x7F7F7F7Fu;
             if (lx == TILE_W - TILE_PPT) rw = 0x7F7F7F7Fu;
             const uint32_t prev_lo = (w_lo << 8) | (lw >> 24), prev_hi = (w_hi << 8) | (w_lo >> 24);
@@ -799,7 +823,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 const uint32_t bl = ((k < 4 ? b_lo : b_hi) >> (8 * (k & 3))) & 0xFFu;
                 w[k] = ((nowall >> k) & 1u) ? max(LEVK(k), bl) : INF;
             }
-            uint32_t lw = __shfl_up(w[TILE_PPT - 1], 1), rw = __shfl_down(w[0], 1);
+            uint32_t lw = LANE_M1(w[TILE_PPT - 1]), rw = LANE_P1(w[0]);
             if (lx == 0) lw = INF;
             if (lx == TILE_W - TILE_PPT) rw = INF;
 #pragma unroll
@@ -831,6 +855,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     const uint32_t headm = (startm | (~wallm & 1u)) & 0xFFu;      // (a lane's first pixel heads a piece also when it continues a run)
     const uint32_t stopm = headm | wallm | 0x100u;
     uint32_t rootmask = 0;
+    uint32_t first_root = NONE;         // level root of the lane's first piece (the statistics pass samples it)
     {
         uint32_t m = headm;
         while (m) {
@@ -847,8 +872,10 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                     r = w2 & 0xFFFFu;
                 }
                 s_par[LX(p)] = (l << 16) | r;
+                if (first_root == NONE) first_root = r;
             } else {
                 rootmask |= 1u << k;
+                if (first_root == NONE) first_root = p;
                 atomicOr(&s_present[(l >> 5) & 7u], 1u << (l & 31u));
                 if (w == NONE) continue;
                 uint32_t q = w & 0xFFFFu;
@@ -939,23 +966,66 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         uint32_t           *s_exp = s_work + NODE_WORDS * n_even;            // [NODE_WORDS * (FOLD_CAP - n_even)]
         for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
         __syncthreads();
-        // one set of atomics per piece.  The piece headed by the node's level root also carries the node itself (+1 in the
-        // node field), a piece with a pixel on a seam carries the open bit (OR-ed separately: an add could carry).
+        // One set of LDS atomics per piece -- except for the pieces of the row's two HOT nodes.  A text-like tile is two or three big
+        // nodes (the background levels) and dozens of speckles: hundreds of pieces add to the same three words, and LDS atomics of a wave
+        // that hit one address are carried out one lane after the other (measured: this pass took 21 % of the kernel for 10 % of its
+        // instructions).  So every tile row (8 lanes) picks two nodes -- the node of its first piece and of the first piece of another node
+        // (sampled from the lanes' first pieces) -- whose pieces are summed in registers, reduced over the row with three DPP steps and
+        // added by ONE lane: at most 32 atomics per word and tile for a hot node.  All other pieces take the atomics below.
+        // The piece headed by the node's level root also carries the node itself (+1 in the node field), a piece with a pixel on a seam
+        // carries the open bit (OR-ed separately: an add could carry).
         {
             const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
             const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
+            const uint32_t chunk = (uint32_t)tid & 7u;
+            uint32_t h1, h2;            // the row's hot level roots (slots; NONE: none)
+            {
+                uint32_t d = first_root == NONE ? 0xFFFFFFFFu : ((chunk << 16) | first_root);
+                ROW8_ALLREDUCE(d, OP_MIN);
+                h1 = d == 0xFFFFFFFFu ? NONE : (d & 0xFFFFu);
+                d = (first_root == NONE || first_root == h1) ? 0xFFFFFFFFu : ((chunk << 16) | first_root);
+                ROW8_ALLREDUCE(d, OP_MIN);
+                h2 = d == 0xFFFFFFFFu ? NONE : (d & 0xFFFFu);
+            }
+            // per hot node: pixels (7 bits) | is-the-root-piece (bit 7) | pieces on a seam (bits 8..14); node 1 in bits 0..15, node 2 in 16..31
+            uint32_t acc = 0, col1 = 0, col2 = 0;
             uint32_t m = headm;
             while (m) {
                 const int k = __ffs((int)m) - 1;
                 m &= m - 1u;
                 const uint32_t len = (uint32_t)__ffs((int)(stopm >> (k + 1)));      // distance to the next head, wall or the lane's end
                 const bool     isroot = ((rootmask >> k) & 1u) != 0;
-                const uint32_t id = piece_node(p0 + k, isroot);
-                atomicAdd(&s_w0[id], len + (isroot ? 1u << CNT_BITS : 0u));
+                const bool     opn = top || bot || (lef && k == 0) || (rig && k + (int)len == TILE_PPT);
+                const uint32_t r = isroot ? p0 + (uint32_t)k : (s_par[LX(p0 + (uint32_t)k)] & 0xFFFFu);
+                const uint32_t cb = ((1u << len) - 1u) << k;
+                const uint32_t add = len | (isroot ? 0x80u : 0u) | (opn ? 0x100u : 0u);
+                if (r == h1) { acc += add; col1 |= cb; }
+                else if (r == h2) { acc += add << 16; col2 |= cb; }
+                else {
+                    const uint32_t id = s_nid[LX(r)];
+                    atomicAdd(&s_w0[id], len + (isroot ? 1u << CNT_BITS : 0u));
+                    atomicOr(&s_row[id], (rowmask_t)1 << ly);
+                    // (the lane's 8 columns lie in one half of the 64-bit column set)
+                    atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + (lx >> 5), cb << (lx & 31));
+                    if (opn) atomicOr(&s_w0[id], 0x80000000u);
+                }
+            }
+            ROW8_ALLREDUCE(acc, OP_ADD);
+            // column sets: the 4 lanes of a quad own the 4 bytes of one dword (lanes 0-3: columns 0-31, lanes 4-7: columns 32-63)
+            col1 <<= 8u * (chunk & 3u); col2 <<= 8u * (chunk & 3u);
+            col1 |= dpp_mov<0xB1>(col1, col1); col1 |= dpp_mov<0x4E>(col1, col1);
+            col2 |= dpp_mov<0xB1>(col2, col2); col2 |= dpp_mov<0x4E>(col2, col2);
+            const uint32_t oth1 = dpp_mov<0x141>(col1, col1), oth2 = dpp_mov<0x141>(col2, col2);     // the other quad's dword
+            // lane 0 of the row adds node 1 (its own dword is the low one), lane 4 node 2 (its own dword is the high one)
+            const uint32_t my_h = chunk == 0 ? h1 : h2, my_acc = chunk == 0 ? (acc & 0xFFFFu) : (acc >> 16);
+            const uint32_t my_lo = chunk == 0 ? col1 : oth2, my_hi = chunk == 0 ? oth1 : col2;
+            if ((chunk & 3u) == 0 && my_h != NONE && (my_acc & 0x7Fu) != 0) {
+                const uint32_t id = s_nid[LX(my_h)];
+                atomicAdd(&s_w0[id], (my_acc & 0x7Fu) + ((my_acc & 0x80u) ? 1u << CNT_BITS : 0u));
                 atomicOr(&s_row[id], (rowmask_t)1 << ly);
-                // (the lane's 8 columns lie in one half of the 64-bit column set)
-                atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + (lx >> 5), ((1u << len) - 1u) << ((lx & 31) + k));
-                if (top || bot || (lef && k == 0) || (rig && k + (int)len == TILE_PPT)) atomicOr(&s_w0[id], 0x80000000u);
+                if (my_lo) atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]), my_lo);
+                if (my_hi) atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + 1, my_hi);
+                if (my_acc >> 8) atomicOr(&s_w0[id], 0x80000000u);
             }
         }
         __syncthreads();

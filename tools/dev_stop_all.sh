@@ -5,7 +5,7 @@
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/scene-text-recognition_amd/lib/stop
-PHASES="0 1 2 3 4 5 7 13 6"
+PHASES="0 1 3 4 5 7 13 6"
 # EXTRA="-DSTR_ER_TILE_V2" tools/dev_stop_all.sh build: the same for another build of the kernel
 if [ "${1:-build}" = "build" ]; then
     mkdir -p $OUT; rm -f $OUT/*
