@@ -125,15 +125,16 @@ def main():
                          "sibling tie (about one plane per 48 S-text frames, 20-50 ms on a host core) needs a few more")
     args = ap.parse_args()
 
-    S = importlib.import_module("scene-text-recognition_amd")
-    # Several contexts in flight use three HIP streams each (main, alt NMS pass, tie pass); with the runtime's default of 4 hardware queues
-    # the long single-workgroup kernels of one context's tie pass sit in front of another context's tile kernel (measured: 4940 -> 5330
-    # frames/s with 16).  The library does not edit its host's environment; this application opts in (str_er_apply_runtime_hint), before
-    # torch's first HIP call -- the runtime reads the setting when it starts.
-    S.apply_runtime_hint()
+    # (torch first: it brings its own HIP runtime, which the library must share -- loaded the other way round the process has two)
     import torch
     import torch.distributed as dist
 
+    S = importlib.import_module("scene-text-recognition_amd")
+    # Several contexts in flight use three HIP streams each (main, alt NMS pass, tie pass); with the runtime's default of 4 hardware queues
+    # the long single-workgroup kernels of one context's tie pass sit in front of another context's tile kernel (measured: 4940 -> 5330
+    # frames/s with 16).  The library does not edit its host's environment; this application opts in (str_er_apply_runtime_hint) before
+    # the process's first HIP call -- the runtime reads the setting when it initialises, which importing torch does not do.
+    S.apply_runtime_hint()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
