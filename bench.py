@@ -107,7 +107,11 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=48,
                     help="frames per batch (= per step) and GPU; 48-64 amortise the per-batch launch latencies best (32 or 96: about 7 %% slower)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
-    ap.add_argument("--kind", choices=["text", "noise"], default="text")
+    ap.add_argument("--kind", choices=["text", "noise", "ties"], default="text",
+                    help="synthetic frames (SURVEY 8d): S-text (default), S-noise (stress), S-ties = S-text with a glyph in every third frame that "
+                         "makes an NMS sibling tie whose outcome changes the pool (about 3 %% of the planes need the reference's flood order walked)")
+    ap.add_argument("--no-ties-leg", action="store_true",
+                    help="skip the `nms_ties_leg` object of the default run (the same measurement as `value`, on S-ties frames, fewer steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--group", action="store_true",
                     help="also run the rest of text_detect: calc_color + er_track + er_grouping(inner_sup) (SURVEY 8(f) rows 1-2)")
@@ -118,7 +122,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-frame-per-call latency leg (`latency_1frame`)")
     ap.add_argument("--ocr", action="store_true",
                     help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
-                         "(synthetic stand-in for the missing classifier/OCR.model: tests/golden/ocr_synth.model.gz)")
+                         "(synthetic stand-in for the missing classifier/OCR.model: scene-text-recognition_amd/data/ocr_synth.model.gz)")
     ap.add_argument("--pipelines", type=int, default=6,
                     help="independent batches in flight per GPU (each has its own context, stream and workspace).  Three hide the "
                          "host-side result handling and the low-parallelism tails of a batch; the flood order walk that decides an NMS "
@@ -192,7 +196,7 @@ def main():
         f.load_cascade(1, cascades[1])
         if args.ocr:
             import gzip
-            f.load_svm_model_text(gzip.open(os.path.join(ROOT, "tests", "golden", "ocr_synth.model.gz")).read(), 1800)
+            f.load_svm_model_text(gzip.open(S.cascade_io.ocr_model_path()).read(), 1800)
         filters.append(f)
     # --ocr alone scores every strong/weak ER (slope 0); with --group the scorer runs where er_ocr runs it: on the members of the text lines
     stages = S.STAGE_ALL | ((S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP) if args.group else 0)
@@ -214,7 +218,12 @@ def main():
     import queue
     import threading
 
-    def run(n_batches):
+    def tie_totals():
+        st = [f.tie_stats() for f in filters]
+        return sum(x["planes_walked"] for x in st), sum(x["walk_ms_total"] for x in st), st[0]["host_threads"]
+
+    def run(n_batches, d_in=None):
+        d_in = d_frames if d_in is None else d_in
         results = [None] * n_batches
         done = [threading.Event() for _ in range(n_batches)]
         turn = threading.Condition()
@@ -223,7 +232,7 @@ def main():
         def worker(p):
             torch.cuda.set_device(dev_index)
             for i in range(p, n_batches, P):
-                results[i] = filters[p].detect_bgr_device(d_frames.data_ptr(), W, H, F, stages)
+                results[i] = filters[p].detect_bgr_device(d_in.data_ptr(), W, H, F, stages)
                 if comm is not None:
                     # the records are still in this context's device array: gather them before the context takes its next
                     # batch, and in batch order -- every rank issues its collectives in the same order
@@ -258,12 +267,18 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ties0 = tie_totals()
     t0 = time.perf_counter()
     prof_sum, r = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ties1 = tie_totals()
+    nms_ties = {"tie_planes_per_batch": round((ties1[0] - ties0[0]) / args.steps, 2),
+                "flood_walk_ms_per_batch": round((ties1[1] - ties0[1]) / args.steps, 2), "host_threads": ties1[2],
+                "note": "planes of a batch whose NMS sibling tie changes the pool: the reference's flood order is walked on a host core for each "
+                        "(host ms summed over planes), on the library's process-wide pool of at most host_threads threads"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -281,6 +296,28 @@ def main():
     else:
         serial_prof = {k: v / max(args.steps, 1) for k, v in prof_sum.items()}
 
+    # ties leg: the same measurement on tie-rich frames (S-ties), so that the cost of exactness is on the line
+    ties_leg = None
+    if not args.no_ties_leg and args.kind == "text" and world == 1 and args.sibling_order == 0 and not args.ocr and not args.group:
+        with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
+            tf = np.stack(list(ex.map(lambda i: S.synth.KINDS["ties"](S.synth.frame_seed(i), W, H), range(F))))
+        d_ties = torch.from_numpy(tf).to(device)
+        torch.cuda.synchronize()
+        run(P, d_ties)
+        n_t = max(P, args.steps // 2)
+        a0 = tie_totals()
+        t1 = time.perf_counter()
+        run(n_t, d_ties)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        a1 = tie_totals()
+        ties_leg = {"value": round(F * n_t / el, 2), "unit": "frames/s", "steps": n_t, "ms_per_step": round(1e3 * el / n_t, 3),
+                    "tie_planes_per_batch": round((a1[0] - a0[0]) / n_t, 2), "tie_plane_share": round((a1[0] - a0[0]) / n_t / (F * bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels']), 4),
+                    "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(),
+                    "note": "S-ties frames (S-text + one double-L glyph in every third frame: an NMS sibling tie with two different outcomes); same "
+                            "batches in flight as `value`; flood_walk_ms = host time of the reference-order walks, summed over planes"}
+        del d_ties
+
     # latency leg: ONE frame per call, one batch in flight (north_star: ">= 500 fps end-to-end on 1920x1080" is a
     # per-frame statement; the headline `value` needs 48-frame batches x 3 in flight)
     latency = None
@@ -293,7 +330,7 @@ def main():
         f1.load_cascade(0, cascades[0]); f1.load_cascade(1, cascades[1])
         if args.ocr:
             import gzip
-            f1.load_svm_model_text(gzip.open(os.path.join(ROOT, "tests", "golden", "ocr_synth.model.gz")).read(), 1800)
+            f1.load_svm_model_text(gzip.open(S.cascade_io.ocr_model_path()).read(), 1800)
         fb = frames[0].nbytes
         for i in range(3):
             f1.detect_bgr_device(d_frames.data_ptr() + (i % F) * fb, W, H, 1, stages)
@@ -387,6 +424,8 @@ def main():
                        "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P,
                        "workspace_bytes_per_batch_in_flight": ws_bytes, "nms_sibling_ties": "exact (reference flood order)" if args.sibling_order == 0 else "key rule",
                        **({"gather": "RCCL through the C ABI (str_er_gather_last)" if comm is not None else "torch.distributed all_gather"} if world > 1 else {})},
+            "nms_ties": nms_ties,
+            **({"nms_ties_leg": ties_leg} if ties_leg else {}),
             **({"pcie_inclusive": pcie} if pcie else {}),
             **({"latency_1frame": latency} if latency else {}),
             "roofline": {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -191,6 +191,10 @@ int  str_er_abi_version(void);
  * (about 8 % in bench.py).  The runtime reads them when it initialises, so they must be in the environment before the
  * process's first HIP call.  The library never sets them by itself; str_er_apply_runtime_hint() does, for a host that
  * opts in: returns 1 if it set something, 0 if the host's environment already decides, < 0 on error.                  */
+/* Exact NMS sibling ties (sibling_order = 0): how many planes of this context's calls so far needed the reference's flood order
+ * walked on a host core, the host time those walks took in all (ms, summed over planes), and how many host threads the
+ * library's process-wide pool for them has at most (cores / 4, at least 1, at most 32; STR_ER_WALK_THREADS overrides).  Any pointer may be NULL. */
+int  str_er_tie_stats(const str_er_ctx *ctx, uint64_t *planes_walked, double *walk_ms_total, int32_t *host_threads);
 const char *str_er_runtime_hint(void);
 int  str_er_apply_runtime_hint(void);
 

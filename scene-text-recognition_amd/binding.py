@@ -200,6 +200,7 @@ def load_library():
     L.str_er_workspace_bytes.argtypes = [vp]
     L.str_er_workspace_bytes.restype = C.c_int64
     L.str_er_runtime_hint.restype = C.c_char_p
+    L.str_er_tie_stats.argtypes = [vp, C.POINTER(C.c_uint64), f64p, i32p]
     if L.str_er_abi_version() != 2:
         raise RuntimeError("libstr_er_hip.so ABI version mismatch")
     _LIB = L
@@ -660,6 +661,12 @@ class ERFilter:
         out = np.empty((dh, dw), np.uint8)
         self._check(self.L.str_er_resize_plane(self.h, _np_ptr(a), a.shape[1], a.shape[0], a.shape[1], _np_ptr(out), dw, dh))
         return out
+
+    def tie_stats(self) -> dict:
+        """Exact NMS ties: planes whose flood order had to be walked on a host core so far, the host time that took, pool size."""
+        n, ms, th = C.c_uint64(), C.c_double(), C.c_int32()
+        self._check(self.L.str_er_tie_stats(self.h, C.byref(n), C.byref(ms), C.byref(th)))
+        return {"planes_walked": int(n.value), "walk_ms_total": float(ms.value), "host_threads": int(th.value)}
 
     def workspace_bytes(self) -> int:
         return int(self.L.str_er_workspace_bytes(self.h))

@@ -13,6 +13,13 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cascades.npz")
+OCR_MODEL_GZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ocr_synth.model.gz")
+
+
+def ocr_model_path() -> str:
+    """The gzip-ed libsvm text model that stands in for the reference's missing classifier/OCR.model: 65 classes, 1800 features,
+    trained on synthetic vectors by the reference's own svm-train with the reference's flags (tests/golden/make_svm_fixture.py)."""
+    return OCR_MODEL_GZ
 
 
 def _num(v: float) -> str:

@@ -60,7 +60,9 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);
 void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool use_index_order = false);
 void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p);
 // planes with ties left (PlaneCtr::n_rel) -> host-addressable memory: pixels, watch keys, watch parents per slot (see er_kernels.hip)
-void launch_export_tie_planes(hipStream_t s, const BatchDev &b, uint8_t *host_buf, size_t slot_bytes, int n_slots, uint32_t *count, uint32_t *slot_plane);
+void launch_export_listed_planes(hipStream_t s, const BatchDev &b, const ReplayItem *items, int n_items, uint8_t *host_buf /* page-locked, device-addressable */);
+void launch_export_tie_planes(hipStream_t s, const BatchDev &b, uint8_t *host_buf, size_t slot_bytes, int n_slots, uint32_t *slot_plane_dev /* n_slots words, device */,
+                              uint32_t *count, uint32_t *slot_plane);
 // exact mode, planes with sibling ties: replay the reference's flood (src/ER.cpp:240-374) to stamp every pixel with the order in
 // which it becomes accessible, then NMS again with the ties decided by those stamps.  scratch: see ReplayItem.
 size_t replay_scratch_bytes(int w, int h);

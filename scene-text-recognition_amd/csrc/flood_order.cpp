@@ -13,7 +13,14 @@
 // means empty" rule as src/ER.cpp:254-345: pixels at the sentinel level are marked but never popped.
 #include "flood_order.h"
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
 #include <vector>
 
 namespace str_er {
@@ -121,6 +128,89 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
         x = cur % W;
         while (priority < HI && head[priority] == NIL) ++priority;
     }
+}
+
+// ---- the pool ----------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct JobSet {                        // the walks of one call
+    size_t n = 0;
+    void (*fn)(size_t, void *) = nullptr;
+    void *arg = nullptr;
+    std::atomic<size_t> next{0}, done{0};
+    std::atomic<int> err{0};
+};
+
+struct Pool {
+    std::mutex mu;
+    std::condition_variable work, finished;
+    std::deque<JobSet *> active;       // sets that still have indices to hand out
+    int n_threads = 0;
+};
+
+void run_one(JobSet *js, size_t k)
+{
+    try { js->fn(k, js->arg); }
+    catch (const std::bad_alloc &) { js->err.store(-1); }
+    catch (...) { js->err.store(-2); }
+}
+
+Pool *pool()
+{
+    static Pool *p = [] {
+        Pool *q = new Pool();          // (never destroyed: its threads outlive every context and wait on it)
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)(hw ? hw / 4 : 2);
+        if (const char *e = std::getenv("STR_ER_WALK_THREADS")) n = std::atoi(e);
+        q->n_threads = n < 1 ? 1 : (n > 32 ? 32 : n);
+        for (int i = 0; i < q->n_threads - 1; ++i) {      // (the caller of flood_walks_run is the n-th worker of its own set)
+            try {
+                std::thread([q] {
+                    std::unique_lock<std::mutex> lk(q->mu);
+                    for (;;) {
+                        q->work.wait(lk, [q] { return !q->active.empty(); });
+                        JobSet *js = q->active.front();
+                        const size_t k = js->next.fetch_add(1);
+                        if (k >= js->n) { if (!q->active.empty() && q->active.front() == js) q->active.pop_front(); continue; }
+                        if (k + 1 >= js->n) q->active.pop_front();
+                        lk.unlock();
+                        run_one(js, k);
+                        lk.lock();
+                        if (js->done.fetch_add(1) + 1 == js->n) q->finished.notify_all();
+                    }
+                }).detach();
+            } catch (...) { q->n_threads = i + 1; break; }       // (no more threads to be had: the callers do the rest themselves)
+        }
+        return q;
+    }();
+    return p;
+}
+
+} // namespace
+
+int flood_walk_threads() { return pool()->n_threads; }
+
+int flood_walks_run(size_t n, void (*fn)(size_t, void *), void *arg)
+{
+    if (n == 0) return 0;
+    JobSet js;
+    js.n = n; js.fn = fn; js.arg = arg;
+    Pool *q = pool();
+    if (n > 1 && q->n_threads > 1) {
+        std::lock_guard<std::mutex> lk(q->mu);
+        q->active.push_back(&js);
+        q->work.notify_all();
+    }
+    for (;;) {                          // the caller takes indices of its own set like any worker
+        const size_t k = js.next.fetch_add(1);
+        if (k >= n) break;
+        run_one(&js, k);
+        js.done.fetch_add(1);
+    }
+    std::unique_lock<std::mutex> lk(q->mu);
+    for (auto it = q->active.begin(); it != q->active.end(); ++it) if (*it == &js) { q->active.erase(it); break; }
+    q->finished.wait(lk, [&] { return js.done.load() >= n; });
+    return js.err.load();
 }
 
 } // namespace str_er

@@ -16,4 +16,10 @@ namespace str_er {
 void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch,
                       uint32_t n_watch, uint32_t *stamp, const uint32_t *group = nullptr);
 
+// The walks of a batch's tie planes run on a small process-wide pool of host threads (started at the first use, never more than
+// flood_walk_threads() of them however many contexts and planes there are; the calling thread works along).  fn(k) is called once for
+// every k < n; an exception inside it is caught.  Returns 0, -1 if a call ran out of memory, -2 if it failed otherwise.
+int flood_walks_run(size_t n, void (*fn)(size_t k, void *arg), void *arg);
+int flood_walk_threads();
+
 } // namespace str_er

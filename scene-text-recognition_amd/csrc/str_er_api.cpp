@@ -126,9 +126,12 @@ struct str_er_ctx {
     uint8_t *h_replay = nullptr; size_t h_replay_bytes = 0;   // page-locked: the planes (and watch lists) the flood order walk reads
     uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
     ReplayItem *d_replay_items = nullptr;
+    uint32_t *d_tie_slot_plane = nullptr;             // plane of every tie slot of the batch (k_tie_slots -> k_export_tie_planes)
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
     uint32_t last_total = 0; bool last_valid = false;   // candidates of the last detect call, still in d_cands (str_er_gather_last)
     uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
+    double   walk_ms_total = 0;                       // host time those walks took, summed over planes (statistics)
+    uint64_t n_batches = 0;
     bool replay_on_gpu = false;                       // STR_ER_REPLAY=gpu: walk the flood with k_flood_order instead of a host core
     uint16_t *d_cand_plane = nullptr, *d_cand_plane2 = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
@@ -720,11 +723,18 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
         const size_t m = items.size();
         if (hneed > c->h_replay_bytes) {
             if (c->h_replay) { (void)hipHostFree(c->h_replay); c->h_replay = nullptr; c->h_replay_bytes = 0; }
-            if (hipHostMalloc(reinterpret_cast<void **>(&c->h_replay), hneed, hipHostMallocDefault) != hipSuccess)
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->h_replay), hneed, hipHostMallocMapped) != hipSuccess)
                 return fail(c, STR_ER_ENOMEM, "hipHostMalloc (flood order walk staging)");
             c->h_replay_bytes = hneed;
         }
         ReplayItem *h_items = reinterpret_cast<ReplayItem *>(c->h_replay);
+        // which planes the device has already put into host memory (k_export_tie_planes: the first TIE_SLOTS tie planes of the batch)
+        std::vector<int> slot_of(m, -1);
+        if (!c->replay_on_gpu && c->h_tie && !from_tree)
+            for (size_t k = 0; k < m; ++k)
+                for (uint32_t q = 0; q < std::min<uint32_t>(*c->h_tie_count, TIE_SLOTS); ++q) if (c->h_tie_plane[q] == items[k].plane) slot_of[k] = (int)q;
+        // (pad_: where the export kernel puts a plane that has no slot, in units of 256 bytes from the arena's start)
+        for (size_t k = 0; k < m; ++k) items[k].pad_ = (c->replay_on_gpu || slot_of[k] >= 0) ? 0xFFFFFFFFu : (uint32_t)(hoff[k] / 256);
         std::memcpy(h_items, items.data(), sizeof(ReplayItem) * m);
         HIP_TRY(c, hipMemcpyAsync(c->d_replay_items, h_items, sizeof(ReplayItem) * m, hipMemcpyHostToDevice, s));
         if (c->replay_on_gpu) {
@@ -735,30 +745,22 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
             bool need_sync = false;
             for (size_t k = 0; k < m; ++k) {
                 const int        i = (int)items[k].plane;
-                const PlaneDesc &pd = b.planes[i];
                 HostPlane       &h = hp[k];
                 h.pix = c->h_replay + hoff[k];
                 h.watch = reinterpret_cast<uint32_t *>(h.pix + ((plane_px(i) + 255) / 256) * 256);
                 h.group = h.watch + NMS_WATCH_CAP;
                 h.stamp = h.group + NMS_WATCH_CAP;          // NMS_WATCH_CAP entries, or w * h when dense
                 h.n_watch = c->h_ctr[i].n_watch;
-                // already here?  (k_export_tie_planes wrote the first TIE_SLOTS tie planes of the batch into host memory)
-                int slot = -1;
-                if (c->h_tie && !from_tree)
-                    for (uint32_t q = 0; q < std::min<uint32_t>(*c->h_tie_count, TIE_SLOTS); ++q) if (c->h_tie_plane[q] == (uint32_t)i) slot = (int)q;
-                if (slot >= 0) {
-                    h.pix = c->h_tie + (size_t)slot * c->tie_slot_bytes;
+                if (slot_of[k] >= 0) {
+                    h.pix = c->h_tie + (size_t)slot_of[k] * c->tie_slot_bytes;
                     uint32_t *wl = reinterpret_cast<uint32_t *>(h.pix + ((plane_px(i) + 255) / 256) * 256);
                     if (!dense(i)) { std::memcpy(h.watch, wl, 4 * (size_t)h.n_watch); std::memcpy(h.group, wl + NMS_WATCH_CAP, 4 * (size_t)h.n_watch); }
                     continue;
                 }
                 need_sync = true;
-                HIP_TRY(c, hipMemcpy2DAsync(h.pix, (size_t)pd.w, pd.pix, (size_t)pd.stride, (size_t)pd.w, (size_t)pd.h, hipMemcpyDeviceToHost, s));
-                if (h.n_watch && !dense(i)) {
-                    HIP_TRY(c, hipMemcpyAsync(h.watch, c->d_watch + (size_t)i * NMS_WATCH_CAP, 4 * (size_t)h.n_watch, hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipMemcpyAsync(h.group, c->d_wparent + (size_t)i * NMS_WATCH_CAP, 4 * (size_t)h.n_watch, hipMemcpyDeviceToHost, s));
-                }
             }
+            // the planes without a slot: one launch writes them (and their watch lists) into the arena
+            if (need_sync) { launch_export_listed_planes(s, bd, c->d_replay_items, (int)m, c->h_replay); HIP_TRY(c, hipGetLastError()); }
             if (need_sync) HIP_TRY(c, hipStreamSynchronize(s));
             const auto tw0 = std::chrono::steady_clock::now();
             auto walk = [&](size_t k) {
@@ -773,10 +775,18 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
                     flood_order_host(h.pix, pd.w, pd.h, pd.w, pd.invert, dp.qscale, dp.hi, nullptr, 0xFFFFFFFFu, h.stamp);
                 }
             };
-            std::vector<std::thread> th;
-            for (size_t k = 1; k < m; ++k) th.emplace_back(walk, k);
-            walk(0);
-            for (auto &t : th) t.join();
+            // (a bounded, process-wide pool: however many contexts have tie planes at the moment, at most flood_walk_threads() host
+            // threads walk; an allocation failure inside a walk comes back as an error code, nothing is thrown across the C ABI)
+            std::vector<double> walk_ms(m, 0.0);
+            struct WalkArg { decltype(walk) *fn; std::vector<double> *ms; } wa{&walk, &walk_ms};
+            const int wrc = flood_walks_run(m, [](size_t k, void *a) {
+                WalkArg *w = static_cast<WalkArg *>(a);
+                const auto t0 = std::chrono::steady_clock::now();
+                (*w->fn)(k);
+                (*w->ms)[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }, &wa);
+            if (wrc != 0) return fail(c, wrc == -1 ? STR_ER_ENOMEM : STR_ER_EHIP, "flood order walk failed on the host (out of memory?)");
+            for (double v : walk_ms) c->walk_ms_total += v;
             if (c->dbg_stats)
                 std::fprintf(stderr, "[str_er] flood order walk: %zu plane(s), %.1f ms on the host\n", m,
                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
@@ -899,8 +909,11 @@ int upload_layout(str_er_ctx *c, const Batch &b)
 // k_tile_tree / k_seam the hook puts node records and counters in place on the context's stream.
 using ImportHook = std::function<int(const Batch &, const BatchDev &)>;
 int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result **out,
-              std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees = nullptr)
+              std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees = nullptr, int attempt = 0)
 {
+    // A batch whose planes outgrow their shares of the tables is laid out again with larger shares and repeated.  Every repeat raises a
+    // share (or fails), and a share stops at one entry per pixel: the repeats end; `attempt` only guards against a slip in that argument.
+    if (attempt > 24) return fail(c, STR_ER_ECAPACITY, "the batch was repeated 24 times with growing tables and still does not fit (internal error)");
     Batch b = b_in;
     assign_node_records(b, c->node_share);
     assign_tables(b, c);
@@ -973,7 +986,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         launch_nms_alt(c->side, bd, dp);
         if (c->h_tie && !c->replay_on_gpu) {
             *c->h_tie_count = 0;        // (the previous batch of this context is done: nothing on the device touches it any more)
-            launch_export_tie_planes(c->side, bd, c->h_tie, c->tie_slot_bytes, TIE_SLOTS, c->h_tie_count, c->h_tie_plane);
+            launch_export_tie_planes(c->side, bd, c->h_tie, c->tie_slot_bytes, TIE_SLOTS, c->d_tie_slot_plane, c->h_tie_count, c->h_tie_plane);
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
     }
@@ -1016,10 +1029,14 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
                 if (rcn != STR_ER_OK) return rcn;
             }
             if (ev_entry >= 0) { c->n_ev = ev_entry; c->profile.resize((size_t)ev_entry); }
-            return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees);
+            return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees, attempt + 1);
         }
     }
-    if (c->auto_caps) {     // the same for the kept-node table (the counter says how many nodes the plane has) and the pool (it does not: double)
+    // the same for the kept-node table (the counter says how many nodes the plane has) and the pool (it does not: double).  Checked here and
+    // once more after the tie pass, whose pools can be larger than the first pass's.
+    auto grow_tables = [&](bool &again) -> int {
+        again = false;
+        if (!c->auto_caps) return STR_ER_OK;
         double need_k = 0;
         bool   more_pool = false;
         for (int i = 0; i < np; ++i) {
@@ -1027,14 +1044,26 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             if (c->h_ctr[i].overflow & 1u) need_k = std::max(need_k, (double)c->h_ctr[i].n_kept / px);
             else if (c->h_ctr[i].overflow & 2u) more_pool = true;
         }
-        if (need_k > 0 || more_pool) {
-            if ((need_k > 0 && c->kept_share >= 1.0) || (more_pool && c->pool_share >= 1.0))
-                return fail(c, STR_ER_ECAPACITY, "kept-node / pool tables exhausted at one entry per pixel (internal error)");
-            if (need_k > 0) c->kept_share = std::min(1.0, std::max(c->kept_share * 1.5, need_k * 1.25));
-            if (more_pool) c->pool_share = std::min(1.0, c->pool_share * 2.0);
-            c->pool_share = std::min(c->pool_share, std::max(c->kept_share, 1.0 / 256));      // (the pool is a subset of the kept nodes)
+        if (need_k == 0 && !more_pool) return STR_ER_OK;
+        const double kept0 = c->kept_share, pool0 = c->pool_share;
+        if (need_k > 0) c->kept_share = std::min(1.0, std::max(c->kept_share * 1.5, need_k * 1.25));
+        if (more_pool) {
+            // (the pool is a subset of the kept nodes: past the kept share it is the kept table that has to grow with it)
+            c->pool_share = std::min(1.0, c->pool_share * 2.0);
+            if (c->pool_share > c->kept_share) c->kept_share = c->pool_share;
+        }
+        if (c->kept_share == kept0 && c->pool_share == pool0)
+            return fail(c, STR_ER_ECAPACITY, "kept-node / pool tables exhausted at one entry per pixel (internal error)");
+        again = true;
+        return STR_ER_OK;
+    };
+    {
+        bool again = false;
+        const int rcg = grow_tables(again);
+        if (rcg != STR_ER_OK) return rcg;
+        if (again) {
             if (ev_entry >= 0) { c->n_ev = ev_entry; c->profile.resize((size_t)ev_entry); }
-            return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees);      // (re-laid out, tables re-allocated on entry)
+            return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees, attempt + 1);      // (re-laid out, tables re-allocated on entry)
         }
     }
     if ((stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0) {
@@ -1059,6 +1088,15 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
             HIP_TRY(c, hipStreamSynchronize(sp));
             if (c->dbg_stats) std::fprintf(stderr, "[str_er] classify again after the tie pass: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count());
+            bool again = false;             // (a pool of the tie pass did not fit: same remedy as above)
+            const int rcg = grow_tables(again);
+            if (rcg != STR_ER_OK) return rcg;
+            if (again) {
+                std::swap(c->d_cands, c->d_cands2);         // (back to the buffers the first pass writes)
+                std::swap(c->d_cand_plane, c->d_cand_plane2);
+                if (ev_entry >= 0) { c->n_ev = ev_entry; c->profile.resize((size_t)ev_entry); }
+                return run_batch(c, b_in, stages, out, t_start, pre_recorded, import_trees, attempt + 1);
+            }
         }
     }
 
@@ -1291,6 +1329,15 @@ int str_er_abi_version(void) { return STR_ER_ABI_VERSION; }
 // tile kernel (bench.py: 4940 -> 5330 frames/s with 16).  The HIP runtime reads the variable when it initialises, so it has to be
 // in the environment before the process's first HIP call.  The library never touches the environment by itself: the host either
 // exports what str_er_runtime_hint() names or calls str_er_apply_runtime_hint() -- an explicit opt-in -- before it initialises HIP.
+int str_er_tie_stats(const str_er_ctx *c, uint64_t *planes_walked, double *walk_ms_total, int32_t *host_threads)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (planes_walked) *planes_walked = c->n_replayed;
+    if (walk_ms_total) *walk_ms_total = c->walk_ms_total;
+    if (host_threads) *host_threads = flood_walk_threads();
+    return STR_ER_OK;
+}
+
 const char *str_er_runtime_hint(void) { return "GPU_MAX_HW_QUEUES=16"; }
 int str_er_apply_runtime_hint(void)
 {
@@ -1453,6 +1500,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_total, 4));
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
     A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
+    A(dev_alloc(c, c->d_tie_slot_plane, (size_t)TIE_SLOTS));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||

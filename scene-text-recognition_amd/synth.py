@@ -8,6 +8,11 @@ function of (kind, seed, width, height) and can be regenerated anywhere with num
             independent per-colour offsets.  Never reaches the sentinel level (p >= 252).
   S-noise : iid uniform 0..255 (stress; hits the level-32 sentinel of SURVEY A.2 constantly).
   S-flat  : constant 128.
+  S-ties  : S-text plus, in every third frame, one "double L" glyph: a grey box holding two dark L-shaped strokes (left + bottom,
+            top + right) that do not touch, each with a core one level below its rim.  Both strokes' boxes cover more than 0.7 of
+            the grey box, so both child chains pass the overlap test of non_maximum_supression (src/ER.cpp:455-462) on the same
+            parent: an NMS sibling tie whose two outcomes give DIFFERENT pools -- the case the reference decides by its flood
+            order.  About one plane in forty (pyr3x8: the Y planes of the first levels of those frames) needs the order walked.
 """
 from __future__ import annotations
 
@@ -83,7 +88,41 @@ def stext_bgr(seed: int, w: int, h: int) -> np.ndarray:
     return np.clip(img, 0, 251).astype(np.uint8)
 
 
-KINDS = {"text": stext_bgr, "noise": snoise_bgr, "flat": sflat_bgr}
+def _erode4(m: np.ndarray) -> np.ndarray:
+    e = m.copy()
+    e[1:, :] &= m[:-1, :]; e[:-1, :] &= m[1:, :]; e[:, 1:] &= m[:, :-1]; e[:, :-1] &= m[:, 1:]
+    e[0, :] = e[-1, :] = False; e[:, 0] = e[:, -1] = False
+    return e
+
+
+def draw_tie_glyph(img: np.ndarray, x0: int, y0: int, gw: int, gh: int, st1: int, st2: int, fill: int, box: int = 80, moat: int = 150) -> None:
+    """The double-L glyph of S-ties into img[..., :] (all colour channels alike) with its top-left corner at (x0, y0)."""
+    h, w = img.shape[:2]
+    img[max(0, y0 - 3):min(h, y0 + gh + 3), max(0, x0 - 3):min(w, x0 + gw + 3)] = moat      # keeps neighbouring glyphs out of the box's component
+    sub = img[y0:y0 + gh, x0:x0 + gw]
+    sub[...] = box
+    gap, m = 2, 1
+    l1 = np.zeros((gh, gw), bool)
+    l2 = np.zeros((gh, gw), bool)
+    l1[m:gh - m, m:m + st1] = True
+    l1[gh - m - st1:gh - m, m:gw - m - gap - st2] = True                 # left + bottom
+    l2[m:m + st2, m + st1 + gap:gw - m] = True
+    l2[m:gh - m - st1 - gap, gw - m - st2:gw - m] = True                 # top + right
+    for l in (l1, l2):
+        sub[l] = fill + 10
+        sub[_erode4(l)] = fill
+
+
+def sties_bgr(seed: int, w: int, h: int) -> np.ndarray:
+    img = stext_bgr(seed, w, h)
+    if seed % 3 == 0 and w >= 160 and h >= 160:
+        r = [int(v) for v in _hash(seed ^ 0x71E5, np.arange(6, dtype=np.uint64))]
+        gw, gh = 76 + r[0] % 36, 76 + r[1] % 36
+        draw_tie_glyph(img, r[2] % (w - gw), r[3] % (h - gh), gw, gh, 3 + r[4] % 3, 3 + (r[4] >> 8) % 3, 20 + r[5] % 30)
+    return img
+
+
+KINDS = {"text": stext_bgr, "noise": snoise_bgr, "flat": sflat_bgr, "ties": sties_bgr}
 
 
 def frames_bgr(kind: str, first_frame: int, n_frames: int, w: int, h: int) -> np.ndarray:

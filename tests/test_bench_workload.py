@@ -57,6 +57,32 @@ def test_bench_workload_pyr3x8(S, cascade_paths, oracle, oracle_cascades):
     f.close()
 
 
+def test_bench_workload_ties(S, cascade_paths, oracle, oracle_cascades):
+    """`bench.py --kind ties` / the `nms_ties_leg` of the default run: S-ties frames 2 and 5 (every third frame carries the double-L
+    glyph).  Their Y planes have an NMS sibling tie with two different outcomes; the library must give the pool of the reference's
+    flood order (the oracle's own child lists) -- and it must have needed the host walk for it."""
+    levels, mask = 8, 0x07
+    f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=3, n_pyr_levels=levels, channel_mask=mask))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    frames = np.stack([S.synth.sties_bgr(S.synth.frame_seed(i), W, H) for i in (2, 4, 5)])
+    before = f.tie_stats()["planes_walked"]
+    res = f.text_detect(frames)
+    pyr = {}
+    for fr in range(3):
+        six = oracle.compute_channels(frames[fr])
+        for c in range(3):
+            pyr[(fr, c)] = oracle.pyramid(six[c], levels)
+    _check_all_planes(oracle, oracle_cascades, res, lambda p: pyr[(p.frame, p.ch)][p.pyr])
+    st = f.tie_stats()
+    assert st["planes_walked"] - before >= 2 and st["walk_ms_total"] > 0 and 1 <= st["host_threads"] <= 32
+    # the tie is real: under the two key rules the oracle's pools of the glyph's plane differ
+    t = oracle.tree_extract(pyr[(0, 0)][0])
+    p1, _ = oracle.nms(t, H, W, sibling_mode=1)
+    p2, a2 = oracle.nms(t, H, W, sibling_mode=2)
+    assert a2 >= 1 and sorted(p1.tolist()) != sorted(p2.tolist())
+    f.close()
+
+
 def test_bench_workload_native6(S, cascade_paths, oracle, oracle_cascades):
     """`bench.py --workload native6`: the reference's six planes (src/ER.cpp:114-128), all 18 planes of the three frames."""
     f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=3))
@@ -74,7 +100,7 @@ def test_bench_workload_config3_ocr(S, cascade_paths, oracle, oracle_cascades):
     of a pyr3x8 S-text frame; detection compared exactly, OCR probabilities within 1e-4 of the oracle's libsvm restatement."""
     from oracle.oracle import OracleSVM
     levels, mask = 8, 0x07
-    model = gzip.open(os.path.join(GOLDEN, "ocr_synth.model.gz")).read()
+    model = gzip.open(S.cascade_io.ocr_model_path()).read()
     import tempfile
     mp = os.path.join(tempfile.mkdtemp(), "ocr_synth.model")
     with open(mp, "wb") as fh:

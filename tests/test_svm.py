@@ -16,9 +16,9 @@ TOL = 1e-4
 
 
 @pytest.fixture(scope="module")
-def model_path(tmp_path_factory):
+def model_path(tmp_path_factory, S):
     p = tmp_path_factory.mktemp("svm") / "ocr_synth.model"
-    p.write_bytes(gzip.open(os.path.join(GOLDEN, "ocr_synth.model.gz")).read())
+    p.write_bytes(gzip.open(S.cascade_io.ocr_model_path()).read())
     return str(p)
 
 

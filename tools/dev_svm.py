@@ -3,7 +3,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import str_er_amd as S
-tmp = tempfile.mkdtemp(); mp = os.path.join(tmp, 'm'); open(mp, 'wb').write(gzip.open(os.path.join(ROOT, 'tests/golden/ocr_synth.model.gz')).read())
+tmp = tempfile.mkdtemp(); mp = os.path.join(tmp, 'm'); open(mp, 'wb').write(gzip.open(os.path.join(ROOT, 'scene-text-recognition_amd/data/ocr_synth.model.gz')).read())
 z = np.load(os.path.join(ROOT, 'tests/golden/svm_vectors.npz'))
 f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=64, max_height=64, max_frames=1)
 f.load_svm_model(mp, 1800)
