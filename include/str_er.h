@@ -409,17 +409,30 @@ void str_er_result_free(str_er_result *r);
 /* ---- one plane in strips over several GPUs (no reference counterpart) -----------------------
  * The level-0 planes of ONE frame cut into n_strips bands of tile rows.  Every participant calls str_er_strip_extract with the
  * frame and its strip number: compute_channels, the tile trees of the strip and the seams inside it, for every channel of the
- * context; *blob (malloc'ed, str_er_strip_free) holds the strip's node records and the node of every pixel of its first and
- * last row -- plain bytes, to be sent to the plane's owner by any transport.  The owner calls str_er_strip_merge with the
- * frame and all n_strips blobs (in strip order): records behind one another, seams across the cuts joined, then the usual
- * passes; the result is the one str_er_detect_bgr gives for the frame (same planes, same records).  Contexts need
- * n_pyr_levels = 1 and equal parameters on all participants.                                                                  */
+ * context; the blob holds the strip's node records and the node of every pixel of its first and last row -- plain bytes, to be
+ * brought to the plane's owner by any transport.  The owner calls str_er_strip_merge with the frame and all n_strips blobs (in
+ * strip order): records behind one another, seams across the cuts joined, then the usual passes; the result is the one
+ * str_er_detect_bgr gives for the level-0 planes of the frame (same planes, same records).  Equal parameters on all participants;
+ * a context with a pyramid strips its level-0 planes only (the smaller planes are dealt out whole: str_er_detect_bgr_planes).
+ * A blob is checked before it is used (sizes against the headers, rows against the cut, every node id against its strip's record
+ * count): a damaged or foreign one gives STR_ER_EFORMAT, never an out-of-range device access.
+ *   _extract      *blob is malloc'ed host memory (str_er_strip_free)
+ *   _extract_dev  *d_blob is a device buffer of the context, valid until its next strip call: with str_er_comm_allgather_bytes
+ *                 (STR_ER_MEM_DEVICE in and out) over an RCCL communicator a blob goes from GPU to GPU without touching a host
+ *   _merge        host blobs, all channels;  _merge_ex: blobs in host or device memory (blob_kind), and plane_select (one byte per
+ *                 channel of the context, or NULL = all): the channels THIS owner puts together -- different planes of one frame
+ *                 can have different owners                                                                                     */
 int  str_er_strip_extract(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind,
                           int32_t strip, int32_t n_strips, void **blob, int64_t *blob_bytes);
+int  str_er_strip_extract_dev(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind,
+                              int32_t strip, int32_t n_strips, const void **d_blob, int64_t *blob_bytes);
 void str_er_strip_free(void *blob);
 int  str_er_strip_merge(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind,
                         const void *const *blobs, const int64_t *blob_bytes, int32_t n_strips, uint32_t stages,
                         str_er_result **out);
+int  str_er_strip_merge_ex(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind,
+                           const void *const *blobs, const int64_t *blob_bytes, int blob_kind, int32_t n_strips,
+                           const uint8_t *plane_select, uint32_t stages, str_er_result **out);
 
 /* ---- multi-GPU: the one exchange of the path ------------------------------------------
  * One process per GPU; frames (or planes) are dealt out to the ranks and only the candidate records travel, where the
@@ -449,6 +462,14 @@ int  str_er_gather_cands(str_er_comm *c, const str_er_cand *local, int32_t n_loc
 int  str_er_gather_last(str_er_comm *c, str_er_ctx *ctx, uint32_t frame_offset, str_er_cand **all, int32_t *n_all,
                         int32_t *counts);
 void str_er_gather_free(str_er_cand *p);
+/* Collective: a variable-length all-gather of plain bytes (the strip blobs of str_er_strip_extract).  `local` is host or device memory
+ * (in_kind).  out_kind STR_ER_MEM_HOST: *all is malloc'ed (str_er_comm_free) and holds the contributions back to back; STR_ER_MEM_DEVICE:
+ * *all points into a device buffer of the communicator, valid until its next collective -- with an RCCL communicator and device input
+ * the bytes never touch the host.  starts[k] / sizes[k] (world entries each): where rank k's bytes are in *all.
+ * A rank whose arguments are bad still joins the exchange of the sizes: every rank then returns an error, none is left waiting.      */
+int  str_er_comm_allgather_bytes(str_er_comm *c, const void *local, int64_t n_local, int in_kind, int out_kind,
+                                 void **all, int64_t *starts, int64_t *sizes);
+void str_er_comm_free(void *p);
 
 /* ---- introspection / measurement --------------------------------------------------- */
 /* Per-kernel-group GPU time of the LAST detect call, measured with HIP events on the

@@ -121,6 +121,11 @@ def load_library():
     L.str_er_strip_free.argtypes = [vp]
     L.str_er_strip_free.restype = None
     L.str_er_strip_merge.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int, vp, vp, C.c_int32, C.c_uint32, C.POINTER(vp)]
+    L.str_er_strip_extract_dev.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.str_er_strip_merge_ex.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int32, vp, C.c_uint32, C.POINTER(vp)]
+    L.str_er_comm_allgather_bytes.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.str_er_comm_free.argtypes = [vp]
+    L.str_er_comm_free.restype = None
     L.str_er_detect_planes.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int,
                                        C.c_uint32, C.POINTER(vp)]
     L.str_er_compute_channels.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]
@@ -464,6 +469,34 @@ class ERFilter:
                                               stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
         return self._collect(rh)
 
+    def strip_extract_dev(self, frame: np.ndarray, strip: int, n_strips: int):
+        """The same, the blob left in a device buffer of this context (valid until its next strip call): (device address, bytes)."""
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, _ = a.shape
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.L.str_er_strip_extract_dev(self.h, _np_ptr(a), w, h, 3 * w, MEM_HOST, strip, n_strips, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def strip_merge_ex(self, frame: np.ndarray, blobs, sizes=None, device_blobs: bool = False, plane_select=None, stages: int = STAGE_ALL,
+                       want_nodes: bool = False) -> Result:
+        """str_er_strip_merge_ex: blobs = bytes objects (host) or device addresses with `sizes` (device_blobs=True); plane_select =
+        one flag per channel of the context: the channels this owner puts together (None: all)."""
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, _ = a.shape
+        k = len(blobs)
+        if device_blobs:
+            ptrs = (C.c_void_p * k)(*[C.c_void_p(int(x)) for x in blobs])
+            szs = (C.c_int64 * k)(*[int(x) for x in sizes])
+        else:
+            bufs = [C.create_string_buffer(bytes(x), len(x)) for x in blobs]
+            ptrs = (C.c_void_p * k)(*[C.cast(x, C.c_void_p) for x in bufs])
+            szs = (C.c_int64 * k)(*[len(x) for x in blobs])
+        sel = np.ascontiguousarray(plane_select, dtype=np.uint8) if plane_select is not None else None
+        rh = C.c_void_p()
+        self._check(self.L.str_er_strip_merge_ex(self.h, _np_ptr(a), w, h, 3 * w, MEM_HOST, ptrs, szs, MEM_DEVICE if device_blobs else MEM_HOST, k,
+                                                 _np_ptr(sel) if sel is not None else None, stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
+        return self._collect(rh)
+
     def detect_bgr_device(self, dptr: int, w: int, h: int, n_frames: int, stages: int = STAGE_ALL,
                           stride: Optional[int] = None, frame_pitch: Optional[int] = None) -> Result:
         """Same, for frames already resident in HBM (dptr = device address)."""
@@ -749,6 +782,29 @@ class Comm:
         counts = (C.c_int32 * self.world)()
         rc = self.L.str_er_gather_last(self.h, erf.h, frame_offset, C.byref(p), C.byref(n), counts)
         return self._take(rc, p, n, counts)
+
+    def allgather_bytes(self, data, device_in: bool = False, device_out: bool = False):
+        """Collective, variable length (str_er_comm_allgather_bytes).  data: bytes / uint8 array, or (device address, n) with
+        device_in.  Host output: list of `world` bytes objects; device output: (base address, starts, sizes) -- the communicator's
+        buffer, valid until its next collective."""
+        if device_in:
+            ptr, n = C.c_void_p(int(data[0])), int(data[1])
+            keep = None
+        else:
+            keep = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8).reshape(-1)
+            ptr, n = (_np_ptr(keep) if len(keep) else None), len(keep)
+        out = C.c_void_p()
+        starts, sizes = (C.c_int64 * self.world)(), (C.c_int64 * self.world)()
+        rc = self.L.str_er_comm_allgather_bytes(self.h, ptr, n, MEM_DEVICE if device_in else MEM_HOST, MEM_DEVICE if device_out else MEM_HOST,
+                                                C.byref(out), starts, sizes)
+        if rc != 0:
+            raise StrErError(rc, (self.L.str_er_comm_last_error(self.h) or b"").decode())
+        if device_out:
+            return int(out.value or 0), [int(v) for v in starts], [int(v) for v in sizes]
+        try:
+            return [C.string_at(out.value + starts[r], sizes[r]) if sizes[r] else b"" for r in range(self.world)]
+        finally:
+            self.L.str_er_comm_free(out)
 
     def close(self) -> None:
         if getattr(self, "h", None):

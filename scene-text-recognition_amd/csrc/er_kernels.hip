@@ -1390,30 +1390,57 @@ void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 // The records of a strip arrive with ids, keys and rows local to the strip (a strip is extracted like a plane of its own: the tile
 // kernel knows nothing of the rows above it).  `delta` makes the ids those of the whole plane (the strip's records sit behind those
 // of the strips above it), key_add = first row * width and y_add = first row put keys and boxes into the whole plane's coordinates.
-__global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add)
+__global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t *bad)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         NodeRec r = rec[i];
-        if (r.par != NONE) r.par = PAR_MAKE(PAR_LVL(r.par), PAR_ID(r.par) + delta);
+        if (r.par != NONE) {
+            // (the records came from another process: a parent outside the strip's records must not become a device index)
+            if (PAR_ID(r.par) >= n) { atomicOr(bad, 1u); r.par = NONE; }
+            else r.par = PAR_MAKE(PAR_LVL(r.par), PAR_ID(r.par) + delta);
+        }
         r.key += key_add;                 // (bits 0..23; the plane has fewer than 2^24 pixels, the level byte is not reached)
         r.y0 += y_add; r.y1 += y_add;
         rec[i] = r;
         aux[i] = 0;
     }
 }
-// ... and the pixel pairs across the cut between two strips are joined like any other seam
-__global__ __launch_bounds__(256) void k_connect_pairs(NodeRec *nr, const uint32_t *pairs, uint32_t n_pairs)
+// ... and the pixel pairs across the cut between two strips are joined like any other seam: bot[x] / top[x] = strip-local node of pixel x of
+// the last row above / the first row below the cut (NONE: a wall).  Neighbouring lanes very often carry the same pair (a flat region
+// along the cut): only the first lane of such a run connects.
+__global__ __launch_bounds__(256) void k_connect_cut(NodeRec *nr, const uint32_t *bot, const uint32_t *top, uint32_t w, uint32_t base_lo, uint32_t n_lo,
+                                                     uint32_t base_hi, uint32_t n_hi, uint32_t *bad)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_pairs) node_connect(nr, pairs[2 * i], pairs[2 * i + 1]);
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t a = NONE, b = NONE;
+    if (x < w) {
+        a = bot[x]; b = top[x];
+        if ((a != NONE && a >= n_lo) || (b != NONE && b >= n_hi)) { atomicOr(bad, 1u); a = b = NONE; }
+    }
+    const uint32_t pa = __shfl_up(a, 1), pb = __shfl_up(b, 1);
+    const bool dup = (threadIdx.x & 63) != 0 && pa == a && pb == b;
+    if (a != NONE && b != NONE && !dup) node_connect(nr, a + base_lo, b + base_hi);
 }
-void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add)
+// node (strip-local record index) of every pixel of one border row of a strip: seam map entry + first record of the pixel's tile
+__global__ __launch_bounds__(256) void k_strip_border_ids(const uint16_t *seam_row, const uint32_t *tile_nbase_row, int w, uint32_t *out)
 {
-    if (n) hipLaunchKernelGGL(k_rebase_records, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, rec, aux, n, delta, key_add, y_add);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const uint32_t e = seam_row[x], nb = tile_nbase_row[x / TILE_W];
+    out[x] = (e == 0xFFFFu || nb == NONE) ? NONE : nb + e;
 }
-void launch_connect_pairs(hipStream_t s, NodeRec *plane_rec, const uint32_t *pairs, uint32_t n_pairs)
+void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t *bad)
 {
-    if (n_pairs) hipLaunchKernelGGL(k_connect_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, s, plane_rec, pairs, n_pairs);
+    if (n) hipLaunchKernelGGL(k_rebase_records, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, rec, aux, n, delta, key_add, y_add, bad);
+}
+void launch_connect_cut(hipStream_t s, NodeRec *plane_rec, const uint32_t *bot, const uint32_t *top, uint32_t w, uint32_t base_lo, uint32_t n_lo, uint32_t base_hi,
+                        uint32_t n_hi, uint32_t *bad)
+{
+    if (w) hipLaunchKernelGGL(k_connect_cut, dim3((w + 255) / 256), dim3(256), 0, s, plane_rec, bot, top, w, base_lo, n_lo, base_hi, n_hi, bad);
+}
+void launch_strip_border_ids(hipStream_t s, const uint16_t *seam_row, const uint32_t *tile_nbase_row, int w, uint32_t *out)
+{
+    if (w > 0) hipLaunchKernelGGL(k_strip_border_ids, dim3((w + 255) / 256), dim3(256), 0, s, seam_row, tile_nbase_row, w, out);
 }
 
 // ------------------------------------------------------------------------------------

@@ -135,6 +135,8 @@ struct str_er_ctx {
     bool replay_on_gpu = false;                       // STR_ER_REPLAY=gpu: walk the flood with k_flood_order instead of a host core
     uint16_t *d_cand_plane = nullptr, *d_cand_plane2 = nullptr;
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    uint8_t *d_strip_out = nullptr, *d_strip_in = nullptr; size_t strip_out_cap = 0, strip_in_cap = 0;   // strip blobs: made here / uploaded for a merge
+    uint32_t *d_strip_flag = nullptr;                 // a strip blob named a node outside its records
     std::vector<void *> allocs;
 
     // pinned host mirrors
@@ -914,6 +916,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     // A batch whose planes outgrow their shares of the tables is laid out again with larger shares and repeated.  Every repeat raises a
     // share (or fails), and a share stops at one entry per pixel: the repeats end; `attempt` only guards against a slip in that argument.
     if (attempt > 24) return fail(c, STR_ER_ECAPACITY, "the batch was repeated 24 times with growing tables and still does not fit (internal error)");
+    c->last_valid = false;             // (str_er_gather_last: the candidate array is being rewritten, or re-allocated)
     Batch b = b_in;
     assign_node_records(b, c->node_share);
     assign_tables(b, c);
@@ -1379,6 +1382,8 @@ void str_er_destroy(str_er_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_strip_out) (void)hipFree(c->d_strip_out);
+    if (c->d_strip_in) (void)hipFree(c->d_strip_in);
     if (c->d_replay) (void)hipFree(c->d_replay);
     if (c->h_replay) (void)hipHostFree(c->h_replay);
     if (c->h_tie) (void)hipHostFree(c->h_tie);
@@ -1501,6 +1506,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
     A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
     A(dev_alloc(c, c->d_tie_slot_plane, (size_t)TIE_SLOTS));
+    A(dev_alloc(c, c->d_strip_flag, (size_t)1));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
@@ -1654,20 +1660,43 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
 // one plane in horizontal strips over several GPUs.
 //
 // Whole planes are the unit the path shards by (8(e)); one large frame has few of them and the three level-0 planes bound the
-// speed-up (3840x2160, 12 levels: 6.0x on 8 GPUs).  The tile kernel is 60 % of the work and has no data flow between tiles, so
-// a plane can be cut into strips of tile rows: every GPU builds the tile trees of its strip and joins the seams INSIDE the strip
-// (str_er_strip_extract); what crosses the wire is the strip's node records (32 bytes per exported node: about a quarter of the
-// strip's pixel bytes on text-like frames) and the node of every pixel of its first / last row.  The owner of the plane puts the
+// speed-up (3840x2160, 12 levels: 6.0x on 8 GPUs).  The tile kernel is the largest part of the work and has no data flow between
+// tiles, so a plane can be cut into strips of tile rows: every GPU builds the tile trees of its strip and joins the seams INSIDE the
+// strip (str_er_strip_extract); what crosses the wire is the strip's node records (32 bytes per exported node: about a quarter of
+// the strip's pixel bytes on text-like frames) and the node of every pixel of its first / last row.  The owner of the plane puts the
 // strips' records behind one another, makes the ids plane-wide, joins the pixel pairs across every cut with the same connect as any
 // other seam and carries on with the usual passes -- resolve, accumulate, prune, NMS, classify (str_er_strip_merge).  The node
 // set of a component tree does not depend on the order in which tiles are joined, so the result is that of the unsplit plane.
-// Level 0 only (contexts with n_pyr_levels = 1); the smaller planes of a pyramid are dealt out whole.
+// Strips are cut from the level-0 planes (in a pyramid context too: its smaller planes are dealt out whole, str_er_detect_bgr_planes).
+// The blob is assembled ON THE DEVICE and can stay there: with an RCCL communicator (str_er_comm_allgather_bytes) it goes from the
+// extracting GPU's memory into the owner's without touching a host; the host-memory entry points copy it once.
+//
+//   blob = StripHeader | StripPlane x n_planes | per plane: records | per plane: node of every pixel of the first row (if the plane
+//          goes on above), of the last row (if it goes on below) -- sections start on 256-byte boundaries
 // =================================================================================================
 namespace {
 
 constexpr uint32_t STRIP_MAGIC = 0x50525453u;      // "STRP"
+constexpr uint32_t STRIP_VERSION = 2;
 struct StripHeader { uint32_t magic, version, w, h, strip, n_strips, row0 /* plane row of the records' row 0 */, rows, n_planes, thresh_step, channel_mask, reserved; };
 struct StripPlane { uint32_t ch, n_nodes, n_walls, start_node, has_top, has_bot; };      // (records: ids, keys and rows local to the strip)
+struct StripLayout { size_t head = 0, total = 0; std::vector<size_t> rec, top, bot; };
+
+StripLayout strip_layout(const std::vector<StripPlane> &sp, uint32_t w)
+{
+    StripLayout L;
+    const size_t n = sp.size();
+    L.head = sizeof(StripHeader) + n * sizeof(StripPlane);
+    size_t at = align_up(L.head, 256);
+    L.rec.resize(n); L.top.resize(n); L.bot.resize(n);
+    for (size_t k = 0; k < n; ++k) { L.rec[k] = at; at = align_up(at + (size_t)sp[k].n_nodes * sizeof(NodeRec), 256); }
+    for (size_t k = 0; k < n; ++k) {
+        L.top[k] = at; if (sp[k].has_top) at = align_up(at + 4 * (size_t)w, 256);
+        L.bot[k] = at; if (sp[k].has_bot) at = align_up(at + 4 * (size_t)w, 256);
+    }
+    L.total = at;
+    return L;
+}
 
 // channels of one BGR frame into the level-0 planes of the pixel pool (what str_er_detect_bgr does for level 0)
 int frame_to_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int &pstride, size_t &psize)
@@ -1688,18 +1717,28 @@ int frame_to_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int
     return STR_ER_OK;
 }
 
+int ensure_strip_buf(str_er_ctx *c, uint8_t *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return STR_ER_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    need += need / 4;
+    if (hipMalloc(reinterpret_cast<void **>(&p), need) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (strip blob)");
+    cap = need;
+    return STR_ER_OK;
+}
+
 } // namespace
 
-int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
-                         void **blob, int64_t *blob_bytes)
+int str_er_strip_extract_dev(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
+                             const void **d_blob, int64_t *blob_bytes)
 {
     if (!c) return STR_ER_EINVAL;
-    if (!bgr || !blob || !blob_bytes || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 || strip < 0 || strip >= n_strips)
+    if (!bgr || !d_blob || !blob_bytes || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 || strip < 0 || strip >= n_strips)
         return fail(c, STR_ER_EINVAL, "bad strip arguments");
-    if (c->prm.n_pyr_levels != 1) return fail(c, STR_ER_EINVAL, "strips are cut from level-0 planes: the context must have n_pyr_levels = 1");
     if (w > c->prm.max_width || h > c->prm.max_height) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
-    *blob = nullptr; *blob_bytes = 0;
+    *d_blob = nullptr; *blob_bytes = 0;
     HIP_TRY(c, hipSetDevice(c->prm.device));
+    c->last_valid = false;
     int pstride = 0; size_t psize = 0;
     int rc = frame_to_planes(c, bgr, w, h, stride, mem_kind, pstride, psize);
     if (rc != STR_ER_OK) return rc;
@@ -1708,16 +1747,16 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
     const int r0 = t0 * TILE_H, r1 = std::min(h, t1 * TILE_H), rows = std::max(0, r1 - r0);
     const size_t npl = c->chans.size();
     std::vector<StripPlane> sp(npl);
-    std::vector<std::vector<uint8_t>> recs(npl);
-    std::vector<std::vector<uint32_t>> top(npl), bot(npl);
     for (size_t k = 0; k < npl; ++k) { sp[k] = StripPlane{}; sp[k].ch = (uint32_t)c->chans[k]; sp[k].start_node = NONE; }
+    hipStream_t s = c->stream;
+    Batch b;
+    const bool ptop = rows > 0 && r0 > 0, pbot = rows > 0 && r1 < h;
     if (rows > 0) {
         // A strip is laid out as a plane with a PHANTOM tile row above and / or below wherever the plane goes on: the strip's first /
         // last row is then an ordinary tile seam -- its nodes stay open and their ids are in the seam map -- and the tile kernel needs to
-        // know nothing about strips (no strip flags, no second code path in the kernel that is 58 % of the step).  Below, the phantom row is simply
+        // know nothing about strips (no strip flags, no second code path in the largest kernel of the step).  Below, the phantom row is simply
         // past the image (one tile row more than the height needs).  Above, the strip is copied behind TILE_H rows of pixels at the
         // sentinel level, which the flood never enters -- hence the restriction to thresh_steps that have such a level.
-        const bool ptop = r0 > 0, pbot = r1 < h;
         const size_t pad_plane = align_up((size_t)pstride * (size_t)(rows + TILE_H), 256);
         if (ptop) {
             if ((int)std::lrintf(255.0f * (float)(1.0 / (double)c->prm.thresh_step)) != 255 / c->prm.thresh_step + 1)
@@ -1725,15 +1764,14 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
             rc = ensure_scratch(c, pad_plane * npl);
             if (rc != STR_ER_OK) return rc;
         }
-        Batch b;
         for (size_t k = 0; k < npl; ++k) {
             const int ch = c->chans[k];
             const uint8_t *src = c->d_pix + (size_t)(ch % 3) * psize + (size_t)r0 * pstride;
             const uint8_t *lay = src;
             if (ptop) {
                 uint8_t *dst = static_cast<uint8_t *>(c->d_scratch) + k * pad_plane;
-                HIP_TRY(c, hipMemsetAsync(dst, ch >= 3 ? 0x00 : 0xFF, (size_t)TILE_H * pstride, c->stream));      // (inverted channels read pixel ^ 0xFF)
-                HIP_TRY(c, hipMemcpyAsync(dst + (size_t)TILE_H * pstride, src, (size_t)rows * pstride, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipMemsetAsync(dst, ch >= 3 ? 0x00 : 0xFF, (size_t)TILE_H * pstride, s));      // (inverted channels read pixel ^ 0xFF)
+                HIP_TRY(c, hipMemcpyAsync(dst + (size_t)TILE_H * pstride, src, (size_t)rows * pstride, hipMemcpyDeviceToDevice, s));
                 lay = dst;
             }
             add_plane(b, lay, w, rows + (ptop ? TILE_H : 0) + (pbot ? TILE_H : 0), pstride, ch >= 3, 0, ch, 0);
@@ -1742,8 +1780,7 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
             pd.n_pairs = pd.n_hpairs + (uint32_t)pd.h * (uint32_t)(pd.tiles_x - 1);
         }
         const DetectParams dp = make_dp(c);
-        hipStream_t s = c->stream;
-        for (;;) {
+        for (int attempt = 0;; ++attempt) {
             assign_node_records(b, c->node_share);
             if (b.nodes > c->node_slots) { rc = alloc_node_records(c, b.nodes + b.nodes / 8); if (rc != STR_ER_OK) return rc; }
             if (b.seam > c->seam_slots || b.n_tiles > c->tile_slots || b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "strip exceeds the context capacity");
@@ -1765,95 +1802,125 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
             for (size_t k = 0; k < npl; ++k)
                 if (c->h_ctr[k].overflow & 8u) need = std::max(need, (double)c->h_ctr[k].n_nodes / (double)((size_t)b.planes[k].tiles_x * b.planes[k].tiles_y * TILE_PX));
             if (need == 0) break;
-            if (c->node_share >= 1.0) return fail(c, STR_ER_ECAPACITY, "node records exhausted at one record per pixel (internal error)");
+            if (c->node_share >= 1.0 || attempt > 24) return fail(c, STR_ER_ECAPACITY, "node records exhausted at one record per pixel (internal error)");
             c->node_share = std::min(1.0, std::max(c->node_share * 1.5, need * 1.25));
         }
-        // what leaves the GPU: the records, and the node of every pixel of the first / last row (seam map: index in the tile's
-        // records; tile_nbase: the tile's first record)
-        hipStream_t s2 = c->stream;
         for (size_t k = 0; k < npl; ++k) {
-            const PlaneDesc &pd = b.planes[k];
-            const PlaneCtr  &pc = c->h_ctr[k];
+            const PlaneCtr &pc = c->h_ctr[k];
             sp[k].n_nodes = pc.n_nodes; sp[k].n_walls = pc.n_walls; sp[k].start_node = r0 == 0 ? pc.start_node : NONE;
             sp[k].has_top = ptop; sp[k].has_bot = pbot;
-            recs[k].resize((size_t)pc.n_nodes * sizeof(NodeRec));
-            if (pc.n_nodes) HIP_TRY(c, hipMemcpyAsync(recs[k].data(), c->na.rec + pd.node_base, recs[k].size(), hipMemcpyDeviceToHost, s2));
-            // seam map: boundary j holds pixel row (j+1)*TILE_H - 1 at [2j * w, +w) and pixel row (j+1)*TILE_H at [(2j+1) * w, +w)
-            std::vector<uint16_t> ext(2 * (size_t)w, 0xFFFFu);
-            std::vector<uint32_t> nb_top((size_t)pd.tiles_x, NONE), nb_bot((size_t)pd.tiles_x, NONE);
-            const int jt = 0, jb = pd.tiles_y - 2;               // the seams under the phantom row above / over the phantom row below
-            if (ptop) {
-                HIP_TRY(c, hipMemcpyAsync(ext.data(), c->d_seam + pd.seam_base + (size_t)(2 * jt + 1) * w, 2 * (size_t)w, hipMemcpyDeviceToHost, s2));
-                HIP_TRY(c, hipMemcpyAsync(nb_top.data(), c->d_tile_nbase + pd.tile_base + (size_t)(jt + 1) * pd.tiles_x, 4 * nb_top.size(), hipMemcpyDeviceToHost, s2));
-            }
-            if (pbot) {
-                HIP_TRY(c, hipMemcpyAsync(ext.data() + w, c->d_seam + pd.seam_base + (size_t)(2 * jb) * w, 2 * (size_t)w, hipMemcpyDeviceToHost, s2));
-                HIP_TRY(c, hipMemcpyAsync(nb_bot.data(), c->d_tile_nbase + pd.tile_base + (size_t)jb * pd.tiles_x, 4 * nb_bot.size(), hipMemcpyDeviceToHost, s2));
-            }
-            HIP_TRY(c, hipStreamSynchronize(s2));
-            auto ids = [&](const uint16_t *row, const std::vector<uint32_t> &nb, std::vector<uint32_t> &out) {
-                out.resize((size_t)w);
-                for (int x = 0; x < w; ++x) {
-                    const uint32_t base = nb[(size_t)(x / TILE_W)];
-                    out[(size_t)x] = (row[x] == 0xFFFFu || base == NONE) ? NONE : base + row[x];
-                }
-            };
-            if (ptop) ids(ext.data(), nb_top, top[k]);
-            if (pbot) ids(ext.data() + w, nb_bot, bot[k]);
         }
     }
-    size_t bytes = sizeof(StripHeader);
-    for (size_t k = 0; k < npl; ++k) bytes += sizeof(StripPlane) + recs[k].size() + 4 * (top[k].size() + bot[k].size());
-    uint8_t *out = static_cast<uint8_t *>(std::malloc(bytes));
-    if (!out) return fail(c, STR_ER_ENOMEM, "strip blob allocation");
-    StripHeader hd{STRIP_MAGIC, 1u, (uint32_t)w, (uint32_t)h, (uint32_t)strip, (uint32_t)n_strips, (uint32_t)std::max(0, r0 - (r0 > 0 ? TILE_H : 0)), (uint32_t)rows, (uint32_t)npl,
-                   (uint32_t)c->prm.thresh_step, c->prm.channel_mask, 0u};
-    uint8_t *p = out;
-    std::memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
-    for (size_t k = 0; k < npl; ++k) {
-        std::memcpy(p, &sp[k], sizeof(StripPlane)); p += sizeof(StripPlane);
-        if (!recs[k].empty()) { std::memcpy(p, recs[k].data(), recs[k].size()); p += recs[k].size(); }
-        if (!top[k].empty()) { std::memcpy(p, top[k].data(), 4 * top[k].size()); p += 4 * top[k].size(); }
-        if (!bot[k].empty()) { std::memcpy(p, bot[k].data(), 4 * bot[k].size()); p += 4 * bot[k].size(); }
+    // what leaves the GPU, put together on the GPU: the records, and the node of every pixel of the first / last row (seam map:
+    // index in the tile's records; tile_nbase: the tile's first record)
+    const StripLayout L = strip_layout(sp, (uint32_t)w);
+    rc = ensure_strip_buf(c, c->d_strip_out, c->strip_out_cap, L.total);
+    if (rc != STR_ER_OK) return rc;
+    std::vector<uint8_t> head(L.head);
+    const StripHeader hd{STRIP_MAGIC, STRIP_VERSION, (uint32_t)w, (uint32_t)h, (uint32_t)strip, (uint32_t)n_strips, (uint32_t)std::max(0, r0 - (r0 > 0 ? TILE_H : 0)), (uint32_t)rows,
+                         (uint32_t)npl, (uint32_t)c->prm.thresh_step, c->prm.channel_mask, 0u};
+    std::memcpy(head.data(), &hd, sizeof(hd));
+    std::memcpy(head.data() + sizeof(hd), sp.data(), npl * sizeof(StripPlane));
+    HIP_TRY(c, hipMemcpyAsync(c->d_strip_out, head.data(), L.head, hipMemcpyHostToDevice, s));
+    for (size_t k = 0; k < npl && rows > 0; ++k) {
+        const PlaneDesc &pd = b.planes[k];
+        if (sp[k].n_nodes) HIP_TRY(c, hipMemcpyAsync(c->d_strip_out + L.rec[k], c->na.rec + pd.node_base, (size_t)sp[k].n_nodes * sizeof(NodeRec), hipMemcpyDeviceToDevice, s));
+        // seam map: boundary j holds pixel row (j+1)*TILE_H - 1 at [2j * w, +w) and pixel row (j+1)*TILE_H at [(2j+1) * w, +w)
+        const int jt = 0, jb = pd.tiles_y - 2;               // the seams under the phantom row above / over the phantom row below
+        if (ptop) launch_strip_border_ids(s, c->d_seam + pd.seam_base + (size_t)(2 * jt + 1) * w, c->d_tile_nbase + pd.tile_base + (size_t)(jt + 1) * pd.tiles_x, w,
+                                          reinterpret_cast<uint32_t *>(c->d_strip_out + L.top[k]));
+        if (pbot) launch_strip_border_ids(s, c->d_seam + pd.seam_base + (size_t)(2 * jb) * w, c->d_tile_nbase + pd.tile_base + (size_t)jb * pd.tiles_x, w,
+                                          reinterpret_cast<uint32_t *>(c->d_strip_out + L.bot[k]));
     }
-    *blob = out; *blob_bytes = (int64_t)bytes;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));        // (also: `head` is pageable memory)
+    *d_blob = c->d_strip_out; *blob_bytes = (int64_t)L.total;
+    return STR_ER_OK;
+}
+
+int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
+                         void **blob, int64_t *blob_bytes)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (!blob || !blob_bytes) return fail(c, STR_ER_EINVAL, "bad strip arguments");
+    *blob = nullptr; *blob_bytes = 0;
+    const void *d = nullptr;
+    int64_t n = 0;
+    const int rc = str_er_strip_extract_dev(c, bgr, w, h, stride, mem_kind, strip, n_strips, &d, &n);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t *out = static_cast<uint8_t *>(std::malloc((size_t)n));
+    if (!out) return fail(c, STR_ER_ENOMEM, "strip blob allocation");
+    if (hipMemcpy(out, d, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { std::free(out); return fail(c, STR_ER_EHIP, "strip blob download"); }
+    *blob = out; *blob_bytes = n;
     return STR_ER_OK;
 }
 
 void str_er_strip_free(void *blob) { std::free(blob); }
 
-int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
-                       const int64_t *blob_bytes, int32_t n_strips, uint32_t stages, str_er_result **out)
+int str_er_strip_merge_ex(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
+                          const int64_t *blob_bytes, int blob_kind, int32_t n_strips, const uint8_t *plane_select, uint32_t stages, str_er_result **out)
 {
     if (!c) return STR_ER_EINVAL;
-    if (!bgr || !blobs || !blob_bytes || !out || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1) return fail(c, STR_ER_EINVAL, "bad strip arguments");
-    if (c->prm.n_pyr_levels != 1) return fail(c, STR_ER_EINVAL, "strips are cut from level-0 planes: the context must have n_pyr_levels = 1");
+    if (!bgr || !blobs || !blob_bytes || !out || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 ||
+        (blob_kind != STR_ER_MEM_HOST && blob_kind != STR_ER_MEM_DEVICE))
+        return fail(c, STR_ER_EINVAL, "bad strip arguments");
     if (w > c->prm.max_width || h > c->prm.max_height) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
     *out = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->prm.device));
     const size_t npl = c->chans.size();
-    struct View { StripPlane sp; const uint8_t *rec; const uint32_t *top, *bot; uint32_t row0; };
-    std::vector<std::vector<View>> view((size_t)n_strips, std::vector<View>(npl));
-    for (int sidx = 0; sidx < n_strips; ++sidx) {
-        const uint8_t *p = static_cast<const uint8_t *>(blobs[sidx]), *end = p + blob_bytes[sidx];
-        StripHeader hd;
-        if (!p || blob_bytes[sidx] < (int64_t)sizeof(hd)) return fail(c, STR_ER_EFORMAT, "strip blob too short");
-        std::memcpy(&hd, p, sizeof(hd)); p += sizeof(hd);
-        if (hd.magic != STRIP_MAGIC || hd.version != 1 || hd.w != (uint32_t)w || hd.h != (uint32_t)h || hd.n_strips != (uint32_t)n_strips ||
-            hd.strip != (uint32_t)sidx || hd.n_planes != npl || hd.thresh_step != (uint32_t)c->prm.thresh_step || hd.channel_mask != c->prm.channel_mask)
-            return fail(c, STR_ER_EFORMAT, "strip blob does not belong to this frame / context (strip " + std::to_string(sidx) + ")");
-        for (size_t k = 0; k < npl; ++k) {
-            View &v = view[(size_t)sidx][k];
-            v.row0 = hd.row0;
-            if (end - p < (int64_t)sizeof(StripPlane)) return fail(c, STR_ER_EFORMAT, "strip blob truncated");
-            std::memcpy(&v.sp, p, sizeof(StripPlane)); p += sizeof(StripPlane);
-            const size_t need = (size_t)v.sp.n_nodes * sizeof(NodeRec) + 4 * (size_t)w * ((v.sp.has_top ? 1 : 0) + (v.sp.has_bot ? 1 : 0));
-            if ((size_t)(end - p) < need || v.sp.ch != (uint32_t)c->chans[k]) return fail(c, STR_ER_EFORMAT, "strip blob truncated");
-            v.rec = p; p += (size_t)v.sp.n_nodes * sizeof(NodeRec);
-            v.top = v.sp.has_top ? reinterpret_cast<const uint32_t *>(p) : nullptr; p += v.sp.has_top ? 4 * (size_t)w : 0;
-            v.bot = v.sp.has_bot ? reinterpret_cast<const uint32_t *>(p) : nullptr; p += v.sp.has_bot ? 4 * (size_t)w : 0;
+    // the planes this call puts together (the others' strips are skipped: another owner merges them)
+    std::vector<size_t> sel;
+    for (size_t k = 0; k < npl; ++k) if (!plane_select || plane_select[k]) sel.push_back(k);
+    if (sel.empty()) return fail(c, STR_ER_EINVAL, "plane_select selects no plane");
+    // ---- the blobs: on the device (as they are, or uploaded once); their headers on the host, checked before anything is trusted ----
+    const size_t head_bytes = sizeof(StripHeader) + npl * sizeof(StripPlane);
+    struct View { StripHeader hd; std::vector<StripPlane> sp; StripLayout L; const uint8_t *d; };
+    std::vector<View> view((size_t)n_strips);
+    size_t up_total = 0;
+    for (int i = 0; i < n_strips; ++i) {
+        if (!blobs[i] || blob_bytes[i] < (int64_t)head_bytes) return fail(c, STR_ER_EFORMAT, "strip blob too short");
+        up_total += align_up((size_t)blob_bytes[i], 256);
+    }
+    if (blob_kind == STR_ER_MEM_HOST) {
+        const int rcb = ensure_strip_buf(c, c->d_strip_in, c->strip_in_cap, up_total);
+        if (rcb != STR_ER_OK) return rcb;
+    }
+    size_t up_at = 0;
+    const int ty_all = (h + TILE_H - 1) / TILE_H;
+    for (int i = 0; i < n_strips; ++i) {
+        View &v = view[(size_t)i];
+        std::vector<uint8_t> head(head_bytes);
+        if (blob_kind == STR_ER_MEM_HOST) {
+            std::memcpy(head.data(), blobs[i], head_bytes);
+            HIP_TRY(c, hipMemcpyAsync(c->d_strip_in + up_at, blobs[i], (size_t)blob_bytes[i], hipMemcpyHostToDevice, c->stream));
+            v.d = c->d_strip_in + up_at;
+            up_at += align_up((size_t)blob_bytes[i], 256);
+        } else {
+            HIP_TRY(c, hipMemcpy(head.data(), blobs[i], head_bytes, hipMemcpyDeviceToHost));
+            v.d = static_cast<const uint8_t *>(blobs[i]);
         }
+        std::memcpy(&v.hd, head.data(), sizeof(StripHeader));
+        const StripHeader &hd = v.hd;
+        if (hd.magic != STRIP_MAGIC || hd.version != STRIP_VERSION || hd.w != (uint32_t)w || hd.h != (uint32_t)h || hd.n_strips != (uint32_t)n_strips ||
+            hd.strip != (uint32_t)i || hd.n_planes != npl || hd.thresh_step != (uint32_t)c->prm.thresh_step || hd.channel_mask != c->prm.channel_mask)
+            return fail(c, STR_ER_EFORMAT, "strip blob does not belong to this frame / context (strip " + std::to_string(i) + ")");
+        // the rows the strip claims are the rows this cut gives it
+        const int s0 = (int)((int64_t)i * ty_all / n_strips), s1 = (int)((int64_t)(i + 1) * ty_all / n_strips);
+        const int r0 = s0 * TILE_H, r1 = std::min(h, s1 * TILE_H), rows = std::max(0, r1 - r0);
+        if (hd.rows != (uint32_t)rows || hd.row0 != (uint32_t)std::max(0, r0 - (r0 > 0 ? TILE_H : 0)))
+            return fail(c, STR_ER_EFORMAT, "strip blob: rows do not match the cut of the frame (strip " + std::to_string(i) + ")");
+        v.sp.resize(npl);
+        std::memcpy(v.sp.data(), head.data() + sizeof(StripHeader), npl * sizeof(StripPlane));
+        for (size_t k = 0; k < npl; ++k) {
+            const StripPlane &p = v.sp[k];
+            const bool top = rows > 0 && r0 > 0, bot = rows > 0 && r1 < h;
+            if (p.ch != (uint32_t)c->chans[k] || p.n_nodes >= (1u << 24) || (p.start_node != NONE && p.start_node >= p.n_nodes) ||
+                (p.has_top != 0) != top || (p.has_bot != 0) != bot || (rows == 0 && p.n_nodes != 0))
+                return fail(c, STR_ER_EFORMAT, "strip blob: inconsistent plane header (strip " + std::to_string(i) + ", plane " + std::to_string(k) + ")");
+        }
+        v.L = strip_layout(v.sp, (uint32_t)w);
+        if ((size_t)blob_bytes[i] != v.L.total) return fail(c, STR_ER_EFORMAT, "strip blob: size does not match its headers (strip " + std::to_string(i) + ")");
     }
     int pstride = 0; size_t psize = 0;
     c->n_ev = 0; c->profile.clear(); rec(c, "begin");
@@ -1861,75 +1928,70 @@ int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, 
     if (rc != STR_ER_OK) return rc;
     rec(c, "channels");
     Batch b;
-    for (int ch : c->chans) {
+    for (size_t k : sel) {
+        const int ch = c->chans[k];
         add_plane(b, c->d_pix + (size_t)(ch % 3) * psize, w, h, pstride, ch >= 3, 0, ch, 0);
         b.planes.back().color_pitch = (uint32_t)psize;
     }
-    b.planes_per_image = (int)npl;
+    b.planes_per_image = sel.size() == npl ? (int)npl : 0;       // (er_track / calc_color need all channels of the frame)
     // the records of all strips of a plane must fit the plane's share
-    std::vector<std::vector<uint32_t>> base(npl, std::vector<uint32_t>((size_t)n_strips + 1, 0));
+    const size_t ns = sel.size();
+    std::vector<std::vector<uint32_t>> base(ns, std::vector<uint32_t>((size_t)n_strips + 1, 0));
     double need = 0;
-    for (size_t k = 0; k < npl; ++k) {
-        for (int sidx = 0; sidx < n_strips; ++sidx) base[k][(size_t)sidx + 1] = base[k][(size_t)sidx] + view[(size_t)sidx][k].sp.n_nodes;
-        need = std::max(need, (double)base[k][(size_t)n_strips] / (double)((size_t)b.planes[k].tiles_x * b.planes[k].tiles_y * TILE_PX));
-        if (base[k][(size_t)n_strips] >= (1u << 24)) return fail(c, STR_ER_ECAPACITY, "more than 2^24 node records in one plane");
+    for (size_t j = 0; j < ns; ++j) {
+        for (int i = 0; i < n_strips; ++i) base[j][(size_t)i + 1] = base[j][(size_t)i] + view[(size_t)i].sp[sel[j]].n_nodes;
+        need = std::max(need, (double)base[j][(size_t)n_strips] / (double)((size_t)b.planes[j].tiles_x * b.planes[j].tiles_y * TILE_PX));
+        if (base[j][(size_t)n_strips] >= (1u << 24)) return fail(c, STR_ER_ECAPACITY, "more than 2^24 node records in one plane");
     }
     if (need > c->node_share) c->node_share = std::min(1.0, need * 1.05);
-    // pixel pairs across the cuts, plane-wide ids; consecutive repeats (a flat region along the cut) once
-    std::vector<std::vector<uint32_t>> pairs(npl);
-    for (size_t k = 0; k < npl; ++k)
-        for (int sidx = 0; sidx + 1 < n_strips; ++sidx) {
-            // (strips without rows have no borders: the cut is between the nearest strips that have)
-            int lo = sidx, hi = sidx + 1;
-            if (!view[(size_t)lo][k].bot) continue;
-            while (hi < n_strips && !view[(size_t)hi][k].top) ++hi;
-            if (hi >= n_strips) continue;
-            const uint32_t *bt = view[(size_t)lo][k].bot, *tp = view[(size_t)hi][k].top;
-            uint32_t pa = NONE, pb = NONE;
-            for (int x = 0; x < w; ++x) {
-                if (bt[x] == NONE || tp[x] == NONE) { pa = pb = NONE; continue; }
-                const uint32_t ia = bt[x] + base[k][(size_t)lo], ib = tp[x] + base[k][(size_t)hi];
-                if (ia == pa && ib == pb) continue;
-                pairs[k].push_back(ia); pairs[k].push_back(ib);
-                pa = ia; pb = ib;
-            }
-        }
-    size_t pair_words = 0;
-    for (auto &v : pairs) pair_words += v.size();
-    rc = ensure_scratch(c, 4 * pair_words + 256);
-    if (rc != STR_ER_OK) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_strip_flag, 0, sizeof(uint32_t), c->stream));
     const ImportHook hook = [&](const Batch &bb, const BatchDev &bd) -> int {
         hipStream_t s = c->stream;
-        uint32_t *d_pairs = static_cast<uint32_t *>(c->d_scratch);
-        size_t poff = 0;
-        for (size_t k = 0; k < npl; ++k) {
-            const PlaneDesc &pd = bb.planes[k];
-            if (base[k][(size_t)n_strips] > pd.node_cap) return fail(c, STR_ER_ECAPACITY, "strip records exceed the plane's share (internal error)");
+        for (size_t j = 0; j < ns; ++j) {
+            const size_t k = sel[j];
+            const PlaneDesc &pd = bb.planes[j];
+            if (base[j][(size_t)n_strips] > pd.node_cap) return fail(c, STR_ER_ECAPACITY, "strip records exceed the plane's share (internal error)");
             PlaneCtr pc{};
-            pc.n_nodes = base[k][(size_t)n_strips];
+            pc.n_nodes = base[j][(size_t)n_strips];
             pc.start_node = NONE;
-            for (int sidx = 0; sidx < n_strips; ++sidx) {
-                const View &v = view[(size_t)sidx][k];
-                pc.n_walls += v.sp.n_walls;
-                if (v.sp.start_node != NONE) pc.start_node = v.sp.start_node + base[k][(size_t)sidx];
-                if (!v.sp.n_nodes) continue;
-                NodeRec *dst = bd.na.rec + pd.node_base + base[k][(size_t)sidx];
-                HIP_TRY(c, hipMemcpyAsync(dst, v.rec, (size_t)v.sp.n_nodes * sizeof(NodeRec), hipMemcpyHostToDevice, s));
-                launch_rebase_records(s, dst, bd.na.aux + pd.node_base + base[k][(size_t)sidx], v.sp.n_nodes, base[k][(size_t)sidx], v.row0 * (uint32_t)w, v.row0);
+            for (int i = 0; i < n_strips; ++i) {
+                const View &v = view[(size_t)i];
+                const StripPlane &p = v.sp[k];
+                pc.n_walls += p.n_walls;
+                if (p.start_node != NONE) pc.start_node = p.start_node + base[j][(size_t)i];
+                if (!p.n_nodes) continue;
+                NodeRec *dst = bd.na.rec + pd.node_base + base[j][(size_t)i];
+                HIP_TRY(c, hipMemcpyAsync(dst, v.d + v.L.rec[k], (size_t)p.n_nodes * sizeof(NodeRec), hipMemcpyDeviceToDevice, s));
+                // (ids, keys and rows from strip-local to plane-wide; a parent id outside the strip's records raises the flag)
+                launch_rebase_records(s, dst, bd.na.aux + pd.node_base + base[j][(size_t)i], p.n_nodes, base[j][(size_t)i], v.hd.row0 * (uint32_t)w, v.hd.row0, c->d_strip_flag);
             }
-            c->h_ctr[k] = pc;
-            HIP_TRY(c, hipMemcpyAsync(c->d_ctr + k, c->h_ctr + k, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
-            if (!pairs[k].empty()) {
-                HIP_TRY(c, hipMemcpyAsync(d_pairs + poff, pairs[k].data(), 4 * pairs[k].size(), hipMemcpyHostToDevice, s));
-                launch_connect_pairs(s, bd.na.rec + pd.node_base, d_pairs + poff, (uint32_t)(pairs[k].size() / 2));
-                poff += pairs[k].size();
+            c->h_ctr[j] = pc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_ctr + j, c->h_ctr + j, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
+            // pixel pairs across the cuts (strips without rows have no borders: the cut is between the nearest strips that have)
+            for (int lo = 0; lo + 1 < n_strips; ++lo) {
+                if (!view[(size_t)lo].sp[k].has_bot) continue;
+                int hi = lo + 1;
+                while (hi < n_strips && !view[(size_t)hi].sp[k].has_top) ++hi;
+                if (hi >= n_strips) continue;
+                launch_connect_cut(s, bd.na.rec + pd.node_base, reinterpret_cast<const uint32_t *>(view[(size_t)lo].d + view[(size_t)lo].L.bot[k]),
+                                   reinterpret_cast<const uint32_t *>(view[(size_t)hi].d + view[(size_t)hi].L.top[k]), (uint32_t)w, base[j][(size_t)lo],
+                                   view[(size_t)lo].sp[k].n_nodes, base[j][(size_t)hi], view[(size_t)hi].sp[k].n_nodes, c->d_strip_flag);
             }
         }
         HIP_TRY(c, hipGetLastError());
+        uint32_t flag = 0;
+        HIP_TRY(c, hipMemcpyAsync(&flag, c->d_strip_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));       // h_ctr is about to be reused for the counters coming back
+        if (flag) return fail(c, STR_ER_EFORMAT, "strip blob: a node id points outside its strip's records");
         return STR_ER_OK;
     };
     return run_batch(c, b, stages, out, t0, true, &hook);
+}
+
+int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
+                       const int64_t *blob_bytes, int32_t n_strips, uint32_t stages, str_er_result **out)
+{
+    return str_er_strip_merge_ex(c, bgr, w, h, stride, mem_kind, blobs, blob_bytes, STR_ER_MEM_HOST, n_strips, nullptr, stages, out);
 }
 
 int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_t h, int64_t stride, int64_t plane_pitch,

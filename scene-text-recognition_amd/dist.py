@@ -21,10 +21,11 @@ import math
 from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 from .binding import CAND_DTYPE
+
+# (torch is imported by the functions that use torch.distributed, not here: the strips flow below runs over the C ABI's own
+# communicators, and a process that loads the system's librccl AND PyTorch's bundled ROCm runtime holds two of them)
 
 
 def shard_frames(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
@@ -34,9 +35,11 @@ def shard_frames(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return first, base + (1 if rank < rem else 0)
 
 
-def gather_candidates(cands: np.ndarray, device: torch.device, frame_offset: int = 0) -> np.ndarray:
+def gather_candidates(cands: np.ndarray, device, frame_offset: int = 0) -> np.ndarray:
     """All ranks receive every rank's candidates, ordered by rank.  `frame_offset` is added to
-    the records' frame field first so frame numbers are global."""
+    the records' frame field first so frame numbers are global.  `device`: a torch.device."""
+    import torch
+    import torch.distributed as dist
     assert cands.dtype == CAND_DTYPE
     world = dist.get_world_size()
     local = cands.copy()
@@ -141,8 +144,68 @@ def detect_plane_share(erf, bgr: np.ndarray, share: Sequence[int], n_levels: int
     return np.concatenate([c for _, c in parts]) if parts else np.zeros(0, CAND_DTYPE)
 
 
+def detect_frame_strips(erf, comm, bgr: np.ndarray, stages: int = 7) -> np.ndarray:
+    """One frame over `comm.world` ranks with its LEVEL-0 planes cut into strips (lifts the ~6x bound of whole-plane
+    sharding on a 4K frame): collective over `comm` (binding.Comm: RCCL, or an in-process group of threads).
+
+      1. every rank extracts strip `rank` of the level-0 planes of every channel (tile trees + the seams inside the strip);
+      2. the blobs are all-gathered -- from the device buffer they were assembled in, into a device buffer of the communicator:
+         with RCCL they never touch a host;
+      3. level-0 plane k is put together by rank k mod world (str_er_strip_merge_ex, plane_select), the planes of the other pyramid
+         levels are dealt out whole, longest first, to the ranks with the least merge work (str_er_detect_bgr_planes);
+      4. the candidate records are gathered: every rank returns ALL candidates, ordered by (plane, key) as a single-GPU text_detect
+         of the same context gives them.
+
+    `erf` is this rank's context (any n_pyr_levels / channel_mask, equal on all ranks)."""
+    a = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w = a.shape[:2]
+    prm = erf.params
+    rank, world = comm.rank, comm.world
+    planes = frame_planes(w, h, prm.n_pyr_levels, prm.channel_mask)
+    nch = sum(1 for p in planes if p[1] == 0)
+    index = {(ch, lvl): i for i, (ch, lvl, _, _) in enumerate(planes)}
+    # 1 + 2: strips of the level-0 planes, device to device
+    dptr, nbytes = erf.strip_extract_dev(a, rank, world)
+    base, starts, sizes = comm.allgather_bytes((dptr, nbytes), device_in=True, device_out=True)
+    # 3: owners.  Level-0 planes round robin; the rest by LPT on top of the merge load (a merge is about 0.4 of a plane's work)
+    own0 = [k for k in range(nch) if k % world == rank]
+    load = [0.0] * world
+    for k in range(nch):
+        load[k % world] += 0.4 * planes[k][2] * planes[k][3] + planes[k][2] * planes[k][3] / world
+    rest = [i for i in range(len(planes)) if planes[i][1] > 0]
+    mine_rest = []
+    for i in sorted(rest, key=lambda i: (-planes[i][2] * planes[i][3], i)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += planes[i][2] * planes[i][3]
+        if r == rank:
+            mine_rest.append(i)
+    parts = []
+    if own0:
+        sel = np.zeros(nch, np.uint8)
+        sel[own0] = 1
+        res = erf.strip_merge_ex(a, [base + s for s in starts], sizes, device_blobs=True, plane_select=sel, stages=stages)
+        c = res.cands.copy()
+        if len(c):
+            c["node"] = np.array([index[(int(x["ch"]), 0)] for x in c], np.int32)
+        parts.append(c)
+    if mine_rest:
+        sel = np.zeros(len(planes), np.uint8)
+        sel[mine_rest] = 1
+        res = erf.text_detect_planes(a, sel, stages)
+        c = res.cands.copy()
+        if len(c):
+            c["node"] = np.array([index[(int(x["ch"]), int(x["pyr"]))] for x in c], np.int32)
+        parts.append(c)
+    mine = np.concatenate(parts) if parts else np.zeros(0, CAND_DTYPE)
+    # 4: the candidate gather (the one exchange of the reference's data flow, src/ER.cpp:63)
+    allc, _ = comm.gather(mine)
+    out = allc[np.lexsort((allc["key"], allc["node"]))]
+    out["node"] = -1
+    return out
+
+
 def detect_frame_plane_sharded(erf, bgr: np.ndarray, rank: int, world: int, n_levels: int, channel_mask: int = 0x3F,
-                               device: torch.device = None, stages: int = 7) -> np.ndarray:
+                               device=None, stages: int = 7) -> np.ndarray:
     """One frame, planes dealt out to the ranks (LPT by pixel count); every rank returns ALL candidates, ordered by
     (plane, key) as a single-GPU `text_detect` with the same pyramid gives them.  `erf` needs capacity for the frame size
     only (its own n_pyr_levels / channel_mask are not used).  Collective over the default process group when world > 1."""
@@ -151,6 +214,7 @@ def detect_frame_plane_sharded(erf, bgr: np.ndarray, rank: int, world: int, n_le
     share = shard_planes_lpt([pw * ph for (_, _, pw, ph) in planes], world)[rank]
     mine = detect_plane_share(erf, bgr, share, n_levels, channel_mask, stages)
     if world > 1:
+        import torch
         mine = gather_candidates(mine, device or torch.device("cpu"))
     out = mine[np.lexsort((mine["key"], mine["node"]))]
     out["node"] = -1

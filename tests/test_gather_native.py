@@ -56,6 +56,68 @@ def test_native_gather_in_process_group(S, world):
         c.close()
 
 
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_allgather_bytes_in_process_group(S, world):
+    """str_er_comm_allgather_bytes (the strip blobs' transport) over the in-process group: ragged and empty
+    contributions, several rounds, every rank receives every rank's bytes."""
+    comms = S.Comm.local_group(world)
+    blob = lambda r, step: bytes(((7 * r + 3 * step + i) % 251 for i in range((0, 5, 70001, 64)[(r + step) % 4])))
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            out[r] = [comms[r].allgather_bytes(blob(r, step)) for step in range(4)]
+        except Exception as e:                                       # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert not errs, errs
+    for step in range(4):
+        for r in range(world):
+            assert out[r][step] == [blob(q, step) for q in range(world)]
+    for c in comms:
+        c.close()
+
+
+def test_a_failing_rank_fails_every_rank(S):
+    """a rank whose own arguments are bad must not leave its peers waiting in the collective -- it announces the failure
+    in the exchange of the sizes, and every rank returns an error."""
+    import ctypes as C
+    world = 3
+    comms = S.Comm.local_group(world)
+    L = S.load_library()
+    rcs = [None] * world
+
+    def rank_main(r):
+        out = C.c_void_p()
+        starts, sizes = (C.c_int64 * world)(), (C.c_int64 * world)()
+        buf = C.create_string_buffer(b"abcdef", 6)
+        # rank 1 passes a NULL buffer with a positive size
+        rcs[r] = L.str_er_comm_allgather_bytes(comms[r].h, None if r == 1 else buf, 6, 0, 0, C.byref(out), starts, sizes)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(30)
+    assert all(not t.is_alive() for t in th), "a rank is still waiting"
+    assert rcs[1] == -1 and all(rc is not None and rc < 0 for rc in rcs), rcs
+    # the communicators are still usable afterwards
+    res = [None] * world
+    th = [threading.Thread(target=lambda r=r: res.__setitem__(r, comms[r].allgather_bytes(bytes([r] * (r + 1))))) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(30)
+    assert res[0] == [bytes([q] * (q + 1)) for q in range(world)] and res[0] == res[1] == res[2]
+    for c in comms:
+        c.close()
+
+
 def test_native_gather_errors(S):
     import ctypes as C
     L = S.load_library()
