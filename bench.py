@@ -109,7 +109,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
     ap.add_argument("--kind", choices=["text", "noise", "ties"], default="text",
                     help="synthetic frames (SURVEY 8d): S-text (default), S-noise (stress), S-ties = S-text with a glyph in every third frame that "
-                         "makes an NMS sibling tie whose outcome changes the pool (about 3 %% of the planes need the reference's flood order walked)")
+                         "makes an NMS sibling tie whose outcome changes the pool (--ties-every 8: 1.2 %% of the planes need the reference's flood "
+                         "order walked, 3: 3.1 %%)")
+    ap.add_argument("--ties-every", type=int, default=8, help="S-ties: one tie glyph in every N-th frame")
     ap.add_argument("--no-ties-leg", action="store_true",
                     help="skip the `nms_ties_leg` object of the default run (the same measurement as `value`, on S-ties frames, fewer steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,7 +210,8 @@ def main():
     # (SURVEY 8(d)); generated on host threads (numpy releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
-        frames = np.stack(list(ex.map(lambda i: S.synth.KINDS[args.kind](S.synth.frame_seed(rank * F + i), W, H), range(F))))
+        make = (lambda sd, w, h: S.synth.sties_bgr(sd, w, h, args.ties_every)) if args.kind == "ties" else S.synth.KINDS[args.kind]
+        frames = np.stack(list(ex.map(lambda i: make(S.synth.frame_seed(rank * F + i), W, H), range(F))))
     d_frames = torch.from_numpy(frames).to(device)
     torch.cuda.synchronize()
 
@@ -300,7 +303,7 @@ def main():
     ties_leg = None
     if not args.no_ties_leg and args.kind == "text" and world == 1 and args.sibling_order == 0 and not args.ocr and not args.group:
         with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
-            tf = np.stack(list(ex.map(lambda i: S.synth.KINDS["ties"](S.synth.frame_seed(i), W, H), range(F))))
+            tf = np.stack(list(ex.map(lambda i: S.synth.sties_bgr(S.synth.frame_seed(i), W, H, args.ties_every), range(F))))
         d_ties = torch.from_numpy(tf).to(device)
         torch.cuda.synchronize()
         run(P, d_ties)
@@ -314,8 +317,10 @@ def main():
         ties_leg = {"value": round(F * n_t / el, 2), "unit": "frames/s", "steps": n_t, "ms_per_step": round(1e3 * el / n_t, 3),
                     "tie_planes_per_batch": round((a1[0] - a0[0]) / n_t, 2), "tie_plane_share": round((a1[0] - a0[0]) / n_t / (F * bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels']), 4),
                     "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(),
-                    "note": "S-ties frames (S-text + one double-L glyph in every third frame: an NMS sibling tie with two different outcomes); same "
-                            "batches in flight as `value`; flood_walk_ms = host time of the reference-order walks, summed over planes"}
+                    "note": f"S-ties frames (S-text + one double-L glyph in every {args.ties_every}th frame: an NMS sibling tie with two different outcomes); same "
+                            "batches in flight as `value`; flood_walk_ms = host time of the reference-order walks, summed over planes.  The walks are "
+                            "bound by host memory latency (~6 ms per 1920x1080 plane): once tie planes per batch x 6 ms / host_threads exceeds the "
+                            "GPU's time per batch the leg is host-bound (measured with a glyph in every 3rd frame, 3.1 % of the planes: 0.47 of `value`)"}
         del d_ties
 
     # latency leg: ONE frame per call, one batch in flight (north_star: ">= 500 fps end-to-end on 1920x1080" is a
@@ -352,7 +357,7 @@ def main():
                    "note": f"1 frame per call, 1 call in flight, call-to-return wall time incl. the candidate copy to the host; median of {n_lat}; "
                            "host_input = the frame starts in pageable host memory (H2D inside the call)"}
 
-    pcie = None
+    pcie = pcie_nv12 = None
     if not args.no_host_frames and not args.ocr and rank == 0:
         # "a frame = BGR upload excluded and included (both reported)".  The frames sit in the stream's page-locked
         # staging buffers (where a decoder would put them); every step uploads its 3*W*H*F bytes again.
@@ -382,6 +387,32 @@ def main():
         pcie = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
                 "h2d_bytes_per_step": int(frames.size),
                 "note": "host BGR frames in page-locked memory -> str_er_stream (upload of one batch overlaps the kernels of the others)"}
+        # ... and the same frames as a video decoder would deliver them: NV12, half the bytes (build-defined ingest, include/str_er.h)
+        with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
+            nv = np.stack(list(ex.map(S.synth.nv12_from_bgr, frames)))
+
+        def stream_steps_nv12(n):
+            for _ in range(n):
+                if st.pending() == P:
+                    st.next()
+                slot, buf = st.acquire()
+                if not filled[slot]:
+                    buf[: nv.size] = nv.reshape(-1)
+                    filled[slot] = True
+                st.submit_nv12(slot, W, H, F, stages)
+            while st.pending():
+                st.next()
+
+        filled = [False] * P
+        stream_steps_nv12(max(P, args.warmup))
+        t1 = time.perf_counter()
+        stream_steps_nv12(args.steps)
+        el = time.perf_counter() - t1
+        pcie_nv12 = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
+                     "h2d_bytes_per_step": int(nv.size),
+                     "note": "the same frames as NV12 (luma + interleaved Cb/Cr at half resolution: what a decoder delivers) through the same stream; "
+                             "the NV12 -> Y/Cr/Cb step is build-defined (chroma replicated 2x2), so the planes -- and the candidates -- are not "
+                             "those of the BGR frames"}
         st.close()
 
     if rank == 0:
@@ -427,6 +458,7 @@ def main():
             "nms_ties": nms_ties,
             **({"nms_ties_leg": ties_leg} if ties_leg else {}),
             **({"pcie_inclusive": pcie} if pcie else {}),
+            **({"pcie_inclusive_nv12": pcie_nv12} if pcie_nv12 else {}),
             **({"latency_1frame": latency} if latency else {}),
             "roofline": {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -193,7 +193,7 @@ int  str_er_abi_version(void);
  * opts in: returns 1 if it set something, 0 if the host's environment already decides, < 0 on error.                  */
 /* Exact NMS sibling ties (sibling_order = 0): how many planes of this context's calls so far needed the reference's flood order
  * walked on a host core, the host time those walks took in all (ms, summed over planes), and how many host threads the
- * library's process-wide pool for them has at most (cores / 4, at least 1, at most 32; STR_ER_WALK_THREADS overrides).  Any pointer may be NULL. */
+ * library's process-wide pool for them has at most (cores / 4, at least 1, at most 16; STR_ER_WALK_THREADS overrides).  Any pointer may be NULL. */
 int  str_er_tie_stats(const str_er_ctx *ctx, uint64_t *planes_walked, double *walk_ms_total, int32_t *host_threads);
 const char *str_er_runtime_hint(void);
 int  str_er_apply_runtime_hint(void);
@@ -218,6 +218,16 @@ int str_er_cascade_info(const str_er_ctx *ctx, int which, int32_t *n_stages, int
 int str_er_detect_bgr(str_er_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h,
                       int64_t stride, int64_t frame_pitch, int32_t n_frames,
                       int mem_kind, uint32_t stages, str_er_result **out);
+
+/* The same for NV12 frames -- what a video decoder delivers: a luma plane of h rows, then one interleaved chroma plane
+ * (Cb, Cr, Cb, Cr ...) of h / 2 rows, `stride` bytes per row both; w and h even.  The reference has no such input (it decodes to
+ * BGR: cv::imread / `cap >> frame`, src/utils.cpp:31, 109); the conversion is BUILD-DEFINED like the pyramid: Y = the luma byte,
+ * Cr(x, y) = V(x/2, y/2), Cb(x, y) = U(x/2, y/2) -- the decoder's samples are the channel values, chroma replicated over its 2 x 2
+ * block (oracle: ero_nv12_to_ycrcb).  Everything after the three planes is the path of str_er_detect_bgr.  Half the bytes of a BGR
+ * frame cross the host link.                                                                                                     */
+int str_er_detect_nv12(str_er_ctx *ctx, const uint8_t *nv12, int32_t w, int32_t h,
+                       int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                       int mem_kind, uint32_t stages, str_er_result **out);
 
 /* The same for a SUBSET of the logical planes of every frame: plane_select[level * n_channels + k] != 0 selects the
  * k-th channel of the context's channel_mask at that pyramid level (n_select = n_pyr_levels * popcount(channel_mask)).
@@ -504,6 +514,9 @@ int         str_er_stream_load_cascade(str_er_stream *s, int which, const char *
 int         str_er_stream_acquire(str_er_stream *s, int32_t *slot, uint8_t **buffer, int64_t *capacity);
 int         str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                                  int32_t n_frames, uint32_t stages, uint64_t *ticket);
+/* ... the staging buffer holds NV12 frames (str_er_detect_nv12): stride >= w, a frame is h + h/2 rows */
+int         str_er_stream_submit_nv12(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                                      int32_t n_frames, uint32_t stages, uint64_t *ticket);
 /* convenience: acquire + copy the frames in (one extra host copy) + submit */
 int         str_er_stream_submit_copy(str_er_stream *s, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                                       int32_t n_frames, uint32_t stages, uint64_t *ticket);

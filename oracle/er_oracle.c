@@ -131,6 +131,21 @@ void ero_compute_channels(const uint8_t *bgr, int stride, int w, int h, uint8_t 
     }
 }
 
+/* NV12 ingest -- BUILD-DEFINED, no reference counterpart (the reference decodes to BGR: src/utils.cpp:31, 109), like the pyramid.
+ * y: w*h luma bytes (y_stride per row); uv: interleaved Cb,Cr pairs, (w/2) pairs x (h/2) rows (uv_stride per row).
+ * planes3 = [Y, Cr, Cb], each w*h contiguous: Y is the luma byte, Cr(x,y) = V(x/2, y/2), Cb(x,y) = U(x/2, y/2).            */
+void ero_nv12_to_ycrcb(const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int w, int h, uint8_t *planes3)
+{
+    const size_t n = (size_t)w * h;
+    for (int r = 0; r < h; ++r)
+        for (int x = 0; x < w; ++x) {
+            const size_t i = (size_t)r * w + x;
+            planes3[i] = y[(size_t)r * y_stride + x];
+            planes3[n + i] = uv[(size_t)(r / 2) * uv_stride + 2 * (x / 2) + 1];
+            planes3[2 * n + i] = uv[(size_t)(r / 2) * uv_stride + 2 * (x / 2)];
+        }
+}
+
 void ero_pyr_dims(int w0, int h0, int level, int *w, int *h)
 {
     const double s = pow(2.0, -0.5 * level);

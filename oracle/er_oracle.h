@@ -77,6 +77,9 @@ void ero_resize_linear_u8(const uint8_t *src, int sstride, int sw, int sh,
 void ero_compute_channels(const uint8_t *bgr, int stride, int w, int h,
                           uint8_t *planes6);
 
+/* NV12 ingest (build-defined, no reference counterpart): planes3 = [Y, Cr, Cb]; chroma replicated over its 2x2 block. */
+void ero_nv12_to_ycrcb(const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int w, int h, uint8_t *planes3);
+
 /* ---- component tree (src/ER.cpp:240-413) -------------------------------- */
 /* Nister-Stewenius flood exactly as the reference runs it, including the
  * level-`highest_level` sentinel behaviour and on-merge pruning.            */

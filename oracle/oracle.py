@@ -74,6 +74,7 @@ class Oracle:
         L.ero_highest_level.argtypes = [C.c_int]
         L.ero_resize_linear_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
         L.ero_compute_channels.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.ero_nv12_to_ycrcb.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.ero_tree_extract.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Tree)]
         L.ero_tree_bruteforce.argtypes = L.ero_tree_extract.argtypes
         L.ero_tree_free.argtypes = [C.POINTER(_Tree)]
@@ -134,6 +135,15 @@ class Oracle:
         out = np.zeros((6, h, w), np.uint8)
         p = C.POINTER(C.c_uint8)
         self.lib.ero_compute_channels(bgr.ctypes.data_as(p), 3 * w, w, h, out.ctypes.data_as(p))
+        return out
+
+    def nv12_to_ycrcb(self, nv12: np.ndarray, w: int, h: int) -> np.ndarray:
+        """(h * 3 // 2, w) NV12 frame -> (3, h, w) planes [Y, Cr, Cb] (build-defined ingest: chroma replicated 2x2)."""
+        a = _u8(nv12).reshape(h + h // 2, w)
+        out = np.zeros((3, h, w), np.uint8)
+        p = C.POINTER(C.c_uint8)
+        uv = a[h:]
+        self.lib.ero_nv12_to_ycrcb(a.ctypes.data_as(p), w, uv.ctypes.data_as(p), w, w, h, out.ctypes.data_as(p))
         return out
 
     def pyr_dims(self, w0: int, h0: int, level: int):

@@ -187,6 +187,8 @@ def load_library():
     L.str_er_stream_load_cascade.argtypes = [vp, C.c_int, C.c_char_p]
     L.str_er_stream_acquire.argtypes = [vp, i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.str_er_stream_submit.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.str_er_stream_submit_nv12.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.str_er_detect_nv12.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int, C.c_uint32, C.POINTER(vp)]
     L.str_er_stream_submit_copy.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.str_er_stream_next.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.str_er_stream_pending.argtypes = [vp]
@@ -430,6 +432,19 @@ class ERFilter:
         rh = C.c_void_p()
         self._check(self.L.str_er_detect_bgr(self.h, _np_ptr(a), w, h, 3 * w, 3 * w * h, f, MEM_HOST,
                                              stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
+        return self._collect(rh)
+
+    def text_detect_nv12(self, nv12: np.ndarray, w: int, h: int, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:
+        """str_er_detect_nv12: frames as a video decoder delivers them, (h * 3 // 2, w) or (F, h * 3 // 2, w) uint8 (luma plane,
+        then interleaved Cb/Cr at half resolution); the NV12 -> Y/Cr/Cb step is build-defined (include/str_er.h)."""
+        a = np.ascontiguousarray(nv12, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[None]
+        f = a.shape[0]
+        assert a.shape[1:] == (h + h // 2, w), a.shape
+        rh = C.c_void_p()
+        self._check(self.L.str_er_detect_nv12(self.h, _np_ptr(a), w, h, w, w * (h + h // 2), f, MEM_HOST,
+                                              stages | (WANT_NODES if want_nodes else 0), C.byref(rh)))
         return self._collect(rh)
 
     def text_detect_planes(self, src: np.ndarray, select, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:
@@ -867,6 +882,12 @@ class FrameStream:
     def submit(self, slot: int, w: int, h: int, n_frames: int, stages: int = STAGE_ALL) -> int:
         t = C.c_uint64()
         self._check(self.L.str_er_stream_submit(self.h, slot, w, h, 3 * w, 3 * w * h, n_frames, stages, C.byref(t)))
+        return int(t.value)
+
+    def submit_nv12(self, slot: int, w: int, h: int, n_frames: int, stages: int = STAGE_ALL) -> int:
+        """The staging buffer holds n_frames tightly packed NV12 frames (w * h * 3 / 2 bytes each)."""
+        t = C.c_uint64()
+        self._check(self.L.str_er_stream_submit_nv12(self.h, slot, w, h, w, w * (h + h // 2), n_frames, stages, C.byref(t)))
         return int(t.value)
 
     def submit_copy(self, frames: np.ndarray, stages: int = STAGE_ALL) -> int:

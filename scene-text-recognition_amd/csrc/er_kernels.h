@@ -35,6 +35,9 @@ struct BatchDev {
 void launch_bgr_to_ycrcb(hipStream_t s, const uint8_t *bgr, int w, int h, int64_t stride,
                          int64_t frame_pitch, int n_frames, uint8_t *y, uint8_t *cr, uint8_t *cb,
                          int dstride, int64_t dst_frame_pitch);
+// NV12 (luma plane, then interleaved Cb/Cr at half resolution, same row stride) -> the same three planes; chroma replicated 2 x 2
+void launch_nv12_to_ycrcb(hipStream_t s, const uint8_t *nv12, int w, int h, int64_t stride, int64_t frame_pitch, int n_frames, uint8_t *y, uint8_t *cr,
+                          uint8_t *cb, int dstride, int64_t dst_frame_pitch);
 // 255 - x for the single-stage compute_channels entry point.
 void launch_invert(hipStream_t s, const uint8_t *src, uint8_t *dst, size_t n);
 // cv::resize INTER_LINEAR 8UC1 semantics; z planes with the given pitches.

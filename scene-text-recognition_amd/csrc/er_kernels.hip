@@ -132,6 +132,48 @@ void launch_bgr_to_ycrcb(hipStream_t s, const uint8_t *bgr, int w, int h, int64_
                        dst_frame_pitch, aligned);
 }
 
+// NV12 ingest (build-defined, like the pyramid; SURVEY 8(f) row 3: "NV12 -> YCrCb directly, skipping BGR").  A decoder's frame is a
+// full-resolution luma plane followed by one interleaved chroma plane at half resolution (Cb, Cr, Cb, Cr ...).  The three planes of
+// the path are, by definition (oracle: ero_nv12_to_ycrcb):  Y = the luma byte;  Cr(x, y) = V(x / 2, y / 2);  Cb(x, y) = U(x / 2, y / 2)
+// -- chroma replicated over its 2 x 2 block, no filter, no range conversion: the decoder's samples ARE the channel values.  Half the
+// bytes of a BGR frame cross the host link.  One lane converts 4 pixels of a row: one luma dword, two chroma pairs.
+__global__ __launch_bounds__(256) void k_nv12_to_ycrcb(const uint8_t *__restrict__ nv12, int w, int h, int64_t stride, int64_t frame_pitch,
+                                                       uint8_t *__restrict__ yp, uint8_t *__restrict__ crp, uint8_t *__restrict__ cbp, int dstride,
+                                                       int64_t dst_frame_pitch, int aligned)
+{
+    const int quad = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int x = quad * 4;
+    if (x >= w) return;
+    const uint8_t *ys = nv12 + (size_t)f * frame_pitch + (size_t)y * stride + x;
+    const uint8_t *uv = nv12 + (size_t)f * frame_pitch + (size_t)h * stride + (size_t)(y >> 1) * stride + x;     // (x is even: pair x / 2 starts at byte x)
+    const size_t   dof = (size_t)f * dst_frame_pitch + (size_t)y * dstride + x;
+    if (aligned && x + 4 <= w) {
+        const uint32_t yy = *reinterpret_cast<const uint32_t *>(ys), c = *reinterpret_cast<const uint32_t *>(uv);     // U0 V0 U1 V1
+        const uint32_t u0 = c & 0xFFu, v0 = (c >> 8) & 0xFFu, u1 = (c >> 16) & 0xFFu, v1 = c >> 24;
+        *reinterpret_cast<uint32_t *>(yp + dof) = yy;
+        *reinterpret_cast<uint32_t *>(crp + dof) = v0 * 0x0101u | (v1 * 0x0101u) << 16;
+        *reinterpret_cast<uint32_t *>(cbp + dof) = u0 * 0x0101u | (u1 * 0x0101u) << 16;
+    } else {
+        for (int k = 0; k < 4 && x + k < w; ++k) {
+            yp[dof + k] = ys[k];
+            cbp[dof + k] = uv[(k & ~1)];
+            crp[dof + k] = uv[(k & ~1) + 1];
+        }
+    }
+}
+
+void launch_nv12_to_ycrcb(hipStream_t s, const uint8_t *nv12, int w, int h, int64_t stride, int64_t frame_pitch, int n_frames, uint8_t *y, uint8_t *cr,
+                          uint8_t *cb, int dstride, int64_t dst_frame_pitch)
+{
+    const int quads = (w + 3) / 4;
+    const int aligned = ((reinterpret_cast<uintptr_t>(nv12) | (uintptr_t)stride | (uintptr_t)frame_pitch) % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(cr) | reinterpret_cast<uintptr_t>(cb) | (uintptr_t)dstride |
+                          (uintptr_t)dst_frame_pitch) % 4 == 0);
+    dim3 grid((quads + 255) / 256, h, n_frames);
+    hipLaunchKernelGGL(k_nv12_to_ycrcb, grid, dim3(256), 0, s, nv12, w, h, stride, frame_pitch, y, cr, cb, dstride, dst_frame_pitch, aligned);
+}
+
 __global__ __launch_bounds__(256) void k_invert(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

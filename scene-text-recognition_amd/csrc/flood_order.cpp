@@ -36,10 +36,16 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
     constexpr uint16_t ACC = 0x8000u, WATCH = 0x4000u, LEVEL = 0x01FFu;
     uint16_t lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (uint16_t)std::lrintf((float)v * qscale);
-    std::vector<uint16_t> st(n);
+    // (the two per-pixel arrays are kept per thread: a fresh 12 MB allocation per walk is ~3000 page faults and a memset -- a third of a
+    // walk that stops early; both are written before they are read)
+    thread_local std::vector<uint16_t> st_buf;
+    thread_local std::vector<uint32_t> link_buf;
+    if (st_buf.size() < n) st_buf.resize(n);
+    if (link_buf.size() < n) link_buf.resize(n);
+    uint16_t *const st = st_buf.data();
     for (int y = 0; y < h; ++y) {
         const uint8_t *row = pix + (size_t)y * stride;
-        uint16_t      *o = st.data() + (size_t)y * w;
+        uint16_t      *o = st + (size_t)y * w;
         for (int x = 0; x < w; ++x) o[x] = lut[row[x] ^ invert];
     }
     // `remaining` = watched pixels whose stamps are still needed.  With groups (the children competing for one parent) only the
@@ -71,7 +77,7 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
     // the 256 LIFO buckets of src/ER.cpp:254-255 as linked lists through one array (a pixel is in at most one bucket at a time):
     // link[p] = next entry << 3 | the edge at which p resumes
     constexpr uint32_t NIL = 0x1FFFFFFFu;
-    std::vector<uint32_t> link(n);
+    uint32_t *const link = link_buf.data();
     uint32_t head[257];
     for (uint32_t &v : head) v = NIL;
     uint32_t priority = (uint32_t)hi, counter = 0;
@@ -162,7 +168,7 @@ Pool *pool()
         unsigned hw = std::thread::hardware_concurrency();
         int n = (int)(hw ? hw / 4 : 2);
         if (const char *e = std::getenv("STR_ER_WALK_THREADS")) n = std::atoi(e);
-        q->n_threads = n < 1 ? 1 : (n > 32 ? 32 : n);
+        q->n_threads = n < 1 ? 1 : (n > 16 ? 16 : n);      // (measured on a 256-core box: 32 walks at once take twice as long each -- they are bound by memory latency)
         for (int i = 0; i < q->n_threads - 1; ++i) {      // (the caller of flood_walks_run is the n-th worker of its own set)
             try {
                 std::thread([q] {

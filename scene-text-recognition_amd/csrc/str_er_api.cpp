@@ -32,7 +32,8 @@ using namespace str_er;
 namespace {
 
 thread_local std::string g_create_error;
-constexpr int TIE_SLOTS = 4;       // planes per batch the device hands to the host for the flood order walk without a round trip
+constexpr int TIE_SLOTS = 16;      // at most so many planes per batch the device hands to the host for the flood order walk without a round trip
+                                   // (a context has as many slots as fit 64 MB of page-locked memory, at least 4: str_er_ctx::n_tie_slots)
 
 struct HostCascade {
     bool loaded = false;
@@ -122,7 +123,7 @@ struct str_er_ctx {
     uint32_t *d_wparent = nullptr;
     // tie planes exported by the device itself (k_export_tie_planes): TIE_SLOTS x tie_slot_bytes of page-locked, device-addressable memory,
     // then the slot -> plane table and the slot counter
-    uint8_t *h_tie = nullptr; size_t tie_slot_bytes = 0; uint32_t *h_tie_plane = nullptr, *h_tie_count = nullptr;
+    uint8_t *h_tie = nullptr; size_t tie_slot_bytes = 0; int n_tie_slots = 0; uint32_t *h_tie_plane = nullptr, *h_tie_count = nullptr;
     uint8_t *h_replay = nullptr; size_t h_replay_bytes = 0;   // page-locked: the planes (and watch lists) the flood order walk reads
     uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
     ReplayItem *d_replay_items = nullptr;
@@ -734,7 +735,7 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
         std::vector<int> slot_of(m, -1);
         if (!c->replay_on_gpu && c->h_tie && !from_tree)
             for (size_t k = 0; k < m; ++k)
-                for (uint32_t q = 0; q < std::min<uint32_t>(*c->h_tie_count, TIE_SLOTS); ++q) if (c->h_tie_plane[q] == items[k].plane) slot_of[k] = (int)q;
+                for (uint32_t q = 0; q < std::min<uint32_t>(*c->h_tie_count, (uint32_t)c->n_tie_slots); ++q) if (c->h_tie_plane[q] == items[k].plane) slot_of[k] = (int)q;
         // (pad_: where the export kernel puts a plane that has no slot, in units of 256 bytes from the arena's start)
         for (size_t k = 0; k < m; ++k) items[k].pad_ = (c->replay_on_gpu || slot_of[k] >= 0) ? 0xFFFFFFFFu : (uint32_t)(hoff[k] / 256);
         std::memcpy(h_items, items.data(), sizeof(ReplayItem) * m);
@@ -989,7 +990,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         launch_nms_alt(c->side, bd, dp);
         if (c->h_tie && !c->replay_on_gpu) {
             *c->h_tie_count = 0;        // (the previous batch of this context is done: nothing on the device touches it any more)
-            launch_export_tie_planes(c->side, bd, c->h_tie, c->tie_slot_bytes, TIE_SLOTS, c->d_tie_slot_plane, c->h_tie_count, c->h_tie_plane);
+            launch_export_tie_planes(c->side, bd, c->h_tie, c->tie_slot_bytes, c->n_tie_slots, c->d_tie_slot_plane, c->h_tie_count, c->h_tie_plane);
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
     }
@@ -1473,10 +1474,11 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     }
     if (p->sibling_order == 0) {
         c->tie_slot_bytes = ((plane_px + 255) / 256) * 256 + 2 * 4 * (size_t)NMS_WATCH_CAP + 256;
-        const size_t tb = (size_t)TIE_SLOTS * c->tie_slot_bytes + 4 * (size_t)TIE_SLOTS + 64;
+        c->n_tie_slots = (int)std::min<size_t>((size_t)TIE_SLOTS, std::max<size_t>(4, ((size_t)64 << 20) / c->tie_slot_bytes));
+        const size_t tb = (size_t)c->n_tie_slots * c->tie_slot_bytes + 4 * (size_t)TIE_SLOTS + 64;
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_tie), tb, hipHostMallocMapped) != hipSuccess) A(fail(nullptr, STR_ER_ENOMEM, "hipHostMalloc (tie plane export)"));
         else {
-            c->h_tie_plane = reinterpret_cast<uint32_t *>(c->h_tie + (size_t)TIE_SLOTS * c->tie_slot_bytes);
+            c->h_tie_plane = reinterpret_cast<uint32_t *>(c->h_tie + (size_t)c->n_tie_slots * c->tie_slot_bytes);
             c->h_tie_count = c->h_tie_plane + TIE_SLOTS;
         }
     }
@@ -1564,7 +1566,7 @@ int str_er_cascade_info(const str_er_ctx *c, int which, int32_t *n_stages, int32
 }
 
 static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
-                           int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out);
+                           int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out, bool nv12 = false);
 
 int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                       int32_t n_frames, int mem_kind, uint32_t stages, str_er_result **out)
@@ -1586,12 +1588,22 @@ int str_er_detect_bgr_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32
     return detect_bgr_impl(c, bgr, w, h, stride, frame_pitch, n_frames, mem_kind, stages, plane_select, out);
 }
 
+int str_er_detect_nv12(str_er_ctx *c, const uint8_t *nv12, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
+                       int32_t n_frames, int mem_kind, uint32_t stages, str_er_result **out)
+{
+    return detect_bgr_impl(c, nv12, w, h, stride, frame_pitch, n_frames, mem_kind, stages, nullptr, out, /*nv12=*/true);
+}
+
+// (nv12: `bgr` is a luma plane of h rows followed by the interleaved chroma plane of h / 2 rows, `stride` bytes per row both)
 static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
-                           int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out)
+                           int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out, bool nv12)
 {
     if (!c) return STR_ER_EINVAL;
-    if (!bgr || !out || w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3) return fail(c, STR_ER_EINVAL, "bad frame arguments");
-    if (n_frames > 1 && frame_pitch < stride * (int64_t)h) return fail(c, STR_ER_EINVAL, "frame_pitch smaller than a frame");
+    const int64_t row_bytes = nv12 ? (int64_t)w : (int64_t)w * 3;                 // bytes of a source row
+    const int64_t src_rows = nv12 ? (int64_t)h + h / 2 : (int64_t)h;              // rows of a source frame
+    if (!bgr || !out || w < 1 || h < 1 || n_frames < 1 || stride < row_bytes) return fail(c, STR_ER_EINVAL, "bad frame arguments");
+    if (nv12 && ((w | h) & 1)) return fail(c, STR_ER_EINVAL, "NV12 frames have even width and height");
+    if (n_frames > 1 && frame_pitch < stride * src_rows) return fail(c, STR_ER_EINVAL, "frame_pitch smaller than a frame");
     if (w > c->prm.max_width || h > c->prm.max_height || n_frames > c->prm.max_frames)
         return fail(c, STR_ER_ECAPACITY, "frame larger than / more frames than the context capacity");
     *out = nullptr;
@@ -1601,14 +1613,14 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
     int64_t dstride = stride, dpitch = frame_pitch;
     if (mem_kind == STR_ER_MEM_HOST) {
         // pack rows tightly while staging
-        dstride = (int64_t)w * 3; dpitch = dstride * h;
+        dstride = row_bytes; dpitch = dstride * src_rows;
         if ((size_t)dpitch * n_frames > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "staging buffer too small");
         if (stride == dstride && (n_frames == 1 || frame_pitch == dpitch))      // already tight: one linear copy
             HIP_TRY(c, hipMemcpyAsync(c->d_in, bgr, (size_t)dpitch * n_frames, hipMemcpyHostToDevice, c->stream));
         else
             for (int f = 0; f < n_frames; ++f)
                 HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)f * dpitch, (size_t)dstride, bgr + (size_t)f * frame_pitch, (size_t)stride,
-                                            (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
+                                            (size_t)row_bytes, (size_t)src_rows, hipMemcpyHostToDevice, c->stream));
         dbgr = c->d_in;
     } else if (mem_kind == STR_ER_MEM_DEVICE) dbgr = bgr;
     else return fail(c, STR_ER_EINVAL, "bad mem_kind");
@@ -1633,8 +1645,12 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
     if (frame_bytes * n_frames > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
     auto plane_sz = [&](int l) { return align_up((size_t)geo[l].stride * geo[l].h, 256); };
     c->n_ev = 0; c->profile.clear(); rec(c, "begin");
-    launch_bgr_to_ycrcb(c->stream, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
-                        c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);
+    if (nv12)
+        launch_nv12_to_ycrcb(c->stream, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
+                             c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);
+    else
+        launch_bgr_to_ycrcb(c->stream, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
+                            c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);
     rec(c, "channels");
     for (int l = 1; l < nl; ++l)
         launch_resize(c->stream, c->d_pix + geo[l - 1].off, geo[l - 1].w, geo[l - 1].h, geo[l - 1].stride, (int64_t)plane_sz(l - 1),

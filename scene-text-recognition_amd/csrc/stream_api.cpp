@@ -29,6 +29,7 @@ struct str_er_stream {
         int32_t  w = 0, h = 0, n_frames = 0;
         int64_t  stride = 0, pitch = 0;
         uint32_t stages = 0;
+        bool     nv12 = false;
         uint64_t ticket = 0;
         int      rc = STR_ER_OK;
         str_er_result *result = nullptr;
@@ -59,7 +60,8 @@ void worker_main(str_er_stream *s, int idx)
             if (s->stop && !sl.has_job) return;
         }
         str_er_result *r = nullptr;
-        const int rc = str_er_detect_bgr(sl.ctx, sl.pinned, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_HOST, sl.stages, &r);
+        const int rc = sl.nv12 ? str_er_detect_nv12(sl.ctx, sl.pinned, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_HOST, sl.stages, &r)
+                               : str_er_detect_bgr(sl.ctx, sl.pinned, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_HOST, sl.stages, &r);
         {
             std::lock_guard<std::mutex> lk(s->mu);
             sl.rc = rc;
@@ -159,20 +161,21 @@ int str_er_stream_acquire(str_er_stream *s, int32_t *slot, uint8_t **buffer, int
     return STR_ER_ESTATE;
 }
 
-int str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
-                         uint32_t stages, uint64_t *ticket)
+static int submit_impl(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                       uint32_t stages, uint64_t *ticket, bool nv12)
 {
     if (!s || slot < 0 || (size_t)slot >= s->slots.size()) return STR_ER_EINVAL;
     str_er_stream::Slot &sl = s->slots[(size_t)slot];
     {
         std::lock_guard<std::mutex> lk(s->mu);
         if (!sl.busy || sl.has_job || sl.done) { s->err = "slot was not acquired (or is already submitted)"; return STR_ER_ESTATE; }
-        if (w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3 || (n_frames > 1 && frame_pitch < stride * (int64_t)h) ||
-            (uint64_t)(n_frames - 1) * (uint64_t)frame_pitch + (uint64_t)stride * (uint64_t)h > (uint64_t)s->slot_bytes) {
+        const int64_t row = nv12 ? (int64_t)w : (int64_t)w * 3, rows = nv12 ? (int64_t)h + h / 2 : (int64_t)h;
+        if (w < 1 || h < 1 || n_frames < 1 || stride < row || (n_frames > 1 && frame_pitch < stride * rows) ||
+            (uint64_t)(n_frames - 1) * (uint64_t)frame_pitch + (uint64_t)stride * (uint64_t)rows > (uint64_t)s->slot_bytes) {
             s->err = "frames do not fit the staging buffer";
             return STR_ER_EINVAL;
         }
-        sl.w = w; sl.h = h; sl.stride = stride; sl.pitch = frame_pitch; sl.n_frames = n_frames; sl.stages = stages;
+        sl.w = w; sl.h = h; sl.stride = stride; sl.pitch = frame_pitch; sl.n_frames = n_frames; sl.stages = stages; sl.nv12 = nv12;
         sl.ticket = s->next_ticket++;
         sl.has_job = true;
         s->order.push_back(slot);
@@ -180,6 +183,18 @@ int str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, i
     }
     s->cv.notify_all();
     return STR_ER_OK;
+}
+
+int str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                         uint32_t stages, uint64_t *ticket)
+{
+    return submit_impl(s, slot, w, h, stride, frame_pitch, n_frames, stages, ticket, false);
+}
+
+int str_er_stream_submit_nv12(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
+                              uint32_t stages, uint64_t *ticket)
+{
+    return submit_impl(s, slot, w, h, stride, frame_pitch, n_frames, stages, ticket, true);
 }
 
 int str_er_stream_submit_copy(str_er_stream *s, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,

@@ -18,7 +18,7 @@ ROCm, device tensors) and "gloo" (CPU tensors, used by the world_size-2 tests).
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 
@@ -96,52 +96,24 @@ def shard_planes_lpt(costs: Sequence[int], world: int) -> List[List[int]]:
 
 def detect_plane_share(erf, bgr: np.ndarray, share: Sequence[int], n_levels: int, channel_mask: int = 0x3F, stages: int = 7) -> np.ndarray:
     """Candidates of the planes `share` (indices into frame_planes()) of one frame, ordered by (plane, key); the `node`
-    field carries the global plane index.  Planes go through the plane entry point (`detect_planes`), the pyramid through
-    `resize_plane`: only the source-channel chains this share needs are built."""
+    field carries the global plane index.  One call with a plane subset (`text_detect_planes` = str_er_detect_bgr_planes):
+    channels, the pyramid (as deep as the share's deepest plane) and the trees stay on the device.  The context must have this
+    very plane layout (n_pyr_levels, channel_mask)."""
     a = np.ascontiguousarray(bgr, dtype=np.uint8)
     h, w = a.shape[:2]
     planes = frame_planes(w, h, n_levels, channel_mask)
-    prm = getattr(erf, "params", None)
-    if prm is not None and hasattr(erf, "text_detect_planes") and prm.n_pyr_levels == n_levels and prm.channel_mask == channel_mask:
-        # the context has this very plane layout: one call with a plane subset -- channels, pyramid and trees stay on the device
-        sel = np.zeros(len(planes), np.uint8)
-        sel[list(share)] = 1
-        if not sel.any():
-            return np.zeros(0, CAND_DTYPE)
-        res = erf.text_detect_planes(a, sel, stages)
-        out = res.cands.copy()
-        idx = {(ch, lvl): i for i, (ch, lvl, _, _) in enumerate(planes)}
-        out["node"] = np.array([idx[(int(c["ch"]), int(c["pyr"]))] for c in out], np.int32) if len(out) else out["node"]
-        return out
-    six = erf.compute_channels(a)
-    chain: Dict[Tuple[int, int], np.ndarray] = {}
-
-    def level_plane(src_ch: int, lvl: int) -> np.ndarray:       # level k = resize of level k-1 (include/str_er.h)
-        if (src_ch, lvl) not in chain:
-            if lvl == 0:
-                chain[(src_ch, 0)] = six[src_ch]
-            else:
-                pw, ph = pyr_dims(w, h, lvl)
-                chain[(src_ch, lvl)] = erf.resize_plane(level_plane(src_ch, lvl - 1), pw, ph)
-        return chain[(src_ch, lvl)]
-
-    by_size: Dict[Tuple[int, int], List[int]] = {}
-    for i in sorted(share):
-        by_size.setdefault((planes[i][2], planes[i][3]), []).append(i)
-    parts = []
-    for idx in by_size.values():
-        stack = []
-        for i in idx:
-            ch, lvl, _, _ = planes[i]
-            p = level_plane(ch % 3, lvl)
-            stack.append(255 - p if ch >= 3 else p)          # an inverted channel at level k = 255 - level k of its source
-        res = erf.detect_planes(np.stack(stack), stages)
-        for i, pr in zip(idx, res.planes):
-            c = pr.cands.copy()
-            c["ch"], c["pyr"], c["node"] = planes[i][0], planes[i][1], i
-            parts.append((i, c))
-    parts.sort(key=lambda t: t[0])
-    return np.concatenate([c for _, c in parts]) if parts else np.zeros(0, CAND_DTYPE)
+    prm = erf.params
+    if prm.n_pyr_levels != n_levels or prm.channel_mask != channel_mask:
+        raise ValueError("the context's n_pyr_levels / channel_mask are not the frame's plane layout")
+    sel = np.zeros(len(planes), np.uint8)
+    sel[list(share)] = 1
+    if not sel.any():
+        return np.zeros(0, CAND_DTYPE)
+    res = erf.text_detect_planes(a, sel, stages)
+    out = res.cands.copy()
+    idx = {(ch, lvl): i for i, (ch, lvl, _, _) in enumerate(planes)}
+    out["node"] = np.array([idx[(int(c["ch"]), int(c["pyr"]))] for c in out], np.int32) if len(out) else out["node"]
+    return out
 
 
 def detect_frame_strips(erf, comm, bgr: np.ndarray, stages: int = 7) -> np.ndarray:
@@ -207,8 +179,8 @@ def detect_frame_strips(erf, comm, bgr: np.ndarray, stages: int = 7) -> np.ndarr
 def detect_frame_plane_sharded(erf, bgr: np.ndarray, rank: int, world: int, n_levels: int, channel_mask: int = 0x3F,
                                device=None, stages: int = 7) -> np.ndarray:
     """One frame, planes dealt out to the ranks (LPT by pixel count); every rank returns ALL candidates, ordered by
-    (plane, key) as a single-GPU `text_detect` with the same pyramid gives them.  `erf` needs capacity for the frame size
-    only (its own n_pyr_levels / channel_mask are not used).  Collective over the default process group when world > 1."""
+    (plane, key) as a single-GPU `text_detect` with the same pyramid gives them.  `erf`'s n_pyr_levels / channel_mask are the
+    frame's.  Collective over the default process group when world > 1."""
     h, w = bgr.shape[:2]
     planes = frame_planes(w, h, n_levels, channel_mask)
     share = shard_planes_lpt([pw * ph for (_, _, pw, ph) in planes], world)[rank]

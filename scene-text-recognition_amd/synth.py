@@ -8,11 +8,12 @@ function of (kind, seed, width, height) and can be regenerated anywhere with num
             independent per-colour offsets.  Never reaches the sentinel level (p >= 252).
   S-noise : iid uniform 0..255 (stress; hits the level-32 sentinel of SURVEY A.2 constantly).
   S-flat  : constant 128.
-  S-ties  : S-text plus, in every third frame, one "double L" glyph: a grey box holding two dark L-shaped strokes (left + bottom,
+  S-ties  : S-text plus, in every eighth frame (`every`), one "double L" glyph: a grey box holding two dark L-shaped strokes (left + bottom,
             top + right) that do not touch, each with a core one level below its rim.  Both strokes' boxes cover more than 0.7 of
             the grey box, so both child chains pass the overlap test of non_maximum_supression (src/ER.cpp:455-462) on the same
             parent: an NMS sibling tie whose two outcomes give DIFFERENT pools -- the case the reference decides by its flood
-            order.  About one plane in forty (pyr3x8: the Y planes of the first levels of those frames) needs the order walked.
+            order.  The Y planes of the first two or three pyramid levels of such a frame need the order walked: with every = 8 that is
+            1.2 % of the planes of a pyr3x8 batch, with every = 3 3.1 %.
 """
 from __future__ import annotations
 
@@ -113,9 +114,9 @@ def draw_tie_glyph(img: np.ndarray, x0: int, y0: int, gw: int, gh: int, st1: int
         sub[_erode4(l)] = fill
 
 
-def sties_bgr(seed: int, w: int, h: int) -> np.ndarray:
+def sties_bgr(seed: int, w: int, h: int, every: int = 8) -> np.ndarray:
     img = stext_bgr(seed, w, h)
-    if seed % 3 == 0 and w >= 160 and h >= 160:
+    if seed % every == 0 and w >= 160 and h >= 160:
         r = [int(v) for v in _hash(seed ^ 0x71E5, np.arange(6, dtype=np.uint64))]
         gw, gh = 76 + r[0] % 36, 76 + r[1] % 36
         draw_tie_glyph(img, r[2] % (w - gw), r[3] % (h - gh), gw, gh, 3 + r[4] % 3, 3 + (r[4] >> 8) % 3, 20 + r[5] % 30)
@@ -129,6 +130,24 @@ def frames_bgr(kind: str, first_frame: int, n_frames: int, w: int, h: int) -> np
     """(n_frames, h, w, 3) uint8, frame i uses seed 0x5EED0000 + first_frame + i."""
     fn = KINDS[kind]
     return np.stack([fn(frame_seed(first_frame + i), w, h) for i in range(n_frames)])
+
+
+def nv12_from_bgr(bgr: np.ndarray) -> np.ndarray:
+    """What a decoder would hand over for this frame: (h * 3 // 2, w) uint8 -- the luma plane, then interleaved Cb/Cr at half
+    resolution.  Luma / chroma with the integer BGR->YCrCb formula of the path (OpenCV 8-bit, shift 14), chroma averaged over its
+    2 x 2 block ((a+b+c+d+2) >> 2).  Input data for the NV12 entry point only; w and h even."""
+    h, w = bgr.shape[:2]
+    assert w % 2 == 0 and h % 2 == 0
+    b, g, r = (bgr[..., k].astype(np.int32) for k in range(3))
+    y = np.clip((1868 * b + 9617 * g + 4899 * r + 8192) >> 14, 0, 255)
+    cr = np.clip(((r - y) * 11682 + (128 << 14) + 8192) >> 14, 0, 255)
+    cb = np.clip(((b - y) * 9241 + (128 << 14) + 8192) >> 14, 0, 255)
+    box = lambda p: (p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + 2) >> 2
+    out = np.empty((h + h // 2, w), np.uint8)
+    out[:h] = y
+    out[h:, 0::2] = box(cb)
+    out[h:, 1::2] = box(cr)
+    return out
 
 
 def gray(bgr: np.ndarray) -> np.ndarray:

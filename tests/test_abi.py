@@ -19,7 +19,7 @@ def declared_symbols():
 
 def test_header_declares_the_reference_surface():
     syms = declared_symbols()
-    for need in ("str_er_create", "str_er_destroy", "str_er_load_cascade", "str_er_detect_bgr", "str_er_detect_planes",
+    for need in ("str_er_create", "str_er_destroy", "str_er_load_cascade", "str_er_detect_bgr", "str_er_detect_nv12", "str_er_detect_planes",
                  "str_er_compute_channels", "str_er_classify_boxes", "str_er_lbp_hist", "str_er_calc_lbp", "str_er_nms_tree",
                  "str_er_result_cands", "str_er_result_free", "str_er_last_error"):
         assert need in syms

@@ -64,7 +64,7 @@ def test_bench_workload_ties(S, cascade_paths, oracle, oracle_cascades):
     levels, mask = 8, 0x07
     f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=3, n_pyr_levels=levels, channel_mask=mask))
     f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
-    frames = np.stack([S.synth.sties_bgr(S.synth.frame_seed(i), W, H) for i in (2, 4, 5)])
+    frames = np.stack([S.synth.sties_bgr(S.synth.frame_seed(i), W, H, every=3) for i in (2, 4, 5)])
     before = f.tie_stats()["planes_walked"]
     res = f.text_detect(frames)
     pyr = {}
@@ -74,7 +74,7 @@ def test_bench_workload_ties(S, cascade_paths, oracle, oracle_cascades):
             pyr[(fr, c)] = oracle.pyramid(six[c], levels)
     _check_all_planes(oracle, oracle_cascades, res, lambda p: pyr[(p.frame, p.ch)][p.pyr])
     st = f.tie_stats()
-    assert st["planes_walked"] - before >= 2 and st["walk_ms_total"] > 0 and 1 <= st["host_threads"] <= 32
+    assert st["planes_walked"] - before >= 2 and st["walk_ms_total"] > 0 and 1 <= st["host_threads"] <= 16
     # the tie is real: under the two key rules the oracle's pools of the glyph's plane differ
     t = oracle.tree_extract(pyr[(0, 0)][0])
     p1, _ = oracle.nms(t, H, W, sibling_mode=1)

@@ -89,34 +89,31 @@ def test_shard_planes_lpt():
 
 
 class _FakeFilter:
-    """Stands in for ERFilter in the CPU test of the sharded flow: 'candidates' are a pure function of the plane's bytes."""
+    """Stands in for ERFilter in the CPU test of the sharded flow: 'candidates' are a pure function of (channel, level) and
+    the frame's bytes; like the library it takes a plane subset (text_detect_planes) and returns records in plane order."""
 
-    def __init__(self, S):
-        self.S = S
-
-    def compute_channels(self, bgr):
-        b = bgr.astype(np.int32)
-        y = ((b[..., 0] + b[..., 1] + b[..., 2]) // 3).astype(np.uint8)
-        return np.stack([y, bgr[..., 1], bgr[..., 2], 255 - y, 255 - bgr[..., 1], 255 - bgr[..., 2]])
-
-    def resize_plane(self, p, dw, dh):
-        ys = (np.arange(dh) * p.shape[0]) // dh
-        xs = (np.arange(dw) * p.shape[1]) // dw
-        return np.ascontiguousarray(p[ys][:, xs])
-
-    def detect_planes(self, planes, stages=7):
+    def __init__(self, S, n_levels, channel_mask):
         from types import SimpleNamespace
+        self.S = S
+        self.params = SimpleNamespace(n_pyr_levels=n_levels, channel_mask=channel_mask)
+
+    def text_detect_planes(self, bgr, select, stages=7):
+        from types import SimpleNamespace
+        h, w = bgr.shape[:2]
+        planes = self.S.dist.frame_planes(w, h, self.params.n_pyr_levels, self.params.channel_mask)
         out = []
-        for j, p in enumerate(planes):
-            n = int(p.sum()) % 5
+        for i, (ch, lvl, pw, ph) in enumerate(planes):
+            if not select[i]:
+                continue
+            seed = int(bgr[..., ch % 3].sum()) + 17 * ch + 101 * lvl
+            n = seed % 5
             c = np.zeros(n, self.S.CAND_DTYPE)
-            c["ch"] = j
-            c["key"] = (np.arange(n) * 7 + int(p[0, 0])) % (p.size)
-            c["key"].sort()
-            c["area"] = int(p.sum()) % 1000
-            c["w"], c["h"] = p.shape[1], p.shape[0]
-            out.append(SimpleNamespace(cands=c))
-        return SimpleNamespace(planes=out)
+            c["ch"], c["pyr"] = ch, lvl
+            c["key"] = np.sort((np.arange(n) * 7 + seed) % (pw * ph))
+            c["area"] = seed % 1000
+            c["w"], c["h"] = pw, ph
+            out.append(c)
+        return SimpleNamespace(cands=np.concatenate(out) if out else np.zeros(0, self.S.CAND_DTYPE))
 
 
 def _plane_worker(rank, world, port, q):
@@ -128,7 +125,7 @@ def _plane_worker(rank, world, port, q):
     try:
         rng = np.random.default_rng(5)
         bgr = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
-        f = _FakeFilter(S)
+        f = _FakeFilter(S, 4, 0x2B)
         got = S.dist.detect_frame_plane_sharded(f, bgr, rank, world, n_levels=4, channel_mask=0x2B, device=torch.device("cpu"))
         n_planes = len(S.dist.frame_planes(64, 48, 4, 0x2B))
         ref = S.dist.detect_plane_share(f, bgr, list(range(n_planes)), 4, 0x2B)       # everything on one rank

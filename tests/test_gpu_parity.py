@@ -423,6 +423,26 @@ def test_default_tables_grow_with_the_content(S, oracle):
     f.close()
 
 
+def test_nv12_ingest(S, cascade_paths, oracle, oracle_cascades):
+    """str_er_detect_nv12: the three planes are the oracle's ero_nv12_to_ycrcb of the same bytes, everything after
+    them is the path of the BGR entry point -- all planes of a 2-level context against the oracle, two frames, a ragged width."""
+    for (W, H) in ((640, 480), (198, 90)):
+        f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=2, n_pyr_levels=2))
+        f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+        nv = np.stack([S.synth.nv12_from_bgr(S.synth.stext_bgr(S.synth.frame_seed(60 + i), W, H)) for i in range(2)])
+        res = f.text_detect_nv12(nv, W, H, want_nodes=True)
+        assert len(res.planes) == 2 * 2 * 6
+        for p in res.planes:
+            three = oracle.nv12_to_ycrcb(nv[p.frame], W, H)
+            src = three[p.ch % 3]
+            img = oracle.pyramid(src, 2)[p.pyr]
+            check_plane_against_oracle(oracle, p, 255 - img if p.ch >= 3 else img, oracle_cascades)
+        assert len(res.cands) > 0
+        with pytest.raises(S.StrErError):
+            f.text_detect_nv12(nv[:, :, :-1].copy(), W - 1, H)                # odd width
+        f.close()
+
+
 # ---- config 5 geometry: 3840x2160, 12-level pyramid ------------------------------------------------------
 def test_4k_plane_and_pyramid_dims(S, cascade_paths, oracle, oracle_cascades):
     f = S.ERFilter(params=S.Params(max_width=3840, max_height=2160, max_frames=1, n_pyr_levels=12, channel_mask=0x01))

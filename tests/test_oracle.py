@@ -226,3 +226,16 @@ def test_golden_text_round_trip(S):
 def test_pyramid_dims(oracle):
     dims = [oracle.pyr_dims(1920, 1080, k) for k in range(8)]
     assert dims == [(1920, 1080), (1358, 764), (960, 540), (679, 382), (480, 270), (339, 191), (240, 135), (170, 95)]
+
+
+def test_nv12_ingest_definition(oracle):
+    """The build-defined NV12 -> Y/Cr/Cb step (no reference counterpart; oracle/er_oracle.c: ero_nv12_to_ycrcb): luma as is, Cb / Cr
+    = the decoder's U / V sample of the pixel's 2 x 2 block."""
+    w, h = 6, 4
+    nv = np.arange((h + h // 2) * w, dtype=np.uint8).reshape(h + h // 2, w)
+    pl = oracle.nv12_to_ycrcb(nv, w, h)
+    assert (pl[0] == nv[:h]).all()
+    for y in range(h):
+        for x in range(w):
+            assert pl[2][y, x] == nv[h + y // 2, 2 * (x // 2)]          # Cb <- U
+            assert pl[1][y, x] == nv[h + y // 2, 2 * (x // 2) + 1]      # Cr <- V
