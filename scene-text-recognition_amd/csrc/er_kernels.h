@@ -20,6 +20,10 @@ struct BatchDev {
     const uint32_t  *seam_block_first;  // its first pair inside that plane
     uint32_t         n_seam_blocks;
     uint32_t        *tile_nbase; // plane-local id of every tile's first node record (NONE: the plane ran out of records)
+    uint16_t        *tile_nrec;  // ... and how many records the tile has
+    uint8_t         *group_done; // per group of tiles: k_group_merge has joined its inner seams (k_seam skips them)
+    uint32_t         n_groups;   // batch-wide
+    int32_t          group_x, group_y;   // tiles per group (0: no grouping in this batch)
     uint16_t        *seam;     // node of every tile-border pixel: index inside its tile's records (0xFFFF: wall)
     uint32_t        *pool;     // kept slots chosen by NMS, ascending key
     uint32_t        *pool_tmp;
@@ -47,6 +51,8 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 
 // sparse: the small-LDS / high-occupancy size of the kernel (text-like frames); dense: the big one (noise-like frames)
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
+// the tiles of every group of BatchDev::group_x x group_y tiles joined in LDS, in place (big: LDS for 2048 records per group, else 1024)
+void launch_group_merge(hipStream_t s, const BatchDev &b, bool big);
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);
 void launch_resolve(hipStream_t s, const BatchDev &b);
 // strips of a plane extracted elsewhere: make a strip's record ids plane-wide; join pixel pairs (plane-local ids) across a cut

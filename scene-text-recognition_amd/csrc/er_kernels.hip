@@ -51,6 +51,16 @@ __device__ __forceinline__ int find_plane_by_tile(const PlaneDesc *pl, int n, ui
     return lo;
 }
 
+__device__ __forceinline__ int find_plane_by_group(const PlaneDesc *pl, int n, uint32_t group)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pl[mid].group_base <= group) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ int find_plane_by_pair(const PlaneDesc *pl, int n, uint32_t pair)
 {
     int lo = 0, hi = n - 1;
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // (sampled from the lanes' first pieces) -- whose pieces are summed in registers, reduced over the row with three DPP steps and
         // added by ONE lane: at most 32 atomics per word and tile for a hot node.  All other pieces take the atomics below.
         // The piece headed by the node's level root also carries the node itself (+1 in the node field), a piece with a pixel on a seam
-        // carries the open bit (OR-ed separately: an add could carry).
+        // carries the side bits (OR-ed separately: an add could carry).
         {
             const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
             const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
@@ -1029,30 +1039,35 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 ROW8_ALLREDUCE(d, OP_MIN);
                 h2 = d == 0xFFFFFFFFu ? NONE : (d & 0xFFFFu);
             }
-            // per hot node: pixels (7 bits) | is-the-root-piece (bit 7) | pieces on a seam (bits 8..14); node 1 in bits 0..15, node 2 in 16..31
-            uint32_t acc = 0, col1 = 0, col2 = 0;
+            // per hot node: pixels (7 bits) | is-the-root-piece (bit 7); node 1 in bits 0..15, node 2 in 16..31.  hsides: the tile sides
+            // (top 1, bottom 2, left 4, right 8) its pieces lie on, node 1 in bits 0..3, node 2 in bits 4..7
+            uint32_t acc = 0, col1 = 0, col2 = 0, hsides = 0;
+            const uint32_t side_tb = (top ? 1u : 0u) | (bot ? 2u : 0u);
             uint32_t m = headm;
             while (m) {
                 const int k = __ffs((int)m) - 1;
                 m &= m - 1u;
                 const uint32_t len = (uint32_t)__ffs((int)(stopm >> (k + 1)));      // distance to the next head, wall or the lane's end
                 const bool     isroot = ((rootmask >> k) & 1u) != 0;
-                const bool     opn = top || bot || (lef && k == 0) || (rig && k + (int)len == TILE_PPT);
+                // the sides of the tile the piece lies on ("open": the node can still change when the tiles are joined; which sides, because
+                // joining goes in two steps -- groups of tiles first, k_group_merge, and a seam inside a group is no border any more)
+                const uint32_t sd = side_tb | ((lef && k == 0) ? 4u : 0u) | ((rig && k + (int)len == TILE_PPT) ? 8u : 0u);
                 const uint32_t r = isroot ? p0 + (uint32_t)k : (s_par[LX(p0 + (uint32_t)k)] & 0xFFFFu);
                 const uint32_t cb = ((1u << len) - 1u) << k;
-                const uint32_t add = len | (isroot ? 0x80u : 0u) | (opn ? 0x100u : 0u);
-                if (r == h1) { acc += add; col1 |= cb; }
-                else if (r == h2) { acc += add << 16; col2 |= cb; }
+                const uint32_t add = len | (isroot ? 0x80u : 0u);
+                if (r == h1) { acc += add; col1 |= cb; hsides |= sd; }
+                else if (r == h2) { acc += add << 16; col2 |= cb; hsides |= sd << 4; }
                 else {
                     const uint32_t id = s_nid[LX(r)];
                     atomicAdd(&s_w0[id], len + (isroot ? 1u << CNT_BITS : 0u));
                     atomicOr(&s_row[id], (rowmask_t)1 << ly);
                     // (the lane's 8 columns lie in one half of the 64-bit column set)
                     atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + (lx >> 5), cb << (lx & 31));
-                    if (opn) atomicOr(&s_w0[id], 0x80000000u);
+                    if (sd) atomicOr(&s_w0[id], sd << 28);
                 }
             }
             ROW8_ALLREDUCE(acc, OP_ADD);
+            ROW8_ALLREDUCE(hsides, OP_OR);
             // column sets: the 4 lanes of a quad own the 4 bytes of one dword (lanes 0-3: columns 0-31, lanes 4-7: columns 32-63)
             col1 <<= 8u * (chunk & 3u); col2 <<= 8u * (chunk & 3u);
             col1 |= dpp_mov<0xB1>(col1, col1); col1 |= dpp_mov<0x4E>(col1, col1);
@@ -1067,7 +1082,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 atomicOr(&s_row[id], (rowmask_t)1 << ly);
                 if (my_lo) atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]), my_lo);
                 if (my_hi) atomicOr(reinterpret_cast<uint32_t *>(&s_col[id]) + 1, my_hi);
-                if (my_acc >> 8) atomicOr(&s_w0[id], 0x80000000u);
+                const uint32_t my_sd = chunk == 0 ? (hsides & 0xFu) : (hsides >> 4);
+                if (my_sd) atomicOr(&s_w0[id], my_sd << 28);
             }
         }
         __syncthreads();
@@ -1097,7 +1113,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 if (w == NONE) continue;
                 const uint32_t pa = s_nid[LX(w & 0xFFFFu)];
                 const uint32_t v = s_w0[a];
-                if (v >> 31) atomicOr(&s_w0[pa], 0x80000000u);
+                if (v >> 28) atomicOr(&s_w0[pa], v & 0xF0000000u);       // open: so is the parent, on the same sides
                 else {
                     atomicAdd(&s_w0[pa], v & ((1u << (2 * CNT_BITS)) - 1u));
                     atomicOr(&s_row[pa], s_row[a]);
@@ -1110,7 +1126,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         PHASE_MARK(7);
         // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
         // node of the flood's start pixel
-        uint32_t expmask = 0, openmask = 0;
+        uint32_t expmask = 0;
         {
             uint32_t m = rootmask, id = aid0;
             const uint32_t sroot = s_start;
@@ -1119,8 +1135,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 m &= m - 1u;
                 const uint32_t v = s_w0[id++];
                 const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
-                const bool     open = (v >> 31) != 0;
-                if (open) openmask |= 1u << k;
+                const bool     open = (v >> 28) != 0;
                 if (open || (int64_t)area > (int64_t)prm.min_area || s_par[OWN(k)] == NONE || p0 + k == sroot) expmask |= 1u << k;
             }
         }
@@ -1128,7 +1143,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         if (tid == 0) take_records(total);
         // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
         // One exported node: everything it needs is in LDS except its own level and whether it is open.
-        auto export_node = [&](uint32_t nbase, uint32_t p, uint32_t a, uint32_t l, bool open) {
+        auto export_node = [&](uint32_t nbase, uint32_t p, uint32_t a, uint32_t l) {
             uint32_t q = s_par[LX(p)], ql = 0;
             if (q != NONE) { ql = (q >> 16) & 0xFFu; q &= 0xFFFFu; }
             while (q != NONE && s_nid[LX(q)] == 0xFFFFu) {      // only the start pixel's node can need this
@@ -1141,7 +1156,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             const rowmask_t          rm = s_row[a];
             const uint32_t px = SLOT_PIXEL(p);
             put_record(nbase + s_nid[LX(p)], (q == NONE) ? NONE : PAR_MAKE(ql, nbase + s_nid[LX(q)]), v & CNT_MASK,
-                       ((v >> CNT_BITS) & CNT_MASK) | (open ? 0u : NODE_CLOSED),
+                       ((v >> CNT_BITS) & CNT_MASK) | ((v >> 28) ? (v >> 28) << 26 : NODE_CLOSED),       // (NODE_SIDE_T .. _R = bits 26..29)
                        (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u)) | (l << 24),
                        ox + __ffsll((long long)cm) - 1, oy + row_lo(rm), ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
         };
@@ -1169,8 +1184,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         } else if (listed) {
             for (uint32_t e = tid; e < total; e += TILE_THREADS) {
                 const uint32_t w = s_exp[e];
-                export_node(nbase, w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu,
-                            (s_w0[(w >> SLOT_BITS) & ((1u << A_BITS) - 1u)] >> 31) != 0);
+                export_node(nbase, w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu);
             }
         } else {
             uint32_t aid = aid0;
@@ -1178,7 +1192,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             for (int k = 0; k < TILE_PPT; ++k) {
                 if (!((rootmask >> k) & 1)) continue;
                 const uint32_t a = aid++;
-                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev_of(k), (openmask >> k) & 1);
+                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev_of(k));
             }
         }
     } else {
@@ -1216,7 +1230,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 const uint32_t w = s_par[LX(p)];
                 const unsigned long long cm = s_col[li];
                 const rowmask_t          rm = s_row[li];
-                put_record(nbase + s_nid[LX(p)], (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, nbase + s_nid[LX(w & 0xFFFFu)]), s_cnt[li], 1u,
+                // (no fold, so nothing is known about sides: a node of a dense tile counts as lying on all four)
+                put_record(nbase + s_nid[LX(p)], (w == NONE) ? NONE : PAR_MAKE((w >> 16) & 0xFFu, nbase + s_nid[LX(w & 0xFFFFu)]), s_cnt[li], 1u | NODE_SIDES,
                            (uint32_t)(gy * pd.w + gx + k) | (lev_of(k) << 24),
                            ox + __ffsll((long long)cm) - 1, oy + row_lo(rm), ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
             }
@@ -1227,6 +1242,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     const uint32_t nbase = s_nbase;
     if (tid == 0) {
         b.tile_nbase[blockIdx.x] = nbase;
+        b.tile_nrec[blockIdx.x] = (uint16_t)total;
         if (tl == 0) b.ctr[pi].start_node = (s_start == NONE || nbase == NONE) ? NONE : nbase + s_nid[LX(s_start)];
     }
     PHASE_MARK(13);
@@ -1278,6 +1294,192 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, b
     if (!b.n_tiles) return;
     if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
     else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
+}
+
+// ------------------------------------------------------------------------------------
+// Component tree, part 1b: the tiles of a GROUP (GX x GY tiles) joined in LDS, in place.
+//
+// The global passes (k_seam, k_resolve, k_reduce) work on device-scope atomics, a few hundred picoseconds per record, and every
+// node that touches any tile border goes through them.  Most of those nodes only touch a seam towards a NEIGHBOURING tile and are
+// complete a tile or two further on.  One workgroup per group loads the records of its tiles (a few hundred: text-like 4 x 8 tiles
+// ~ 430, noise 2 x 4 ~ 1400), joins the pixel pairs of the seams INSIDE the group with the same connect on LDS words, hands the
+// statistics of unified nodes to their survivors (k_resolve's job), and folds every node whose component does not reach the group's
+// OUTER border into its parent (k_reduce's job) -- what is left for the global passes are the nodes on the outer border: a quarter
+// (4 x 8) or a third (2 x 4) of before.  Everything stays where it is: survivors keep their record, unified nodes are marked
+// NODE_DEAD (k_resolve skips them), folded ones NODE_CLOSED (they never push again), so the seam map and every id stay valid.
+// A group with more records than fit LDS is left alone (group_done stays 0: k_seam joins its inner seams as before).
+// ------------------------------------------------------------------------------------
+constexpr int GROUP_THREADS = 256;
+constexpr int GROUP_MAX_TILES = 32;
+
+template <int CAP>
+__global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
+{
+    __shared__ uint32_t s_par[CAP], s_cnt[CAP], s_nod[CAP], s_key[CAP], s_x0[CAP], s_y0[CAP], s_x1[CAP], s_y1[CAP];
+    __shared__ uint32_t s_toff[GROUP_MAX_TILES + 1], s_tbase[GROUP_MAX_TILES];
+    __shared__ uint32_t s_levels[8];
+    const int       tid = threadIdx.x;
+    const int       GX = b.group_x, GY = b.group_y;
+    const int       pi = find_plane_by_group(b.planes, b.n_planes, blockIdx.x);
+    const PlaneDesc pd = b.planes[pi];
+    const int       groups_x = (pd.tiles_x + GX - 1) / GX;
+    const uint32_t  gl = blockIdx.x - pd.group_base;
+    const int       tx0 = (int)(gl % (uint32_t)groups_x) * GX, ty0 = (int)(gl / (uint32_t)groups_x) * GY;
+    const int       gw = min(GX, pd.tiles_x - tx0), gh = min(GY, pd.tiles_y - ty0);
+    const int       nt = gw * gh;
+    if (nt < 2) return;
+    if (tid < 8) s_levels[tid] = 0;
+    if (tid == 0) {
+        uint32_t at = 0;
+        bool ok = true;
+        for (int t = 0; t < nt; ++t) {
+            const uint32_t tile = pd.tile_base + (uint32_t)(ty0 + t / gw) * pd.tiles_x + (uint32_t)(tx0 + t % gw);
+            const uint32_t nb = b.tile_nbase[tile];
+            s_toff[t] = at; s_tbase[t] = nb;
+            if (nb == NONE) ok = false;
+            at += b.tile_nrec[tile];
+        }
+        s_toff[nt] = (ok && at <= (uint32_t)CAP) ? at : NONE;
+    }
+    __syncthreads();
+    const uint32_t N = s_toff[nt];
+    if (N == NONE || N == 0) return;
+    NodeRec *const nr = b.na.rec + pd.node_base;
+    auto tile_of = [&](uint32_t i) -> int {         // (records are grouped by tile: the tile whose range holds local index i)
+        int lo = 0, hi = nt - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_toff[mid] <= i) lo = mid; else hi = mid - 1; }
+        return lo;
+    };
+    // ---- load; parent ids become local; only the sides on the group's OUTER border stay ----
+    for (uint32_t i = tid; i < N; i += GROUP_THREADS) {
+        const int      t = tile_of(i);
+        const uint32_t gid = s_tbase[t] + (i - s_toff[t]);
+        const uint4    a = reinterpret_cast<const uint4 *>(nr + gid)[0], c = reinterpret_cast<const uint4 *>(nr + gid)[1];
+        const int      ix = t % gw, iy = t / gw;
+        const uint32_t inner = (ix + 1 < gw ? NODE_SIDE_R : 0u) | (ix > 0 ? NODE_SIDE_L : 0u) | (iy + 1 < gh ? NODE_SIDE_B : 0u) | (iy > 0 ? NODE_SIDE_T : 0u);
+        s_par[i] = a.x == NONE ? NONE : PAR_MAKE(PAR_LVL(a.x), PAR_ID(a.x) - s_tbase[t] + s_toff[t]);
+        s_cnt[i] = a.y; s_nod[i] = a.z & ~inner; s_key[i] = a.w;
+        s_x0[i] = c.x; s_y0[i] = c.y; s_x1[i] = c.z; s_y1[i] = c.w;
+        atomicOr(&s_levels[(a.w >> 24) >> 5], 1u << ((a.w >> 24) & 31u));
+    }
+    __syncthreads();
+    // ---- the pixel pairs of the inner seams (same connect as node_connect, on LDS words) ----
+    auto lfind = [&](uint32_t &a, uint32_t la) -> uint32_t {
+        uint32_t wa = LD_WG(&s_par[a]);
+        while (wa != NONE && PAR_LVL(wa) == la) {
+            const uint32_t nx = PAR_ID(wa);
+            const uint32_t w2 = LD_WG(&s_par[nx]);
+            if (w2 != NONE && PAR_LVL(w2) == la) s_par[a] = w2;       // path halving, same node
+            a = nx; wa = w2;
+        }
+        return wa;
+    };
+    auto lconnect = [&](uint32_t a, uint32_t bb) {
+        uint32_t la = s_key[a] >> 24, lb = s_key[bb] >> 24;
+        for (;;) {
+            uint32_t wa = lfind(a, la);
+            uint32_t wb = lfind(bb, lb);
+            if (a == bb) return;
+            if (la > lb || (la == lb && a < bb)) { uint32_t t; t = a; a = bb; bb = t; t = la; la = lb; lb = t; t = wa; wa = wb; wb = t; }
+            if (la == lb || wa == NONE || PAR_LVL(wa) > lb) {
+                const uint32_t old = atomicCAS(&s_par[a], wa, PAR_MAKE(lb, bb));
+                if (old != wa) continue;
+                if (wa == NONE) return;
+            }
+            a = PAR_ID(wa); la = PAR_LVL(wa);
+        }
+    };
+    {
+        const uint16_t *seam = b.seam + pd.seam_base;
+        const uint32_t  n_hp = (uint32_t)((gh - 1) * gw * TILE_W), n_vp = (uint32_t)((gw - 1) * gh * TILE_H);
+        const size_t    voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
+        for (uint32_t p0 = 0; p0 < n_hp + n_vp; p0 += GROUP_THREADS) {
+            const uint32_t p = p0 + (uint32_t)tid;
+            uint32_t a = NONE, bb = NONE;
+            if (p < n_hp) {
+                const int iy = (int)(p / (uint32_t)(gw * TILE_W)), xg = (int)(p % (uint32_t)(gw * TILE_W));      // boundary under tile row iy; column inside the group
+                const int x = tx0 * TILE_W + xg, j = ty0 + iy;
+                if (x < pd.w) {
+                    const uint32_t ea = seam[((size_t)j * 2) * pd.w + x], eb = seam[((size_t)j * 2 + 1) * pd.w + x];
+                    if (ea != 0xFFFFu && eb != 0xFFFFu) { a = s_toff[iy * gw + xg / TILE_W] + ea; bb = s_toff[(iy + 1) * gw + xg / TILE_W] + eb; }
+                }
+            } else if (p < n_hp + n_vp) {
+                const uint32_t q = p - n_hp;
+                const int ix = (int)(q / (uint32_t)(gh * TILE_H)), yg = (int)(q % (uint32_t)(gh * TILE_H));
+                const int y = ty0 * TILE_H + yg, k = tx0 + ix;
+                if (y < pd.h) {
+                    const uint32_t ea = seam[voff + ((size_t)k * 2) * pd.h + y], eb = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
+                    if (ea != 0xFFFFu && eb != 0xFFFFu) { a = s_toff[(yg / TILE_H) * gw + ix] + ea; bb = s_toff[(yg / TILE_H) * gw + ix + 1] + eb; }
+                }
+            }
+            // (neighbouring lanes very often carry the same pair -- a flat region along the seam: the first lane of such a run connects)
+            const uint32_t pa = __shfl_up(a, 1), pb = __shfl_up(bb, 1);
+            const bool dup = (tid & 63) != 0 && pa == a && pb == bb;
+            if (a != NONE && !dup) lconnect(a, bb);
+        }
+    }
+    __syncthreads();
+    // ---- unified nodes hand their own statistics to the surviving level root; the others get a canonical parent (k_resolve) ----
+    for (uint32_t i = tid; i < N; i += GROUP_THREADS) {
+        const uint32_t l = s_key[i] >> 24, w = s_par[i];
+        if (w == NONE) continue;
+        uint32_t q = PAR_ID(w);
+        const uint32_t lq = PAR_LVL(w);
+        for (;;) { const uint32_t w2 = s_par[q]; if (w2 == NONE || PAR_LVL(w2) != lq) break; q = PAR_ID(w2); }
+        if (lq == l) {
+            const uint32_t f = s_nod[i];
+            atomicAdd(&s_cnt[q], s_cnt[i]);
+            atomicAdd(&s_nod[q], (f & NODE_CNT) - 1u);          // (its folded descendants; the node itself is the survivor's)
+            atomicOr(&s_nod[q], f & NODE_SIDES);
+            atomicMin(&s_x0[q], s_x0[i]); atomicMin(&s_y0[q], s_y0[i]); atomicMax(&s_x1[q], s_x1[i]); atomicMax(&s_y1[q], s_y1[i]);
+            atomicMin(&s_key[q], s_key[i]);                     // same level: the top byte is equal, the minimum is over the pixel index
+            atomicOr(&s_nod[i], NODE_DEAD);
+        }
+        // (a unified node's parent word names its survivor from now on: whoever reads it later walks one hop)
+        if (q != PAR_ID(w)) s_par[i] = PAR_MAKE(lq, q);
+    }
+    __syncthreads();
+    // ---- bottom-up over the levels: a node whose component reaches the group's outer border passes its sides on to its parent; any
+    // other node is complete -- it adds its totals to its parent (k_reduce) and is closed ----
+    for (int wd = 0; wd < 8; ++wd) {
+        uint32_t pm = s_levels[wd];
+        while (pm) {
+            const uint32_t t = (uint32_t)wd * 32u + (uint32_t)__ffs((int)pm) - 1u;
+            pm &= pm - 1u;
+            for (uint32_t i = tid; i < N; i += GROUP_THREADS) {
+                if ((s_key[i] >> 24) != t) continue;
+                const uint32_t f = s_nod[i], w = s_par[i];
+                if ((f & (NODE_DEAD | NODE_CLOSED)) || w == NONE) continue;
+                const uint32_t q = PAR_ID(w);
+                if (f & NODE_SIDES) atomicOr(&s_nod[q], f & NODE_SIDES);
+                else {
+                    atomicAdd(&s_cnt[q], s_cnt[i]);
+                    atomicAdd(&s_nod[q], f & NODE_CNT);
+                    atomicMin(&s_x0[q], s_x0[i]); atomicMin(&s_y0[q], s_y0[i]); atomicMax(&s_x1[q], s_x1[i]); atomicMax(&s_y1[q], s_y1[i]);
+                    s_nod[i] = f | NODE_CLOSED;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- back to the records, in place (ids global again) ----
+    for (uint32_t i = tid; i < N; i += GROUP_THREADS) {
+        const int      t = tile_of(i);
+        const uint32_t gid = s_tbase[t] + (i - s_toff[t]);
+        uint32_t       w = s_par[i];
+        if (w != NONE) { const uint32_t q = PAR_ID(w); const int tq = tile_of(q); w = PAR_MAKE(PAR_LVL(w), s_tbase[tq] + (q - s_toff[tq])); }
+        uint4 *dst = reinterpret_cast<uint4 *>(nr + gid);
+        dst[0] = make_uint4(w, s_cnt[i], s_nod[i], s_key[i]);
+        dst[1] = make_uint4(s_x0[i], s_y0[i], s_x1[i], s_y1[i]);
+    }
+    if (tid == 0) b.group_done[blockIdx.x] = 1;
+}
+
+void launch_group_merge(hipStream_t s, const BatchDev &b, bool big)
+{
+    if (!b.n_groups || b.group_x <= 0 || b.group_y <= 0 || b.group_x * b.group_y > GROUP_MAX_TILES) return;
+    if (big) hipLaunchKernelGGL(k_group_merge<2048>, dim3(b.n_groups), dim3(GROUP_THREADS), 0, s, b);
+    else     hipLaunchKernelGGL(k_group_merge<1024>, dim3(b.n_groups), dim3(GROUP_THREADS), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1367,18 +1569,29 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
         const uint16_t *seam = b.seam + pd.seam_base;
         const uint32_t *tnb = b.tile_nbase + pd.tile_base;
         uint32_t la, lb, ta, tb;
+        // (a seam inside a group of tiles that k_group_merge has put together is no seam any more)
+        const uint32_t GX = (uint32_t)b.group_x, GY = (uint32_t)b.group_y, groups_x = GX ? ((uint32_t)pd.tiles_x + GX - 1u) / GX : 0u;
+        bool inner = false;
         if (i < pd.n_hpairs) {
             const uint32_t j = i / pd.w, x = i - j * pd.w;
-            la = seam[((size_t)j * 2) * pd.w + x];
-            lb = seam[((size_t)j * 2 + 1) * pd.w + x];
             ta = j * pd.tiles_x + x / (uint32_t)TILE_W; tb = ta + pd.tiles_x;
+            if (GX && (j + 1u) % GY != 0u) inner = b.group_done[pd.group_base + (j / GY) * groups_x + (x / (uint32_t)TILE_W) / GX] != 0;
+            la = lb = 0xFFFFu;
+            if (!inner) {
+                la = seam[((size_t)j * 2) * pd.w + x];
+                lb = seam[((size_t)j * 2 + 1) * pd.w + x];
+            }
         } else {
             const uint32_t i2 = i - pd.n_hpairs;
             const uint32_t k = i2 / pd.h, y = i2 - k * pd.h;
             const size_t   voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
-            la = seam[voff + ((size_t)k * 2) * pd.h + y];
-            lb = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
             ta = (y / (uint32_t)TILE_H) * pd.tiles_x + k; tb = ta + 1;
+            if (GX && (k + 1u) % GX != 0u) inner = b.group_done[pd.group_base + ((y / (uint32_t)TILE_H) / GY) * groups_x + k / GX] != 0;
+            la = lb = 0xFFFFu;
+            if (!inner) {
+                la = seam[voff + ((size_t)k * 2) * pd.h + y];
+                lb = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
+            }
         }
         if (la != 0xFFFFu && lb != 0xFFFFu) {
             const uint32_t ba = tnb[ta], bb = tnb[tb];
@@ -1534,7 +1747,9 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
             const NodeRec   me = nr[x];          // (plain loads: k_seam's writes are visible since the kernel boundary, and a parent
             const uint32_t  l = me.key >> 24;    //  word rewritten by a lane of THIS kernel points to the same node either way)
             const uint32_t  w = me.par;
-            if (w != NONE && PAR_LVL(w) == l) {
+            if (me.nod & NODE_DEAD) {
+                // unified and handed over inside its group of tiles already (k_group_merge)
+            } else if (w != NONE && PAR_LVL(w) == l) {
                 uint32_t r = PAR_ID(w);
                 for (;;) {
                     const uint32_t w2 = nr[r].par;

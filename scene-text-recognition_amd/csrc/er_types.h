@@ -45,7 +45,8 @@ struct PlaneDesc {
     uint32_t node_cap;      // node records this plane may use (a share of its pixel count; overflow -> the host grows the share and repeats)
     uint32_t kept_cap;      // entries of the kept-node arrays / of the pool arrays that belong to this plane (by default a share of its pixel
     uint32_t pool_cap;      // count: a 240 x 135 pyramid level does not need the table of a 1920 x 1080 plane)
-    uint32_t pad2_[2];
+    uint32_t group_base;    // first group of tiles of this plane (k_group_merge; batch-wide numbering, for the batch's group size)
+    uint32_t pad2_;
 };
 static_assert(sizeof(PlaneDesc) == 96 && offsetof(PlaneDesc, node_cap) == 76, "PlaneDesc layout (host and device)");
 
@@ -94,6 +95,9 @@ struct NodeRec {
 static_assert(sizeof(NodeRec) == 32, "two dwordx4 stores");
 constexpr uint32_t NODE_DEAD = 1u << 24;     // unified into another node of the same level (k_resolve)
 constexpr uint32_t NODE_CLOSED = 2u << 24;   // never touches a seam: totals were final in the tile, never pushes
+// open nodes: the sides of their TILE their component lies on (after k_group_merge: of their group of tiles)
+constexpr uint32_t NODE_SIDE_T = 4u << 24, NODE_SIDE_B = 8u << 24, NODE_SIDE_L = 16u << 24, NODE_SIDE_R = 32u << 24;
+constexpr uint32_t NODE_SIDES = NODE_SIDE_T | NODE_SIDE_B | NODE_SIDE_L | NODE_SIDE_R;
 constexpr uint32_t NODE_CNT = 0xFFFFFFu;
 struct NodeArrays {
     NodeRec  *rec;

@@ -138,6 +138,9 @@ struct str_er_ctx {
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
     uint8_t *d_strip_out = nullptr, *d_strip_in = nullptr; size_t strip_out_cap = 0, strip_in_cap = 0;   // strip blobs: made here / uploaded for a merge
     uint32_t *d_strip_flag = nullptr;                 // a strip blob named a node outside its records
+    uint16_t *d_tile_nrec = nullptr;                  // records per tile (k_tile_tree -> k_group_merge)
+    uint8_t  *d_group_done = nullptr;                 // per group of tiles: joined in LDS (k_group_merge -> k_seam)
+    int       group_mode = -1;                        // STR_ER_GROUPS: -1 automatic (4 x 8 tiles with the small tile kernel, 2 x 4 with the big one), 0 off
     std::vector<void *> allocs;
 
     // pinned host mirrors
@@ -357,6 +360,7 @@ struct Batch {
     size_t kept = 0, pool = 0;                  // entries of the kept-node / pool arrays handed to the planes
     uint32_t kept_floor = 0, pool_floor = 0;    // str_er_nms_tree: the plane's tables must hold the imported tree
     int planes_per_image = 0;       // BGR frames: planes of one (frame, pyramid level), consecutive in `planes`; 0 = no colour image
+    uint32_t n_groups = 0; int group_x = 0, group_y = 0;       // k_group_merge: groups of group_x x group_y tiles (0: none); assign_groups()
 };
 
 void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int invert, uint32_t frame, int ch, int pyr)
@@ -392,6 +396,16 @@ void assign_node_records(Batch &b, double share)
 
 // Kept-node and pool tables.  Explicit caps (str_er_params) are given to every plane; by default a plane's share follows its padded
 // pixel count -- a 240 x 135 pyramid level does not need the table of a 1920 x 1080 plane -- and grows with the context's shares.
+// groups of gx x gy tiles per plane (k_group_merge), numbered batch-wide
+void assign_groups(Batch &b, int gx, int gy)
+{
+    b.group_x = gx; b.group_y = gy; b.n_groups = 0;
+    for (PlaneDesc &d : b.planes) {
+        d.group_base = b.n_groups;
+        if (gx > 0 && gy > 0) b.n_groups += (uint32_t)((d.tiles_x + gx - 1) / gx) * (uint32_t)((d.tiles_y + gy - 1) / gy);
+    }
+}
+
 void assign_tables(Batch &b, const str_er_ctx *c)
 {
     b.kept = b.pool = 0;
@@ -447,6 +461,7 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.node_blocks = c->node_blocks;
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
+    d.tile_nrec = c->d_tile_nrec; d.group_done = c->d_group_done; d.n_groups = b.n_groups; d.group_x = b.group_x; d.group_y = b.group_y;
     d.na = c->na; d.ka = c->ka; d.tile_nbase = c->d_tile_nbase; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch; d.wstamp = c->d_wstamp; d.wparent = c->d_wparent;
     return d;
@@ -919,6 +934,10 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     if (attempt > 24) return fail(c, STR_ER_ECAPACITY, "the batch was repeated 24 times with growing tables and still does not fit (internal error)");
     c->last_valid = false;             // (str_er_gather_last: the candidate array is being rewritten, or re-allocated)
     Batch b = b_in;
+    // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
+    // batches (small tile kernel: ~14 records per tile) take 4 x 8 tiles per group, noise-like ones (~170) 2 x 4.
+    const bool grouped = !import_trees && c->group_mode != 0;
+    if (grouped) assign_groups(b, c->tile_sparse ? 4 : 2, c->tile_sparse ? 8 : 4); else assign_groups(b, 0, 0);
     assign_node_records(b, c->node_share);
     assign_tables(b, c);
     const int ev_entry = pre_recorded ? c->n_ev : -1;
@@ -972,6 +991,11 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         std::fprintf(stderr, "[str_er] tile_tree alone: %.4f ms\n", ms);
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
+    if (grouped && b.n_groups) {
+        HIP_TRY(c, hipMemsetAsync(c->d_group_done, 0, b.n_groups, s));
+        launch_group_merge(s, bd, !c->tile_sparse);
+    }
+    rec(c, "group");
     if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
     rec(c, "seam");
     launch_resolve(s, bd);                            rec(c, "resolve");
@@ -1437,6 +1461,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         if (!std::strcmp(tk, "sparse")) { c->tile_mode = 1; c->tile_sparse = true; }
         else if (!std::strcmp(tk, "dense")) { c->tile_mode = 2; c->tile_sparse = false; }
     }
+    if (const char *g = std::getenv("STR_ER_GROUPS")) c->group_mode = std::atoi(g) == 0 ? 0 : -1;      // developer switch: 0 = tiles joined by the global passes only
     c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
     c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
     if (const char *nb = std::getenv("STR_ER_NODE_BLOCKS")) c->node_blocks_cap = (uint32_t)std::max(1, std::atoi(nb));
@@ -1503,6 +1528,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
+    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_done, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
