@@ -12,7 +12,8 @@ struct BatchDev {
     int32_t          n_planes;
     uint32_t         n_tiles;  // batch-wide
     uint32_t         n_pairs;  // batch-wide seam pixel pairs
-    uint32_t         node_blocks; // workgroups per plane of the per-record kernels
+    uint32_t         n_node_blocks; // workgroups of the per-record kernels, batch-wide
+    const uint16_t  *nb_plane;   // plane of every such workgroup (a plane has PlaneDesc::nb_count of them, from nb_base on)
     NodeArrays       na;
     KeptArrays       ka;
     const uint16_t  *tile_plane;        // plane of every tile
@@ -22,6 +23,7 @@ struct BatchDev {
     uint32_t        *tile_nbase; // plane-local id of every tile's first node record (NONE: the plane ran out of records)
     uint16_t        *tile_nrec;  // ... and how many records the tile has
     uint8_t         *group_done; // per group of tiles: k_group_merge has joined its inner seams (k_seam skips them)
+    const uint16_t  *group_plane; // plane of every group
     uint32_t         n_groups;   // batch-wide
     int32_t          group_x, group_y;   // tiles per group (0: no grouping in this batch)
     uint16_t        *seam;     // node of every tile-border pixel: index inside its tile's records (0xFFFF: wall)
@@ -51,8 +53,8 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 
 // sparse: the small-LDS / high-occupancy size of the kernel (text-like frames); dense: the big one (noise-like frames)
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
-// the tiles of every group of BatchDev::group_x x group_y tiles joined in LDS, in place (big: LDS for 2048 records per group, else 1024)
-void launch_group_merge(hipStream_t s, const BatchDev &b, bool big);
+// the tiles of every group of BatchDev::group_x x group_y tiles joined in LDS, in place (variant: LDS capacity / lanes, see er_kernels.hip)
+void launch_group_merge(hipStream_t s, const BatchDev &b, int variant);
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);
 void launch_resolve(hipStream_t s, const BatchDev &b);
 // strips of a plane extracted elsewhere: make a strip's record ids plane-wide; join pixel pairs (plane-local ids) across a cut

@@ -51,16 +51,6 @@ __device__ __forceinline__ int find_plane_by_tile(const PlaneDesc *pl, int n, ui
     return lo;
 }
 
-__device__ __forceinline__ int find_plane_by_group(const PlaneDesc *pl, int n, uint32_t group)
-{
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (pl[mid].group_base <= group) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
 __device__ __forceinline__ int find_plane_by_pair(const PlaneDesc *pl, int n, uint32_t pair)
 {
     int lo = 0, hi = n - 1;
@@ -1309,10 +1299,9 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, b
 // NODE_DEAD (k_resolve skips them), folded ones NODE_CLOSED (they never push again), so the seam map and every id stay valid.
 // A group with more records than fit LDS is left alone (group_done stays 0: k_seam joins its inner seams as before).
 // ------------------------------------------------------------------------------------
-constexpr int GROUP_THREADS = 256;
-constexpr int GROUP_MAX_TILES = 32;
+constexpr int GROUP_MAX_TILES = 64;
 
-template <int CAP>
+template <int CAP, int GROUP_THREADS>
 __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
 {
     __shared__ uint32_t s_par[CAP], s_cnt[CAP], s_nod[CAP], s_key[CAP], s_x0[CAP], s_y0[CAP], s_x1[CAP], s_y1[CAP];
@@ -1320,7 +1309,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     __shared__ uint32_t s_levels[8];
     const int       tid = threadIdx.x;
     const int       GX = b.group_x, GY = b.group_y;
-    const int       pi = find_plane_by_group(b.planes, b.n_planes, blockIdx.x);
+    const int       pi = b.group_plane[blockIdx.x];
     const PlaneDesc pd = b.planes[pi];
     const int       groups_x = (pd.tiles_x + GX - 1) / GX;
     const uint32_t  gl = blockIdx.x - pd.group_base;
@@ -1329,17 +1318,19 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     const int       nt = gw * gh;
     if (nt < 2) return;
     if (tid < 8) s_levels[tid] = 0;
-    if (tid == 0) {
-        uint32_t at = 0;
-        bool ok = true;
-        for (int t = 0; t < nt; ++t) {
-            const uint32_t tile = pd.tile_base + (uint32_t)(ty0 + t / gw) * pd.tiles_x + (uint32_t)(tx0 + t % gw);
-            const uint32_t nb = b.tile_nbase[tile];
-            s_toff[t] = at; s_tbase[t] = nb;
-            if (nb == NONE) ok = false;
-            at += b.tile_nrec[tile];
+    if (tid < 64) {
+        // the tiles' record ranges: one lane per tile (first wave), offsets by a wave scan -- a lane walking the tiles one after the other
+        // spends a global round trip per tile before anybody else can start
+        uint32_t nb = 0, cnt = 0;
+        if (tid < nt) {
+            const uint32_t tile = pd.tile_base + (uint32_t)(ty0 + tid / gw) * pd.tiles_x + (uint32_t)(tx0 + tid % gw);
+            nb = b.tile_nbase[tile];
+            cnt = b.tile_nrec[tile];
         }
-        s_toff[nt] = (ok && at <= (uint32_t)CAP) ? at : NONE;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const bool bad = __any(tid < nt && nb == NONE);
+        if (tid < nt) { s_toff[tid] = incl - cnt; s_tbase[tid] = nb; }
+        if (tid == nt - 1) s_toff[nt] = (!bad && incl <= (uint32_t)CAP) ? incl : NONE;
     }
     __syncthreads();
     const uint32_t N = s_toff[nt];
@@ -1475,11 +1466,18 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     if (tid == 0) b.group_done[blockIdx.x] = 1;
 }
 
-void launch_group_merge(hipStream_t s, const BatchDev &b, bool big)
+// variant: LDS for 512 / 1024 / 2048 / 3072 records per group, 256 / 512 / 1024 lanes
+void launch_group_merge(hipStream_t s, const BatchDev &b, int variant)
 {
     if (!b.n_groups || b.group_x <= 0 || b.group_y <= 0 || b.group_x * b.group_y > GROUP_MAX_TILES) return;
-    if (big) hipLaunchKernelGGL(k_group_merge<2048>, dim3(b.n_groups), dim3(GROUP_THREADS), 0, s, b);
-    else     hipLaunchKernelGGL(k_group_merge<1024>, dim3(b.n_groups), dim3(GROUP_THREADS), 0, s, b);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((k_group_merge<512, 256>), dim3(b.n_groups), dim3(256), 0, s, b); break;
+    case 1: hipLaunchKernelGGL((k_group_merge<1024, 256>), dim3(b.n_groups), dim3(256), 0, s, b); break;
+    case 2: hipLaunchKernelGGL((k_group_merge<1024, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
+    case 3: hipLaunchKernelGGL((k_group_merge<2048, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
+    case 4: hipLaunchKernelGGL((k_group_merge<2048, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
+    default: hipLaunchKernelGGL((k_group_merge<3072, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1701,7 +1699,9 @@ void launch_strip_border_ids(hipStream_t s, const uint16_t *seam_row, const uint
 // ------------------------------------------------------------------------------------
 // Part 3: per-node passes over the plane's records.  Grid = (NODE_BLOCKS, planes); a block strides over its plane's nodes.
 // ------------------------------------------------------------------------------------
-// (BatchDev::node_blocks x 256 lanes per plane, chosen by the host from the record counts of the previous batch)
+// (a plane gets workgroups of 256 lanes by its size -- PlaneDesc::nb_count of them, BatchDev::nb_plane lists the plane of every workgroup:
+// the largest plane as many as the record counts of the previous batch ask for, a 240 x 135 pyramid level ONE; with the same number for
+// every plane (round 2) a pyr3x8 batch launched 27 000 workgroups per pass, most of them for planes with a hundred records)
 
 __device__ __forceinline__ uint32_t plane_nodes(const BatchDev &b, int pi)
 {
@@ -1733,12 +1733,13 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // -- open, alive, not a tree root -- is counted in the parent's dependency counter (aux).
 __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 {
-    const int       pi = blockIdx.y;
+    const int       pi = b.nb_plane[blockIdx.x];
+    const uint32_t  bi = blockIdx.x - b.planes[pi].nb_base, nbp = b.planes[pi].nb_count;     // this plane's workgroups: bi of nbp
     const uint32_t  n = plane_nodes(b, pi);
     NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
     uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
     const int       lane = threadIdx.x & 63;
-    for (uint32_t x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += gridDim.x * blockDim.x) {
+    for (uint32_t x0 = bi * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += nbp * blockDim.x) {
         const uint32_t  x = x0 + (uint32_t)lane;
         uint32_t        push_to = NONE;         // the parent this node will push its totals to
         uint32_t        hand_to = NONE;         // the surviving level root this (unified) node hands its own statistics to
@@ -1815,7 +1816,7 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 void launch_resolve(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_resolve, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_resolve, dim3(b.n_node_blocks), dim3(256), 0, s, b);
 }
 
 // er_merge's accumulation (src/ER.cpp:153-165): every live open node adds its (final) totals to its parent.  One launch for
@@ -1860,12 +1861,13 @@ __device__ __forceinline__ bool node_arrive(uint32_t *ctr, uint32_t k, uint32_t 
 
 __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
 {
-    const int       pi = blockIdx.y;
+    const int       pi = b.nb_plane[blockIdx.x];
+    const uint32_t  bi = blockIdx.x - b.planes[pi].nb_base, nbp = b.planes[pi].nb_count;
     const uint32_t  n = plane_nodes(b, pi);
     NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
     uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
     const int       lane = threadIdx.x & 63;
-    for (uint32_t x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += gridDim.x * blockDim.x) {
+    for (uint32_t x0 = bi * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += nbp * blockDim.x) {
         const uint32_t x = x0 + lane;
         bool     act = false;
         uint32_t q = NONE, c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
@@ -1913,7 +1915,7 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
 void launch_reduce(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_reduce, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_reduce, dim3(b.n_node_blocks), dim3(256), 0, s, b);
 }
 
 // Root of the tree that holds the flood's start pixel (er_stack.back(), src/ER.cpp:346).
@@ -1960,7 +1962,8 @@ void launch_root(hipStream_t s, const BatchDev &b, const DetectParams &p)
 // trees (regions sealed off by sentinel-level pixels) were never visited by the flood.
 __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 {
-    const int       pi = blockIdx.y;
+    const int       pi = b.nb_plane[blockIdx.x];
+    const uint32_t  bi = blockIdx.x - b.planes[pi].nb_base, nbp = b.planes[pi].nb_count;
     PlaneCtr       &c = b.ctr[pi];
     const uint32_t  root = c.root_node;
     if (root == NONE) return;
@@ -1969,7 +1972,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
     const NodeRec  *nr = b.na.rec + pd.node_base;
     uint32_t       *aux = b.na.aux + pd.node_base;
     const bool      walls = c.n_walls != 0;
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+    for (uint32_t x = bi * blockDim.x + threadIdx.x; x < n; x += nbp * blockDim.x) {
         const uint32_t f = nr[x].nod;
         if (f & NODE_DEAD) continue;
         if (x != root) {
@@ -1994,7 +1997,7 @@ __global__ __launch_bounds__(256) void k_select(BatchDev b, DetectParams prm)
 void launch_select(hipStream_t s, const BatchDev &b, const DetectParams &p)
 {
     if (!b.n_planes) return;
-    hipLaunchKernelGGL(k_select, dim3(b.node_blocks, b.n_planes), dim3(256), 0, s, b, p);
+    hipLaunchKernelGGL(k_select, dim3(b.n_node_blocks), dim3(256), 0, s, b, p);
 }
 
 // Kept-node records (flat form of struct ER, inc/ER.h:42-80).

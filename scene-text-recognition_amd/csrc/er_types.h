@@ -40,13 +40,14 @@ struct PlaneDesc {
     uint32_t pool_base;     // offset in the pool arrays (capacity pool_cap)
     uint32_t frame;
     uint8_t  ch, pyr;
-    uint8_t  pad0, pad1;
+    uint8_t  nb_count;      // workgroups of the per-record kernels (k_resolve, k_reduce, k_select) this plane gets
+    uint8_t  pad1;
     uint32_t color_pitch;   // BGR frames: bytes between the Y, Cr, Cb planes of this level (pix - (ch % 3) * color_pitch is Y); 0 = no colour image
     uint32_t node_cap;      // node records this plane may use (a share of its pixel count; overflow -> the host grows the share and repeats)
     uint32_t kept_cap;      // entries of the kept-node arrays / of the pool arrays that belong to this plane (by default a share of its pixel
     uint32_t pool_cap;      // count: a 240 x 135 pyramid level does not need the table of a 1920 x 1080 plane)
     uint32_t group_base;    // first group of tiles of this plane (k_group_merge; batch-wide numbering, for the batch's group size)
-    uint32_t pad2_;
+    uint32_t nb_base;       // ... and the first of them
 };
 static_assert(sizeof(PlaneDesc) == 96 && offsetof(PlaneDesc, node_cap) == 76, "PlaneDesc layout (host and device)");
 

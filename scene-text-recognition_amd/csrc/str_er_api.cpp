@@ -138,8 +138,11 @@ struct str_er_ctx {
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
     uint8_t *d_strip_out = nullptr, *d_strip_in = nullptr; size_t strip_out_cap = 0, strip_in_cap = 0;   // strip blobs: made here / uploaded for a merge
     uint32_t *d_strip_flag = nullptr;                 // a strip blob named a node outside its records
+    uint16_t *d_nb_plane = nullptr; std::vector<uint16_t> h_nb_plane; uint32_t n_node_blocks = 0;      // plane of every workgroup of the per-record kernels
     uint16_t *d_tile_nrec = nullptr;                  // records per tile (k_tile_tree -> k_group_merge)
+    uint16_t *d_group_plane = nullptr; std::vector<uint16_t> h_group_plane;      // plane of every group of tiles
     uint8_t  *d_group_done = nullptr;                 // per group of tiles: joined in LDS (k_group_merge -> k_seam)
+    int       dbg_group[3] = {0, 0, -1};              // developer knobs STR_ER_GROUP_X / _Y / _KERNEL
     int       group_mode = -1;                        // STR_ER_GROUPS: -1 automatic (4 x 8 tiles with the small tile kernel, 2 x 4 with the big one), 0 off
     std::vector<void *> allocs;
 
@@ -458,10 +461,10 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
 {
     BatchDev d{};
     d.planes = c->d_planes; d.ctr = c->d_ctr; d.n_planes = (int32_t)b.planes.size();
-    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.node_blocks = c->node_blocks;
+    d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.n_node_blocks = c->n_node_blocks; d.nb_plane = c->d_nb_plane;
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
-    d.tile_nrec = c->d_tile_nrec; d.group_done = c->d_group_done; d.n_groups = b.n_groups; d.group_x = b.group_x; d.group_y = b.group_y;
+    d.tile_nrec = c->d_tile_nrec; d.group_done = c->d_group_done; d.group_plane = c->d_group_plane; d.n_groups = b.n_groups; d.group_x = b.group_x; d.group_y = b.group_y;
     d.na = c->na; d.ka = c->ka; d.tile_nbase = c->d_tile_nbase; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch; d.wstamp = c->d_wstamp; d.wparent = c->d_wparent;
     return d;
@@ -888,10 +891,23 @@ int group_phase_overlap(str_er_ctx *c, const std::vector<uint32_t> &img, bool in
 }
 
 // Plane descriptors, zeroed counters and the tile / seam-block lookup tables of a laid-out batch go to the device.
-int upload_layout(str_er_ctx *c, const Batch &b)
+int upload_layout(str_er_ctx *c, Batch &b)
 {
     hipStream_t s = c->stream;
     const int np = (int)b.planes.size();
+    {   // workgroups of the per-record kernels: by plane size, the largest plane node_blocks of them
+        size_t most_tiles = 1;
+        for (const PlaneDesc &pd : b.planes) most_tiles = std::max(most_tiles, (size_t)pd.tiles_x * pd.tiles_y);
+        const uint32_t nb = std::min<uint32_t>(std::max<uint32_t>(c->node_blocks, 1u), 32u);
+        uint32_t at = 0;
+        for (PlaneDesc &pd : b.planes) {
+            const size_t t = (size_t)pd.tiles_x * pd.tiles_y;
+            pd.nb_count = (uint8_t)std::max<size_t>(1, (t * nb + most_tiles - 1) / most_tiles);
+            pd.nb_base = at;
+            at += pd.nb_count;
+        }
+        c->n_node_blocks = at;
+    }
     std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
     HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
@@ -900,10 +916,21 @@ int upload_layout(str_er_ctx *c, const Batch &b)
         std::vector<uint32_t> key;
         key.reserve(np * 2 + 1);
         key.push_back((uint32_t)np);
+        key.push_back(c->node_blocks);
+        key.push_back((uint32_t)b.group_x * 256u + (uint32_t)b.group_y);
         for (const PlaneDesc &pd : b.planes) { key.push_back((uint32_t)pd.w); key.push_back((uint32_t)pd.h); }
         if (key != c->layout_key) {
             c->layout_key.clear();          // the tables are being rebuilt: a failure below must not leave the old key naming them
-            c->h_tile_plane.clear(); c->h_sb_plane.clear(); c->h_sb_first.clear();
+            c->h_tile_plane.clear(); c->h_sb_plane.clear(); c->h_sb_first.clear(); c->h_nb_plane.clear();
+            for (int i = 0; i < np; ++i) c->h_nb_plane.insert(c->h_nb_plane.end(), (size_t)b.planes[i].nb_count, (uint16_t)i);
+            HIP_TRY(c, hipMemcpyAsync(c->d_nb_plane, c->h_nb_plane.data(), 2 * c->h_nb_plane.size(), hipMemcpyHostToDevice, s));
+            c->h_group_plane.clear();
+            if (b.group_x > 0 && b.group_y > 0)
+                for (int i = 0; i < np; ++i) {
+                    const PlaneDesc &pd = b.planes[i];
+                    c->h_group_plane.insert(c->h_group_plane.end(), (size_t)((pd.tiles_x + b.group_x - 1) / b.group_x) * ((pd.tiles_y + b.group_y - 1) / b.group_y), (uint16_t)i);
+                }
+            if (!c->h_group_plane.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_group_plane, c->h_group_plane.data(), 2 * c->h_group_plane.size(), hipMemcpyHostToDevice, s));
             for (int i = 0; i < np; ++i) {
                 const PlaneDesc &pd = b.planes[i];
                 c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
@@ -937,7 +964,11 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
     // batches (small tile kernel: ~14 records per tile) take 4 x 8 tiles per group, noise-like ones (~170) 2 x 4.
     const bool grouped = !import_trees && c->group_mode != 0;
-    if (grouped) assign_groups(b, c->tile_sparse ? 4 : 2, c->tile_sparse ? 8 : 4); else assign_groups(b, 0, 0);
+    {
+        int gx = c->tile_sparse ? 4 : 2, gy = 4;         // (tools/dev_groups.sh: 4 x 4 tiles on text-like batches, 2 x 4 on noise)
+        if (c->dbg_group[0] > 0) { gx = c->dbg_group[0]; gy = c->dbg_group[1]; }
+        if (grouped) assign_groups(b, gx, gy); else assign_groups(b, 0, 0);
+    }
     assign_node_records(b, c->node_share);
     assign_tables(b, c);
     const int ev_entry = pre_recorded ? c->n_ev : -1;
@@ -993,7 +1024,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     }
     if (grouped && b.n_groups) {
         HIP_TRY(c, hipMemsetAsync(c->d_group_done, 0, b.n_groups, s));
-        launch_group_merge(s, bd, !c->tile_sparse);
+        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 2 : 4));       // (measured, tools/dev_groups.sh)
     }
     rec(c, "group");
     if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
@@ -1462,6 +1493,9 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         else if (!std::strcmp(tk, "dense")) { c->tile_mode = 2; c->tile_sparse = false; }
     }
     if (const char *g = std::getenv("STR_ER_GROUPS")) c->group_mode = std::atoi(g) == 0 ? 0 : -1;      // developer switch: 0 = tiles joined by the global passes only
+    if (const char *g = std::getenv("STR_ER_GROUP_X")) c->dbg_group[0] = std::atoi(g);
+    if (const char *g = std::getenv("STR_ER_GROUP_Y")) c->dbg_group[1] = std::atoi(g);
+    if (const char *g = std::getenv("STR_ER_GROUP_KERNEL")) c->dbg_group[2] = std::atoi(g);
     c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
     c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
     if (const char *nb = std::getenv("STR_ER_NODE_BLOCKS")) c->node_blocks_cap = (uint32_t)std::max(1, std::atoi(nb));
@@ -1528,7 +1562,8 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
-    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_done, c->tile_slots));
+    A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * 32));
+    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_done, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     A(dev_alloc(c, c->d_total, 4));
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
