@@ -983,7 +983,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     auto put_record = [&](uint32_t id, uint32_t par, uint32_t cnt, uint32_t nod_flags, uint32_t key_lvl, uint32_t x0, uint32_t y0,
                           uint32_t x1, uint32_t y1) {
         uint4 *dst = reinterpret_cast<uint4 *>(nrec + id);
-        dst[0] = make_uint4(par, cnt, nod_flags, key_lvl);
+        dst[0] = make_uint4(par, key_lvl, cnt, nod_flags);
         dst[1] = make_uint4(x0, y0, x1, y1);
         b.na.aux[pd.node_base + id] = 0;           // dependency counter of k_resolve / k_reduce
     };
@@ -1349,9 +1349,9 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         const int      ix = t % gw, iy = t / gw;
         const uint32_t inner = (ix + 1 < gw ? NODE_SIDE_R : 0u) | (ix > 0 ? NODE_SIDE_L : 0u) | (iy + 1 < gh ? NODE_SIDE_B : 0u) | (iy > 0 ? NODE_SIDE_T : 0u);
         s_par[i] = a.x == NONE ? NONE : PAR_MAKE(PAR_LVL(a.x), PAR_ID(a.x) - s_tbase[t] + s_toff[t]);
-        s_cnt[i] = a.y; s_nod[i] = a.z & ~inner; s_key[i] = a.w;
+        s_key[i] = a.y; s_cnt[i] = a.z; s_nod[i] = a.w & ~inner;
         s_x0[i] = c.x; s_y0[i] = c.y; s_x1[i] = c.z; s_y1[i] = c.w;
-        atomicOr(&s_levels[(a.w >> 24) >> 5], 1u << ((a.w >> 24) & 31u));
+        atomicOr(&s_levels[(a.y >> 24) >> 5], 1u << ((a.y >> 24) & 31u));
     }
     __syncthreads();
     // ---- the pixel pairs of the inner seams (same connect as node_connect, on LDS words) ----
@@ -1460,7 +1460,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         uint32_t       w = s_par[i];
         if (w != NONE) { const uint32_t q = PAR_ID(w); const int tq = tile_of(q); w = PAR_MAKE(PAR_LVL(w), s_tbase[tq] + (q - s_toff[tq])); }
         uint4 *dst = reinterpret_cast<uint4 *>(nr + gid);
-        dst[0] = make_uint4(w, s_cnt[i], s_nod[i], s_key[i]);
+        dst[0] = make_uint4(w, s_key[i], s_cnt[i], s_nod[i]);
         dst[1] = make_uint4(s_x0[i], s_y0[i], s_x1[i], s_y1[i]);
     }
     if (tid == 0) b.group_done[blockIdx.x] = 1;
@@ -1835,13 +1835,22 @@ constexpr uint32_t NODE_CLAIMED = 0xFFFFFFFFu;
 // comes from the coherence point, so the push has been performed there before the decrement is even issued.  (Waiting for the
 // acknowledgement of non-returning atomics -- s_waitcnt vmcnt(0), a workgroup-scope release -- is not enough: measured, subtree
 // totals came out short now and then.)
+// (pixels and nodes are neighbours in the record: one 64-bit add -- neither half can carry, a plane has fewer than 2^24 pixels and nodes)
 __device__ __forceinline__ uint32_t node_push(NodeRec *dst, uint32_t c, uint32_t nd, uint32_t bx0, uint32_t by0, uint32_t bx1, uint32_t by1)
 {
-    uint32_t r = RMW_AGENT(add, &dst->cnt, c);
-    r |= RMW_AGENT(add, &dst->nod, nd);
+    const unsigned long long cn = RMW_AGENT(add, static_cast<unsigned long long *>(__builtin_assume_aligned(&dst->cnt, 8)), (unsigned long long)c | ((unsigned long long)nd << 32));
+    uint32_t r = (uint32_t)cn | (uint32_t)(cn >> 32);
     r |= RMW_AGENT(min, &dst->x0, bx0); r |= RMW_AGENT(min, &dst->y0, by0);
     r |= RMW_AGENT(max, &dst->x1, bx1); r |= RMW_AGENT(max, &dst->y1, by1);
     return r;
+}
+// a node's totals once all its children have pushed: three 64-bit device-scope loads (pixels | nodes, the two corners of the box)
+__device__ __forceinline__ void node_totals(const NodeRec *n, uint32_t &c, uint32_t &nodw, uint32_t &bx0, uint32_t &by0, uint32_t &bx1, uint32_t &by1)
+{
+    const unsigned long long cn = LD_AGENT(static_cast<const unsigned long long *>(__builtin_assume_aligned(&n->cnt, 8)));
+    const unsigned long long a = LD_AGENT(static_cast<const unsigned long long *>(__builtin_assume_aligned(&n->x0, 8))), z = LD_AGENT(static_cast<const unsigned long long *>(__builtin_assume_aligned(&n->x1, 8)));
+    c = (uint32_t)cn; nodw = (uint32_t)(cn >> 32);
+    bx0 = (uint32_t)a; by0 = (uint32_t)(a >> 32); bx1 = (uint32_t)z; by1 = (uint32_t)(z >> 32);
 }
 __device__ __forceinline__ bool node_claim(uint32_t *ctr)
 {
@@ -1873,10 +1882,12 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
         uint32_t q = NONE, c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
         if (x < n) {
             const uint32_t w = nr[x].par, f = nr[x].nod;          // parent and flags are final since k_resolve
-            act = w != NONE && !(f & (NODE_DEAD | NODE_CLOSED)) && LD_AGENT(&aux[x]) == 0 && node_claim(&aux[x]);
+            // (the claim itself tells whether the node is ready: a counter that is not 0 makes it fail)
+            act = w != NONE && !(f & (NODE_DEAD | NODE_CLOSED)) && node_claim(&aux[x]);
             if (act) {
-                q = PAR_ID(w); c = LD_AGENT(&nr[x].cnt); nd = LD_AGENT(&nr[x].nod) & NODE_CNT;
-                bx0 = LD_AGENT(&nr[x].x0); by0 = LD_AGENT(&nr[x].y0); bx1 = LD_AGENT(&nr[x].x1); by1 = LD_AGENT(&nr[x].y1);
+                q = PAR_ID(w);
+                node_totals(nr + x, c, nd, bx0, by0, bx1, by1);
+                nd &= NODE_CNT;
             }
         }
         // first step: lanes of the wave that share a parent combine (ballot + butterfly): one set of atomics and one
@@ -1902,11 +1913,12 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
         // the lanes that now own a parent carry it upward
         uint32_t g = q;
         while (cont) {
-            const uint32_t w = LD_AGENT(&nr[g].par), f = LD_AGENT(&nr[g].nod);
-            if (w == NONE || (f & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
+            const uint32_t w = nr[g].par;                                  // (final since k_resolve, like the flags)
+            uint32_t gc, gf, gx0, gy0, gx1, gy1;
+            node_totals(nr + g, gc, gf, gx0, gy0, gx1, gy1);
+            if (w == NONE || (gf & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
             const uint32_t p = PAR_ID(w);
-            cont = node_arrive(&aux[p], 1u, node_push(nr + p, LD_AGENT(&nr[g].cnt), f & NODE_CNT, LD_AGENT(&nr[g].x0), LD_AGENT(&nr[g].y0),
-                                                      LD_AGENT(&nr[g].x1), LD_AGENT(&nr[g].y1)));
+            cont = node_arrive(&aux[p], 1u, node_push(nr + p, gc, gf & NODE_CNT, gx0, gy0, gx1, gy1));
             g = p;
         }
     }

@@ -86,13 +86,16 @@ constexpr int NMS_WATCH_CAP = 256;   // watched key pixels per plane; more -> th
 
 // One tree node that left its tile ("exported"): 32 bytes, written by k_tile_tree with two 16-byte stores, index =
 // PlaneDesc::node_base + plane-local id.  Ids are handed out densely per plane (PlaneCtr::n_nodes), a tile at a time.
-struct NodeRec {
+struct alignas(16) NodeRec {
     uint32_t par;           // NONE (tree root) or level of the parent << 24 | plane-local id of the parent; CAS-ed by k_seam
+    uint32_t key;           // bits 0..23 min linear pixel index of the node's own-level pixels; bits 24..31 the node's level
+    // (cnt | nod and each corner of the box are 8-byte aligned pairs: k_reduce moves them with ONE 64-bit device-scope operation each --
+    // those operations, not bytes, are what the accumulation costs)
     uint32_t cnt;           // pixels: own -> subtree total
     uint32_t nod;           // bits 0..23 nodes: 1 -> subtree total (pruned ones included); bits 24.. NODE_* flags
-    uint32_t key;           // bits 0..23 min linear pixel index of the node's own-level pixels; bits 24..31 the node's level
     uint32_t x0, y0, x1, y1; // bbox: own -> subtree (atomicMin / atomicMax)
 };
+static_assert(offsetof(NodeRec, cnt) == 8 && offsetof(NodeRec, x0) == 16 && offsetof(NodeRec, x1) == 24, "64-bit pairs");
 static_assert(sizeof(NodeRec) == 32, "two dwordx4 stores");
 constexpr uint32_t NODE_DEAD = 1u << 24;     // unified into another node of the same level (k_resolve)
 constexpr uint32_t NODE_CLOSED = 2u << 24;   // never touches a seam: totals were final in the tile, never pushes
