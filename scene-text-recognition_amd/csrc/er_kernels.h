@@ -71,7 +71,7 @@ void launch_kept(hipStream_t s, const BatchDev &b, const DetectParams &p);
 // pass 0: every plane; sibling ties by key (exact mode: provisional, planes with ties are counted in n_amb and get a watch list).
 // use_index_order: exact mode on an uploaded tree -- the table order is the child-list order.
 void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool use_index_order = false);
-void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p);
+void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p, uint32_t *alt_list /* NMS_ALT_CAP words, device */);
 // planes with ties left (PlaneCtr::n_rel) -> host-addressable memory: pixels, watch keys, watch parents per slot (see er_kernels.hip)
 void launch_export_listed_planes(hipStream_t s, const BatchDev &b, const ReplayItem *items, int n_items, uint8_t *host_buf /* page-locked, device-addressable */);
 void launch_export_tie_planes(hipStream_t s, const BatchDev &b, uint8_t *host_buf, size_t slot_bytes, int n_slots, uint32_t *slot_plane_dev /* n_slots words, device */,

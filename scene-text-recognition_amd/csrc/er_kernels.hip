@@ -1020,8 +1020,10 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
             const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
             const uint32_t chunk = (uint32_t)tid & 7u;
-            uint32_t h1, h2;            // the row's hot level roots (slots; NONE: none)
-            {
+            // (the big kernel is picked for batches that are mostly noise: a row's pieces are all different nodes there, nothing is hot)
+            constexpr bool HOT = FOLD_CAP == FOLD_CAP_SPARSE;
+            uint32_t h1 = NONE, h2 = NONE;            // the row's hot level roots (slots; NONE: none)
+            if (HOT) {
                 uint32_t d = first_root == NONE ? 0xFFFFFFFFu : ((chunk << 16) | first_root);
                 ROW8_ALLREDUCE(d, OP_MIN);
                 h1 = d == 0xFFFFFFFFu ? NONE : (d & 0xFFFFu);
@@ -1056,6 +1058,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                     if (sd) atomicOr(&s_w0[id], sd << 28);
                 }
             }
+          if (HOT) {
             ROW8_ALLREDUCE(acc, OP_ADD);
             ROW8_ALLREDUCE(hsides, OP_OR);
             // column sets: the 4 lanes of a quad own the 4 bytes of one dword (lanes 0-3: columns 0-31, lanes 4-7: columns 32-63)
@@ -1075,6 +1078,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 const uint32_t my_sd = chunk == 0 ? (hsides & 0xFu) : (hsides >> 4);
                 if (my_sd) atomicOr(&s_w0[id], my_sd << 28);
             }
+          }
         }
         __syncthreads();
         PHASE_MARK(5);
@@ -2092,7 +2096,11 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     __shared__ uint32_t s_levels[8];
     const bool       pass1 = pass != NMS_PASS_FIRST;          // a repeat: the plane's counters stay as the first pass left them
     const bool       alt = pass == NMS_PASS_ALT;
-    const int        pi = pass == NMS_PASS_STAMP ? (int)items[blockIdx.x].plane : (int)blockIdx.x;
+    // (the opposite-rule pass runs on the handful of planes k_alt_list found, `scratch` = its list: one workgroup per listed plane instead
+    // of one per plane of the batch, of which all but a few returned at once)
+    const uint32_t   pi_ = pass == NMS_PASS_STAMP ? items[blockIdx.x].plane : alt ? reinterpret_cast<const uint32_t *>(scratch)[blockIdx.x] : blockIdx.x;
+    if (pi_ == NONE) return;
+    const int        pi = (int)pi_;
     PlaneCtr        &c = b.ctr[pi];
     if (alt && !(c.n_rel != 0 && c.n_amb == 1 && c.tie_nc == 2)) return;
     const PlaneDesc &pd = b.planes[pi];
@@ -2297,10 +2305,28 @@ void launch_nms(hipStream_t s, const BatchDev &b, const DetectParams &p, bool us
 
 // exact mode: planes whose only tie is one two-way tie are tried under the opposite rule; equal pools settle them (n_rel = 0).
 // Touches only NMS scratch and the counters n_rel / n_watch, so it may run beside the kernels that consume the pools.
-void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p)
+// the planes whose only tie is one relevant two-way tie (the only ones the opposite-rule pass can settle), at most NMS_ALT_CAP of them; a
+// plane that finds no room keeps its tie for the flood order walk
+__global__ __launch_bounds__(1024) void k_alt_list(BatchDev b, uint32_t *list)
+{
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    for (int i = threadIdx.x; i < NMS_ALT_CAP; i += blockDim.x) list[i] = NONE;
+    __syncthreads();
+    for (int pi = threadIdx.x; pi < b.n_planes; pi += blockDim.x) {
+        const PlaneCtr &c = b.ctr[pi];
+        if (c.n_rel != 0 && c.n_amb == 1 && c.tie_nc == 2) {
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < (uint32_t)NMS_ALT_CAP) list[at] = (uint32_t)pi;
+        }
+    }
+}
+
+void launch_nms_alt(hipStream_t s, const BatchDev &b, const DetectParams &p, uint32_t *alt_list)
 {
     if (!b.n_planes || p.sibling_order != 0) return;
-    hipLaunchKernelGGL(k_nms, dim3(b.n_planes), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, (const uint8_t *)nullptr, (int)NMS_ORD_KEY_MIN,
+    hipLaunchKernelGGL(k_alt_list, dim3(1), dim3(1024), 0, s, b, alt_list);
+    hipLaunchKernelGGL(k_nms, dim3(NMS_ALT_CAP), dim3(NMS_THREADS), 0, s, b, p, (const ReplayItem *)nullptr, reinterpret_cast<const uint8_t *>(alt_list), (int)NMS_ORD_KEY_MIN,
                        (int)NMS_PASS_ALT);
 }
 

@@ -82,6 +82,7 @@ struct ReplayItem {
     uint32_t pad_;
     uint64_t off;           // byte offset of the plane's scratch (stamp u32[w*h], link u32[w*h], level u8[w*h]) in the replay buffer
 };
+constexpr int NMS_ALT_CAP = 64;      // planes per batch the opposite-rule NMS pass can take
 constexpr int NMS_WATCH_CAP = 256;   // watched key pixels per plane; more -> the replay floods the whole plane
 
 // One tree node that left its tile ("exported"): 32 bytes, written by k_tile_tree with two 16-byte stores, index =

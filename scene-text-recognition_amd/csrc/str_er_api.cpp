@@ -127,6 +127,7 @@ struct str_er_ctx {
     uint8_t *h_replay = nullptr; size_t h_replay_bytes = 0;   // page-locked: the planes (and watch lists) the flood order walk reads
     uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
     ReplayItem *d_replay_items = nullptr;
+    uint32_t *d_alt_list = nullptr;                   // planes of the opposite-rule NMS pass (k_alt_list)
     uint32_t *d_tie_slot_plane = nullptr;             // plane of every tie slot of the batch (k_tie_slots -> k_export_tie_planes)
     uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
     uint32_t last_total = 0; bool last_valid = false;   // candidates of the last detect call, still in d_cands (str_er_gather_last)
@@ -1042,7 +1043,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     if (alt_pass) {       // beside classify: it only decides whether a tie needs the flood order walk
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        launch_nms_alt(c->side, bd, dp);
+        launch_nms_alt(c->side, bd, dp, c->d_alt_list);
         if (c->h_tie && !c->replay_on_gpu) {
             *c->h_tie_count = 0;        // (the previous batch of this context is done: nothing on the device touches it any more)
             launch_export_tie_planes(c->side, bd, c->h_tie, c->tie_slot_bytes, c->n_tie_slots, c->d_tie_slot_plane, c->h_tie_count, c->h_tie_plane);
@@ -1569,6 +1570,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
     A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
     A(dev_alloc(c, c->d_tie_slot_plane, (size_t)TIE_SLOTS));
+    A(dev_alloc(c, c->d_alt_list, (size_t)NMS_ALT_CAP));
     A(dev_alloc(c, c->d_strip_flag, (size_t)1));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
@@ -2486,7 +2488,7 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     bd.n_seam_blocks = 0;
     const DetectParams dp = make_dp(c);
     launch_nms(s, bd, dp, /*use_index_order=*/plane == nullptr);
-    if (plane) launch_nms_alt(s, bd, dp);
+    if (plane) launch_nms_alt(s, bd, dp, c->d_alt_list);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
