@@ -2,13 +2,13 @@
 # Run on a GPU box (via gpurun) from the repo root: bench lines + rocprofv3 summaries for profiles/.
 # Usage: tools/collect_profiles.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (the profiled runs keep ONE batch in flight: a kernel's average duration is then its isolated launch duration, the quantity roofline.avg_launch_ms reports)
-B="python $ROOT/bench.py --steps 6 --warmup 2 --pipelines 1 --no-cpu-baseline --no-latency --no-host-frames"
+B="python $ROOT/bench.py --steps 6 --warmup 2 --pipelines 1 --no-cpu-baseline --no-latency --no-host-frames --no-ties-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $B > $OUT/pmc_write.log 2>&1
