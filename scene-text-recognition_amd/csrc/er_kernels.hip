@@ -1245,29 +1245,36 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     // kernel adds tile_nbase) ---------------------------------------------------------------
     // seam layout per plane: for every horizontal tile boundary j (1..tiles_y-1) two rows
     // of w entries (pixel row j*TH-1, then j*TH); then for every vertical boundary i two
-    // columns of h entries (pixel column i*TW-1, then i*TW).  Each lane writes its own pixels.
+    // columns of h entries (pixel column i*TW-1, then i*TW).
+    // The 64 pixels of the tile's top row belong to 8 lanes (the first 8 of wave 0), those of the bottom row to the last 8 of the last wave.
+    // Had the owners written them, 8 lanes of a wave would walk through 8 pixels each while 56 watch (the kernel is bound by the number of
+    // instructions its waves issue, whatever the lanes do): instead every lane of the wave takes ONE pixel -- it fetches the owner's bit
+    // sets with one shuffle -- and the wave writes the row with one store (round 3: 289 -> 95 instructions per wave for this phase).
     {
         uint16_t *seam = b.seam + pd.seam_base;
         const uint32_t voff = 2u * pd.w * (pd.tiles_y - 1);
-        const bool top = ly == 0 && ty > 0, bot = ly == TILE_H - 1 && ty + 1 < pd.tiles_y;
-        const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
-        // record (inside the tile) of the node of the lane's pixel k: the level root of the piece it lies in
-        auto pixel_node = [&](int k) -> uint16_t {
-            if (((wallm >> k) & 1u) || nbase == NONE) return (uint16_t)0xFFFFu;
-            const int hk = 31 - __clz((int)(headm & ((2u << k) - 1u)));       // head of the piece
-            return s_nid[LX(((rootmask >> hk) & 1u) ? p0 + (uint32_t)hk : (s_par[LX(p0 + (uint32_t)hk)] & 0xFFFFu))];
+        // record (inside the tile) of the node of pixel k of the lane whose first slot is q0: the level root of the piece it lies in
+        auto node_of = [&](uint32_t wm, uint32_t hm, uint32_t rm, uint32_t q0, int k) -> uint16_t {
+            if (((wm >> k) & 1u) || nbase == NONE) return (uint16_t)0xFFFFu;
+            const int      hk = 31 - __clz((int)(hm & ((2u << k) - 1u)));       // head of the piece
+            const uint32_t hp = q0 + (uint32_t)hk;
+            return s_nid[LX(((rm >> hk) & 1u) ? hp : (s_par[LX(hp)] & 0xFFFFu))];
         };
-        if ((top || bot) && gy < pd.h) {
-#pragma unroll
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (gx + k >= pd.w) continue;
-                const uint16_t id = pixel_node(k);
-                if (top) seam[((size_t)(ty - 1) * 2 + 1) * pd.w + gx + k] = id;
-                if (bot) seam[((size_t)ty * 2) * pd.w + gx + k] = id;
-            }
+        const int  wv = tid >> 6, lane = tid & 63;
+        const bool do_top = wv == 0 && ty > 0, do_bot = wv == TILE_THREADS / 64 - 1 && ty + 1 < pd.tiles_y;      // (wave-uniform)
+        const uint32_t sets = wallm | (headm << 8) | (rootmask << 16);
+        if (do_top || do_bot) {
+            const int      owner = (do_top ? 0 : 64 - TILE_W / TILE_PPT) + (lane >> 3);      // lane of this wave that holds the pixel
+            const uint32_t os = (uint32_t)__shfl((int)sets, owner);
+            const uint32_t otid = (uint32_t)(tid & ~63) + (uint32_t)owner;
+            const int      col = ox + lane, row = do_top ? oy : oy + TILE_H - 1;
+            if (col < pd.w && row < pd.h)
+                seam[(do_top ? ((size_t)(ty - 1) * 2 + 1) : ((size_t)ty * 2)) * pd.w + col] =
+                    node_of(os & 0xFFu, (os >> 8) & 0xFFu, os >> 16, otid * TILE_PPT + (otid >> 2), lane & 7);
         }
-        if (lef && gy < pd.h && gx < pd.w) seam[voff + ((size_t)(tx - 1) * 2 + 1) * pd.h + gy] = pixel_node(0);
-        if (rig && gy < pd.h && gx + TILE_PPT - 1 < pd.w) seam[voff + ((size_t)tx * 2) * pd.h + gy] = pixel_node(TILE_PPT - 1);
+        const bool lef = lx == 0 && tx > 0, rig = lx == TILE_W - TILE_PPT && tx + 1 < pd.tiles_x;
+        if ((lef || rig) && gy < pd.h && (lef ? gx : gx + TILE_PPT - 1) < pd.w)
+            seam[voff + (lef ? ((size_t)(tx - 1) * 2 + 1) : ((size_t)tx * 2)) * pd.h + gy] = node_of(wallm, headm, rootmask, p0, lef ? 0 : TILE_PPT - 1);
     }
     PHASE_MARK(6);
 }

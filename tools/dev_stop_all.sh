@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer aid: where do k_tile_tree's time and VALU instructions go?  Builds the library once per phase with
 # -DSTR_ER_STOP_AFTER=n (the kernel returns after phase n) into gpurun_out/stoplibs/, then (on the GPU box: `tools/dev_stop_all.sh run`)
-# times the kernel alone for every variant and counts its VALU instructions with rocprofv3.
+# times the kernel alone for every variant and counts its vector / scalar / LDS / branch instructions with rocprofv3.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/scene-text-recognition_amd/lib/stop
@@ -24,7 +24,7 @@ else
     for n in $PHASES; do
         echo "== stop after phase $n"
         STR_ER_LIB=$OUT/libstop_$n.so python $ROOT/tools/dev_stop.py text 2>&1 | grep "tile_tree alone" | tail -1
-        STR_ER_LIB=$OUT/libstop_$n.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/pmc_$n -o p -- python $ROOT/tools/dev_stop.py text > /dev/null 2>&1
+        STR_ER_LIB=$OUT/libstop_$n.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d /tmp/pmc_$n -o p -- python $ROOT/tools/dev_stop.py text > /dev/null 2>&1
         python - <<PY
 import csv, glob
 rows = []
@@ -34,8 +34,8 @@ acc = {}
 for r in rows:
     if "k_tile_tree" not in r.get("Kernel_Name", ""): continue
     acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-w = sum(acc.get("SQ_WAVES", [0])) or 1
-print("   per wave:", {k: round(sum(v) / w, 1) for k, v in acc.items() if k != "SQ_WAVES"}, "waves/launch", w / max(1, len(acc.get("SQ_WAVES", [1]))))
+w = 795648.0          # waves of one launch of dev_stop.py (32 frames of pyr3x8)
+print("   per wave:", {k: round(sum(v) / len(v) / w, 1) for k, v in acc.items()})
 PY
     done
 fi
