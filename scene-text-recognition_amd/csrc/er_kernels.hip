@@ -474,13 +474,19 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
     return !(same || (link && ok && wa == NONE));
 }
 
-// All edges of a worklist.  A connect takes anything from one to a dozen passes, so a lane moves on to its next edge as soon as it is
-// done with one; a wave leaves when its lanes have nothing left.  Every lane walks its own contiguous part of the list (lane i: entries
-// [i n / 256, (i + 1) n / 256), so that all lanes and all four waves get their share also when n is no multiple of 256): at any moment
-// the 256 lanes work in 256 different places of the tile (fewer lost CASes) and a lane's next edge touches the nodes it has just
-// compressed.
-// (Measured, 32 frames text / noise, and not adopted: a workgroup-wide cursor that hands the next entries to whichever lanes are idle
-// -- round 1's form -- 3.19 / 9.8 ms against 3.11 / 8.5: the ballots and the LDS atomic per refill cost more than the balance gains;
+// The edge list of the connect round (see k_tile_tree): entry = slot of the edge's second (horizontal: the edge is (left of p, p),
+// one slot back, two across the unused word after every 32 pixels) or first (vertical, bit 15 set: (p, pixel below p)) pixel.  A connect
+// takes anything from one to a dozen passes, so a lane takes its next edge as soon as it is done with one.  Every WAVE owns a contiguous
+// quarter of the list and hands its entries, in list order, to whichever of its lanes are idle (ballot + mbcnt: no LDS traffic, no
+// barrier): a wave leaves after ~(passes of its quarter) / 64 iterations instead of after the passes of its unluckiest lane.
+// (Measured, 32 frames text / noise, and not adopted.  Round 3: a static contiguous deal per lane -- round 2's form, 2.62 against 2.27 once the
+// list was one; the k-th batch of 64 entries spread over the wave's whole share: no difference; the two ends carried as KEYS, (level << 16) |
+// slot -- one compare orders them, the CAS value is the other key, a lane without an edge holds two equal keys and runs the pass as a
+// no-op: 19 vector instructions per pass instead of 34 in the listing, but the compiler's loop has more branches: vector -0.8 %, scalar
+// +6.7 %, branch +23 % per wave, 2.31 / 5.59 against 2.25 / 5.38 (masked idle lanes: 2.34 / 5.71) -- the kernel's time follows the TOTAL
+// number of instructions its waves issue, of whatever kind; handing out only when 8 / 16 / 24 lanes are idle: no difference.
+// Round 2: a workgroup-wide cursor that hands the next entries to whichever lanes are idle -- round 1's form -- 3.19 / 9.8 ms against
+// 3.11 / 8.5: the ballots and the LDS atomic per refill cost more than the balance gains;
 // lane i takes entries i, i + 256, ...: 3.28 / 10.2; both finds of a pass in one loop so that their loads are in flight together:
 // 3.62 / 11.5, the loop runs as long as the longer chain with both halves' instructions; walking up a's chain to b's level in a loop of
 // finds inside the pass: 3.67 / 12.3; the vertical round first: 3.21 / 10.8; three rounds with the vertical edges between equal levels first
@@ -490,89 +496,35 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 // and inner vertical edges of its own 8-row band by itself (wave-wide scans, no workgroup barriers, nobody else on its words), the three row
 // pairs between bands in a workgroup-wide round afterwards: 3.22 / 8.4 against 2.99 / 8.07 -- the bands' edge counts differ; round 1's attempts -- fewer waves in the loop, two edges
 // per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
-__device__ __forceinline__ void tile_connect_all(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges, int round)
-{
-    bool           active = false;
-    // lane i takes entries [i n / 256, (i + 1) n / 256): all lanes and all four waves get their share also when n is not a multiple of 256
-    uint32_t       next = (threadIdx.x * n_edges) / TILE_THREADS;
-    const uint32_t n_end = ((threadIdx.x + 1u) * n_edges) / TILE_THREADS;
-    uint32_t       a = 0, b = 0, la = 0, lb = 0;
-    for (;;) {
-        if (!active && next < n_end) {
-            // an entry is the slot p of the edge's second (round 0) or first (round 1) pixel: the edge is (left of p, p) --
-            // one slot back, two across the unused word after every 32 pixels -- or (p, pixel below p)
-            const uint32_t p = s_elist[next++];
-            if (round == 0) { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
-            else { a = p; b = p + (uint32_t)TILE_WS; }
-            la = s_lev[LX(a)]; lb = s_lev[LX(b)];
-            active = true;
-            CNT(0, 1);
-        }
-        if (!__any(active)) break;
-        if (active) active = connect_pass(s_par, a, b, la, lb);
-    }
-}
-
-// The edge list of the single connect round (see k_tile_tree): entry = slot of the edge's second (horizontal: the edge is (left of p, p),
-// one slot back, two across the unused word after every 32 pixels) or first (vertical, bit 15 set: (p, pixel below p)) pixel.  A connect
-// takes anything from one to a dozen passes, so a lane takes its next edge as soon as it is done with one.  Every WAVE owns a contiguous
-// quarter of the list and hands its entries to whichever of its lanes are idle (ballot + mbcnt: no LDS traffic, no barrier): a wave
-// leaves after ~(passes of its quarter) / 64 iterations instead of after the passes of its unluckiest lane.
-// STR_ER_DYN: 1 = idle lanes take the next entries in list order, 2 = the k-th batch of 64 is spread over the wave's whole share
-// (entry c -> (c % 64) * ceil(m / 64) + c / 64), 0 = static contiguous deal per lane (round 2's form).
-#ifndef STR_ER_DYN
-#define STR_ER_DYN 1
-#endif
 __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges_)
 {
     constexpr uint32_t NW = TILE_THREADS / 64;
     const uint32_t n_edges = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_edges_);
     bool           active = false;
     uint32_t       a = 0, b = 0, la = 0, lb = 0;
-    auto take = [&](uint32_t idx) {
-        const uint32_t e = s_elist[idx];
-        const uint32_t p = e & 0x7FFFu;
-        if (e & 0x8000u) { a = p; b = p + (uint32_t)TILE_WS; }
-        else { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
-        la = s_lev[LX(a)]; lb = s_lev[LX(b)];
-        active = true;
-        CNT(0, 1);
-    };
-#if STR_ER_DYN == 0
-    uint32_t       next = (threadIdx.x * n_edges) / TILE_THREADS;
-    const uint32_t n_end = ((threadIdx.x + 1u) * n_edges) / TILE_THREADS;
-    for (;;) {
-        if (!active && next < n_end) take(next++);
-        if (!__any(active)) break;
-        if (active) active = connect_pass(s_par, a, b, la, lb);
-    }
-#else
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t w0 = (wv * n_edges) / NW, m = ((wv + 1u) * n_edges) / NW - w0;     // the wave's share: entries [w0, w0 + m)
-#if STR_ER_DYN == 2
-    const uint32_t per = (m + 63u) / 64u, c_end = per * 64u;
-#else
-    const uint32_t c_end = m;
-#endif
     uint32_t       cur = 0;                                                           // wave-uniform cursor
     for (;;) {
-        if (cur < c_end) {
+        if (cur < m) {
             const unsigned long long idle = __ballot(!active);
             if (idle) {
                 const uint32_t c = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-#if STR_ER_DYN == 2
-                const uint32_t e = (c & 63u) * per + (c >> 6);
-                if (!active && c < c_end && e < m) take(w0 + e);
-#else
-                if (!active && c < c_end) take(w0 + c);
-#endif
+                if (!active && c < m) {
+                    const uint32_t e = s_elist[w0 + c];
+                    const uint32_t p = e & 0x7FFFu;
+                    if (e & 0x8000u) { a = p; b = p + (uint32_t)TILE_WS; }
+                    else { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
+                    la = s_lev[LX(a)]; lb = s_lev[LX(b)];
+                    active = true;
+                    CNT(0, 1);
+                }
                 cur += (uint32_t)__popcll(idle);
             }
         }
         if (!__any(active)) break;
         if (active) active = connect_pass(s_par, a, b, la, lb);
     }
-#endif
 }
 
 // Data-parallel-primitive moves: the source lane is named in the instruction (no LDS-pipe bpermute, no address register).  A "row" is
@@ -662,7 +614,9 @@ constexpr int FOLD_CAP_SPARSE = TILE_H > 32 ? 1024 : 480;   // 16 (32) granules:
 // pixel) nor by LDS bandwidth: what made it faster in round 2 was fewer instructions per wave, 4435 -> 3270 (vector 2105 -> 1749, scalar
 // 1960 -> 1213, LDS 370 -> 308), for 3.73 -> 3.03 ms per 32 text frames.
 // (Measured and not adopted: one compacted list of all pieces of the tile, processed by all lanes evenly -- fewer instructions, but the
-// two extra barriers and the dependent LDS reads of the list cost what they save.)
+// two extra barriers and the dependent LDS reads of the list cost what they save; round 3: the parent word of a lane's NEXT piece fetched
+// while the current one is walked / added up, in the flatten and the statistics loops -- 2.11 against 2.08 ms: the four instructions per
+// round cost more than the latency they hide.)
 // ------------------------------------------------------------------------------------
 #define LEVK(k) ((((k) < 4 ? lev_lo : lev_hi) >> (8 * ((k) & 3))) & 0xFFu)
 template <int FOLD_CAP>
@@ -670,22 +624,27 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
 {
     constexpr int WORK_WORDS = NODE_WORDS * FOLD_CAP;
     constexpr int STAT_CHUNK = FOLD_CAP < 512 ? FOLD_CAP : 512;   // dense tiles: nodes whose statistics are accumulated per pass
-#ifdef STR_ER_OLD_ROUNDS
-    static_assert(WORK_WORDS * 4 >= 2 * TILE_PX + 2 * TILE_THREADS, "the 16-bit edge list of a round (one entry per pixel at most) and the lane masks must fit s_work");
-#else
     // the edge list: at most 63 horizontal edges per row and 32 vertical ones per pair of rows (local minima, see below); behind it the levels of
     // every wave's first row (3 words per lane), which the wave above needs
     constexpr int ELIST_CAP = TILE_H * (TILE_W - 1) + (TILE_H - 1) * (TILE_W / 2);
     constexpr int ROWLV_AT = (ELIST_CAP + 1) / 2;                 // word offset in s_work
     static_assert(ROWLV_AT + 3 * 8 * (TILE_THREADS / 64) <= WORK_WORDS, "edge list + first-row levels must fit s_work");
-#endif
     __shared__ uint32_t s_par[TILE_SLOTS];
     __shared__ __attribute__((aligned(8))) uint32_t s_work[WORK_WORDS];    // edge worklist + lane masks, later the per-node statistics
     __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
     uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
     __shared__ uint32_t s_wsum[TILE_THREADS / 64];
     __shared__ uint32_t s_walls, s_start, s_nbase;
-    __shared__ uint32_t s_present[8];        // which levels have a node in this tile
+    __shared__ uint32_t s_present[8];        // which levels have a node in this tile (big kernel)
+    // Small kernel: the fold (closed nodes add their totals to their parents, bottom-up over the levels) is done by ONE wave over a list of the
+    // tile's level roots sorted by level -- see "fold" below.  The list is made by counting: s_hist[l] = roots at level l (counted where the
+    // roots are found), turned into start offsets between the two barriers of the id scan, used as cursors where the ids are handed out.
+    // It lives in the tail of s_work (never touched by the edge list), the list behind the statistics.
+    constexpr bool W0FOLD = FOLD_CAP == FOLD_CAP_SPARSE;
+    constexpr int  HIST_WORDS = 256;
+    constexpr int  HIST_AT = WORK_WORDS - HIST_WORDS;
+    static_assert(!W0FOLD || ROWLV_AT + 3 * 8 * (TILE_THREADS / 64) <= HIST_AT, "level histogram must lie behind the edge list");
+    uint32_t *const s_hist = s_work + HIST_AT;
 
     const int       tid = threadIdx.x;
     const int       pi = b.tile_plane[blockIdx.x];
@@ -698,18 +657,15 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     const int       gx = ox + lx, gy = oy + ly;
 
     if (tid == 0) s_walls = 0;
-    if (tid < 8) s_present[tid] = 0;
+    if (W0FOLD) { for (int i = tid; i < HIST_WORDS; i += TILE_THREADS) s_hist[i] = 0; }
+    else if (tid < 8) s_present[tid] = 0;
     PHASE_INIT();
 
     // ---- load 8 consecutive pixels of one scanline, quantise (src/ER.cpp:250) ----------
     uint32_t lev_lo = 0, lev_hi = 0;    // the 8 levels, one byte each (walls: 0, see wallm)
     uint32_t wallm = 0, startm = 0;     // bit k: pixel k is a wall / starts a run of equal level (bit 0: unless it continues the run of the pixel to its left)
     bool     left_wall;                 // the pixel left of the lane's first one is a wall (or the tile's edge)
-#ifdef STR_ER_OLD_ROUNDS
-    uint16_t *const s_msk = reinterpret_cast<uint16_t *>(s_work) + TILE_PX;     // the lanes' bit sets, behind the edge list
-#else
     uint32_t *const s_rowlv = s_work + ROWLV_AT;
-#endif
     {
         uint32_t lev[TILE_PPT];
         int      nvalid = 0;
@@ -760,14 +716,10 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         left_wall = left_lev == WALL;
         const bool joins = lev[0] != WALL && lev[0] == left_lev;
         if (lev[0] != WALL && !joins) startm |= 1u;
-#ifdef STR_ER_OLD_ROUNDS
-        s_msk[tid] = (uint16_t)(wallm | (startm << 8));
-#else
         if ((ly & 7) == 0) {        // a wave's first row: the last row of the wave above reads it from LDS (the other rows are exchanged by shuffles)
             uint32_t *d = s_rowlv + 3 * ((tid >> 6) * 8 + (tid & 7));
             d[0] = lev_lo; d[1] = lev_hi; d[2] = wallm;
         }
-#endif
         {
             uint32_t val = head;                       // head of the lane's last run
             bool     pass = joins && head == p0;
@@ -784,34 +736,6 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     }
     PHASE_MARK(0);
 
-#ifdef STR_ER_OLD_ROUNDS
-    // ---- connect the in-tile edges, in two balanced rounds -------------------------------------
-    // horizontal: a run starts here and the pixel to its left is no wall (an equal-level left neighbour is already linked: by the
-    // run pointers above); vertical: neither this pixel nor the one below is a wall and a run starts in either row -- in the other
-    // columns the column to the left joins the same two nodes.  The list is compacted into LDS and dealt out evenly, so a lane
-    // whose pixels happen to need many connects does not hold its whole wave back.
-    uint16_t *const s_elist = reinterpret_cast<uint16_t *>(s_work);     // one 16-bit slot per edge
-    for (int round = 0; round < 2; ++round) {
-        uint32_t emask = 0;
-        if (round == 0) emask = startm & ~((wallm << 1) | (left_wall ? 1u : 0u)) & 0xFFu;
-        else if (ly + 1 < TILE_H) {
-            const uint32_t mb = s_msk[tid + TILE_W / TILE_PPT];
-            emask = (startm | (mb >> 8)) & ~(wallm | mb) & 0xFFu;
-        }
-        uint32_t n_edges;
-        uint32_t off = block_excl_scan(__popc(emask), s_wsum, &n_edges);
-        while (emask) {
-            const int k = __ffs((int)emask) - 1;
-            emask &= emask - 1u;
-            s_elist[off++] = (uint16_t)(p0 + k);       // the other end follows from the round: left neighbour / pixel below
-        }
-        __syncthreads();
-        tile_connect_all(s_par, s_lev, s_elist, n_edges, round);
-        __syncthreads();
-        PHASE_MARK(1 + round);
-    }
-
-#else
     // ---- connect the in-tile edges: one list, one round -----------------------------------------------------------------------
     // Which pixel pairs need a connect.  The component tree of the tile is the tree of ANY spanning subgraph of its pixel grid that holds a
     // minimum spanning forest for the edge weight max(level, level): the components of {level <= t} are those of the edges of weight <= t, and
@@ -889,7 +813,6 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         PHASE_MARK(2);
     }
 
-#endif
     // ---- flatten + level roots, one pass over the lane's pieces.  The head of a piece that is not a level root is pointed straight at
     // its level root (the other pixels of a piece point at the head or, where a find halved a path, at some pixel further up in the same
     // node); the parent word of a level root is made to point at the parent node's level root.  No barrier in between: a walk follows
@@ -918,7 +841,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             } else {
                 rootmask |= 1u << k;
                 if (first_root == NONE) first_root = p;
-                atomicOr(&s_present[(l >> 5) & 7u], 1u << (l & 31u));
+                if (W0FOLD) atomicAdd(&s_hist[l & 0xFFu], 1u);
+                else atomicOr(&s_present[(l >> 5) & 7u], 1u << (l & 31u));
                 if (w == NONE) continue;
                 uint32_t q = w & 0xFFFFu;
                 for (;;) {
@@ -956,15 +880,46 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     }
     // ---- dense ids for ALL level roots of the tile, in pixel order ---------------------------------
     uint32_t total_all;
-    const uint32_t aid0 = block_excl_scan(__popc(rootmask), s_wsum, &total_all);
+    uint32_t aid0;
+    if (W0FOLD) {
+        // block_excl_scan with the level offsets computed by the first wave between its two barriers: s_hist[l] becomes the position of
+        // level l's first root in the sorted list (levels 0 .. hi - 1: a root is no wall)
+        const uint32_t v = (uint32_t)__popc(rootmask), incl = wave_incl_scan(v);
+        __syncthreads();
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        if (tid < 64) {
+            uint32_t carry = 0;
+            for (int base = 0; base < prm.hi; base += 64) {
+                const uint32_t c = s_hist[base + tid], in = wave_incl_scan(c);
+                s_hist[base + tid] = carry + in - c;
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)in, 63);
+            }
+        }
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < TILE_THREADS / 64; ++i) {
+            if (i < (tid >> 6)) off += s_wsum[i];
+            tot += s_wsum[i];
+        }
+        total_all = tot;
+        aid0 = off + incl - v;
+    } else {
+        aid0 = block_excl_scan(__popc(rootmask), s_wsum, &total_all);
+    }
     // (a lane holds half a level root on average on text-like frames: the loops over "the lane's roots" below run over the set bits)
     auto lev_of = [&](int k) -> uint32_t { return ((k < 4 ? lev_lo : lev_hi) >> (8 * (k & 3))) & 0xFFu; };
+    // fold path of the small kernel: statistics [0, NODE_WORDS n), the sorted list (a word per root) behind them, the level cursors in the tail
+    const uint32_t n_even_all = (total_all + 1u) & ~1u;
+    const bool     w0fold = W0FOLD && (uint32_t)(NODE_WORDS + 1) * n_even_all <= (uint32_t)HIST_AT;
+    uint32_t *const s_order = s_work + NODE_WORDS * n_even_all;
     {
         uint32_t m = rootmask, id = aid0;
         while (m) {
             const int k = __ffs((int)m) - 1;
             m &= m - 1u;
             s_nid[OWN(k)] = (uint16_t)id++;
+            if (w0fold) s_order[atomicAdd(&s_hist[lev_of(k)], 1u)] = p0 + (uint32_t)k;
         }
     }
     __syncthreads();
@@ -990,7 +945,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     // dense id of the node of the piece headed by p
     auto piece_node = [&](uint32_t p, bool isroot) -> uint32_t { return s_nid[LX(isroot ? p : (s_par[LX(p)] & 0xFFFFu))]; };
 
-    if (total_all <= (uint32_t)FOLD_CAP) {
+    if (W0FOLD ? w0fold : total_all <= (uint32_t)FOLD_CAP) {
         // ---- fold path.  Statistics of every node of the tile live in LDS:
         //   s_w0[a]  = pixels (CNT_BITS bits) | nodes (CNT_BITS bits) | open (bit 31)
         //   s_row[a] = set of tile rows, s_col[a] = set of tile columns the component touches.
@@ -1006,7 +961,15 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         rowmask_t          *s_row = reinterpret_cast<rowmask_t *>(s_work + n_even);                  // [n_even]
         unsigned long long *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * n_even); // [n_even]
         uint32_t           *s_exp = s_work + NODE_WORDS * n_even;            // [NODE_WORDS * (FOLD_CAP - n_even)]
-        for (uint32_t i = tid; i < total_all; i += TILE_THREADS) { s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull; }
+        for (uint32_t i = tid; i < total_all; i += TILE_THREADS) {
+            s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull;
+            if (W0FOLD) {
+                // the sorted list, slot of the root -> its id | its parent's id << 16 (0xFFFF: none): what the fold needs, looked up by all lanes
+                // here instead of by the one wave that folds, level after level
+                const uint32_t p = s_order[i], w = s_par[LX(p)];
+                s_order[i] = (uint32_t)s_nid[LX(p)] | ((w == NONE ? 0xFFFFu : (uint32_t)s_nid[LX(w & 0xFFFFu)]) << 16);
+            }
+        }
         __syncthreads();
         // One set of LDS atomics per piece -- except for the pieces of the row's two HOT nodes.  A text-like tile is two or three big
         // nodes (the background levels) and dozens of speckles: hundreds of pieces add to the same three words, and LDS atomics of a wave
@@ -1082,6 +1045,41 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         }
         __syncthreads();
         PHASE_MARK(5);
+      if (W0FOLD) {
+        // bottom-up over the levels present in the tile (children are at lower levels than parents), by the first wave alone: the roots of a
+        // level are consecutive entries of the sorted list, one lane each.  A text-like tile has ~90 nodes on ~7 levels: the owners' form
+        // below has all four waves compare their pixels' levels with every level and meet at a barrier per level for a handful of
+        // nodes each (301 instructions per wave); here three waves go straight to the barrier behind the fold.  The wave's LDS operations
+        // are carried out in the order it issues them, so a level sees the sums of the levels below without any barrier.
+        if (tid < 64) {
+            uint32_t begin = 0;
+            for (int base = 0; base < prm.hi; base += 64) {
+                const uint32_t end = s_hist[base + tid];                 // cursor of level base + lane = where its entries end
+                const uint32_t prev = (uint32_t)__shfl_up((int)end, 1);          // the level below (lane 0: see `begin`)
+                unsigned long long pm = __ballot(end != (tid == 0 ? begin : prev));
+                while (pm) {
+                    const int      l = __ffsll((long long)pm) - 1;
+                    pm &= pm - 1ull;
+                    const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
+                    for (uint32_t e = begin + (uint32_t)tid; e < e1; e += 64u) {
+                        const uint32_t en = s_order[e], a = en & 0xFFFFu, pa = en >> 16;
+                        if (pa == 0xFFFFu) continue;
+                        const uint32_t v = s_w0[a];
+                        if (v >> 28) atomicOr(&s_w0[pa], v & 0xF0000000u);       // open: so is the parent, on the same sides
+                        else {
+                            atomicAdd(&s_w0[pa], v & ((1u << (2 * CNT_BITS)) - 1u));
+                            atomicOr(&s_row[pa], s_row[a]);
+                            atomicOr(&s_col[pa], s_col[a]);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    begin = e1;
+                }
+                begin = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
+            }
+        }
+        __syncthreads();
+      } else {
         uint32_t rootspread = 0;        // rootmask with pixel k at bit 8 (k & 3) + 4 (k >> 2)
 #pragma unroll
         for (int k = 0; k < TILE_PPT; ++k) rootspread |= ((rootmask >> k) & 1u) << (8 * (k & 3) + 4 * (k >> 2));
@@ -1117,6 +1115,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             __syncthreads();
           }
         }
+      }
         PHASE_MARK(7);
         // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
         // node of the flood's start pixel
