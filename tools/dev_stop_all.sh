@@ -23,8 +23,8 @@ else
     cd /tmp && export TMPDIR=/tmp
     for n in $PHASES; do
         echo "== stop after phase $n"
-        STR_ER_LIB=$OUT/libstop_$n.so python $ROOT/tools/dev_stop.py text 2>&1 | grep "tile_tree alone" | tail -1
-        STR_ER_LIB=$OUT/libstop_$n.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d /tmp/pmc_$n -o p -- python $ROOT/tools/dev_stop.py text > /dev/null 2>&1
+        STR_ER_LIB=$OUT/libstop_$n.so python $ROOT/tools/dev_stop.py ${KIND:-text} 2>&1 | grep "tile_tree alone" | tail -1
+        STR_ER_LIB=$OUT/libstop_$n.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d /tmp/pmc_$n -o p -- python $ROOT/tools/dev_stop.py ${KIND:-text} > /dev/null 2>&1
         python - <<PY
 import csv, glob
 rows = []
