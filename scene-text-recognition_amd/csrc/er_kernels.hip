@@ -501,30 +501,33 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
 {
     constexpr uint32_t NW = TILE_THREADS / 64;
     const uint32_t n_edges = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_edges_);
-    bool           active = false;
     uint32_t       a = 0, b = 0, la = 0, lb = 0;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t w0 = (wv * n_edges) / NW, m = ((wv + 1u) * n_edges) / NW - w0;     // the wave's share: entries [w0, w0 + m)
     uint32_t       cur = 0;                                                           // wave-uniform cursor
+    // which lanes have an edge in hand: a wave-uniform 64-bit mask kept in scalar registers (a per-lane flag costs a vector compare wherever
+    // the wave needs to know "is anybody idle / busy")
+    unsigned long long busy = 0;
     for (;;) {
-        if (cur < m) {
-            const unsigned long long idle = __ballot(!active);
-            if (idle) {
-                const uint32_t c = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (!active && c < m) {
-                    const uint32_t e = s_elist[w0 + c];
-                    const uint32_t p = e & 0x7FFFu;
-                    if (e & 0x8000u) { a = p; b = p + (uint32_t)TILE_WS; }
-                    else { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
-                    la = s_lev[LX(a)]; lb = s_lev[LX(b)];
-                    active = true;
-                    CNT(0, 1);
-                }
-                cur += (uint32_t)__popcll(idle);
+        if (cur < m && ~busy != 0ull) {
+            const unsigned long long idle = ~busy;
+            const uint32_t c = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const bool     tk = __builtin_amdgcn_inverse_ballot_w64(idle) && c < m;
+            if (tk) {
+                const uint32_t e = s_elist[w0 + c];
+                const uint32_t p = e & 0x7FFFu;
+                if (e & 0x8000u) { a = p; b = p + (uint32_t)TILE_WS; }
+                else { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
+                la = s_lev[LX(a)]; lb = s_lev[LX(b)];
+                CNT(0, 1);
             }
+            busy |= __builtin_amdgcn_ballot_w64(tk);
+            cur += (uint32_t)__popcll(idle);
         }
-        if (!__any(active)) break;
-        if (active) active = connect_pass(s_par, a, b, la, lb);
+        if (busy == 0ull) break;
+        bool more = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(busy)) more = connect_pass(s_par, a, b, la, lb);
+        busy = __builtin_amdgcn_ballot_w64(more);
     }
 }
 
