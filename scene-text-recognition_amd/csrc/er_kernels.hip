@@ -476,7 +476,7 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 }
 
 // The edge list of the connect round (see k_tile_tree): entry = slot of the edge's second (horizontal: the edge is (left of p, p),
-// one slot back, two across the unused word after every 32 pixels) or first (vertical, bit 15 set: (p, pixel below p)) pixel.  A connect
+// one slot back, two across the unused word after every 32 pixels: bit 14) or first (vertical, bit 15 set: (p, pixel below p)) pixel.  A connect
 // takes anything from one to a dozen passes, so a lane takes its next edge as soon as it is done with one.  Every WAVE owns a contiguous
 // quarter of the list and hands its entries, in list order, to whichever of its lanes are idle (ballot + mbcnt: no LDS traffic, no
 // barrier): a wave leaves after ~(passes of its quarter) / 64 iterations instead of after the passes of its unluckiest lane.
@@ -515,9 +515,10 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
             const bool     tk = __builtin_amdgcn_inverse_ballot_w64(idle) && c < m;
             if (tk) {
                 const uint32_t e = s_elist[w0 + c];
-                const uint32_t p = e & 0x7FFFu;
-                if (e & 0x8000u) { a = p; b = p + (uint32_t)TILE_WS; }
-                else { a = p - 1u - (p % 33u == 0u ? 1u : 0u); b = p; }
+                const uint32_t p = e & 0x3FFFu;
+                const bool     vert = (e & 0x8000u) != 0;
+                a = vert ? p : p - 1u - ((e >> 14) & 1u);
+                b = vert ? p + (uint32_t)TILE_WS : p;
                 la = s_lev[LX(a)]; lb = s_lev[LX(b)];
                 CNT(0, 1);
             }
@@ -808,7 +809,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         while (em) {
             const int k = __ffs((int)em) - 1;
             em &= em - 1u;
-            s_elist[off++] = (uint16_t)(k < 8 ? p0 + k : (p0 + k - 8) | 0x8000u);
+            // (bit 14: the left neighbour lies across the unused word, a lane's first pixel at a multiple of 32)
+            s_elist[off++] = (uint16_t)(k < 8 ? (p0 + k) | ((k == 0 && (tid & 3) == 0) ? 0x4000u : 0u) : (p0 + k - 8) | 0x8000u);
         }
         __syncthreads();
         tile_connect_list(s_par, s_lev, s_elist, n_edges);
