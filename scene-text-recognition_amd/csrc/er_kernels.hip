@@ -1308,10 +1308,10 @@ void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, b
 // The global passes (k_seam, k_resolve, k_reduce) work on device-scope atomics, a few hundred picoseconds per record, and every
 // node that touches any tile border goes through them.  Most of those nodes only touch a seam towards a NEIGHBOURING tile and are
 // complete a tile or two further on.  One workgroup per group loads the records of its tiles (a few hundred: text-like 4 x 8 tiles
-// ~ 430, noise 2 x 4 ~ 1400), joins the pixel pairs of the seams INSIDE the group with the same connect on LDS words, hands the
+// ~ 430, noise 2 x 5 ~ 2300), joins the pixel pairs of the seams INSIDE the group with the same connect on LDS words, hands the
 // statistics of unified nodes to their survivors (k_resolve's job), and folds every node whose component does not reach the group's
 // OUTER border into its parent (k_reduce's job) -- what is left for the global passes are the nodes on the outer border: a quarter
-// (4 x 8) or a third (2 x 4) of before.  Everything stays where it is: survivors keep their record, unified nodes are marked
+// (4 x 8) or a third (2 x 5) of before.  Everything stays where it is: survivors keep their record, unified nodes are marked
 // NODE_DEAD (k_resolve skips them), folded ones NODE_CLOSED (they never push again), so the seam map and every id stay valid.
 // A group with more records than fit LDS is left alone (group_done stays 0: k_seam joins its inner seams as before).
 // ------------------------------------------------------------------------------------
@@ -1492,7 +1492,10 @@ void launch_group_merge(hipStream_t s, const BatchDev &b, int variant)
     case 2: hipLaunchKernelGGL((k_group_merge<1024, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
     case 3: hipLaunchKernelGGL((k_group_merge<2048, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
     case 4: hipLaunchKernelGGL((k_group_merge<2048, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
-    default: hipLaunchKernelGGL((k_group_merge<3072, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
+    case 5: hipLaunchKernelGGL((k_group_merge<3072, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
+    // 2528 records: 32 B each + the tile tables = 64 of the 1280-byte LDS granules, so TWO workgroups fit a CU
+    case 6: hipLaunchKernelGGL((k_group_merge<2528, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
+    default: hipLaunchKernelGGL((k_group_merge<2528, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
     }
 }
 

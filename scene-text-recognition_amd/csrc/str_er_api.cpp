@@ -144,7 +144,7 @@ struct str_er_ctx {
     uint16_t *d_group_plane = nullptr; std::vector<uint16_t> h_group_plane;      // plane of every group of tiles
     uint8_t  *d_group_done = nullptr;                 // per group of tiles: joined in LDS (k_group_merge -> k_seam)
     int       dbg_group[3] = {0, 0, -1};              // developer knobs STR_ER_GROUP_X / _Y / _KERNEL
-    int       group_mode = -1;                        // STR_ER_GROUPS: -1 automatic (4 x 8 tiles with the small tile kernel, 2 x 4 with the big one), 0 off
+    int       group_mode = -1;                        // STR_ER_GROUPS: -1 automatic (4 x 4 tiles with the small tile kernel, 2 x 5 with the big one), 0 off
     std::vector<void *> allocs;
 
     // pinned host mirrors
@@ -963,10 +963,10 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     c->last_valid = false;             // (str_er_gather_last: the candidate array is being rewritten, or re-allocated)
     Batch b = b_in;
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
-    // batches (small tile kernel: ~14 records per tile) take 4 x 8 tiles per group, noise-like ones (~170) 2 x 4.
+    // batches (small tile kernel: ~14 records per tile) take 4 x 4 tiles per group, noise-like ones (~250) 2 x 5.
     const bool grouped = !import_trees && c->group_mode != 0;
     {
-        int gx = c->tile_sparse ? 4 : 2, gy = 4;         // (tools/dev_groups.sh: 4 x 4 tiles on text-like batches, 2 x 4 on noise)
+        int gx = c->tile_sparse ? 4 : 2, gy = c->tile_sparse ? 4 : 5;       // (tools/dev_groups.sh: 4 x 4 tiles on text-like batches, 2 x 5 on noise)
         if (c->dbg_group[0] > 0) { gx = c->dbg_group[0]; gy = c->dbg_group[1]; }
         if (grouped) assign_groups(b, gx, gy); else assign_groups(b, 0, 0);
     }
@@ -1025,7 +1025,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     }
     if (grouped && b.n_groups) {
         HIP_TRY(c, hipMemsetAsync(c->d_group_done, 0, b.n_groups, s));
-        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 2 : 4));       // (measured, tools/dev_groups.sh)
+        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 2 : 6));       // (measured, tools/dev_groups.sh)
     }
     rec(c, "group");
     if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
