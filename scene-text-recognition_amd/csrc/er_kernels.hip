@@ -884,48 +884,49 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         }
         s_start = sr;
     }
-    // ---- dense ids for ALL level roots of the tile, in pixel order ---------------------------------
+    // ---- dense ids for ALL level roots of the tile.  Big kernel: in pixel order (a block-wide scan).  Small kernel: in LEVEL order -- the
+    // id of a root is its place in the list of the tile's roots sorted by level: s_hist[l] (roots at level l, counted in the loop above)
+    // becomes the place of level l's first root (first wave, one scan over the levels), every root takes the next place of its level.
+    // The statistics arrays are indexed by these ids, so the nodes of one level are neighbours there, and entry i of the list describes
+    // node i: everything from here to the export works on nodes (a lane per node, ~90 of them in a text-like tile), not on pixels.
     uint32_t total_all;
-    uint32_t aid0;
-    if (W0FOLD) {
-        // block_excl_scan with the level offsets computed by the first wave between its two barriers: s_hist[l] becomes the position of
-        // level l's first root in the sorted list (levels 0 .. hi - 1: a root is no wall)
-        const uint32_t v = (uint32_t)__popc(rootmask), incl = wave_incl_scan(v);
+    uint32_t aid0 = 0;
+    if constexpr (W0FOLD) {
         __syncthreads();
-        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
         if (tid < 64) {
             uint32_t carry = 0;
-            for (int base = 0; base < prm.hi; base += 64) {
+            for (int base = 0; base < prm.hi; base += 64) {      // (levels 0 .. hi - 1: a root is no wall)
                 const uint32_t c = s_hist[base + tid], in = wave_incl_scan(c);
                 s_hist[base + tid] = carry + in - c;
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)in, 63);
             }
+            if (tid == 0) s_wsum[0] = carry;
         }
         __syncthreads();
-        uint32_t off = 0, tot = 0;
-#pragma unroll
-        for (int i = 0; i < TILE_THREADS / 64; ++i) {
-            if (i < (tid >> 6)) off += s_wsum[i];
-            tot += s_wsum[i];
-        }
-        total_all = tot;
-        aid0 = off + incl - v;
+        total_all = s_wsum[0];
     } else {
         aid0 = block_excl_scan(__popc(rootmask), s_wsum, &total_all);
     }
     // (a lane holds half a level root on average on text-like frames: the loops over "the lane's roots" below run over the set bits)
     auto lev_of = [&](int k) -> uint32_t { return ((k < 4 ? lev_lo : lev_hi) >> (8 * (k & 3))) & 0xFFu; };
-    // fold path of the small kernel: statistics [0, NODE_WORDS n), the sorted list (a word per root) behind them, the level cursors in the tail
+    // fold path of the small kernel: statistics [0, NODE_WORDS n), the list (a word per node) behind them, the level cursors in the tail.
+    // list entry: slot of the level root (12 bits) | level << 12 | id of the parent << 20 (ORDER_NOPAR: none)
+    constexpr uint32_t ORDER_NOPAR = 0x1FFu;
     const uint32_t n_even_all = (total_all + 1u) & ~1u;
-    const bool     w0fold = W0FOLD && (uint32_t)(NODE_WORDS + 1) * n_even_all <= (uint32_t)HIST_AT;
+    const bool     w0fold = W0FOLD && (uint32_t)(NODE_WORDS + 1) * n_even_all <= (uint32_t)HIST_AT && total_all < ORDER_NOPAR;
     uint32_t *const s_order = s_work + NODE_WORDS * n_even_all;
     {
         uint32_t m = rootmask, id = aid0;
         while (m) {
             const int k = __ffs((int)m) - 1;
             m &= m - 1u;
-            s_nid[OWN(k)] = (uint16_t)id++;
-            if (w0fold) s_order[atomicAdd(&s_hist[lev_of(k)], 1u)] = p0 + (uint32_t)k;
+            if constexpr (W0FOLD) {
+                const uint32_t l = lev_of(k), pos = atomicAdd(&s_hist[l], 1u);
+                s_nid[OWN(k)] = (uint16_t)pos;
+                if (w0fold) s_order[pos] = (p0 + (uint32_t)k) | (l << 12);
+            } else {
+                s_nid[OWN(k)] = (uint16_t)id++;
+            }
         }
     }
     __syncthreads();
@@ -970,10 +971,10 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         for (uint32_t i = tid; i < total_all; i += TILE_THREADS) {
             s_w0[i] = 0; s_row[i] = 0; s_col[i] = 0ull;
             if (W0FOLD) {
-                // the sorted list, slot of the root -> its id | its parent's id << 16 (0xFFFF: none): what the fold needs, looked up by all lanes
-                // here instead of by the one wave that folds, level after level
-                const uint32_t p = s_order[i], w = s_par[LX(p)];
-                s_order[i] = (uint32_t)s_nid[LX(p)] | ((w == NONE ? 0xFFFFu : (uint32_t)s_nid[LX(w & 0xFFFFu)]) << 16);
+                // the parent's id joins the list entry: what the fold needs, looked up by all lanes here instead of by the one wave that
+                // folds, level after level
+                const uint32_t en = s_order[i], w = s_par[LX(en & 0xFFFu)];
+                s_order[i] = en | ((w == NONE ? ORDER_NOPAR : (uint32_t)s_nid[LX(w & 0xFFFFu)]) << 20);
             }
         }
         __syncthreads();
@@ -1068,8 +1069,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                     pm &= pm - 1ull;
                     const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
                     for (uint32_t e = begin + (uint32_t)tid; e < e1; e += 64u) {
-                        const uint32_t en = s_order[e], a = en & 0xFFFFu, pa = en >> 16;
-                        if (pa == 0xFFFFu) continue;
+                        const uint32_t a = e, pa = s_order[e] >> 20;
+                        if (pa == ORDER_NOPAR) continue;
                         const uint32_t v = s_w0[a];
                         if (v >> 28) atomicOr(&s_w0[pa], v & 0xF0000000u);       // open: so is the parent, on the same sides
                         else {
@@ -1123,23 +1124,6 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         }
       }
         PHASE_MARK(7);
-        // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
-        // node of the flood's start pixel
-        uint32_t expmask = 0;
-        {
-            uint32_t m = rootmask, id = aid0;
-            const uint32_t sroot = s_start;
-            while (m) {
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1u;
-                const uint32_t v = s_w0[id++];
-                const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
-                const bool     open = (v >> 28) != 0;
-                if (open || (int64_t)area > (int64_t)prm.min_area || s_par[OWN(k)] == NONE || p0 + k == sroot) expmask |= 1u << k;
-            }
-        }
-        const uint32_t eid0 = block_excl_scan(__popc(expmask), s_wsum, &total);
-        if (tid == 0) take_records(total);
         // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
         // One exported node: everything it needs is in LDS except its own level and whether it is open.
         auto export_node = [&](uint32_t nbase, uint32_t p, uint32_t a, uint32_t l) {
@@ -1159,39 +1143,92 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                        (uint32_t)((oy + (int)(px >> 6)) * pd.w + ox + (int)(px & 63u)) | (l << 24),
                        ox + __ffsll((long long)cm) - 1, oy + row_lo(rm), ox + 63 - __clzll((long long)cm), oy + row_hi(rm));
         };
-        // The exported nodes are listed behind the statistics (slot | a << SLOT_BITS | level << (SLOT_BITS + A_BITS))
-        // and written out one per lane; a tile too full for the list writes them from the owners.
-        const bool listed = (uint32_t)NODE_WORDS * n_even + total <= (uint32_t)NODE_WORDS * (uint32_t)FOLD_CAP;
-        {
-            uint32_t m = rootmask, id = eid0, aid = aid0;
-            while (m) {
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1u;
-                const uint32_t a = aid++;
-                if ((expmask >> k) & 1) {
-                    if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (lev_of(k) << (SLOT_BITS + A_BITS));
-                    s_nid[OWN(k)] = (uint16_t)id++;
-                } else {
-                    s_nid[OWN(k)] = (uint16_t)0xFFFFu;
+        if constexpr (W0FOLD) {
+            // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the node of the flood's start pixel.
+            // A lane per node (two rounds for a tile with more than 256); the exported ones get consecutive record ids in list order.
+            const uint32_t sroot = s_start;
+            uint32_t       en[2] = {0u, 0u}, keep = 0, cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)(r * TILE_THREADS);
+                if (i < total_all) {
+                    en[r] = s_order[i];
+                    const uint32_t v = s_w0[i];
+                    const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
+                    if ((v >> 28) != 0 || (int64_t)area > (int64_t)prm.min_area || (en[r] >> 20) == ORDER_NOPAR || (en[r] & 0xFFFu) == sroot) {
+                        keep |= 1u << r;
+                        ++cnt;
+                    }
                 }
             }
-        }
-        __syncthreads();
-        const uint32_t nbase = s_nbase;
-        if (nbase == NONE) {
-            // no records: nothing leaves this tile
-        } else if (listed) {
-            for (uint32_t e = tid; e < total; e += TILE_THREADS) {
-                const uint32_t w = s_exp[e];
-                export_node(nbase, w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu);
+            const uint32_t eid0 = block_excl_scan(cnt, s_wsum, &total);
+            if (tid == 0) take_records(total);
+            // (the scan's barriers separate the last reads of s_nid as "all-node id" from the rewrite)
+            {
+                uint32_t id = eid0;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if ((uint32_t)tid + (uint32_t)(r * TILE_THREADS) < total_all) s_nid[LX(en[r] & 0xFFFu)] = (uint16_t)(((keep >> r) & 1u) ? id++ : 0xFFFFu);
+            }
+            __syncthreads();
+            const uint32_t nbase = s_nbase;
+            if (nbase != NONE) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if ((keep >> r) & 1u) export_node(nbase, en[r] & 0xFFFu, (uint32_t)tid + (uint32_t)(r * TILE_THREADS), (en[r] >> 12) & 0xFFu);
             }
         } else {
-            uint32_t aid = aid0;
-#pragma unroll 1
-            for (int k = 0; k < TILE_PPT; ++k) {
-                if (!((rootmask >> k) & 1)) continue;
-                const uint32_t a = aid++;
-                if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev_of(k));
+            // which nodes leave the tile: open ones, closed ones the reference keeps, tile roots and the
+            // node of the flood's start pixel
+            uint32_t expmask = 0;
+            {
+                uint32_t m = rootmask, id = aid0;
+                const uint32_t sroot = s_start;
+                while (m) {
+                    const int k = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const uint32_t v = s_w0[id++];
+                    const uint32_t area = (v & CNT_MASK) + ((v >> CNT_BITS) & CNT_MASK);
+                    const bool     open = (v >> 28) != 0;
+                    if (open || (int64_t)area > (int64_t)prm.min_area || s_par[OWN(k)] == NONE || p0 + k == sroot) expmask |= 1u << k;
+                }
+            }
+            const uint32_t eid0 = block_excl_scan(__popc(expmask), s_wsum, &total);
+            if (tid == 0) take_records(total);
+            // The exported nodes are listed behind the statistics (slot | a << SLOT_BITS | level << (SLOT_BITS + A_BITS))
+            // and written out one per lane; a tile too full for the list writes them from the owners.
+            const bool listed = (uint32_t)NODE_WORDS * n_even + total <= (uint32_t)NODE_WORDS * (uint32_t)FOLD_CAP;
+            {
+                uint32_t m = rootmask, id = eid0, aid = aid0;
+                while (m) {
+                    const int k = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const uint32_t a = aid++;
+                    if ((expmask >> k) & 1) {
+                        if (listed) s_exp[id] = (p0 + k) | (a << SLOT_BITS) | (lev_of(k) << (SLOT_BITS + A_BITS));
+                        s_nid[OWN(k)] = (uint16_t)id++;
+                    } else {
+                        s_nid[OWN(k)] = (uint16_t)0xFFFFu;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nbase = s_nbase;
+            if (nbase == NONE) {
+                // no records: nothing leaves this tile
+            } else if (listed) {
+                for (uint32_t e = tid; e < total; e += TILE_THREADS) {
+                    const uint32_t w = s_exp[e];
+                    export_node(nbase, w & ((1u << SLOT_BITS) - 1u), (w >> SLOT_BITS) & ((1u << A_BITS) - 1u), (w >> (SLOT_BITS + A_BITS)) & 0xFFu);
+                }
+            } else {
+                uint32_t aid = aid0;
+    #pragma unroll 1
+                for (int k = 0; k < TILE_PPT; ++k) {
+                    if (!((rootmask >> k) & 1)) continue;
+                    const uint32_t a = aid++;
+                    if ((expmask >> k) & 1) export_node(nbase, p0 + k, a, lev_of(k));
+                }
             }
         }
     } else {
@@ -1237,7 +1274,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             __syncthreads();
         }
     }
-    __syncthreads();
+    if (!(W0FOLD && w0fold)) __syncthreads();       // (the small kernel's fold path has read s_nbase behind a barrier already and writes no LDS after it)
     const uint32_t nbase = s_nbase;
     if (tid == 0) {
         b.tile_nbase[blockIdx.x] = nbase;

@@ -8,6 +8,8 @@ for so in "" $ROOT/scene-text-recognition_amd/lib/var/*.so; do
     echo "== $name"
     case " $PARITY " in *" $name "*) timeout 300 python $ROOT/tools/dev_cliff_one.py 2>&1 | tail -1;; esac
     for kind in text noise; do
-        echo -n "   $kind: "; timeout 300 python $ROOT/tools/dev_stop.py $kind 2>&1 | grep "tile_tree alone" | tail -2 | tr '\n' ' '; echo
+        # 12 launches, the first two dropped: minimum and median (single launches of the text-like batch scatter by +-1.5 %)
+        echo -n "   $kind: "; DEV_STOP_ITERS=12 timeout 300 python $ROOT/tools/dev_stop.py $kind 2>&1 | grep "tile_tree alone" | tail -10 |
+            awk '{print $(NF-1)}' | sort -n | awk '{v[NR]=$1} END {printf "min %.4f  median %.4f ms\n", v[1], (v[int((NR+1)/2)] + v[int(NR/2)+1]) / 2}'
     done
 done

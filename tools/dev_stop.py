@@ -14,7 +14,7 @@ f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_le
 f.load_cascade(0, sp); f.load_cascade(1, wp)
 src = S.synth.frames_bgr(kind, 0, 4, W, H)
 d = torch.from_numpy(np.stack([src[i % 4] for i in range(F)])).cuda()
-for it in range(4):
+for it in range(int(os.environ.get('DEV_STOP_ITERS', '4'))):
     try:
         f.detect_bgr_device(d.data_ptr(), W, H, F)
     except S.StrErError:
