@@ -849,14 +849,16 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 if (first_root == NONE) first_root = p;
                 if (W0FOLD) atomicAdd(&s_hist[l & 0xFFu], 1u);
                 else atomicOr(&s_present[(l >> 5) & 7u], 1u << (l & 31u));
-                if (w == NONE) continue;
-                uint32_t q = w & 0xFFFFu;
-                for (;;) {
-                    const uint32_t wq = LD_WG(&s_par[LX(q)]);
-                    if ((wq >> 16) != (w >> 16)) break;
-                    q = wq & 0xFFFFu;
+                if constexpr (!W0FOLD) {        // (small kernel: done per NODE further down, a lane per node instead of a round of this loop)
+                    if (w == NONE) continue;
+                    uint32_t q = w & 0xFFFFu;
+                    for (;;) {
+                        const uint32_t wq = LD_WG(&s_par[LX(q)]);
+                        if ((wq >> 16) != (w >> 16)) break;
+                        q = wq & 0xFFFFu;
+                    }
+                    s_par[LX(p)] = (w & 0xFFFF0000u) | q;
                 }
-                s_par[LX(p)] = (w & 0xFFFF0000u) | q;
             }
         }
     }
@@ -949,6 +951,20 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         dst[1] = make_uint4(x0, y0, x1, y1);
         b.na.aux[pd.node_base + id] = 0;           // dependency counter of k_resolve / k_reduce
     };
+    // small kernel: the parent word of level root p made to point at the parent node's level root (the big kernel does it while flattening)
+    auto fix_parent = [&](uint32_t p) -> uint32_t {
+        const uint32_t w = s_par[LX(p)];
+        if (w == NONE) return NONE;
+        uint32_t q = w & 0xFFFFu;
+        for (;;) {
+            const uint32_t wq = LD_WG(&s_par[LX(q)]);
+            if ((wq >> 16) != (w >> 16)) break;
+            q = wq & 0xFFFFu;
+        }
+        const uint32_t nw = (w & 0xFFFF0000u) | q;
+        s_par[LX(p)] = nw;
+        return nw;
+    };
     // dense id of the node of the piece headed by p
     auto piece_node = [&](uint32_t p, bool isroot) -> uint32_t { return s_nid[LX(isroot ? p : (s_par[LX(p)] & 0xFFFFu))]; };
 
@@ -973,7 +989,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             if (W0FOLD) {
                 // the parent's id joins the list entry: what the fold needs, looked up by all lanes here instead of by the one wave that
                 // folds, level after level
-                const uint32_t en = s_order[i], w = s_par[LX(en & 0xFFFu)];
+                const uint32_t en = s_order[i], w = fix_parent(en & 0xFFFu);
                 s_order[i] = en | ((w == NONE ? ORDER_NOPAR : (uint32_t)s_nid[LX(w & 0xFFFFu)]) << 20);
             }
         }
@@ -1236,6 +1252,9 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // STAT_CHUNK nodes per pass; the global passes do all the accumulation.
         total = total_all;
         if (tid == 0) take_records(total);
+        if constexpr (W0FOLD) {
+            for (uint32_t m = rootmask; m; m &= m - 1u) fix_parent(p0 + (uint32_t)__ffs((int)m) - 1u);
+        }
         uint32_t            *s_cnt = s_work;                       // [STAT_CHUNK]
         rowmask_t           *s_row = reinterpret_cast<rowmask_t *>(s_work + STAT_CHUNK);          // [STAT_CHUNK]
         unsigned long long  *s_col = reinterpret_cast<unsigned long long *>(s_work + (1 + ROW_WORDS) * STAT_CHUNK); // [STAT_CHUNK]
