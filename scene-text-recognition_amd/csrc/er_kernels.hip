@@ -621,7 +621,10 @@ constexpr int FOLD_CAP_SPARSE = TILE_H > 32 ? 1024 : 480;   // 16 (32) granules:
 // (Measured and not adopted: one compacted list of all pieces of the tile, processed by all lanes evenly -- fewer instructions, but the
 // two extra barriers and the dependent LDS reads of the list cost what they save; round 3: the parent word of a lane's NEXT piece fetched
 // while the current one is walked / added up, in the flatten and the statistics loops -- 2.11 against 2.08 ms: the four instructions per
-// round cost more than the latency they hide.)
+// round cost more than the latency they hide; a launch of resident workgroups that walk through the tiles -- the next tile's pixels requested
+// a tile ahead, tiles handed out by a batch-wide cursor read two tiles ahead: 2.33 against 1.93 ms; 2 / 4 / 8 / 16 tiles per workgroup in a
+// plain launch: 2.05 / 2.11 / 2.23 / 2.44 -- the loop costs ~150 instructions per wave and tile (descriptors, spills, a barrier), HBM latency
+// was hidden by the seven other workgroups of the CU all along, and the hardware's dispatcher balances better than a cursor.)
 // ------------------------------------------------------------------------------------
 #define LEVK(k) ((((k) < 4 ? lev_lo : lev_hi) >> (8 * ((k) & 3))) & 0xFFu)
 template <int FOLD_CAP>
