@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
                                                int64_t dplane_pitch, int64_t dframe_pitch, int planes_per_frame,
                                                ResizeGeom g)
 {
-    __shared__ uint32_t s_src[RS_ROWS * RS_WORDS];
+    __shared__ uint32_t s_src[RS_ROWS * RS_WORDS + 2];      // (+2: a lane reads three dwords from its first tap on)
     const int tx0 = blockIdx.x * 256;
     const int dx0 = tx0 + (int)threadIdx.x * 4;
     const int dy0 = blockIdx.y * RESIZE_ROWS;
@@ -298,15 +298,82 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
     const int nwords = (x_hi - x_lo) / 4 + 1, nrows = y_hi - y_lo + 1;
     const bool staged = nwords <= RS_WORDS && nrows <= RS_ROWS && (sstride & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 3) == 0;
     if (staged) {
-        for (int i = threadIdx.x; i < nrows * nwords; i += 64) {
-            const int r = i / nwords, wd = i - r * nwords;
-            s_src[r * RS_WORDS + wd] = *reinterpret_cast<const uint32_t *>(s + (size_t)(y_lo + r) * sstride + x_lo + 4 * wd);
+        // a lane fetches words lane and lane + 64 of every row: all loads of the window (up to 32 per lane) are issued before the first one is
+        // waited for -- a loop of load / wait / write pays the memory latency once per round, and that, not arithmetic, was the kernel's time
+        static_assert(RS_WORDS <= 128, "two words per lane and row");
+        uint32_t v[RS_ROWS][2];
+        const uint8_t *src0 = s + (size_t)y_lo * sstride + x_lo + 4 * (int)threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; ++r) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                v[r][j] = 0;
+                if (r < nrows && (int)threadIdx.x + 64 * j < nwords) v[r][j] = *reinterpret_cast<const uint32_t *>(src0 + (size_t)r * sstride + 256 * j);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; ++r) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (r < nrows && (int)threadIdx.x + 64 * j < nwords && (int)threadIdx.x + 64 * j < RS_WORDS) s_src[r * RS_WORDS + threadIdx.x + 64 * j] = v[r][j];
         }
         __syncthreads();
     }
     if (!active) return;
     const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_src);
     const bool full = dx0 + 4 <= g.dw && (dstride & 3) == 0;
+    if (staged && g.scale_x <= 1.5) {
+        // The taps of the lane's 4 columns lie within 7 source bytes (reduction <= 1.5): per SOURCE row the lane reads the three dwords
+        // that hold them, shifts them to its first tap (two v_alignbyte) and picks the 4 left and the 4 right taps with two byte
+        // permutes whose selectors are fixed for the tile; the horizontal sums of a source row are kept for the next output row, which
+        // mostly needs it again.  A third of the LDS reads of the form below (the byte reads bound this kernel: a byte read costs the
+        // LDS what a dword read costs), same arithmetic, same result.
+        const int      base = sx[0] & ~3, s0 = sx[0] - base;
+        const uint32_t selL = (uint32_t)(sx[0] - sx[0]) | (uint32_t)(sx[1] - sx[0]) << 8 | (uint32_t)(sx[2] - sx[0]) << 16 | (uint32_t)(sx[3] - sx[0]) << 24;
+        const uint32_t selR = (uint32_t)(sx1[0] - sx[0]) | (uint32_t)(sx1[1] - sx[0]) << 8 | (uint32_t)(sx1[2] - sx[0]) << 16 | (uint32_t)(sx1[3] - sx[0]) << 24;
+        const uint32_t *col = s_src + (base - x_lo) / 4;
+        auto hrow = [&](int y, int (&h)[4]) {           // horizontal pass of source row y for the lane's 4 columns
+            const uint32_t *p = col + (y - y_lo) * RS_WORDS;
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)s0), hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)s0);
+            const uint32_t L = __builtin_amdgcn_perm(hi, lo, selL), R = __builtin_amdgcn_perm(hi, lo, selR);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = (int)((L >> (8 * k)) & 0xFFu) * a0[k] + (int)((R >> (8 * k)) & 0xFFu) * a1[k];
+        };
+        int ca = -1, cb = -1;               // source rows whose sums are in hA / hB (rows are >= 0)
+        int hA[4] = {0, 0, 0, 0}, hB[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int r = 0; r < RESIZE_ROWS; ++r) {
+            const int dy = dy0 + r;
+            if (dy >= g.dh) break;
+            float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+            int   sy = (int)floorf(fy);
+            fy -= (float)sy;
+            const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+            const int ya = min(max(sy, 0), g.sh - 1), yb = min(max(sy + 1, 0), g.sh - 1);
+            // (ya, yb are the same for every lane: uniform branches)
+            if (ya == cb) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hA[k] = hB[k];
+                ca = cb;
+            } else if (ya != ca) { hrow(ya, hA); ca = ya; }
+            if (yb == ca) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hB[k] = hA[k];
+                cb = yb;
+            } else if (yb != cb) { hrow(yb, hB); cb = yb; }
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = min(max((((b0 * (hA[k] >> 4)) >> 16) + ((b1 * (hB[k] >> 4)) >> 16) + 2) >> 2, 0), 255);
+                v |= (uint32_t)o << (8 * k);
+            }
+            uint8_t *o = d + (size_t)dy * dstride + dx0;
+            if (full) *reinterpret_cast<uint32_t *>(o) = v;
+            else for (int k = 0; k < 4 && dx0 + k < g.dw; ++k) o[k] = (uint8_t)(v >> (8 * k));
+        }
+        return;
+    }
 #pragma unroll 4
     for (int r = 0; r < RESIZE_ROWS; ++r) {
         const int dy = min(dy0 + r, g.dh - 1);
