@@ -1753,6 +1753,7 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
 //   blob = StripHeader | StripPlane x n_planes | per plane: records | per plane: node of every pixel of the first row (if the plane
 //          goes on above), of the last row (if it goes on below) -- sections start on 256-byte boundaries
 // =================================================================================================
+extern "C++" {          // (helpers with C++ types, inside the file's extern "C" block)
 namespace {
 
 constexpr uint32_t STRIP_MAGIC = 0x50525453u;      // "STRP"
@@ -1807,6 +1808,7 @@ int ensure_strip_buf(str_er_ctx *c, uint8_t *&p, size_t &cap, size_t need)
 }
 
 } // namespace
+} // extern "C++"
 
 int str_er_strip_extract_dev(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
                              const void **d_blob, int64_t *blob_bytes)

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > 
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $B > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq1 -o p -- $B > $OUT/pmc_sq1.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2 -o p -- $B > $OUT/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2 -o p -- $B > $OUT/pmc_sq2.log 2>&1
 # bench.py reads roofline.traffic from profiles/pmc_tile_tree.json: write it from the counter passes above before the bench lines are taken
 python $ROOT/tools/make_profile_summary.py $TAG --pmc-json-only > $OUT/pmc_json.log 2>&1
 python $ROOT/bench.py > $OUT/bench_${TAG}_pyr3x8_text.json 2> $OUT/bench_err.log
