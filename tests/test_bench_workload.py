@@ -134,7 +134,7 @@ def test_bench_workload_config3_ocr(S, cascade_paths, oracle, oracle_cascades):
 
 @pytest.mark.parametrize("mode", ["sparse", "dense"])
 def test_soak_random_planes(S, oracle, monkeypatch, mode):
-    """Bounded soak of the lock-free tree kernels (was tools/soak.py): random planes -- sizes up to 400x300, five value
+    """Bounded soak of the lock-free tree kernels (was tools/soak.py): random planes -- sizes up to 400x300, six value
     distributions, thresh steps 1-16, MIN_AREA 1/20/120 -- node for node against the oracle, for 25 s per tile-kernel size."""
     monkeypatch.setenv("STR_ER_TILE_KERNEL", mode)
     # (STR_ER_SOAK_SECONDS / STR_ER_SOAK_SEED: a longer or different soak by hand)
@@ -145,8 +145,14 @@ def test_soak_random_planes(S, oracle, monkeypatch, mode):
         while time.time() - t0 < budget:
             step = int(rng.choice([1, 2, 4, 8, 8, 8, 16]))
             w, h = int(rng.integers(1, 400)), int(rng.integers(1, 300))
-            kind = int(rng.integers(0, 5))
-            if kind == 0:
+            kind = int(rng.integers(0, 6))
+            if kind == 5:
+                # speckles of random density on a flat plane: tiles with anything from a handful to a thousand nodes (the small tile kernel changes
+                # its way of working at 256 and at ~330 nodes per tile, both kernels at their fold capacity)
+                img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+                m = rng.random((h, w)) < rng.uniform(0.01, 0.6)
+                img[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+            elif kind == 0:
                 img = rng.integers(0, 256, (h, w), dtype=np.uint8)
             elif kind == 1:
                 img = (rng.integers(0, 2, (h, w)) * int(rng.integers(1, 255))).astype(np.uint8)
