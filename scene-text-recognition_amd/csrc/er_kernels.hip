@@ -984,6 +984,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     // fold path of the small kernel: statistics [0, NODE_WORDS n), the list (a word per node) behind them, the level cursors in the tail.
     // list entry: slot of the level root (12 bits) | level << 12 | id of the parent << 20 (ORDER_NOPAR: none)
     constexpr uint32_t ORDER_NOPAR = 0x1FFu;
+    static_assert(!W0FOLD || (TILE_SLOTS <= 4096 && (NODE_WORDS + 1) * 2 * TILE_THREADS >= HIST_AT), "list entry: 12-bit slots; the per-node passes take two nodes per lane");
     const uint32_t n_even_all = (total_all + 1u) & ~1u;
     const bool     w0fold = W0FOLD && (uint32_t)(NODE_WORDS + 1) * n_even_all <= (uint32_t)HIST_AT && total_all < ORDER_NOPAR;
     uint32_t *const s_order = s_work + NODE_WORDS * n_even_all;
