@@ -765,32 +765,83 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         vx ^= inv; vy ^= inv;
         const uint32_t invalidm = ~((1u << nvalid) - 1u);
         uint32_t head = p0;
+        uint32_t first_lev, last_lev;       // levels of the lane's pixels 0 and 7 (WALL: a wall)
+        if (prm.hi <= 0x7F && (prm.thresh_step & (prm.thresh_step - 1)) == 0) {
+            // thresh_step 4, 8, 16, ...: the float product p * float(1 / step) is exact, so rint_half_even of it is the integer
+            //   t + ((r + (t & 1) + step / 2 - 1) >> s)   with t = p >> s, r = p mod step, step = 2^s
+            // -- four pixels per instruction, a byte each (levels <= 64).  Walls, levels without the walls, run starts: byte-parallel as well
+            // (bit 7 of (x | 0x80) - y is set iff x >= y for bytes below 0x80); the 8 flags are gathered from bit 7 of the 8 bytes with shifts.
+            constexpr uint32_t B1 = 0x01010101u, H7 = 0x80808080u;
+            const uint32_t sft = 31u - (uint32_t)__clz(prm.thresh_step);
+            const uint32_t Mt = (0xFFu >> sft) * B1, Mr = ((1u << sft) - 1u) * B1, Cr = ((1u << (sft - 1u)) - 1u) * B1, HIb = (uint32_t)prm.hi * B1;
+            // (pixels outside the image read as 255: the sentinel level, a wall)
+            vx |= nvalid >= 4 ? 0u : 0xFFFFFFFFu << (8 * nvalid);
+            vy |= nvalid >= 8 ? 0u : (nvalid <= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (nvalid - 4)));
+            auto quant = [&](uint32_t v) -> uint32_t {
+                const uint32_t t = (v >> sft) & Mt, r = v & Mr;
+                return t + (((r + (t & B1) + Cr) >> sft) & B1);
+            };
+            auto gather8 = [](uint32_t lo7, uint32_t hi7) -> uint32_t {      // bit 7 of the 8 bytes of (lo7, hi7) -> bits 0 .. 7
+                uint32_t z = (lo7 >> 7) | (hi7 >> 3);
+                z |= z >> 7;
+                z |= z >> 14;
+                return z & 0xFFu;
+            };
+            auto nz7 = [](uint32_t d) -> uint32_t { return (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u; };      // bit 7 of the bytes that are not 0
+            const uint32_t qx = quant(vx), qy = quant(vy);
+            const uint32_t wx7 = ((qx | H7) - HIb) & H7, wy7 = ((qy | H7) - HIb) & H7;       // bit 7: that pixel is a wall
+            const uint32_t wbx = wx7 | (wx7 - (wx7 >> 7)), wby = wy7 | (wy7 - (wy7 >> 7));     // 0xFF in the bytes of walls
+            wallm = gather8(wx7, wy7);
+            lev_lo = qx & ~wbx; lev_hi = qy & ~wby;
+            const uint32_t ex = qx | wbx, ey = qy | wby;                                     // the levels, walls as 0xFF
+            // pixel k > 0 starts a run iff it is no wall and differs from pixel k - 1
+            startm = gather8(nz7(ex ^ (ex << 8)) & ~wx7, nz7(ey ^ ((ey << 8) | (ex >> 24))) & ~wy7) & 0xFEu;
+            // s_lev: 16 bits per pixel, walls 0xFFFF -- level byte and wall byte interleaved
+            typedef uint32_t lev4_t __attribute__((ext_vector_type(4), aligned(2)));
+            lev4_t pk;
+            pk.x = __builtin_amdgcn_perm(wbx, ex, 0x05010400u); pk.y = __builtin_amdgcn_perm(wbx, ex, 0x07030602u);
+            pk.z = __builtin_amdgcn_perm(wby, ey, 0x05010400u); pk.w = __builtin_amdgcn_perm(wby, ey, 0x07030602u);
+            *reinterpret_cast<lev4_t *>(&s_lev[OWN(0)]) = pk;
+            // runs: every pixel of a run points at the run's first pixel
+            const uint32_t contm = ~(startm | wallm);          // bit k (k > 0): pixel k continues the run of pixel k - 1
 #pragma unroll
-        for (int k = 0; k < TILE_PPT; ++k) {
-            const uint32_t q0 = (uint32_t)__float2int_rn((float)(((k < 4 ? vx : vy) >> (8 * (k & 3))) & 0xFFu) * prm.qscale);
-            const bool     wall = q0 >= (uint32_t)prm.hi || ((invalidm >> k) & 1u);
-            const uint32_t q = wall ? WALL : q0;
-            lev[k] = q;
-            s_lev[OWN(k)] = (uint16_t)q;
-            wallm |= (wall ? 1u : 0u) << k;
-            if (k < 4) lev_lo |= (wall ? 0u : q0) << (8 * (k & 3)); else lev_hi |= (wall ? 0u : q0) << (8 * (k & 3));
-            if (k > 0) {
-                // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; every pixel of a run points at the
-                // run's first pixel
-                const bool same = !wall && q == lev[k > 0 ? k - 1 : 0];
-                startm |= ((wall || same) ? 0u : 1u) << k;
+            for (int k = 1; k < TILE_PPT; ++k) {
+                const bool     same = ((contm >> k) & 1u) != 0;
+                const uint32_t q = ((k < 4 ? ex : ey) >> (8 * (k & 3))) & 0xFFu;
                 s_par[OWN(k)] = same ? ((q << 16) | head) : NONE;
                 head = same ? head : p0 + k;
             }
+            first_lev = (ex & 0xFFu) == 0xFFu ? WALL : (ex & 0xFFu);
+            last_lev = (ey >> 24) == 0xFFu ? WALL : (ey >> 24);
+        } else {
+    #pragma unroll
+            for (int k = 0; k < TILE_PPT; ++k) {
+                const uint32_t q0 = (uint32_t)__float2int_rn((float)(((k < 4 ? vx : vy) >> (8 * (k & 3))) & 0xFFu) * prm.qscale);
+                const bool     wall = q0 >= (uint32_t)prm.hi || ((invalidm >> k) & 1u);
+                const uint32_t q = wall ? WALL : q0;
+                lev[k] = q;
+                s_lev[OWN(k)] = (uint16_t)q;
+                wallm |= (wall ? 1u : 0u) << k;
+                if (k < 4) lev_lo |= (wall ? 0u : q0) << (8 * (k & 3)); else lev_hi |= (wall ? 0u : q0) << (8 * (k & 3));
+                if (k > 0) {
+                    // runs: inside the lane's own 8 pixels, equal-level neighbours are one node; every pixel of a run points at the
+                    // run's first pixel
+                    const bool same = !wall && q == lev[k > 0 ? k - 1 : 0];
+                    startm |= ((wall || same) ? 0u : 1u) << k;
+                    s_par[OWN(k)] = same ? ((q << 16) | head) : NONE;
+                    head = same ? head : p0 + k;
+                }
+            }
+            first_lev = lev[0]; last_lev = lev[TILE_PPT - 1];
         }
         // ... and across the lane boundary: if the lane's first pixel continues the run of the pixel to
         // its left, it points at the head of that run.  The 8 lanes of a tile row are neighbours in the
         // wave; a lane that is one single run and itself continues leftwards forwards the head it got.
-        uint32_t left_lev = LANE_M1(lev[TILE_PPT - 1]);
+        uint32_t left_lev = LANE_M1(last_lev);
         if (lx == 0) left_lev = WALL;
         left_wall = left_lev == WALL;
-        const bool joins = lev[0] != WALL && lev[0] == left_lev;
-        if (lev[0] != WALL && !joins) startm |= 1u;
+        const bool joins = first_lev != WALL && first_lev == left_lev;
+        if (first_lev != WALL && !joins) startm |= 1u;
         if ((ly & 7) == 0) {        // a wave's first row: the last row of the wave above reads it from LDS (the other rows are exchanged by shuffles)
             uint32_t *d = s_rowlv + 3 * ((tid >> 6) * 8 + (tid & 7));
             d[0] = lev_lo; d[1] = lev_hi; d[2] = wallm;
@@ -803,7 +854,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             { const uint32_t lv = LANE_M2(val), lp = LANE_M2((uint32_t)pass); if (pass) { val = lv; pass = lp != 0; } }
             { const uint32_t lv = LANE_M4(val), lp = LANE_M4((uint32_t)pass); if (pass) { val = lv; pass = lp != 0; } }
             const uint32_t t = LANE_M1(val);
-            s_par[OWN(0)] = joins ? ((lev[0] << 16) | t) : NONE;
+            s_par[OWN(0)] = joins ? ((first_lev << 16) | t) : NONE;
         }
         const uint32_t walls = (uint32_t)__popc(wallm & ((1u << nvalid) - 1u));    // pixels of the image at the sentinel level
         __syncthreads();
