@@ -26,7 +26,7 @@ else
         STR_ER_LIB=$OUT/libstop_$n.so python $ROOT/tools/dev_stop.py ${KIND:-text} 2>&1 | grep "tile_tree alone" | tail -1
         STR_ER_LIB=$OUT/libstop_$n.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d /tmp/pmc_$n -o p -- python $ROOT/tools/dev_stop.py ${KIND:-text} > /dev/null 2>&1
         python - <<PY
-import csv, glob
+import csv, glob, os
 rows = []
 for f in glob.glob("/tmp/pmc_$n/**/*counter_collection.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
@@ -34,7 +34,7 @@ acc = {}
 for r in rows:
     if "k_tile_tree" not in r.get("Kernel_Name", ""): continue
     acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-w = 795648.0          # waves of one launch of dev_stop.py (32 frames of pyr3x8)
+w = float(os.environ.get("DEV_STOP_WAVES", "795648"))          # waves of one launch of dev_stop.py (32 frames of pyr3x8, 3 channels)
 print("   per wave:", {k: round(sum(v) / len(v) / w, 1) for k, v in acc.items()})
 PY
     done
