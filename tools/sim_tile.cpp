@@ -69,7 +69,10 @@ static bool prune_v(const Tile &t, int p) { /* edge (p,p+TW) */
     return false;
 }
 
-// variant bits: 1 = wave-dynamic schedule, 2 = combined single round, 4 = early-out for redundant cross-level edge
+// variant bits: 1 = wave-dynamic schedule, 2 = combined single round, 4 = early-out for redundant cross-level edge, 8 = hand-out in list order,
+// 16 = equal-level vertical edges first, 32 = block-maximum edges dropped (64: closed form for the vertical ones), 128 = the combined list sorted by
+// edge weight (256: heaviest first).  The kernel as built: 1 + 2 + 8 + 32 + 64 = 107.  (128 / 256, text / noise plane: cost per wave 865 -> 902 / 921,
+// 3488 -> 3516 / 3227: the order of the edges is not worth a sort.)
 
 
 static void run_rounds(Tile &t, vector<uint16_t> *elist_round, int nrounds, const int *round_kind_of_list, Stats &st)
@@ -220,6 +223,10 @@ int main(int argc, char **argv)
                 const int p0 = tid * 8;
                 while (i0 < el[0].size() && (el[0][i0] & 0x7FFF) < p0 + 8) c.push_back(el[0][i0++]);
                 while (i1 < el[1].size() && (el[1][i1] & 0x7FFF) < p0 + 8) c.push_back(el[1][i1++]);
+            }
+            if (VARIANT & 128) {      // the list sorted by the edge's weight max(level, level) (stable; 256: heaviest first)
+                auto wt = [&](uint16_t e) -> uint32_t { const int p = e & 0x7FFF; return (e & 0x8000) ? max(t.lev[p], t.lev[p + TW]) : max(t.lev[p - 1], t.lev[p]); };
+                stable_sort(c.begin(), c.end(), [&](uint16_t x, uint16_t y) { return (VARIANT & 256) ? wt(x) > wt(y) : wt(x) < wt(y); });
             }
             vector<uint16_t> lists[1] = {c};
             int kinds[1] = {0};
