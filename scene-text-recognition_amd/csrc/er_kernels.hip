@@ -599,6 +599,15 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
     }
 }
 
+// Orders a wave's own LDS accesses around a point (no instruction: the hardware keeps a wave's LDS operations in order; this keeps the compiler from
+// moving them across).
+#define WAVE_SYNC()                                               \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+
 // Data-parallel-primitive moves: the source lane is named in the instruction (no LDS-pipe bpermute, no address register).  A "row" is
 // 16 lanes = two tile rows of 8 lanes; a lane whose source lies outside its row keeps `v` (the callers ignore those lanes).
 template <int CTRL, int ROW_MASK = 0xF>
@@ -3120,6 +3129,9 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
         const unsigned long long tp0 = wall_clock64();
 #endif
         // ---- phase 1: histograms --------------------------------------------------------------
+        // Every wave works on an ER of its own with scratch of its own (hist[wv], tile[wv], its row): between its steps it only has to wait for
+        // ITSELF -- a wave's LDS operations are carried out in the order it issues them -- so the steps are separated by a wave-level fence, not
+        // by a workgroup barrier: the 16 waves' ERs differ in size, and a barrier per step had every wave wait for the largest four times per ER.
         if (run_cascades) {
             for (int it = 0; it < CLS_PER_BLOCK / CLS64_WAVES; ++it) {
                 const uint32_t cpos = c0 + it * CLS64_WAVES + wv;
@@ -3139,7 +3151,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                 uint8_t  *tile = sh.u.p1.tile[wv];
                 for (int i = lane; i < 1024; i += 64) hist[i] = 0;
                 for (int i = lane; i < 26 * 26; i += 64) tile[i] = 0;
-                __syncthreads();
+                WAVE_SYNC();
                 if (ok) {
                     const double R1 = (bw > bh) ? (double)bh / bw : (double)bw / bh;
                     const int    k = (int)(26.0 * sqrt(R1));
@@ -3155,7 +3167,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                         }
                     }
                 }
-                __syncthreads();
+                WAVE_SYNC();
                 if (ok) {
                     for (int idx = lane; idx < 24 * 24; idx += 64) {
                         const int i = idx / 24, j = idx - i * 24;
@@ -3168,7 +3180,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                         atomicAdd(&hist[(i / 12) * 512 + (j / 12) * 256 + code], 1u);
                     }
                 }
-                __syncthreads();
+                WAVE_SYNC();
                 if (ok) {
                     uint8_t *row = sh.rows + (size_t)(it * CLS64_WAVES + wv) * CLS_ROW;
                     for (int i = lane; i < 256; i += 64) {     // 4 bins per lane per step, one 32-bit store
@@ -3176,8 +3188,9 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                         *reinterpret_cast<uint32_t *>(row + 4 * i) = v;
                     }
                 }
-                __syncthreads();
+                WAVE_SYNC();
             }
+            __syncthreads();            // every wave's rows are in place; the scratch (aliased by the tables below) is free
         }
 #ifdef STR_ER_PHASE_PROF
         unsigned long long tp1 = wall_clock64();
