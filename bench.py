@@ -42,11 +42,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0    # ... and what a float4 copy reaches (same guide)
 WORKLOADS = {
     "pyr3x8": dict(n_pyr_levels=8, channel_mask=0x07, label="1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels (BASELINE configs[1]/[2])"),
     "native6": dict(n_pyr_levels=1, channel_mask=0x3F, label="1920x1080 BGR, reference-native 6 planes x 1 level"),
 }
+
+
+def effective_cpus() -> int:
+    """CPUs this process can keep busy: os.cpu_count() cut down to the container's cgroup CPU quota (the GPU boxes report 256 cores and grant 16)."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = max(1, min(n, -(-q // per)))
+        except Exception:
+            pass
+    return n
 
 
 def plane_pixels(workload: str) -> int:
@@ -69,7 +88,7 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
     cfg = WORKLOADS[workload]
     o = Oracle()
     cs, cw = o.cascade_load(cascades[0]), o.cascade_load(cascades[1])
-    ncores = os.cpu_count() or 1
+    ncores = effective_cpus()
 
     def planes_of(frame):
         six = o.compute_channels(frame)
@@ -96,7 +115,7 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
         frames_done += 1
     return {"value": round(frames_done / t_total, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
             "sample": f"{frames_done} S-{kind} 1920x1080 frame(s), workload {workload}, {t_total:.1f} s of CPU wall time, "
-                      f"oracle/er_oracle.c -O2, one thread per plane ({nthreads} threads on {ncores} host cores)"}
+                      f"oracle/er_oracle.c -O2, one thread per plane ({nthreads} threads; the box reports {os.cpu_count()} cores, its CPU quota grants {ncores})"}
 
 
 def main():
@@ -298,6 +317,7 @@ def main():
                 serial_prof[k] = serial_prof.get(k, 0.0) + v / n_cal
     else:
         serial_prof = {k: v / max(args.steps, 1) for k, v in prof_sum.items()}
+    r_tree_stats = filters[0].last_tree_stats()
 
     # ties leg: the same measurement on tie-rich frames (S-ties), so that the cost of exactness is on the line
     ties_leg = None
@@ -316,7 +336,7 @@ def main():
         a1 = tie_totals()
         ties_leg = {"value": round(F * n_t / el, 2), "unit": "frames/s", "steps": n_t, "ms_per_step": round(1e3 * el / n_t, 3),
                     "tie_planes_per_batch": round((a1[0] - a0[0]) / n_t, 2), "tie_plane_share": round((a1[0] - a0[0]) / n_t / (F * bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels']), 4),
-                    "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(),
+                    "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(), "host_cpu_quota": effective_cpus(),
                     "note": f"S-ties frames (S-text + one double-L glyph in every {args.ties_every}th frame: an NMS sibling tie with two different outcomes); same "
                             "batches in flight as `value`; flood_walk_ms = host time of the reference-order walks, summed over planes.  The walks are "
                             "bound by host memory latency (~6 ms per 1920x1080 plane): once tie planes per batch x 6 ms / host_threads exceeds the "
@@ -430,7 +450,7 @@ def main():
         tile_ms = serial_prof.get("tile_tree", 0.0) or tile_ms_overlapped
         tile_bytes = px * F
         achieved = tile_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, "not measured in this run (no rocprofv3 counter pass)"
         pmc = os.path.join(ROOT, "profiles", "pmc_tile_tree.json")
         if os.path.exists(pmc):
             try:
@@ -438,8 +458,23 @@ def main():
                     j = json.load(fh)
                 if j.get("workload") == args.workload and j.get("frames_per_launch"):
                     traffic = j["hbm_bytes_per_launch"] * F / j["frames_per_launch"]
+                    traffic_source = ("STORED figure, not measured in this run: profiles/pmc_tile_tree.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                      f"passes of this command, collected {j.get('collected', 'earlier')}; FETCH doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to "
+                                      f"{F} frames per launch")
             except Exception:
                 traffic = None
+        # the other passes of the component tree, priced the same way: algorithmic bytes = what the pass has to read and write once
+        # (32-byte node records + their 4-byte counters, two 16-bit seam entries per pixel pair across a tile border) over the pass's isolated time
+        ts = r_tree_stats
+        tree_bytes = {"group": 2 * 36 * ts["records"], "seam": 4 * ts["seam_pairs"], "resolve": 2 * 36 * ts["records"], "accumulate": 2 * 36 * ts["records"]}
+        tree_roof = {}
+        for k, nb in tree_bytes.items():
+            ms_k = serial_prof.get(k, 0.0)
+            if ms_k > 0:
+                gbs = nb / (ms_k * 1e-3) / 1e9
+                tree_roof[k] = {"ms": round(ms_k, 4), "bytes": int(nb), "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5)}
+        tree_roof["note"] = (f"k_group_merge / k_seam / k_resolve / k_reduce of one batch ({ts['records']} exported node records, {ts['seam_pairs']} border pixel pairs, "
+                             f"{ts['tiles']} tiles): isolated times as for k_tile_tree; bound by LDS / device-scope atomic latency, not by HBM (DESIGN 3.2)")
         out = {
             "metric": "frames/sec (ER extract + 2-stage classify), 1920x1080",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -461,11 +496,13 @@ def main():
             **({"pcie_inclusive_nv12": pcie_nv12} if pcie_nv12 else {}),
             **({"latency_1frame": latency} if latency else {}),
             "roofline": {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_peak": round(achieved / HBM_MEASURED_GBS, 5),
+                         "measured_peak": HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": tile_bytes, "avg_launch_ms": round(tile_ms, 4),
                          "timing": "isolated launch: HIP events on the library's stream, one batch in flight, mean of 3 launches after the timed region",
                          "overlapped_event_ms": round(tile_ms_overlapped, 4),
                          "path_bytes_per_frame": int(b_alg), "path_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)},
+            "tree_passes_roofline": tree_roof,
             "gpu_ms_per_step_by_kernel_group": {k: round(v / args.steps, 4) for k, v in prof_sum.items()},
             "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in serial_prof.items()},
         }

@@ -193,8 +193,13 @@ int  str_er_abi_version(void);
  * opts in: returns 1 if it set something, 0 if the host's environment already decides, < 0 on error.                  */
 /* Exact NMS sibling ties (sibling_order = 0): how many planes of this context's calls so far needed the reference's flood order
  * walked on a host core, the host time those walks took in all (ms, summed over planes), and how many host threads the
- * library's process-wide pool for them has at most (cores / 4, at least 1, at most 16; STR_ER_WALK_THREADS overrides).  Any pointer may be NULL. */
+ * library's process-wide pool for them has at most (the CPUs the process may use -- hardware threads cut down to a container's cgroup CPU quota --, at least 1,
+ * at most 64; STR_ER_WALK_THREADS overrides).  Any pointer may be NULL. */
 int  str_er_tie_stats(const str_er_ctx *ctx, uint64_t *planes_walked, double *walk_ms_total, int32_t *host_threads);
+/* What the component-tree passes of this context's last detect call worked on: node records the tile kernel exported (32 bytes each; what
+ * k_group_merge / k_resolve / k_reduce read and write), pixel pairs across tile borders (k_seam: two 16-bit seam entries each) and tiles.
+ * Measurement aid (bench.py prices the passes against the HBM roofline with it); the reference has no counterpart.  Any pointer may be NULL. */
+int  str_er_last_tree_stats(const str_er_ctx *ctx, uint64_t *records, uint64_t *seam_pairs, uint64_t *tiles);
 const char *str_er_runtime_hint(void);
 int  str_er_apply_runtime_hint(void);
 

@@ -202,6 +202,7 @@ def load_library():
     L.str_er_result_times.restype = f64p
     L.str_er_result_cands_to_device.argtypes = [vp, vp, vp, C.c_int32, i32p]
     L.str_er_result_free.argtypes = [vp]
+    L.str_er_last_tree_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.str_er_last_profile.argtypes = [vp, C.POINTER(C.c_char_p), f64p, C.c_int32]
     L.str_er_set_profiling.argtypes = [vp, C.c_int]
     L.str_er_workspace_bytes.argtypes = [vp]
@@ -412,6 +413,12 @@ class ERFilter:
             return res
         finally:
             L.str_er_result_free(rh)
+
+    def last_tree_stats(self) -> dict:
+        """Node records / border pixel pairs / tiles of the last detect call (str_er_last_tree_stats)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.str_er_last_tree_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"records": int(a.value), "seam_pairs": int(b.value), "tiles": int(c.value)}
 
     def last_profile(self) -> dict:
         names = (C.c_char_p * 16)()
@@ -783,12 +790,15 @@ class Comm:
             self.L.str_er_gather_free(p)
         return out, np.array(counts[:], np.int32)
 
-    def gather(self, cands: np.ndarray, frame_offset: int = 0):
-        """Collective: (all ranks' records ordered by rank, per-rank counts); `frame_offset` is added to this rank's frames."""
+    def gather(self, cands: np.ndarray, frame_offset: int = 0, failed: bool = False):
+        """Collective: (all ranks' records ordered by rank, per-rank counts); `frame_offset` is added to this rank's frames.
+        failed=True: this rank has nothing valid to contribute -- it still takes part (a count of -1), and EVERY rank's call returns an
+        error instead of one rank leaving the others waiting in the collective."""
         a = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
         p, n = C.c_void_p(), C.c_int32()
         counts = (C.c_int32 * self.world)()
-        rc = self.L.str_er_gather_cands(self.h, _np_ptr(a) if len(a) else None, len(a), frame_offset, C.byref(p), C.byref(n), counts)
+        rc = self.L.str_er_gather_cands(self.h, _np_ptr(a) if len(a) and not failed else None, -1 if failed else len(a), frame_offset,
+                                        C.byref(p), C.byref(n), counts)
         return self._take(rc, p, n, counts)
 
     def gather_last(self, erf: "ERFilter", frame_offset: int = 0):

@@ -736,6 +736,11 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     uint32_t *const s_hist = s_work + HIST_AT;
 
     const int       tid = threadIdx.x;
+#ifdef STR_ER_PAD_LDS
+    // developer aid: extra LDS per workgroup, to see what fewer resident workgroups per CU cost
+    __shared__ uint32_t s_pad[STR_ER_PAD_LDS / 4];
+    if (b.n_tiles == 0xFFFFFFFFu) s_pad[tid] = tid;
+#endif
     const int       pi = b.tile_plane[blockIdx.x];
     const PlaneDesc pd = b.planes[pi];
     const uint32_t  tl = blockIdx.x - pd.tile_base;
@@ -1854,7 +1859,8 @@ void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 // The records of a strip arrive with ids, keys and rows local to the strip (a strip is extracted like a plane of its own: the tile
 // kernel knows nothing of the rows above it).  `delta` makes the ids those of the whole plane (the strip's records sit behind those
 // of the strips above it), key_add = first row * width and y_add = first row put keys and boxes into the whole plane's coordinates.
-__global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t *bad)
+__global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t w,
+                                                        uint32_t h, uint32_t *bad)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         NodeRec r = rec[i];
@@ -1863,8 +1869,12 @@ __global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *
             if (PAR_ID(r.par) >= n) { atomicOr(bad, 1u); r.par = NONE; }
             else r.par = PAR_MAKE(PAR_LVL(r.par), PAR_ID(r.par) + delta);
         }
-        r.key += key_add;                 // (bits 0..23; the plane has fewer than 2^24 pixels, the level byte is not reached)
-        r.y0 += y_add; r.y1 += y_add;
+        // ... nor a box or a key outside the plane: k_kept hands the box to k_classify, which reads the plane's pixels over it, and the NMS tie
+        // pass indexes its per-pixel stamps with the key.  A bad record is flagged (the merge fails with EFORMAT) and made harmless.
+        const uint32_t key = (r.key & 0xFFFFFFu) + key_add;
+        const bool     ok = r.x0 <= r.x1 && r.x1 < w && r.y0 <= r.y1 && r.y1 < h - min(h, y_add) && key < w * h;
+        if (!ok) { atomicOr(bad, 1u); r.x0 = r.x1 = r.y0 = r.y1 = 0; r.key &= 0xFF000000u; }
+        else { r.key += key_add; r.y0 += y_add; r.y1 += y_add; }      // (bits 0..23; the plane has fewer than 2^24 pixels, the level byte is not reached)
         rec[i] = r;
         aux[i] = 0;
     }
@@ -1893,9 +1903,10 @@ __global__ __launch_bounds__(256) void k_strip_border_ids(const uint16_t *seam_r
     const uint32_t e = seam_row[x], nb = tile_nbase_row[x / TILE_W];
     out[x] = (e == 0xFFFFu || nb == NONE) ? NONE : nb + e;
 }
-void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t *bad)
+void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t w, uint32_t h,
+                           uint32_t *bad)
 {
-    if (n) hipLaunchKernelGGL(k_rebase_records, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, rec, aux, n, delta, key_add, y_add, bad);
+    if (n) hipLaunchKernelGGL(k_rebase_records, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, rec, aux, n, delta, key_add, y_add, w, h, bad);
 }
 void launch_connect_cut(hipStream_t s, NodeRec *plane_rec, const uint32_t *bot, const uint32_t *top, uint32_t w, uint32_t base_lo, uint32_t n_lo, uint32_t base_hi,
                         uint32_t n_hi, uint32_t *bad)

@@ -16,7 +16,9 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <mutex>
 #include <new>
@@ -137,6 +139,40 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
 }
 
 // ---- the pool ----------------------------------------------------------------------------------------------------------------
+// CPUs this process can keep busy: hardware threads, cut down to the cgroup's CPU quota where there is one (v2: cpu.max "quota period",
+// v1: cpu.cfs_quota_us / cpu.cfs_period_us)
+int flood_host_cpus()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw ? (int)hw : 2;
+    auto read2 = [](const char *path, long long &a, long long &b) -> bool {
+        std::FILE *f = std::fopen(path, "r");
+        if (!f) return false;
+        char tok[64] = {0};
+        const int got = std::fscanf(f, "%63s %lld", tok, &b);
+        std::fclose(f);
+        if (got < 1 || std::strcmp(tok, "max") == 0) return false;
+        a = std::atoll(tok);
+        return got == 2 && a > 0 && b > 0;
+    };
+    long long quota = 0, period = 0;
+    bool have = read2("/sys/fs/cgroup/cpu.max", quota, period);
+    if (!have) {
+        long long dummy = 0;
+        std::FILE *f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        if (f) { if (std::fscanf(f, "%lld", &quota) != 1) quota = 0; std::fclose(f); }
+        f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (f) { if (std::fscanf(f, "%lld", &period) != 1) period = 0; std::fclose(f); }
+        (void)dummy;
+        have = quota > 0 && period > 0;
+    }
+    if (have) {
+        const long long q = (quota + period - 1) / period;
+        if (q >= 1 && q < n) n = (int)q;
+    }
+    return n < 1 ? 1 : n;
+}
+
 namespace {
 
 struct JobSet {                        // the walks of one call
@@ -165,10 +201,13 @@ Pool *pool()
 {
     static Pool *p = [] {
         Pool *q = new Pool();          // (never destroyed: its threads outlive every context and wait on it)
-        unsigned hw = std::thread::hardware_concurrency();
-        int n = (int)(hw ? hw / 4 : 2);
+        // As many threads as the process may really run at once, at most 64: the walks of a batch are independent and latency-bound.  "May
+        // run" is not hardware_concurrency(): a container's CPU quota (cgroup cpu.max) caps the process below the core count -- the round-3
+        // boxes report 256 cores and grant 16, which is why 32 walks at once took twice as long each as 16 there (round 3 read that as
+        // memory latency and capped the pool at 16 for every host).
+        int n = flood_host_cpus();
         if (const char *e = std::getenv("STR_ER_WALK_THREADS")) n = std::atoi(e);
-        q->n_threads = n < 1 ? 1 : (n > 16 ? 16 : n);      // (measured on a 256-core box: 32 walks at once take twice as long each -- they are bound by memory latency)
+        q->n_threads = n < 1 ? 1 : (n > 64 ? 64 : n);
         for (int i = 0; i < q->n_threads - 1; ++i) {      // (the caller of flood_walks_run is the n-th worker of its own set)
             try {
                 std::thread([q] {

@@ -21,5 +21,7 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
 // every k < n; an exception inside it is caught.  Returns 0, -1 if a call ran out of memory, -2 if it failed otherwise.
 int flood_walks_run(size_t n, void (*fn)(size_t k, void *arg), void *arg);
 int flood_walk_threads();
+// hardware threads this process can keep busy: hardware_concurrency() cut down to the container's CPU quota (cgroup cpu.max) if there is one
+int flood_host_cpus();
 
 } // namespace str_er

@@ -94,6 +94,7 @@ struct str_er_ctx {
     int64_t table_bytes = 0;
     double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
     bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
+    uint64_t last_tree_records = 0, last_tree_pairs = 0, last_tree_tiles = 0;     // of the last batch (str_er_last_tree_stats)
     bool   dbg_tile_only = false, dbg_stats = false;   // developer aids (STR_ER_DEBUG_TILE_ONLY / _STATS), read once at create
     int    tile_mode = 0;             // 0 auto (from the node density of the previous batch), 1 sparse, 2 dense (STR_ER_TILE_KERNEL)
     int64_t ws_bytes = 0;
@@ -740,8 +741,12 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
             items.push_back(it);
             pos += scratch_need(i);
             hoff.push_back(hneed);
-            hneed += ((plane_px(i) + 255) / 256) * 256 + 3 * 4 * (size_t)NMS_WATCH_CAP + (dense(i) && !c->replay_on_gpu ? plane_px(i) * 4 : 0);
+            // (every term a multiple of 256: the export kernel places a plane at 256 * pad_ -- a dense stamp area of w * h * 4 bytes with
+            // w * h % 64 != 0 used to leave the NEXT plane's offset unaligned, and the device then wrote where the walk did not read)
+            hneed += ((plane_px(i) + 255) / 256) * 256 + ((3 * 4 * (size_t)NMS_WATCH_CAP + 255) / 256) * 256 +
+                     (dense(i) && !c->replay_on_gpu ? ((plane_px(i) * 4 + 255) / 256) * 256 : 0);
         }
+        for (size_t o : hoff) if (o % 256 != 0) return fail(c, STR_ER_ESTATE, "tie plane arena: unaligned plane offset");
         const size_t m = items.size();
         if (hneed > c->h_replay_bytes) {
             if (c->h_replay) { (void)hipHostFree(c->h_replay); c->h_replay = nullptr; c->h_replay_bytes = 0; }
@@ -1075,6 +1080,16 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    {   // what the tree passes of this batch worked on (str_er_last_tree_stats: bench.py prices them against the HBM roofline)
+        uint64_t recs = 0, pairs = 0, tiles = 0;
+        for (int i = 0; i < np; ++i) {
+            const PlaneDesc &pd = b.planes[i];
+            if (!(c->h_ctr[i].overflow & 8u)) recs += c->h_ctr[i].n_nodes;
+            pairs += (uint64_t)(pd.tiles_y > 0 ? pd.tiles_y - 1 : 0) * (uint64_t)pd.w + (uint64_t)(pd.tiles_x > 0 ? pd.tiles_x - 1 : 0) * (uint64_t)pd.h;
+            tiles += (uint64_t)pd.tiles_x * (uint64_t)pd.tiles_y;
+        }
+        c->last_tree_records = recs; c->last_tree_pairs = pairs; c->last_tree_tiles = tiles;
+    }
     {   // a plane ran out of node records: the counters say how many it wanted -- grow the share and do the batch again
         double need = 0;
         for (int i = 0; i < np; ++i)
@@ -1395,6 +1410,15 @@ int str_er_tie_stats(const str_er_ctx *c, uint64_t *planes_walked, double *walk_
     if (planes_walked) *planes_walked = c->n_replayed;
     if (walk_ms_total) *walk_ms_total = c->walk_ms_total;
     if (host_threads) *host_threads = flood_walk_threads();
+    return STR_ER_OK;
+}
+
+int str_er_last_tree_stats(const str_er_ctx *c, uint64_t *records, uint64_t *seam_pairs, uint64_t *tiles)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (records) *records = c->last_tree_records;
+    if (seam_pairs) *seam_pairs = c->last_tree_pairs;
+    if (tiles) *tiles = c->last_tree_tiles;
     return STR_ER_OK;
 }
 
@@ -2044,7 +2068,8 @@ int str_er_strip_merge_ex(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t 
                 NodeRec *dst = bd.na.rec + pd.node_base + base[j][(size_t)i];
                 HIP_TRY(c, hipMemcpyAsync(dst, v.d + v.L.rec[k], (size_t)p.n_nodes * sizeof(NodeRec), hipMemcpyDeviceToDevice, s));
                 // (ids, keys and rows from strip-local to plane-wide; a parent id outside the strip's records raises the flag)
-                launch_rebase_records(s, dst, bd.na.aux + pd.node_base + base[j][(size_t)i], p.n_nodes, base[j][(size_t)i], v.hd.row0 * (uint32_t)w, v.hd.row0, c->d_strip_flag);
+                launch_rebase_records(s, dst, bd.na.aux + pd.node_base + base[j][(size_t)i], p.n_nodes, base[j][(size_t)i], v.hd.row0 * (uint32_t)w, v.hd.row0, (uint32_t)w, (uint32_t)h,
+                                      c->d_strip_flag);
             }
             c->h_ctr[j] = pc;
             HIP_TRY(c, hipMemcpyAsync(c->d_ctr + j, c->h_ctr + j, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));

@@ -22,7 +22,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-from .binding import CAND_DTYPE
+from .binding import CAND_DTYPE, StrErError
 
 # (torch is imported by the functions that use torch.distributed, not here: the strips flow below runs over the C ABI's own
 # communicators, and a process that loads the system's librccl AND PyTorch's bundled ROCm runtime holds two of them)
@@ -136,9 +136,18 @@ def detect_frame_strips(erf, comm, bgr: np.ndarray, stages: int = 7) -> np.ndarr
     planes = frame_planes(w, h, prm.n_pyr_levels, prm.channel_mask)
     nch = sum(1 for p in planes if p[1] == 0)
     index = {(ch, lvl): i for i, (ch, lvl, _, _) in enumerate(planes)}
-    # 1 + 2: strips of the level-0 planes, device to device
-    dptr, nbytes = erf.strip_extract_dev(a, rank, world)
-    base, starts, sizes = comm.allgather_bytes((dptr, nbytes), device_in=True, device_out=True)
+    # 1 + 2: strips of the level-0 planes, device to device.  A rank whose extract fails (a thresh_step without a sentinel level is
+    # rejected only where a strip has rows above it, i.e. on ranks > 0; out of memory; ...) STILL joins the all-gather, with a length
+    # of -1: the C ABI announces that in its header round, every rank gets an error and none is left waiting in the collective.
+    local_err = None
+    try:
+        dptr, nbytes = erf.strip_extract_dev(a, rank, world)
+    except StrErError as e:
+        local_err, dptr, nbytes = e, 0, -1
+    try:
+        base, starts, sizes = comm.allgather_bytes((dptr, nbytes), device_in=True, device_out=True)
+    except StrErError as e:
+        raise (local_err or e) from (e if local_err else None)
     # 3: owners.  Level-0 planes round robin; the rest by LPT on top of the merge load (a merge is about 0.4 of a plane's work)
     own0 = [k for k in range(nch) if k % world == rank]
     load = [0.0] * world
@@ -152,25 +161,32 @@ def detect_frame_strips(erf, comm, bgr: np.ndarray, stages: int = 7) -> np.ndarr
         if r == rank:
             mine_rest.append(i)
     parts = []
-    if own0:
-        sel = np.zeros(nch, np.uint8)
-        sel[own0] = 1
-        res = erf.strip_merge_ex(a, [base + s for s in starts], sizes, device_blobs=True, plane_select=sel, stages=stages)
-        c = res.cands.copy()
-        if len(c):
-            c["node"] = np.array([index[(int(x["ch"]), 0)] for x in c], np.int32)
-        parts.append(c)
-    if mine_rest:
-        sel = np.zeros(len(planes), np.uint8)
-        sel[mine_rest] = 1
-        res = erf.text_detect_planes(a, sel, stages)
-        c = res.cands.copy()
-        if len(c):
-            c["node"] = np.array([index[(int(x["ch"]), int(x["pyr"]))] for x in c], np.int32)
-        parts.append(c)
+    try:
+        if own0:
+            sel = np.zeros(nch, np.uint8)
+            sel[own0] = 1
+            res = erf.strip_merge_ex(a, [base + s for s in starts], sizes, device_blobs=True, plane_select=sel, stages=stages)
+            c = res.cands.copy()
+            if len(c):
+                c["node"] = np.array([index[(int(x["ch"]), 0)] for x in c], np.int32)
+            parts.append(c)
+        if mine_rest:
+            sel = np.zeros(len(planes), np.uint8)
+            sel[mine_rest] = 1
+            res = erf.text_detect_planes(a, sel, stages)
+            c = res.cands.copy()
+            if len(c):
+                c["node"] = np.array([index[(int(x["ch"]), int(x["pyr"]))] for x in c], np.int32)
+            parts.append(c)
+    except StrErError as e:
+        local_err = e
     mine = np.concatenate(parts) if parts else np.zeros(0, CAND_DTYPE)
-    # 4: the candidate gather (the one exchange of the reference's data flow, src/ER.cpp:63)
-    allc, _ = comm.gather(mine)
+    # 4: the candidate gather (the one exchange of the reference's data flow, src/ER.cpp:63); a rank whose merge failed joins it
+    # as "cannot take part" for the same reason as above
+    try:
+        allc, _ = comm.gather(mine, failed=local_err is not None)
+    except StrErError as e:
+        raise (local_err or e) from (e if local_err else None)
     out = allc[np.lexsort((allc["key"], allc["node"]))]
     out["node"] = -1
     return out

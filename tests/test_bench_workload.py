@@ -140,7 +140,7 @@ def test_soak_random_planes(S, oracle, monkeypatch, mode):
     # (STR_ER_SOAK_SECONDS / STR_ER_SOAK_SEED: a longer or different soak by hand)
     rng = np.random.default_rng((11 if mode == "sparse" else 12) + int(os.environ.get("STR_ER_SOAK_SEED", "0")))
     budget, t0, n = float(os.environ.get("STR_ER_SOAK_SECONDS", "25")), time.time(), 0
-    filters = {}
+    filters, seen_t = {}, set()
     try:
         while time.time() - t0 < budget:
             step = int(rng.choice([1, 2, 4, 8, 8, 8, 16]))
@@ -167,15 +167,22 @@ def test_soak_random_planes(S, oracle, monkeypatch, mode):
             else:
                 img = S.synth.gray(S.synth.stext_bgr(int(rng.integers(0, 1 << 30)), w, h)) if w >= 8 and h >= 8 else \
                     rng.integers(0, 256, (h, w), dtype=np.uint8)
-            if step not in filters:
-                filters[step] = S.ERFilter(params=S.Params(thresh_step=step, min_area=int(rng.choice([1, 20, 120])), max_width=400,
-                                                           max_height=300, max_frames=1, kept_cap=130000, pool_cap=40000))
-            f = filters[step]
+            # the NMS parameters too (stability_t had only been run at 2 and 3, overlap_coef at 0.3 / 0.6 / 0.7): a pool of contexts per
+            # thresh step, each with its own MIN_AREA, MAX_AREA, STABILITY_T in {0, 1, 2, 3, 5} and OVERLAP_COEF in [0.2, 0.9]
+            # (inc/ER.h:113, src/ER.cpp:416-505; str_er_create accepts stability_t 0 .. 255)
+            key = (step, int(rng.integers(0, 3)))
+            if key not in filters:
+                filters[key] = S.ERFilter(params=S.Params(thresh_step=step, min_area=int(rng.choice([1, 20, 120])), max_area=int(rng.choice([300, 5000, 900000])),
+                                                          stability_t=int(rng.choice([0, 1, 2, 3, 5])), overlap_coef=float(np.round(rng.uniform(0.2, 0.9), 3)),
+                                                          max_width=400, max_height=300, max_frames=1, kept_cap=130000, pool_cap=130000))
+                seen_t.add(filters[key].params.stability_t)
+            f = filters[key]
             p = f.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS, want_nodes=True).planes[0]
-            check_plane_against_oracle(oracle, p, img, None, step=step, min_area=f.params.min_area)
+            check_plane_against_oracle(oracle, p, img, None, step=step, min_area=f.params.min_area, max_area=f.params.max_area,
+                                       stability_t=f.params.stability_t, overlap_coef=f.params.overlap_coef)
             n += 1
     finally:
         for f in filters.values():
             f.close()
-    print(f"soak[{mode}]: {n} planes in {time.time() - t0:.1f} s, all equal to the oracle")
-    assert n > 200
+    print(f"soak[{mode}]: {n} planes in {time.time() - t0:.1f} s on {len(filters)} parameter sets (stability_t {sorted(seen_t)}), all equal to the oracle")
+    assert n > 200 and len(seen_t) >= 3

@@ -71,6 +71,36 @@ def test_config5_whole_frame_against_the_oracle_and_in_strips(S, cascade_paths, 
             assert out[r][FIELDS].tolist() == fused.cands[FIELDS].tolist(), (world, r)
 
 
+def test_a_rank_that_cannot_extract_takes_every_rank_out_of_the_collective(S, cascade_paths):
+    """thresh_step 3 has no sentinel level: str_er_strip_extract_dev rejects it only where a strip has rows above it, i.e. on ranks > 0,
+    while rank 0 extracts fine and enters the all-gather (it then waited forever).  The failing ranks now join the exchange as
+    "cannot take part", so EVERY rank raises -- within seconds -- and the failing rank reports its own error."""
+    W, H = 640, 360
+    frame = S.synth.stext_bgr(S.synth.frame_seed(3), W, H)
+    for world in (2, 3):
+        comms = S.Comm.local_group(world)
+        errs, done = [None] * world, [False] * world
+
+        def rank_main(r):
+            f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, thresh_step=3, channel_mask=0x07))
+            f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+            try:
+                S.dist.detect_frame_strips(f, comms[r], frame)
+            except S.StrErError as e:
+                errs[r] = e
+            done[r] = True
+            f.close()
+
+        th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        assert all(done), "a rank is still waiting in the collective"
+        assert all(e is not None for e in errs), errs
+        assert "thresh_step" in str(errs[1])            # the rank that failed says why
+
+
 def test_strips_in_a_pyramid_context_and_bad_blobs(S, cascade_paths, oracle, oracle_cascades):
     """Strips are cut from the level-0 planes of a pyramid context too; device blobs and host blobs are the same bytes; a merge with
     plane_select gives that channel's records; blobs that were damaged on the way are refused, not followed."""

@@ -423,6 +423,33 @@ def test_default_tables_grow_with_the_content(S, oracle):
     f.close()
 
 
+def test_stability_t_zero_overflows_the_default_pool_share(S, oracle):
+    """STABILITY_T = 0 (accepted by str_er_create, 0 .. 255; ctor inc/ER.h:113): every chain of the NMS scores itself against itself, so nearly every kept
+    node that passes the size filter is pooled (src/ER.cpp:464-497) -- far more than a plane's default share of pool entries (pixels / 256 + 256).
+    The tables must grow and the batch repeat (this was the case that overflowed); node table and pool equal the oracle's."""
+    f = S.ERFilter(8, 1, 900000, 0, 0.7, max_width=400, max_height=300, max_frames=1)
+    ws0 = f.workspace_bytes()
+    rng = np.random.default_rng(17)
+    base = np.add.outer(np.arange(300), np.arange(400)) * 0.4
+    imgs = [rng.integers(0, 256, (300, 400), dtype=np.uint8), np.clip(base + rng.integers(-6, 7, (300, 400)), 0, 255).astype(np.uint8)]
+    pooled = []
+    for _ in range(2):          # (the second round runs on the grown tables)
+        for img in imgs:
+            p = f.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS, want_nodes=True).planes[0]
+            check_plane_against_oracle(oracle, p, img, None, min_area=1, stability_t=0)
+            pooled.append(p.n_pool)
+    assert max(pooled) > 400 * 300 // 256 + 256, pooled
+    assert f.workspace_bytes() > ws0
+    f.close()
+    # ... and the other corner values of the parameter on one plane each
+    img = S.synth.gray(S.synth.stext_bgr(21, 400, 300))
+    for st, ov, mx in ((1, 0.2, 900000), (5, 0.9, 2000), (255, 0.5, 900000), (0, 0.95, 150)):
+        g = S.ERFilter(8, 20, mx, st, ov, max_width=400, max_height=300, max_frames=1)
+        p = g.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS, want_nodes=True).planes[0]
+        check_plane_against_oracle(oracle, p, img, None, min_area=20, max_area=mx, stability_t=st, overlap_coef=ov)
+        g.close()
+
+
 def test_nv12_ingest(S, cascade_paths, oracle, oracle_cascades):
     """str_er_detect_nv12: the three planes are the oracle's ero_nv12_to_ycrcb of the same bytes, everything after
     them is the path of the BGR entry point -- all planes of a 2-level context against the oracle, two frames, a ragged width."""

@@ -69,3 +69,59 @@ def test_config4_dataflow_eight_ranks_in_one_process(S, cascade_paths):
         assert got[FIELDS].tolist() == whole[FIELDS].tolist()
     for c in comms:
         c.close()
+
+
+def test_config4_at_its_size_eight_contexts_and_the_oracle(S, cascade_paths, oracle, oracle_cascades):
+    """BASELINE configs[3] at its stated size (missing #2): a batch of 64 frames of 1920x1080, 8 per rank, through 8 contexts
+    (one per rank, all on this box's one device) and the candidate gather of the C ABI (in-process group of 8).  Every rank must end up
+    with the records ONE 64-frame call gives, and a sample of the batch -- frames 0, 31 and 63, all six planes of each -- is compared with
+    the oracle node table for node table, pool, classes and scores (the reference's loop over the planes: src/ER.cpp:50-60)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from conftest import check_plane_against_oracle
+
+    W, H, WORLD, PER = 1920, 1080, 8, 8
+    N = WORLD * PER
+    with ThreadPoolExecutor(8) as ex:
+        frames = np.stack(list(ex.map(lambda i: S.synth.stext_bgr(S.synth.frame_seed(i), W, H), range(N))))
+    one = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=N))
+    one.load_cascade(0, cascade_paths[0]); one.load_cascade(1, cascade_paths[1])
+    whole_res = one.text_detect(frames, want_nodes=True)
+    whole = whole_res.cands
+    assert len(whole_res.planes) == N * 6
+    # the oracle on a sample of the batch
+    sample = [p for p in whole_res.planes if p.frame in (0, 31, 63)]
+    assert len(sample) == 18
+    six = {fr: oracle.compute_channels(frames[fr]) for fr in (0, 31, 63)}
+
+    def one_plane(p):
+        check_plane_against_oracle(oracle, p, six[p.frame][p.ch], oracle_cascades)
+        return p.n_pool
+    with ThreadPoolExecutor(8) as ex:
+        assert sum(ex.map(one_plane, sample)) > 0
+    one.close()
+    comms = S.Comm.local_group(WORLD)
+    out, errs = [None] * WORLD, []
+
+    def rank_main(r):
+        try:
+            first, n = S.dist.shard_frames(N, r, WORLD)
+            f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=PER))
+            f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+            mine = f.text_detect(frames[first:first + n]).cands
+            out[r] = comms[r].gather(mine, frame_offset=first)
+            f.close()
+        except Exception as e:                                       # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    for r in range(WORLD):
+        got, counts = out[r]
+        assert int(counts.sum()) == len(whole) and len(counts) == WORLD and (counts > 0).all()
+        assert got[FIELDS].tolist() == whole[FIELDS].tolist()
+    for c in comms:
+        c.close()
