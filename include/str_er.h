@@ -195,6 +195,7 @@ int  str_er_abi_version(void);
  * walked on a host core, the host time those walks took in all (ms, summed over planes), and how many host threads the
  * library's process-wide pool for them has at most (the CPUs the process may use -- hardware threads cut down to a container's cgroup CPU quota --, at least 1,
  * at most 64; STR_ER_WALK_THREADS overrides).  Any pointer may be NULL. */
+/* (The pool's threads are detached and live as long as the process: do not dlclose() the library once a tie has been walked.) */
 int  str_er_tie_stats(const str_er_ctx *ctx, uint64_t *planes_walked, double *walk_ms_total, int32_t *host_threads);
 /* What the component-tree passes of this context's last detect call worked on: node records the tile kernel exported (32 bytes each; what
  * k_group_merge / k_resolve / k_reduce read and write), pixel pairs across tile borders (k_seam: two 16-bit seam entries each) and tiles.

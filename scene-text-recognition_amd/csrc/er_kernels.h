@@ -60,6 +60,7 @@ void launch_resolve(hipStream_t s, const BatchDev &b);
 // strips of a plane extracted elsewhere: make a strip's record ids plane-wide; join pixel pairs (plane-local ids) across a cut
 void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t n, uint32_t delta, uint32_t key_add, uint32_t y_add, uint32_t w, uint32_t h,
                            uint32_t *bad);
+void launch_check_forest(hipStream_t s, NodeRec *plane_rec, uint32_t n, uint32_t *bad);
 void launch_connect_cut(hipStream_t s, NodeRec *plane_rec, const uint32_t *bot, const uint32_t *top, uint32_t w, uint32_t base_lo, uint32_t n_lo, uint32_t base_hi,
                         uint32_t n_hi, uint32_t *bad);
 void launch_strip_border_ids(hipStream_t s, const uint16_t *seam_row, const uint32_t *tile_nbase_row, int w, uint32_t *out);

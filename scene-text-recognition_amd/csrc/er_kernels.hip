@@ -564,13 +564,155 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 // and inner vertical edges of its own 8-row band by itself (wave-wide scans, no workgroup barriers, nobody else on its words), the three row
 // pairs between bands in a workgroup-wide round afterwards: 3.22 / 8.4 against 2.99 / 8.07 -- the bands' edge counts differ; round 1's attempts -- fewer waves in the loop, two edges
 // per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
+// LDS byte address of an object in shared memory (what a ds_* instruction takes)
+template <class T>
+__device__ __forceinline__ uint32_t lds_addr(const T *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) T *)p;
+}
+
 __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_t *s_lev, const uint16_t *s_elist, uint32_t n_edges_)
 {
     constexpr uint32_t NW = TILE_THREADS / 64;
     const uint32_t n_edges = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_edges_);
-    uint32_t       a = 0, b = 0, la = 0, lb = 0;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t w0 = (wv * n_edges) / NW, m = ((wv + 1u) * n_edges) / NW - w0;     // the wave's share: entries [w0, w0 + m)
+#ifndef STR_ER_CONNECT_CXX
+    // ---- the loop below, written by hand (round 4).  The kernel runs at the knee of vector issue (a SIMD's 8 waves keep its vector unit ~85 % busy:
+    // tools/issue_caps.hip -- plain 32-bit vector instructions issue at 0.22-0.24 per cycle and SIMD, only v_mov / add / sub / and / or / xor / lshrrev at
+    // 0.37-0.41) and of the scalar unit, and the compiler's loop spent 49 vector + ~45 scalar instructions per iteration: lane masks kept as 0 / 1 in
+    // vector registers and compared back, exec saved / restored / branched around every `if`.  Here: the two ends of an edge are KEYS,
+    // (level << 16) | slot -- the very word a parent pointer holds --, one compare of the keys with their slot halves flipped orders them, the CAS
+    // writes the other key as it is, level tests are 16-bit sub-word compares (SDWA), the lanes' states are masks in scalar registers, and exec is
+    // simply set: 19 vector instructions per pass + 14 for a hand-out.
+    // Needs s_par at LDS address 0 (a key's low half << 2 is then the address); checked here, folded away by the compiler.
+    static_assert(TILE_SLOTS <= 4096 && TILE_WS == 66, "edge entry: 12-bit slot, codes for + 1 / + 2 / + 66");
+    if (lds_addr(s_par) != 0u) __builtin_trap();
+    {
+        uint32_t ka, kb, wa, wb, aa, ab, t0, t1, t2;
+        unsigned long long busy, m1, m2, m3, m4, sx;
+        uint32_t cur, tmp;
+        asm volatile(
+            "s_mov_b64 %[sx], exec\n"
+            "s_mov_b64 %[busy], 0\n"
+            "s_mov_b32 %[cur], 0\n"
+            "LOOP_%=:\n"
+            // ---- hand the next entries of the wave's share to its idle lanes (list order, ballot + mbcnt)
+            "s_cmp_ge_u32 %[cur], %[m]\n"
+            "s_cbranch_scc1 NOHAND_%=\n"
+            "s_not_b64 vcc, %[busy]\n"                     // idle lanes (SCC: any)
+            "s_cbranch_scc0 NOHAND_%=\n"
+            "v_mbcnt_lo_u32_b32 %[t0], vcc_lo, 0\n"
+            "v_mbcnt_hi_u32_b32 %[t0], vcc_hi, %[t0]\n"
+            "v_add_u32 %[t0], %[cur], %[t0]\n"
+            "v_cmp_gt_u32_e64 %[m1], %[m], %[t0]\n"
+            "s_and_b64 %[m1], %[m1], vcc\n"                 // the lanes that take an entry
+            "s_bcnt1_i32_b64 %[tmp], vcc\n"
+            "s_add_u32 %[cur], %[cur], %[tmp]\n"
+            "s_or_b64 %[busy], %[busy], %[m1]\n"
+            "s_mov_b64 exec, %[m1]\n"
+            "v_lshl_add_u32 %[t1], %[t0], 1, %[elist]\n"
+            "ds_read_u16 %[t2], %[t1]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            // entry: slot of the edge's first pixel | code << 12; second pixel = first + 1 (code 0), + 2 (1: across the unused word), + 66 (2: below)
+            "v_and_b32 %[aa], 0xfff, %[t2]\n"
+            "v_lshrrev_b32 %[t0], 12, %[t2]\n"
+            "v_lshrrev_b32 %[t1], 1, %[t0]\n"
+            "v_mad_u32_u24 %[t0], %[t1], 63, %[t0]\n"
+            "v_add3_u32 %[ab], %[aa], %[t0], 1\n"
+            "v_lshl_add_u32 %[t0], %[aa], 1, %[lev]\n"
+            "v_lshl_add_u32 %[t1], %[ab], 1, %[lev]\n"
+            "ds_read_u16 %[t0], %[t0]\n"
+            "ds_read_u16 %[t1], %[t1]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_lshl_or_b32 %[ka], %[t0], 16, %[aa]\n"
+            "v_lshl_or_b32 %[kb], %[t1], 16, %[ab]\n"
+            "NOHAND_%=:\n"
+            "s_cmp_eq_u64 %[busy], 0\n"
+            "s_cbranch_scc1 DONE_%=\n"
+            "s_mov_b64 exec, %[busy]\n"
+            // ---- one pass: the level roots of both ends ...
+            "v_lshlrev_b32_sdwa %[aa], %[two], %[ka] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "v_lshlrev_b32_sdwa %[ab], %[two], %[kb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "ds_read_b32 %[wa], %[aa]\n"
+            "ds_read_b32 %[wb], %[ab]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_cmp_eq_u32_sdwa %[m1], %[wa], %[ka] src0_sel:WORD_1 src1_sel:WORD_1\n"      // same level: not the root yet (NONE reads as level 0xFFFF)
+            "v_cmp_eq_u32_sdwa %[m2], %[wb], %[kb] src0_sel:WORD_1 src1_sel:WORD_1\n"
+            "s_or_b64 %[m3], %[m1], %[m2]\n"
+            "s_cbranch_scc0 ROOTS_%=\n"
+            // (walks with path halving: a pixel is re-pointed at its grandparent while the grandparent is of the same level; only non-roots are
+            // rewritten, and only with a pixel of the same node, so a race with the CAS below -- which targets roots -- is benign)
+            "s_mov_b64 exec, %[m1]\n"
+            "s_cbranch_execz HOPB_%=\n"
+            "HOPA_%=:\n"
+            "v_lshlrev_b32_sdwa %[t0], %[two], %[wa] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "ds_read_b32 %[t1], %[t0]\n"
+            "v_mov_b32 %[ka], %[wa]\n"
+            "v_mov_b32 %[t2], %[aa]\n"
+            "v_mov_b32 %[aa], %[t0]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_mov_b32 %[wa], %[t1]\n"
+            "v_cmp_eq_u32_sdwa vcc, %[t1], %[ka] src0_sel:WORD_1 src1_sel:WORD_1\n"
+            "s_and_b64 exec, exec, vcc\n"
+            "ds_write_b32 %[t2], %[t1]\n"
+            "s_cbranch_execnz HOPA_%=\n"
+            "HOPB_%=:\n"
+            "s_mov_b64 exec, %[m2]\n"
+            "s_cbranch_execz HOPX_%=\n"
+            "HOPBL_%=:\n"
+            "v_lshlrev_b32_sdwa %[t0], %[two], %[wb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+            "ds_read_b32 %[t1], %[t0]\n"
+            "v_mov_b32 %[kb], %[wb]\n"
+            "v_mov_b32 %[t2], %[ab]\n"
+            "v_mov_b32 %[ab], %[t0]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_mov_b32 %[wb], %[t1]\n"
+            "v_cmp_eq_u32_sdwa vcc, %[t1], %[kb] src0_sel:WORD_1 src1_sel:WORD_1\n"
+            "s_and_b64 exec, exec, vcc\n"
+            "ds_write_b32 %[t2], %[t1]\n"
+            "s_cbranch_execnz HOPBL_%=\n"
+            "HOPX_%=:\n"
+            "s_mov_b64 exec, %[busy]\n"
+            "ROOTS_%=:\n"
+            // ... then the lower root (lower level; same level: larger slot -- the smallest pixel stays the node's root) goes under the other one, or climbs
+            // (gfx940 family: a vector instruction that reads an SGPR / VCC written by a vector compare needs two instructions in between)
+            "v_xor_b32 %[t0], 0xffff, %[ka]\n"
+            "v_xor_b32 %[t1], 0xffff, %[kb]\n"
+            "v_cmp_gt_u32 vcc, %[t0], %[t1]\n"              // a is the higher one: swap
+            "v_cmp_ne_u32_e64 %[m1], %[ka], %[kb]\n"        // not yet one node
+            "s_nop 0\n"
+            "v_cndmask_b32 %[t2], %[ka], %[kb], vcc\n"      // lo
+            "v_cndmask_b32 %[kb], %[kb], %[ka], vcc\n"      // hi
+            "v_xor_b32 %[t1], %[t2], %[kb]\n"
+            "v_cndmask_b32 %[t0], %[wa], %[wb], vcc\n"      // parent word of lo
+            "v_cmp_gt_u32_e64 %[m2], %[c64k], %[t1]\n"      // equal levels: the same node
+            "v_cndmask_b32 %[aa], %[aa], %[ab], vcc\n"      // address of lo
+            "v_or_b32 %[t1], 0xffff, %[kb]\n"
+            "v_cmp_gt_u32_e64 %[m3], %[t0], %[t1]\n"        // lo's parent is above hi (or there is none): hi slots in between
+            "s_or_b64 %[m2], %[m2], %[m3]\n"
+            "s_and_b64 %[m2], %[m2], %[m1]\n"               // link
+            "s_mov_b64 exec, %[m2]\n"
+            "ds_cmpst_rtn_b32 %[t1], %[aa], %[t0], %[kb]\n"
+            "v_cmp_eq_u32_e64 %[m4], -1, %[t0]\n"           // lo had no parent: the edge is done once linked
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_cmp_eq_u32_e64 %[m3], %[t1], %[t0]\n"        // linked
+            "s_mov_b64 exec, %[busy]\n"
+            "s_and_b64 %[m4], %[m4], %[m3]\n"               // (m3, m4 were written under exec = link lanes: zero elsewhere)
+            "s_orn2_b64 vcc, %[m3], %[m2]\n"                // linked, or climbing: carry on with lo's (former) parent; a lost CAS repeats the pair
+            "s_and_b64 vcc, vcc, %[m1]\n"
+            "v_cndmask_b32 %[ka], %[t2], %[t0], vcc\n"
+            "s_andn2_b64 %[busy], %[m1], %[m4]\n"
+            "s_branch LOOP_%=\n"
+            "DONE_%=:\n"
+            "s_mov_b64 exec, %[sx]\n"
+            : [ka] "=&v"(ka), [kb] "=&v"(kb), [wa] "=&v"(wa), [wb] "=&v"(wb), [aa] "=&v"(aa), [ab] "=&v"(ab), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+              [busy] "=&s"(busy), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [sx] "=&s"(sx), [cur] "=&s"(cur), [tmp] "=&s"(tmp)
+            : [m] "s"(m), [elist] "s"(lds_addr(s_elist) + 2u * w0), [lev] "s"(lds_addr(s_lev)), [two] "v"(2u), [c64k] "s"(0x10000u)
+            : "vcc", "scc", "memory");
+    }
+#else
+    uint32_t       a = 0, b = 0, la = 0, lb = 0;
     uint32_t       cur = 0;                                                           // wave-uniform cursor
     // which lanes have an edge in hand: a wave-uniform 64-bit mask kept in scalar registers (a per-lane flag costs a vector compare wherever
     // the wave needs to know "is anybody idle / busy")
@@ -581,11 +723,9 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
             const uint32_t c = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const bool     tk = __builtin_amdgcn_inverse_ballot_w64(idle) && c < m;
             if (tk) {
-                const uint32_t e = s_elist[w0 + c];
-                const uint32_t p = e & 0x3FFFu;
-                const bool     vert = (e & 0x8000u) != 0;
-                a = vert ? p : p - 1u - ((e >> 14) & 1u);
-                b = vert ? p + (uint32_t)TILE_WS : p;
+                const uint32_t e = s_elist[w0 + c], t = e >> 12;
+                a = e & 0xFFFu;
+                b = a + 1u + t + 63u * (t >> 1);
                 la = s_lev[LX(a)]; lb = s_lev[LX(b)];
                 CNT(0, 1);
             }
@@ -597,6 +737,7 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
         if (__builtin_amdgcn_inverse_ballot_w64(busy)) more = connect_pass(s_par, a, b, la, lb);
         busy = __builtin_amdgcn_ballot_w64(more);
     }
+#endif
 }
 
 // Orders a wave's own LDS accesses around a point (no instruction: the hardware keeps a wave's LDS operations in order; this keeps the compiler from
@@ -718,13 +859,27 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     constexpr int ELIST_CAP = TILE_H * (TILE_W - 1) + (TILE_H - 1) * (TILE_W / 2);
     constexpr int ROWLV_AT = (ELIST_CAP + 1) / 2;                 // word offset in s_work
     static_assert(ROWLV_AT + 3 * 8 * (TILE_THREADS / 64) <= WORK_WORDS, "edge list + first-row levels must fit s_work");
-    __shared__ uint32_t s_par[TILE_SLOTS];
-    __shared__ __attribute__((aligned(8))) uint32_t s_work[WORK_WORDS];    // edge worklist + lane masks, later the per-node statistics
-    __shared__ uint16_t s_lev[TILE_SLOTS];   // levels; once the connects are done the same array
-    uint16_t *const     s_nid = s_lev;       // holds the dense node id of every level-root pixel
-    __shared__ uint32_t s_wsum[TILE_THREADS / 64];
-    __shared__ uint32_t s_walls, s_start, s_nbase;
-    __shared__ uint32_t s_present[8];        // which levels have a node in this tile (big kernel)
+    // (ONE object in shared memory, the parent words first: the connect loop takes "slot << 2" as the LDS address of a parent word, so s_par must lie at
+    // LDS address 0 -- which a kernel's only shared object does; tile_connect_list checks it)
+    struct TileLds {
+        uint32_t par[TILE_SLOTS];
+        uint32_t work[WORK_WORDS] __attribute__((aligned(8)));     // edge worklist + lane masks, later the per-node statistics
+        uint16_t lev[TILE_SLOTS];      // levels; once the connects are done the same array holds the dense node id of every level-root pixel
+        uint32_t wsum[TILE_THREADS / 64];
+        uint32_t walls, start, nbase;
+        uint32_t present[8];           // which levels have a node in this tile (big kernel)
+#ifdef STR_ER_PAD_LDS
+        uint32_t pad[STR_ER_PAD_LDS / 4];     // developer aid: extra LDS per workgroup, to see what fewer resident workgroups per CU cost
+#endif
+    };
+    __shared__ TileLds s_lds;
+    uint32_t (&s_par)[TILE_SLOTS] = s_lds.par;
+    uint32_t (&s_work)[WORK_WORDS] = s_lds.work;
+    uint16_t (&s_lev)[TILE_SLOTS] = s_lds.lev;
+    uint16_t *const     s_nid = s_lev;
+    uint32_t (&s_wsum)[TILE_THREADS / 64] = s_lds.wsum;
+    uint32_t &s_walls = s_lds.walls, &s_start = s_lds.start, &s_nbase = s_lds.nbase;
+    uint32_t (&s_present)[8] = s_lds.present;
     // Small kernel: the fold (closed nodes add their totals to their parents, bottom-up over the levels) is done by ONE wave over a list of the
     // tile's level roots sorted by level -- see "fold" below.  The list is made by counting: s_hist[l] = roots at level l (counted where the
     // roots are found), turned into start offsets between the two barriers of the id scan, used as cursors where the ids are handed out.
@@ -737,9 +892,7 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
 
     const int       tid = threadIdx.x;
 #ifdef STR_ER_PAD_LDS
-    // developer aid: extra LDS per workgroup, to see what fewer resident workgroups per CU cost
-    __shared__ uint32_t s_pad[STR_ER_PAD_LDS / 4];
-    if (b.n_tiles == 0xFFFFFFFFu) s_pad[tid] = tid;
+    if (b.n_tiles == 0xFFFFFFFFu) s_lds.pad[tid] = tid;
 #endif
     const int       pi = b.tile_plane[blockIdx.x];
     const PlaneDesc pd = b.planes[pi];
@@ -950,7 +1103,10 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             const int k = __ffs((int)em) - 1;
             em &= em - 1u;
             // (bit 14: the left neighbour lies across the unused word, a lane's first pixel at a multiple of 32)
-            s_elist[off++] = (uint16_t)(k < 8 ? (p0 + k) | ((k == 0 && (tid & 3) == 0) ? 0x4000u : 0u) : (p0 + k - 8) | 0x8000u);
+            // entry = slot of the edge's FIRST pixel (left / upper) | code << 12: the second one is 1 (code 0), 2 (1: the left neighbour lies across
+            // the unused word, a lane's first pixel at a multiple of 32) or TILE_WS = 66 (2: the pixel below) slots further on
+            const uint32_t cross = (k == 0 && (tid & 3) == 0) ? 1u : 0u;
+            s_elist[off++] = (uint16_t)(k < 8 ? (p0 + k - 1u - cross) | (cross << 12) : (p0 + k - 8) | 0x2000u);
         }
         __syncthreads();
         tile_connect_list(s_par, s_lev, s_elist, n_edges);
@@ -1879,6 +2035,30 @@ __global__ __launch_bounds__(256) void k_rebase_records(NodeRec *rec, uint32_t *
         aux[i] = 0;
     }
 }
+// The forest the strips' records form is checked before anything walks it (the records came from another process): a parent word must name a record
+// of a level not below the node's own, carry that record's level, and the parent chains must END -- a cycle would keep every find, resolve and
+// accumulate loop downstream spinning for ever (found by tools/san_fuzz.py: a damaged blob hung the merge).  Brent's cycle detection per record,
+// O(chain length); an offending record is cut loose (parent NONE) and the flag raised: the merge then fails with EFORMAT and nothing hangs.
+__global__ __launch_bounds__(256) void k_check_forest(NodeRec *rec, uint32_t n, uint32_t *bad)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t w = LD_AGENT(&rec[i].par);
+        if (w == NONE) continue;
+        bool ok = PAR_ID(w) < n && PAR_LVL(w) == (rec[PAR_ID(w)].key >> 24) && PAR_LVL(w) >= (rec[i].key >> 24);
+        if (ok) {
+            uint32_t tortoise = i, hare = PAR_ID(w), power = 1, lam = 1;
+            for (;;) {
+                if (hare == tortoise) { ok = false; break; }
+                const uint32_t wh = LD_AGENT(&rec[hare].par);
+                if (wh == NONE || PAR_ID(wh) >= n) break;
+                if (power == lam) { tortoise = hare; power *= 2; lam = 0; }
+                hare = PAR_ID(wh);
+                ++lam;
+            }
+        }
+        if (!ok) { ST_AGENT(&rec[i].par, NONE); atomicOr(bad, 1u); }
+    }
+}
 // ... and the pixel pairs across the cut between two strips are joined like any other seam: bot[x] / top[x] = strip-local node of pixel x of
 // the last row above / the first row below the cut (NONE: a wall).  Neighbouring lanes very often carry the same pair (a flat region
 // along the cut): only the first lane of such a run connects.
@@ -1907,6 +2087,10 @@ void launch_rebase_records(hipStream_t s, NodeRec *rec, uint32_t *aux, uint32_t 
                            uint32_t *bad)
 {
     if (n) hipLaunchKernelGGL(k_rebase_records, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, rec, aux, n, delta, key_add, y_add, w, h, bad);
+}
+void launch_check_forest(hipStream_t s, NodeRec *plane_rec, uint32_t n, uint32_t *bad)
+{
+    if (n) hipLaunchKernelGGL(k_check_forest, dim3((n + 255) / 256 < 4096u ? (n + 255) / 256 : 4096u), dim3(256), 0, s, plane_rec, n, bad);
 }
 void launch_connect_cut(hipStream_t s, NodeRec *plane_rec, const uint32_t *bot, const uint32_t *top, uint32_t w, uint32_t base_lo, uint32_t n_lo, uint32_t base_hi,
                         uint32_t n_hi, uint32_t *bad)

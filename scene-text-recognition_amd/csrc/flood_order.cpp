@@ -40,8 +40,14 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
     for (int v = 0; v < 256; ++v) lut[v] = (uint16_t)std::lrintf((float)v * qscale);
     // (the two per-pixel arrays are kept per thread: a fresh 12 MB allocation per walk is ~3000 page faults and a memset -- a third of a
     // walk that stops early; both are written before they are read)
+    // Kept for the planes a video stream brings again and again, up to 1920 x 1080 x 2 pixels; the scratch of a larger plane (one 4K plane: 50 MB)
+    // is handed back when its walk ends, so that up to 64 pool threads and every caller thread do not hold it for the life of the process.
     thread_local std::vector<uint16_t> st_buf;
     thread_local std::vector<uint32_t> link_buf;
+    struct Shrink {
+        std::vector<uint16_t> &a; std::vector<uint32_t> &b;
+        ~Shrink() { if (a.size() > ((size_t)1 << 22)) { std::vector<uint16_t>().swap(a); std::vector<uint32_t>().swap(b); } }
+    } shrink{st_buf, link_buf};
     if (st_buf.size() < n) st_buf.resize(n);
     if (link_buf.size() < n) link_buf.resize(n);
     uint16_t *const st = st_buf.data();

@@ -148,16 +148,25 @@ int ensure(str_er_comm *c, uint8_t *&p, size_t &cap, size_t need)
 
 extern "C" {
 
-int str_er_comm_unique_id(void *id128)
+// (nothing is thrown across the C ABI)
+#define COMM_GUARD(cm)                                                                                    \
+    catch (const std::bad_alloc &) { return cfail_noexcept((cm), STR_ER_ENOMEM, "out of host memory"); }  \
+    catch (...) { return cfail_noexcept((cm), STR_ER_EHIP, "internal error (exception)"); }
+static int cfail_noexcept(str_er_comm *c, int code, const char *msg)
 {
+    try { return cfail(c, code, msg); } catch (...) { return code; }
+}
+
+int str_er_comm_unique_id(void *id128)
+try {
     if (!id128) return STR_ER_EINVAL;
     Rccl *r = rccl();
     if (!r) return STR_ER_ESTATE;
     return r->GetUniqueId(id128) == 0 ? STR_ER_OK : STR_ER_EHIP;
-}
+} COMM_GUARD(nullptr)
 
 int str_er_comm_create(int32_t device, int32_t rank, int32_t world, const void *id128, str_er_comm **out)
-{
+try {
     if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return STR_ER_EINVAL;
     *out = nullptr;
     Rccl *r = rccl();
@@ -183,10 +192,10 @@ int str_er_comm_create(int32_t device, int32_t rank, int32_t world, const void *
     }
     *out = c;
     return STR_ER_OK;
-}
+} COMM_GUARD(nullptr)
 
 int str_er_comm_local_group(int32_t world, str_er_comm_group **out)
-{
+try {
     if (!out || world < 1 || world > 1024) return STR_ER_EINVAL;
     str_er_comm_group *g = new (std::nothrow) str_er_comm_group();
     if (!g) return STR_ER_ENOMEM;
@@ -195,19 +204,19 @@ int str_er_comm_local_group(int32_t world, str_er_comm_group **out)
     g->g->send.assign((size_t)world, nullptr);
     *out = g;
     return STR_ER_OK;
-}
+} COMM_GUARD(nullptr)
 
 void str_er_comm_local_group_free(str_er_comm_group *g) { delete g; }
 
 int str_er_comm_create_local(str_er_comm_group *g, int32_t rank, str_er_comm **out)
-{
+try {
     if (!g || !out || rank < 0 || rank >= g->g->world) return STR_ER_EINVAL;
     str_er_comm *c = new (std::nothrow) str_er_comm();
     if (!c) return STR_ER_ENOMEM;
     c->rank = rank; c->world = g->g->world; c->group = g->g;
     *out = c;
     return STR_ER_OK;
-}
+} COMM_GUARD(nullptr)
 
 void str_er_comm_destroy(str_er_comm *c)
 {
@@ -344,14 +353,14 @@ static int gather_impl(str_er_comm *c, int local_rc, const char *local_msg, cons
 
 int str_er_gather_cands(str_er_comm *c, const str_er_cand *local, int32_t n_local, uint32_t frame_offset, str_er_cand **all, int32_t *n_all,
                         int32_t *counts)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     const bool bad = n_local < 0 || (n_local > 0 && !local);
     return gather_impl(c, bad ? STR_ER_EINVAL : 0, "bad arguments", local, nullptr, bad ? 0u : (uint32_t)n_local, frame_offset, all, n_all, counts);
-}
+} COMM_GUARD(c)
 
 int str_er_gather_last(str_er_comm *c, str_er_ctx *ctx, uint32_t frame_offset, str_er_cand **all, int32_t *n_all, int32_t *counts)
-{
+try {
     if (!c || !ctx) return STR_ER_EINVAL;
     const void *d = nullptr;
     uint32_t    n = 0;
@@ -362,13 +371,13 @@ int str_er_gather_last(str_er_comm *c, str_er_ctx *ctx, uint32_t frame_offset, s
     if (lrc == STR_ER_OK && c->group) { lrc = STR_ER_EINVAL; msg = "str_er_gather_last needs an RCCL communicator (device records); use str_er_gather_cands"; }
     if (lrc == STR_ER_OK && dev != c->device) { lrc = STR_ER_EINVAL; msg = "context and communicator are on different devices"; }
     return gather_impl(c, lrc, msg, nullptr, d, lrc == STR_ER_OK ? n : 0u, frame_offset, all, n_all, counts);
-}
+} COMM_GUARD(c)
 
 // Variable-length all-gather of bytes (strip blobs).  out_kind HOST: *all is malloc'ed (str_er_comm_free), the contributions
 // back to back; out_kind DEVICE: *all points into the communicator's device buffer (valid until its next collective), rank k's bytes at
 // starts[k].  starts / sizes: world entries each.
 int str_er_comm_allgather_bytes(str_er_comm *c, const void *local, int64_t n_local, int in_kind, int out_kind, void **all, int64_t *starts, int64_t *sizes)
-{
+try {
     if (!c || !all || !starts || !sizes) return STR_ER_EINVAL;
     *all = nullptr;
     const bool bad = n_local < 0 || (n_local > 0 && !local) || (in_kind != STR_ER_MEM_HOST && in_kind != STR_ER_MEM_DEVICE) ||
@@ -395,7 +404,7 @@ int str_er_comm_allgather_bytes(str_er_comm *c, const void *local, int64_t n_loc
     }
     *all = out;
     return STR_ER_OK;
-}
+} COMM_GUARD(c)
 
 void str_er_comm_free(void *p) { std::free(p); }
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -246,6 +247,15 @@ bool parse_number(const std::string &t, double &v)
     return end != t.c_str();
 }
 
+// (int) of a parsed number, as the reference's (int)stod(...) -- but a value an int cannot hold (inf, nan, 1e99: undefined behaviour in the
+// reference, found by the fuzz loop under UBSan) is a format error here
+bool to_int(double v, int32_t &out)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return false;
+    out = (int32_t)v;
+    return true;
+}
+
 int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
 {
     std::vector<std::string> tok;
@@ -276,14 +286,18 @@ int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
         t = next();
         double v;
         if (!t || !parse_number(*t, v)) break;
-        n.stage_n.push_back((int32_t)v);
+        int32_t iv;
+        if (!to_int(v, iv)) return fail(c, STR_ER_EFORMAT, "cascade: stage size is not an integer");
+        n.stage_n.push_back(iv);
     }
     if (!t || *t != "threshold" || n.stage_n.empty()) return fail(c, STR_ER_EFORMAT, "cascade: missing threshold");
     for (size_t j = 0; j < n.stage_n.size(); ++j) {
         t = next();
         double v;
         if (!t || !parse_number(*t, v)) return fail(c, STR_ER_EFORMAT, "cascade: short threshold list");
-        n.stage_thresh.push_back((int32_t)v); // (int)stod(...), src/adaboost.cpp:919
+        int32_t iv;
+        if (!to_int(v, iv)) return fail(c, STR_ER_EFORMAT, "cascade: stage threshold outside the range of int");
+        n.stage_thresh.push_back(iv); // (int)stod(...), src/adaboost.cpp:919
     }
     const int per = n.real ? 5 : 4;
     for (;;) {
@@ -295,11 +309,15 @@ int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
         }
         if (got == 0) break;
         if (got < per) return fail(c, STR_ER_EFORMAT, "cascade: incomplete stump row");
-        const int d = (int)v[1];
-        if (d < 0 || d >= 1024) return fail(c, STR_ER_EFORMAT, "cascade: feature index outside the 1024-bin histogram");
+        int32_t d;
+        if (!to_int(v[1], d) || d < 0 || d >= 1024) return fail(c, STR_ER_EFORMAT, "cascade: feature index outside the 1024-bin histogram");
         n.dim.push_back((uint16_t)d);
         if (n.real) { n.thr.push_back(v[2]); n.dir.push_back(1.0); n.vp.push_back(v[3]); n.vn.push_back(v[4]); }
-        else { n.dir.push_back((double)(int)v[2]); n.thr.push_back(v[3]); n.vp.push_back(1.0 * v[0]); n.vn.push_back(-1.0 * v[0]); }
+        else {
+            int32_t dr;
+            if (!to_int(v[2], dr)) return fail(c, STR_ER_EFORMAT, "cascade: stump direction is not an integer");
+            n.dir.push_back((double)dr); n.thr.push_back(v[3]); n.vp.push_back(1.0 * v[0]); n.vn.push_back(-1.0 * v[0]);
+        }
     }
     long long total = 0;
     for (int32_t s : n.stage_n) { if (s < 0) return fail(c, STR_ER_EFORMAT, "cascade: negative stage size"); total += s; }
@@ -404,6 +422,9 @@ void assign_node_records(Batch &b, double share)
 // groups of gx x gy tiles per plane (k_group_merge), numbered batch-wide
 void assign_groups(Batch &b, int gx, int gy)
 {
+    // (a half-given or oversized group shape -- STR_ER_GROUP_X without _Y, a negative value, more than 64 tiles -- means NO grouping: with
+    // group_x > 0 and group_y = 0 k_seam divided by zero on the device)
+    if (gx <= 0 || gy <= 0 || gx * gy > 64) gx = gy = 0;
     b.group_x = gx; b.group_y = gy; b.n_groups = 0;
     for (PlaneDesc &d : b.planes) {
         d.group_base = b.n_groups;
@@ -1395,6 +1416,19 @@ int stage_input(str_er_ctx *c, const uint8_t *src, size_t bytes, int mem_kind, c
 // =================================================================================================
 // C ABI
 // =================================================================================================
+// Nothing is thrown across the C ABI: every entry point that takes a context is a function-try-block (the std::vector / std::string work behind
+// them -- parsers of untrusted bytes, per-batch tables -- can run out of memory).
+static int abi_caught(str_er_ctx *c, int code, const char *what)
+{
+    if (!c) return code;
+    try { c->err = what; } catch (...) { }
+    return code;
+}
+#define ABI_GUARD(ctx)                                                                                   \
+    catch (const std::bad_alloc &) { return abi_caught((ctx), STR_ER_ENOMEM, "out of host memory"); }      \
+    catch (const std::length_error &) { return abi_caught((ctx), STR_ER_ENOMEM, "out of host memory (container size)"); } \
+    catch (...) { return abi_caught((ctx), STR_ER_EHIP, "internal error (exception)"); }
+
 extern "C" {
 
 int str_er_abi_version(void) { return STR_ER_ABI_VERSION; }
@@ -1405,22 +1439,22 @@ int str_er_abi_version(void) { return STR_ER_ABI_VERSION; }
 // in the environment before the process's first HIP call.  The library never touches the environment by itself: the host either
 // exports what str_er_runtime_hint() names or calls str_er_apply_runtime_hint() -- an explicit opt-in -- before it initialises HIP.
 int str_er_tie_stats(const str_er_ctx *c, uint64_t *planes_walked, double *walk_ms_total, int32_t *host_threads)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (planes_walked) *planes_walked = c->n_replayed;
     if (walk_ms_total) *walk_ms_total = c->walk_ms_total;
     if (host_threads) *host_threads = flood_walk_threads();
     return STR_ER_OK;
-}
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 int str_er_last_tree_stats(const str_er_ctx *c, uint64_t *records, uint64_t *seam_pairs, uint64_t *tiles)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (records) *records = c->last_tree_records;
     if (seam_pairs) *seam_pairs = c->last_tree_pairs;
     if (tiles) *tiles = c->last_tree_tiles;
     return STR_ER_OK;
-}
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 const char *str_er_runtime_hint(void) { return "GPU_MAX_HW_QUEUES=16"; }
 int str_er_apply_runtime_hint(void)
@@ -1608,30 +1642,30 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
 }
 
 int str_er_set_thresh_step(str_er_ctx *c, int32_t t)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (t < 1 || t > 255) return fail(c, STR_ER_EINVAL, "thresh_step must be in [1,255]");
     c->prm.thresh_step = t;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_set_min_area(str_er_ctx *c, int32_t m)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     c->prm.min_area = m;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_load_cascade_mem(str_er_ctx *c, int which, const char *text, size_t len)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!text || (which != STR_ER_CASCADE_STRONG && which != STR_ER_CASCADE_WEAK)) return fail(c, STR_ER_EINVAL, "bad cascade argument");
     HIP_TRY(c, hipSetDevice(c->prm.device));
     return parse_cascade(c, c->casc[which], text, len);
-}
+} ABI_GUARD(c)
 
 int str_er_load_cascade(str_er_ctx *c, int which, const char *path)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!path) return fail(c, STR_ER_EINVAL, "null path");
     FILE *f = std::fopen(path, "rb");
@@ -1642,29 +1676,29 @@ int str_er_load_cascade(str_er_ctx *c, int which, const char *path)
     while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n);
     std::fclose(f);
     return str_er_load_cascade_mem(c, which, buf.data(), buf.size());
-}
+} ABI_GUARD(c)
 
 int str_er_cascade_info(const str_er_ctx *c, int which, int32_t *n_stages, int32_t *n_stumps)
-{
+try {
     if (!c || (which != 0 && which != 1)) return STR_ER_EINVAL;
     if (n_stages) *n_stages = c->casc[which].loaded ? c->casc[which].dev.n_stages : 0;
     if (n_stumps) *n_stumps = c->casc[which].loaded ? c->casc[which].dev.n_stumps : 0;
     return STR_ER_OK;
-}
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
                            int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out, bool nv12 = false);
 
 int str_er_detect_bgr(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                       int32_t n_frames, int mem_kind, uint32_t stages, str_er_result **out)
-{
+try {
     return detect_bgr_impl(c, bgr, w, h, stride, frame_pitch, n_frames, mem_kind, stages, nullptr, out);
-}
+} ABI_GUARD(c)
 
 int str_er_detect_bgr_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                              int32_t n_frames, int mem_kind, uint32_t stages, const uint8_t *plane_select, int32_t n_select,
                              str_er_result **out)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!plane_select || n_select != c->ppf) return fail(c, STR_ER_EINVAL, "plane_select needs one flag per logical plane of a frame (levels x channels of the context)");
     if (stages & (STR_ER_STAGE_TRACK | STR_ER_STAGE_GROUP | STR_ER_STAGE_OCR_LINES))
@@ -1673,13 +1707,13 @@ int str_er_detect_bgr_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32
     for (int i = 0; i < n_select; ++i) any |= plane_select[i] != 0;
     if (!any) return fail(c, STR_ER_EINVAL, "plane_select selects nothing");
     return detect_bgr_impl(c, bgr, w, h, stride, frame_pitch, n_frames, mem_kind, stages, plane_select, out);
-}
+} ABI_GUARD(c)
 
 int str_er_detect_nv12(str_er_ctx *c, const uint8_t *nv12, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                        int32_t n_frames, int mem_kind, uint32_t stages, str_er_result **out)
-{
+try {
     return detect_bgr_impl(c, nv12, w, h, stride, frame_pitch, n_frames, mem_kind, stages, nullptr, out, /*nv12=*/true);
-}
+} ABI_GUARD(c)
 
 // (nv12: `bgr` is a luma plane of h rows followed by the interleaved chroma plane of h / 2 rows, `stride` bytes per row both)
 static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
@@ -1836,7 +1870,7 @@ int ensure_strip_buf(str_er_ctx *c, uint8_t *&p, size_t &cap, size_t need)
 
 int str_er_strip_extract_dev(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
                              const void **d_blob, int64_t *blob_bytes)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!bgr || !d_blob || !blob_bytes || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 || strip < 0 || strip >= n_strips)
         return fail(c, STR_ER_EINVAL, "bad strip arguments");
@@ -1941,11 +1975,11 @@ int str_er_strip_extract_dev(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32
     HIP_TRY(c, hipStreamSynchronize(s));        // (also: `head` is pageable memory)
     *d_blob = c->d_strip_out; *blob_bytes = (int64_t)L.total;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
                          void **blob, int64_t *blob_bytes)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!blob || !blob_bytes) return fail(c, STR_ER_EINVAL, "bad strip arguments");
     *blob = nullptr; *blob_bytes = 0;
@@ -1958,13 +1992,13 @@ int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h
     if (hipMemcpy(out, d, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { std::free(out); return fail(c, STR_ER_EHIP, "strip blob download"); }
     *blob = out; *blob_bytes = n;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 void str_er_strip_free(void *blob) { std::free(blob); }
 
 int str_er_strip_merge_ex(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
                           const int64_t *blob_bytes, int blob_kind, int32_t n_strips, const uint8_t *plane_select, uint32_t stages, str_er_result **out)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!bgr || !blobs || !blob_bytes || !out || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 ||
         (blob_kind != STR_ER_MEM_HOST && blob_kind != STR_ER_MEM_DEVICE))
@@ -2073,6 +2107,8 @@ int str_er_strip_merge_ex(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t 
             }
             c->h_ctr[j] = pc;
             HIP_TRY(c, hipMemcpyAsync(c->d_ctr + j, c->h_ctr + j, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
+            // (before anything walks the parent chains: levels consistent, no cycles -- a damaged blob must end in EFORMAT, not in a hang)
+            launch_check_forest(s, bd.na.rec + pd.node_base, pc.n_nodes, c->d_strip_flag);
             // pixel pairs across the cuts (strips without rows have no borders: the cut is between the nearest strips that have)
             for (int lo = 0; lo + 1 < n_strips; ++lo) {
                 if (!view[(size_t)lo].sp[k].has_bot) continue;
@@ -2088,21 +2124,21 @@ int str_er_strip_merge_ex(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t 
         uint32_t flag = 0;
         HIP_TRY(c, hipMemcpyAsync(&flag, c->d_strip_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));       // h_ctr is about to be reused for the counters coming back
-        if (flag) return fail(c, STR_ER_EFORMAT, "strip blob: a node id points outside its strip's records");
+        if (flag) return fail(c, STR_ER_EFORMAT, "strip blob: damaged node records (an id outside its strip's records, a box or key outside the plane, inconsistent levels or a cycle of parents)");
         return STR_ER_OK;
     };
     return run_batch(c, b, stages, out, t0, true, &hook);
-}
+} ABI_GUARD(c)
 
 int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
                        const int64_t *blob_bytes, int32_t n_strips, uint32_t stages, str_er_result **out)
-{
+try {
     return str_er_strip_merge_ex(c, bgr, w, h, stride, mem_kind, blobs, blob_bytes, STR_ER_MEM_HOST, n_strips, nullptr, stages, out);
-}
+} ABI_GUARD(c)
 
 int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_t h, int64_t stride, int64_t plane_pitch,
                          int32_t n_planes, int mem_kind, uint32_t stages, str_er_result **out)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!planes || !out || w < 1 || h < 1 || n_planes < 1 || stride < w) return fail(c, STR_ER_EINVAL, "bad plane arguments");
     if (n_planes > 1 && plane_pitch < stride * (int64_t)h) return fail(c, STR_ER_EINVAL, "plane_pitch smaller than a plane");
@@ -2128,10 +2164,10 @@ int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_
     for (int i = 0; i < n_planes; ++i)
         add_plane(b, dp + (size_t)i * dpitch, w, h, dstride, 0, 0, i & 255, 0);
     return run_batch(c, b, stages, out, t0, false);
-}
+} ABI_GUARD(c)
 
 int str_er_compute_channels(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, uint8_t *planes6)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!bgr || !planes6 || w < 1 || h < 1 || stride < (int64_t)w * 3) return fail(c, STR_ER_EINVAL, "bad arguments");
     HIP_TRY(c, hipSetDevice(c->prm.device));
@@ -2145,7 +2181,7 @@ int str_er_compute_channels(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_
     HIP_TRY(c, hipMemcpyAsync(planes6, d, 6 * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
                       double *hist, uint8_t *tiles, uint8_t *cls, double *ss, double *sw, bool cascades, uint8_t *codes = nullptr)
@@ -2190,25 +2226,25 @@ static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h,
 
 int str_er_classify_boxes(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes,
                           int32_t n, uint8_t *cls, double *score_strong, double *score_weak)
-{
+try {
     return boxes_call(c, plane, w, h, stride, boxes, n, nullptr, nullptr, cls, score_strong, score_weak, true);
-}
+} ABI_GUARD(c)
 
 int str_er_lbp_hist(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
                     double *hist, uint8_t *tiles26)
-{
+try {
     if (c && !hist) return fail(c, STR_ER_EINVAL, "null hist");
     return boxes_call(c, plane, w, h, stride, boxes, n, hist, tiles26, nullptr, nullptr, nullptr, false);
-}
+} ABI_GUARD(c)
 
 int str_er_calc_lbp(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n, uint8_t *lbp24)
-{
+try {
     if (c && !lbp24) return fail(c, STR_ER_EINVAL, "null lbp24");
     return boxes_call(c, plane, w, h, stride, boxes, n, nullptr, nullptr, nullptr, nullptr, nullptr, false, lbp24);
-}
+} ABI_GUARD(c)
 
 int str_er_cascade_predict(str_er_ctx *c, int which, const double *fv, int32_t n, double *out)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if ((which != 0 && which != 1) || n < 0 || (n > 0 && (!fv || !out))) return fail(c, STR_ER_EINVAL, "bad arguments");
     if (!c->casc[which].loaded) return fail(c, STR_ER_ESTATE, "cascade not loaded");
@@ -2224,11 +2260,11 @@ int str_er_cascade_predict(str_er_ctx *c, int which, const double *fv, int32_t n
     HIP_TRY(c, hipMemcpyAsync(out, s + in_b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 // ---- libsvm text model (svm_save_model format, src/svm.cpp:2641-2736; reader :2767-2982) -------------
 int str_er_load_svm_model_mem(str_er_ctx *c, const char *text, size_t len, int32_t dim)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!text || dim < 1) return fail(c, STR_ER_EINVAL, "bad arguments");
     HIP_TRY(c, hipSetDevice(c->prm.device));
@@ -2259,8 +2295,9 @@ int str_er_load_svm_model_mem(str_er_ctx *c, const char *text, size_t len, int32
         if (key == "svm_type") ok_type = line.find("c_svc") != std::string::npos;
         else if (key == "kernel_type") ok_kernel = line.find("rbf") != std::string::npos;
         else if (key == "gamma") gamma = std::strtod(line.c_str() + from, nullptr);
-        else if (key == "nr_class") k = std::atoi(line.c_str() + from);
-        else if (key == "total_sv") l = std::atoi(line.c_str() + from);
+        else if (key == "nr_class") { const long v = std::strtol(line.c_str() + from, nullptr, 10); k = v < 0 || v > 128 ? -1 : (int)v; }
+        // (every support vector is a line of the text: a count beyond the text's length is a damaged header, not a table to allocate)
+        else if (key == "total_sv") { const long v = std::strtol(line.c_str() + from, nullptr, 10); l = v < 0 || (unsigned long)v > len || v > (1L << 28) ? -1 : (int)v; }
         else if (key == "rho") numbers(line, from, rho);
         else if (key == "probA") numbers(line, from, pa);
         else if (key == "probB") numbers(line, from, pb);
@@ -2296,7 +2333,10 @@ int str_er_load_svm_model_mem(str_er_ctx *c, const char *text, size_t len, int32
     }
     std::vector<int32_t> ilab(k), insv(k), start(k), pi(np), pj(np);
     int tot = 0;
-    for (int i = 0; i < k; ++i) { ilab[i] = (int32_t)lab[i]; insv[i] = (int32_t)nsv[i]; start[i] = tot; tot += insv[i]; }
+    for (int i = 0; i < k; ++i) {
+        if (!to_int(lab[i], ilab[i]) || !to_int(nsv[i], insv[i]) || insv[i] < 0 || insv[i] > l) return fail(c, STR_ER_EFORMAT, "svm model: label / nr_sv entries are not counts");
+        start[i] = tot; tot += insv[i];
+    }
     if (tot != l) return fail(c, STR_ER_EFORMAT, "svm model: nr_sv does not add up to total_sv");
     for (int i = 0, p = 0; i < k; ++i) for (int j = i + 1; j < k; ++j, ++p) { pi[p] = i; pj[p] = j; }
     size_t off = 0;
@@ -2328,10 +2368,10 @@ int str_er_load_svm_model_mem(str_er_ctx *c, const char *text, size_t len, int32
     c->svm = m;
     c->svm_loaded = true;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_load_svm_model(str_er_ctx *c, const char *path, int32_t dim)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!path) return fail(c, STR_ER_EINVAL, "null path");
     FILE *f = std::fopen(path, "rb");
@@ -2342,19 +2382,19 @@ int str_er_load_svm_model(str_er_ctx *c, const char *path, int32_t dim)
     while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n);
     std::fclose(f);
     return str_er_load_svm_model_mem(c, buf.data(), buf.size(), dim);
-}
+} ABI_GUARD(c)
 
 int str_er_svm_info(const str_er_ctx *c, int32_t *nr_class, int32_t *total_sv, int32_t *dim)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (nr_class) *nr_class = c->svm_loaded ? c->svm.k : 0;
     if (total_sv) *total_sv = c->svm_loaded ? c->svm.l : 0;
     if (dim) *dim = c->svm_loaded ? c->svm.dim : 0;
     return STR_ER_OK;
-}
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, int32_t dim, int32_t *label, double *prob, double *dec)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (n < 0 || (n > 0 && (!x || !label || !prob))) return fail(c, STR_ER_EINVAL, "bad arguments");
     if (!c->svm_loaded) return fail(c, STR_ER_ESTATE, "svm model not loaded");
@@ -2383,17 +2423,17 @@ int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, in
     if (dec) HIP_TRY(c, hipMemcpyAsync(dec, s + o_dec, (size_t)n * np * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
                          int32_t *label, double *prob, uint8_t *q_out)
-{
+try {
     return str_er_ocr_chain_run_slope(c, plane, w, h, stride, boxes, nullptr, n, label, prob, q_out);
-}
+} ABI_GUARD(c)
 
 int str_er_ocr_chain_run_slope(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes,
                                const double *slope, int32_t n, int32_t *label, double *prob, uint8_t *q_out)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
     const bool want_svm = label != nullptr || prob != nullptr;
@@ -2461,7 +2501,7 @@ int str_er_ocr_chain_run_slope(str_er_ctx *c, const uint8_t *plane, int32_t w, i
         }
     }
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, const uint8_t *plane, int64_t stride, int32_t rows, int32_t cols,
                          int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous)
@@ -2542,16 +2582,16 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
 
 int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
                     int32_t cap, int32_t *n_pool, int32_t *ambiguous)
-{
+try {
     return nms_tree_impl(c, nodes, n_nodes, nullptr, 0, rows, cols, pool_idx, cap, n_pool, ambiguous);
-}
+} ABI_GUARD(c)
 
 int str_er_nms_tree_plane(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, const uint8_t *plane, int32_t cols, int32_t rows,
                           int64_t stride, int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous)
-{
+try {
     if (!plane) return c ? fail(c, STR_ER_EINVAL, "null plane") : STR_ER_EINVAL;
     return nms_tree_impl(c, nodes, n_nodes, plane, stride, rows, cols, pool_idx, cap, n_pool, ambiguous);
-}
+} ABI_GUARD(c)
 
 int str_er_flood_order(const uint8_t *plane, int32_t w, int32_t h, int64_t stride, int32_t thresh_step, uint32_t *stamp)
 {
@@ -2562,15 +2602,15 @@ int str_er_flood_order(const uint8_t *plane, int32_t w, int32_t h, int64_t strid
 }
 
 int str_er_internal_last_cands(str_er_ctx *c, const void **d_cands, uint32_t *n, int *device)
-{
+try {
     if (!c || !c->last_valid) return STR_ER_ESTATE;
     *d_cands = c->d_cands; *n = c->last_total; *device = c->prm.device;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_resize_plane(str_er_ctx *c, const uint8_t *src, int32_t sw, int32_t sh, int64_t sstride, uint8_t *dst, int32_t dw,
                         int32_t dh)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw) return fail(c, STR_ER_EINVAL, "bad arguments");
     HIP_TRY(c, hipSetDevice(c->prm.device));
@@ -2582,7 +2622,7 @@ int str_er_resize_plane(str_er_ctx *c, const uint8_t *src, int32_t sw, int32_t s
     HIP_TRY(c, hipMemcpyAsync(dst, c->d_pix, nd, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 // ---- results ---------------------------------------------------------------------------------
 int32_t str_er_result_n_planes(const str_er_result *r) { return r ? (int32_t)r->planes.size() : 0; }
@@ -2703,12 +2743,12 @@ const uint8_t *str_er_result_text_alive(const str_er_result *r, int32_t *n)
 }
 
 int str_er_set_min_ocr_prob(str_er_ctx *c, double p)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!(p >= 0.0 && p <= 1.0)) return fail(c, STR_ER_EINVAL, "min_ocr_prob must be in [0, 1]");
     c->min_ocr_prob = p;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n)
 {
@@ -2720,7 +2760,7 @@ const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t 
 
 int str_er_er_grouping(str_er_ctx *c, const str_er_cand *cands, const str_er_track *tracks, int32_t n, int overlap_sup, int inner_sup,
                        str_er_result **out)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!out || n < 0 || (n > 0 && (!cands || !tracks))) return fail(c, STR_ER_EINVAL, "bad arguments");
     *out = nullptr;
@@ -2754,13 +2794,13 @@ int str_er_er_grouping(str_er_ctx *c, const str_er_cand *cands, const str_er_tra
     if (rc != STR_ER_OK) { delete r; return rc; }
     *out = r;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 const double *str_er_result_times(const str_er_result *r) { return r ? r->times : nullptr; }
 
 int str_er_calc_color(str_er_ctx *c, const uint8_t *mask_plane, int32_t w, int32_t h, int64_t stride, const uint8_t *color_img, int32_t cw,
                       int32_t ch, int64_t cstride, const int32_t *boxes, int32_t n, double *colors)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!mask_plane || !color_img || w < 1 || h < 1 || stride < w || cw < 1 || ch < 1 || cstride < (int64_t)cw * 3 || n < 0 ||
         (n > 0 && (!boxes || !colors)))
@@ -2790,10 +2830,10 @@ int str_er_calc_color(str_er_ctx *c, const uint8_t *mask_plane, int32_t w, int32
     HIP_TRY(c, hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) { colors[3 * (size_t)i] = tr[(size_t)i].color1; colors[3 * (size_t)i + 1] = tr[(size_t)i].color2; colors[3 * (size_t)i + 2] = tr[(size_t)i].color3; }
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_er_track(str_er_ctx *c, const str_er_cand *cands, const double *colors, int32_t n, uint8_t *tracked, int32_t *cx, int32_t *cy)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (n < 0 || (n > 0 && (!cands || !colors || !tracked))) return fail(c, STR_ER_EINVAL, "bad arguments");
     if (n == 0) return STR_ER_OK;
@@ -2825,10 +2865,10 @@ int str_er_er_track(str_er_ctx *c, const str_er_cand *cands, const double *color
         if (cy) cy[i] = tr[(size_t)i].cy;
     }
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int str_er_result_cands_to_device(str_er_ctx *c, const str_er_result *r, void *dst_dev, int32_t cap, int32_t *n)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     if (!r || !dst_dev || cap < 0 || !n) return fail(c, STR_ER_EINVAL, "bad arguments");
     HIP_TRY(c, hipSetDevice(c->prm.device));
@@ -2839,25 +2879,25 @@ int str_er_result_cands_to_device(str_er_ctx *c, const str_er_result *r, void *d
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 void str_er_result_free(str_er_result *r) { delete r; }
 
 int str_er_last_profile(const str_er_ctx *c, const char **names, double *ms, int32_t cap)
-{
+try {
     if (!c) return 0;
     int k = 0;
     for (size_t i = 1; i < c->profile.size(); ++i, ++k)
         if (k < cap) { if (names) names[k] = c->profile[i].first; if (ms) ms[k] = c->profile[i].second; }
     return k;
-}
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 int str_er_set_profiling(str_er_ctx *c, int enable)
-{
+try {
     if (!c) return STR_ER_EINVAL;
     c->profiling = enable != 0;
     return STR_ER_OK;
-}
+} ABI_GUARD(c)
 
 int64_t str_er_workspace_bytes(const str_er_ctx *c) { return c ? c->ws_bytes : 0; }
 

@@ -78,8 +78,13 @@ void worker_main(str_er_stream *s, int idx)
 
 extern "C" {
 
+// (nothing is thrown across the C ABI: thread start, vectors and strings can run out of resources)
+#define STREAM_GUARD(st)                                                                                          \
+    catch (const std::bad_alloc &) { str_er_stream *s_ = (st); if (s_) { try { s_->err = "out of host memory"; } catch (...) { } } return STR_ER_ENOMEM; } \
+    catch (...) { str_er_stream *s_ = (st); if (s_) { try { s_->err = "internal error (exception)"; } catch (...) { } } return STR_ER_EHIP; }
+
 int str_er_stream_create(const str_er_params *p, int32_t depth, str_er_stream **out)
-{
+try {
     if (!p || !out || depth < 1 || depth > 16) return STR_ER_EINVAL;
     *out = nullptr;
     str_er_stream *s = new (std::nothrow) str_er_stream();
@@ -106,7 +111,7 @@ int str_er_stream_create(const str_er_params *p, int32_t depth, str_er_stream **
     for (int i = 0; i < depth; ++i) s->slots[(size_t)i].worker = std::thread(worker_main, s, i);
     *out = s;
     return STR_ER_OK;
-}
+} STREAM_GUARD(nullptr)
 
 void str_er_stream_destroy(str_er_stream *s)
 {
@@ -135,17 +140,17 @@ str_er_ctx *str_er_stream_context(str_er_stream *s, int32_t i)
 const char *str_er_stream_last_error(const str_er_stream *s) { return s ? s->err.c_str() : "null stream"; }
 
 int str_er_stream_load_cascade(str_er_stream *s, int which, const char *path)
-{
+try {
     if (!s) return STR_ER_EINVAL;
     for (auto &sl : s->slots) {
         const int rc = str_er_load_cascade(sl.ctx, which, path);
         if (rc != STR_ER_OK) { s->err = str_er_last_error(sl.ctx); return rc; }
     }
     return STR_ER_OK;
-}
+} STREAM_GUARD(s)
 
 int str_er_stream_acquire(str_er_stream *s, int32_t *slot, uint8_t **buffer, int64_t *capacity)
-{
+try {
     if (!s || !slot || !buffer) return STR_ER_EINVAL;
     std::lock_guard<std::mutex> lk(s->mu);
     for (size_t i = 0; i < s->slots.size(); ++i)
@@ -159,7 +164,7 @@ int str_er_stream_acquire(str_er_stream *s, int32_t *slot, uint8_t **buffer, int
     s->err = s->order.empty() ? "all staging buffers are acquired and none is submitted"
                               : "all staging buffers are in flight: collect a result with str_er_stream_next first";
     return STR_ER_ESTATE;
-}
+} STREAM_GUARD(s)
 
 static int submit_impl(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
                        uint32_t stages, uint64_t *ticket, bool nv12)
@@ -187,19 +192,19 @@ static int submit_impl(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int
 
 int str_er_stream_submit(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
                          uint32_t stages, uint64_t *ticket)
-{
+try {
     return submit_impl(s, slot, w, h, stride, frame_pitch, n_frames, stages, ticket, false);
-}
+} STREAM_GUARD(s)
 
 int str_er_stream_submit_nv12(str_er_stream *s, int32_t slot, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
                               uint32_t stages, uint64_t *ticket)
-{
+try {
     return submit_impl(s, slot, w, h, stride, frame_pitch, n_frames, stages, ticket, true);
-}
+} STREAM_GUARD(s)
 
 int str_er_stream_submit_copy(str_er_stream *s, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch,
                               int32_t n_frames, uint32_t stages, uint64_t *ticket)
-{
+try {
     if (!s || !bgr || w < 1 || h < 1 || n_frames < 1 || stride < (int64_t)w * 3) return STR_ER_EINVAL;
     int32_t  slot = -1;
     uint8_t *buf = nullptr;
@@ -216,10 +221,10 @@ int str_er_stream_submit_copy(str_er_stream *s, const uint8_t *bgr, int32_t w, i
         for (int y = 0; y < h; ++y)
             std::memcpy(buf + (size_t)f * fb + (size_t)y * row, bgr + (size_t)f * (size_t)frame_pitch + (size_t)y * (size_t)stride, row);
     return str_er_stream_submit(s, slot, w, h, (int64_t)row, (int64_t)fb, n_frames, stages, ticket);
-}
+} STREAM_GUARD(s)
 
 int str_er_stream_next(str_er_stream *s, str_er_result **out, uint64_t *ticket)
-{
+try {
     if (!s || !out) return STR_ER_EINVAL;
     *out = nullptr;
     std::unique_lock<std::mutex> lk(s->mu);
@@ -236,7 +241,7 @@ int str_er_stream_next(str_er_stream *s, str_er_result **out, uint64_t *ticket)
     lk.unlock();
     s->cv.notify_all();
     return rc;
-}
+} STREAM_GUARD(s)
 
 int32_t str_er_stream_pending(str_er_stream *s)
 {

@@ -145,6 +145,33 @@ def test_strips_in_a_pyramid_context_and_bad_blobs(S, cascade_paths, oracle, ora
         with pytest.raises(S.StrErError) as e2:
             owner.strip_merge(frame, [bytes(b0)] + blobs[1:])
         assert e2.value.code == -5
+        # a CYCLE of parents between two records of one level (tools/san_fuzz.py found that a damaged blob could hang the merge: every walk
+        # up a parent chain spins for ever): caught by the forest check, EFORMAT, and quickly
+        recs = np.frombuffer(bytes(blobs[0]), np.uint32, count=8 * n0, offset=rec0).reshape(n0, 8)
+        lv = recs[:, 1] >> 24
+        pair = next(((i, j) for i in range(n0) for j in range(i + 1, n0) if lv[i] == lv[j]), None)
+        assert pair is not None
+        b0 = bytearray(blobs[0])
+        struct.pack_into("<I", b0, rec0 + 32 * pair[0], (int(lv[pair[1]]) << 24) | pair[1])
+        struct.pack_into("<I", b0, rec0 + 32 * pair[1], (int(lv[pair[0]]) << 24) | pair[0])
+        import time as _time
+        t0 = _time.time()
+        with pytest.raises(S.StrErError) as e3:
+            owner.strip_merge(frame, [bytes(b0)] + blobs[1:])
+        assert e3.value.code == -5 and _time.time() - t0 < 20
+        # ... a parent of a LOWER level than the node, and a box outside the plane
+        b0 = bytearray(blobs[0])
+        hi = int(np.argmax(lv)); lo = int(np.argmin(lv))
+        if lv[hi] > lv[lo]:
+            struct.pack_into("<I", b0, rec0 + 32 * hi, (int(lv[lo]) << 24) | lo)
+            with pytest.raises(S.StrErError) as e4:
+                owner.strip_merge(frame, [bytes(b0)] + blobs[1:])
+            assert e4.value.code == -5
+        b0 = bytearray(blobs[0])
+        struct.pack_into("<I", b0, rec0 + 32 * 0 + 24, 60000)        # x1 far outside the plane
+        with pytest.raises(S.StrErError) as e5:
+            owner.strip_merge(frame, [bytes(b0)] + blobs[1:])
+        assert e5.value.code == -5
         again = owner.strip_merge(frame, blobs)                     # ... and the context is fine afterwards
         assert again.cands[FIELDS].tolist() == lvl0[FIELDS].tolist()
         for f in workers + [owner]:
