@@ -290,12 +290,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ties0 = tie_totals()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     prof_sum, r = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_per_wall = (time.process_time() - cpu0) / max(elapsed, 1e-9)      # host CPUs this process kept busy during the timed region
     ties1 = tie_totals()
     nms_ties = {"tie_planes_per_batch": round((ties1[0] - ties0[0]) / args.steps, 2),
                 "flood_walk_ms_per_batch": round((ties1[1] - ties0[1]) / args.steps, 2), "host_threads": ties1[2],
@@ -329,14 +331,16 @@ def main():
         run(P, d_ties)
         n_t = max(P, args.steps // 2)
         a0 = tie_totals()
+        cpu1 = time.process_time()
         t1 = time.perf_counter()
         run(n_t, d_ties)
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
+        ties_cpu = (time.process_time() - cpu1) / max(el, 1e-9)
         a1 = tie_totals()
         ties_leg = {"value": round(F * n_t / el, 2), "unit": "frames/s", "steps": n_t, "ms_per_step": round(1e3 * el / n_t, 3),
                     "tie_planes_per_batch": round((a1[0] - a0[0]) / n_t, 2), "tie_plane_share": round((a1[0] - a0[0]) / n_t / (F * bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels']), 4),
-                    "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(), "host_cpu_quota": effective_cpus(),
+                    "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(), "host_cpu_quota": effective_cpus(), "host_cpus_busy": round(ties_cpu, 2),
                     "note": f"S-ties frames (S-text + one double-L glyph in every {args.ties_every}th frame: an NMS sibling tie with two different outcomes); same "
                             "batches in flight as `value`; flood_walk_ms = host time of the reference-order walks, summed over planes.  The walks are "
                             "bound by host memory latency (~6 ms per 1920x1080 plane): once tie planes per batch x 6 ms / host_threads exceeds the "
@@ -487,7 +491,7 @@ def main():
                        "frames_per_gpu_per_step": F,
                        "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
-                       "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P,
+                       "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P, "host_cpus_busy": round(host_cpu_per_wall, 2),
                        "workspace_bytes_per_batch_in_flight": ws_bytes, "nms_sibling_ties": "exact (reference flood order)" if args.sibling_order == 0 else "key rule",
                        **({"gather": "RCCL through the C ABI (str_er_gather_last)" if comm is not None else "torch.distributed all_gather"} if world > 1 else {})},
             "nms_ties": nms_ties,

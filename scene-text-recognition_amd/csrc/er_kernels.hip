@@ -762,11 +762,17 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t keep, uint32_t v)
 #define LANE_P1(v) dpp_mov<0x101>((v), (v))      // row_shl:1 -- the value of lane + 1
 
 // All-reduce over the 8 lanes of a tile row (butterfly: lane ^ 1, lane ^ 2, then lane <-> 7 - lane): every lane ends up with the result.
-#define ROW8_ALLREDUCE(v, OP)                                  \
+// The operation and the lane exchange are ONE instruction (v_min_u32_dpp ...): written out, because the compiler turned "move with DPP, then
+// combine" into copy + v_mov_b32_dpp + operation -- three vector instructions per step, eighteen steps in the statistics phase of every tile --
+// and this kernel is bound by the number of instructions it issues.  (s_nop 1: a DPP source written by the previous vector instruction needs two
+// wait states; the compiler does not see into the asm.)
+#define DPP_FUSED(OPNAME, CTRL, v)                                                                              \
+    ({ uint32_t r_; asm("s_nop 1\n\t" OPNAME "_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r_) : "v"(v)); r_; })
+#define ROW8_ALLREDUCE(v, OPNAME)                              \
     do {                                                       \
-        v = OP(v, dpp_mov<0xB1>((v), (v)));   /* quad_perm:[1,0,3,2] */ \
-        v = OP(v, dpp_mov<0x4E>((v), (v)));   /* quad_perm:[2,3,0,1] */ \
-        v = OP(v, dpp_mov<0x141>((v), (v)));  /* row_half_mirror */     \
+        v = DPP_FUSED(OPNAME, "quad_perm:[1,0,3,2]", v);       \
+        v = DPP_FUSED(OPNAME, "quad_perm:[2,3,0,1]", v);       \
+        v = DPP_FUSED(OPNAME, "row_half_mirror", v);           \
     } while (0)
 #define OP_ADD(a, b) ((a) + (b))
 #define OP_OR(a, b)  ((a) | (b))
@@ -1308,10 +1314,10 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
             uint32_t h1 = NONE, h2 = NONE;            // the row's hot level roots (slots; NONE: none)
             if (HOT) {
                 uint32_t d = first_root == NONE ? 0xFFFFFFFFu : ((chunk << 16) | first_root);
-                ROW8_ALLREDUCE(d, OP_MIN);
+                ROW8_ALLREDUCE(d, "v_min_u32");
                 h1 = d == 0xFFFFFFFFu ? NONE : (d & 0xFFFFu);
                 d = (first_root == NONE || first_root == h1) ? 0xFFFFFFFFu : ((chunk << 16) | first_root);
-                ROW8_ALLREDUCE(d, OP_MIN);
+                ROW8_ALLREDUCE(d, "v_min_u32");
                 h2 = d == 0xFFFFFFFFu ? NONE : (d & 0xFFFFu);
             }
             // per hot node: pixels (7 bits) | is-the-root-piece (bit 7); node 1 in bits 0..15, node 2 in 16..31.  hsides: the tile sides
@@ -1342,12 +1348,12 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                 }
             }
           if (HOT) {
-            ROW8_ALLREDUCE(acc, OP_ADD);
-            ROW8_ALLREDUCE(hsides, OP_OR);
+            ROW8_ALLREDUCE(acc, "v_add_u32");
+            ROW8_ALLREDUCE(hsides, "v_or_b32");
             // column sets: the 4 lanes of a quad own the 4 bytes of one dword (lanes 0-3: columns 0-31, lanes 4-7: columns 32-63)
             col1 <<= 8u * (chunk & 3u); col2 <<= 8u * (chunk & 3u);
-            col1 |= dpp_mov<0xB1>(col1, col1); col1 |= dpp_mov<0x4E>(col1, col1);
-            col2 |= dpp_mov<0xB1>(col2, col2); col2 |= dpp_mov<0x4E>(col2, col2);
+            col1 = DPP_FUSED("v_or_b32", "quad_perm:[1,0,3,2]", col1); col1 = DPP_FUSED("v_or_b32", "quad_perm:[2,3,0,1]", col1);
+            col2 = DPP_FUSED("v_or_b32", "quad_perm:[1,0,3,2]", col2); col2 = DPP_FUSED("v_or_b32", "quad_perm:[2,3,0,1]", col2);
             const uint32_t oth1 = dpp_mov<0x141>(col1, col1), oth2 = dpp_mov<0x141>(col2, col2);     // the other quad's dword
             // lane 0 of the row adds node 1 (its own dword is the low one), lane 4 node 2 (its own dword is the high one)
             const uint32_t my_h = chunk == 0 ? h1 : h2, my_acc = chunk == 0 ? (acc & 0xFFFFu) : (acc >> 16);

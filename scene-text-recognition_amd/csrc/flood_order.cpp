@@ -39,7 +39,10 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
     uint16_t lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (uint16_t)std::lrintf((float)v * qscale);
     // (the two per-pixel arrays are kept per thread: a fresh 12 MB allocation per walk is ~3000 page faults and a memset -- a third of a
-    // walk that stops early; both are written before they are read)
+    // walk that stops early; both are written before they are read.  Round 4, measured and not adopted: one byte of state per pixel and the level
+    // looked up from the plane when the walk first touches a pixel -- no pass over the whole plane in front of a walk that stops early -- is 11 %
+    // SLOWER on the boxes' EPYC 9575F (16.0 -> 17.9 ms for a whole 1920 x 1080 plane, tools/walk_bench.cpp): two dependent loads per new pixel
+    // instead of one, and the walk is a chain of mispredicted branches and dependent loads, ~8 ns per pixel, whatever the bytes)
     // Kept for the planes a video stream brings again and again, up to 1920 x 1080 x 2 pixels; the scratch of a larger plane (one 4K plane: 50 MB)
     // is handed back when its walk ends, so that up to 64 pool threads and every caller thread do not hold it for the life of the process.
     thread_local std::vector<uint16_t> st_buf;

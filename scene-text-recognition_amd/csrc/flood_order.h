@@ -2,6 +2,7 @@
 // accessible, computed on the host for the few planes whose NMS has a sibling tie that can change the pool (er_kernels.hip,
 // k_nms).  See flood_order.cpp for why this one step runs on a host core.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 namespace str_er {

@@ -96,6 +96,7 @@ struct str_er_ctx {
     double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
     bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
     uint64_t last_tree_records = 0, last_tree_pairs = 0, last_tree_tiles = 0;     // of the last batch (str_er_last_tree_stats)
+    bool   spin_wait = false;          // STR_ER_SPIN_WAIT=1: always hipStreamSynchronize (busy-waits on a core), see wait_stream
     bool   dbg_tile_only = false, dbg_stats = false;   // developer aids (STR_ER_DEBUG_TILE_ONLY / _STATS), read once at create
     int    tile_mode = 0;             // 0 auto (from the node density of the previous batch), 1 sparse, 2 dense (STR_ER_TILE_KERNEL)
     int64_t ws_bytes = 0;
@@ -170,6 +171,21 @@ int fail(str_er_ctx *c, int code, const std::string &msg)
 {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
+}
+
+// Waiting for a stream.  hipStreamSynchronize busy-waits (so does hipEventSynchronize on a hipEventBlockingSync event, measured): with a batch in
+// flight on each of six contexts that is six host cores spinning -- and the GPU boxes grant a process 16 (cgroup quota), which the flood order walks
+// of the NMS ties need (round 4: the S-ties bench leg, 86 ms of walks per batch on 16 pool threads + 6 spinning waiters = throttled).  So: poll for
+// ~300 us -- a one-frame call's waits end inside that, its latency is as before -- then sleep between polls.
+static hipError_t wait_stream(str_er_ctx *c, hipStream_t s)
+{
+    if (!c || c->spin_wait) return hipStreamSynchronize(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
 }
 
 #define HIP_TRY(ctx, expr)                                                                         \
@@ -590,7 +606,7 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
     HIP_TRY(c, hipMemcpyAsync(lab.data(), sc + o_lab, 4 * n_m, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(pall.data(), sc + o_prob, 8 * pall.size(), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(mlab.data(), m.label, 4 * (size_t)m.k, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(c, s));
     for (size_t j = 0; j < n_m; ++j) {
         int idx = -1;
         for (int k = 0; k < m.k; ++k) if (mlab[(size_t)k] == lab[j]) { idx = k; break; }
@@ -674,7 +690,7 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
     HIP_TRY(c, hipMemcpyAsync(n_sorted.data(), gb.n_sorted, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(pair_off.data(), gb.pair_off, 4 * ((size_t)G + 1), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(sorted.data(), gb.sorted, 4 * n_c, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(c, s));
     const size_t n_pairs = pair_off[(size_t)G];
     if (n_pairs > c->group_pair_cap) {               // the optimistic buffer was too small: the fill kernel did nothing
         rc = grow_pairs(n_pairs + n_pairs / 4);
@@ -685,7 +701,7 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
     }
     std::vector<uint32_t> pairs(n_pairs);
     if (n_pairs) HIP_TRY(c, hipMemcpyAsync(pairs.data(), gb.pairs, 4 * n_pairs, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(c, s));
 
     std::vector<GroupEr>  ers;
     std::vector<TextLine> lines;
@@ -809,7 +825,7 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
             }
             // the planes without a slot: one launch writes them (and their watch lists) into the arena
             if (need_sync) { launch_export_listed_planes(s, bd, c->d_replay_items, (int)m, c->h_replay); HIP_TRY(c, hipGetLastError()); }
-            if (need_sync) HIP_TRY(c, hipStreamSynchronize(s));
+            if (need_sync) HIP_TRY(c, wait_stream(c, s));
             const auto tw0 = std::chrono::steady_clock::now();
             auto walk = [&](size_t k) {
                 const int        i = (int)items[k].plane;
@@ -851,7 +867,7 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
         HIP_TRY(c, hipGetLastError());
         c->n_replayed += m;
         // (the arena and the item table are reused by the next round; the last round is left to the caller's synchronisation)
-        if (at < amb.size()) HIP_TRY(c, hipStreamSynchronize(s));
+        if (at < amb.size()) HIP_TRY(c, wait_stream(c, s));
     }
     replayed = true;
     return STR_ER_OK;
@@ -969,7 +985,7 @@ int upload_layout(str_er_ctx *c, Batch &b)
                 HIP_TRY(c, hipMemcpyAsync(c->d_sb_plane, c->h_sb_plane.data(), 2 * c->h_sb_plane.size(), hipMemcpyHostToDevice, s));
                 HIP_TRY(c, hipMemcpyAsync(c->d_sb_first, c->h_sb_first.data(), 4 * c->h_sb_first.size(), hipMemcpyHostToDevice, s));
             }
-            HIP_TRY(c, hipStreamSynchronize(s));   // pageable host vectors: make sure the copies are done
+            HIP_TRY(c, wait_stream(c, s));   // pageable host vectors: make sure the copies are done
             c->layout_key = key;
         }
     }
@@ -1044,7 +1060,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     rec(c, "tile_tree");
     if (c->dbg_tile_only) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
-        (void)hipStreamSynchronize(s);
+        (void)wait_stream(c, s);
         (void)hipEventElapsedTime(&ms, c->ev[c->n_ev - 2], c->ev[c->n_ev - 1]);
         std::fprintf(stderr, "[str_er] tile_tree alone: %.4f ms\n", ms);
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
@@ -1100,7 +1116,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(c, s));
     {   // what the tree passes of this batch worked on (str_er_last_tree_stats: bench.py prices them against the HBM roofline)
         uint64_t recs = 0, pairs = 0, tiles = 0;
         for (int i = 0; i < np; ++i) {
@@ -1182,7 +1198,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
             HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
-            HIP_TRY(c, hipStreamSynchronize(sp));
+            HIP_TRY(c, wait_stream(c, sp));
             if (c->dbg_stats) std::fprintf(stderr, "[str_er] classify again after the tie pass: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count());
             bool again = false;             // (a pool of the tie pass did not fit: same remedy as above)
             const int rcg = grow_tables(again);
@@ -1253,7 +1269,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     double t_group_s = 0;
     if (stages & STR_ER_STAGE_GROUP) {
         const auto tg0 = std::chrono::steady_clock::now();
-        if (hipStreamSynchronize(s) != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, "sync before grouping"); }
+        if (wait_stream(c, s) != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, "sync before grouping"); }
         std::vector<uint32_t> img;
         const int n_img = np / b.planes_per_image;
         uint32_t off2 = 0;
@@ -1306,7 +1322,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), sc + o_lab, 4 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(pall.data(), sc + o_prob, 8 * pall.size(), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(mlab.data(), m.label, 4 * (size_t)m.k, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) e = wait_stream(c, s);
             if (e != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, std::string("OCR stage: ") + hipGetErrorString(e)); }
             for (size_t i = 0; i < n_ocr; ++i) {
                 if (list[i] >= total) continue;
@@ -1335,7 +1351,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
                 if (e == hipSuccess) e = hipMemcpyAsync(par.data(), c->ka.parent + pd.kept_base, 4 * (size_t)nk, hipMemcpyDeviceToHost, s);
                 if (e == hipSuccess) e = hipMemcpyAsync(box.data(), c->ka.box + 4 * (size_t)pd.kept_base, 8 * (size_t)nk, hipMemcpyDeviceToHost, s);
                 if (e == hipSuccess) e = hipMemcpyAsync(lev.data(), c->ka.level + pd.kept_base, (size_t)nk, hipMemcpyDeviceToHost, s);
-                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e == hipSuccess) e = wait_stream(c, s);
             }
             if (e != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, std::string("node copy: ") + hipGetErrorString(e)); }
             // order by (key, level) so the table is deterministic; remap parents and the root
@@ -1354,7 +1370,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             c->h_ctr[i].root_slot = nk ? rank[c->h_ctr[i].root_slot] : 0;
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(c, s));
 
     uint32_t off = 0;
     for (int i = 0; i < np; ++i) {
@@ -1600,6 +1616,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
             c->h_tie_count = c->h_tie_plane + TIE_SLOTS;
         }
     }
+    c->spin_wait = std::getenv("STR_ER_SPIN_WAIT") != nullptr;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
         A(fail(nullptr, STR_ER_EHIP, "side stream creation failed"));
@@ -1936,7 +1953,7 @@ try {
             launch_seam(s, bd, !c->tile_sparse);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * npl, hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, wait_stream(c, s));
             double need = 0;
             for (size_t k = 0; k < npl; ++k)
                 if (c->h_ctr[k].overflow & 8u) need = std::max(need, (double)c->h_ctr[k].n_nodes / (double)((size_t)b.planes[k].tiles_x * b.planes[k].tiles_y * TILE_PX));
@@ -1972,7 +1989,7 @@ try {
                                           reinterpret_cast<uint32_t *>(c->d_strip_out + L.bot[k]));
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(s));        // (also: `head` is pageable memory)
+    HIP_TRY(c, wait_stream(c, s));        // (also: `head` is pageable memory)
     *d_blob = c->d_strip_out; *blob_bytes = (int64_t)L.total;
     return STR_ER_OK;
 } ABI_GUARD(c)
@@ -2123,7 +2140,7 @@ try {
         HIP_TRY(c, hipGetLastError());
         uint32_t flag = 0;
         HIP_TRY(c, hipMemcpyAsync(&flag, c->d_strip_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));       // h_ctr is about to be reused for the counters coming back
+        HIP_TRY(c, wait_stream(c, s));       // h_ctr is about to be reused for the counters coming back
         if (flag) return fail(c, STR_ER_EFORMAT, "strip blob: damaged node records (an id outside its strip's records, a box or key outside the plane, inconsistent levels or a cycle of parents)");
         return STR_ER_OK;
     };
@@ -2179,7 +2196,7 @@ try {
     launch_invert(c->stream, d, d + 3 * n, 3 * n);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(planes6, d, 6 * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c, c->stream));
     return STR_ER_OK;
 } ABI_GUARD(c)
 
@@ -2220,7 +2237,7 @@ static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h,
         HIP_TRY(c, hipMemcpyAsync(ss, s + o_ss, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(sw, s + o_sw, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c, c->stream));
     return STR_ER_OK;
 }
 
@@ -2258,7 +2275,7 @@ try {
     launch_cascade_fv(c->stream, reinterpret_cast<const double *>(s), n, reinterpret_cast<double *>(s + in_b), c->casc[which].dev);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, s + in_b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c, c->stream));
     return STR_ER_OK;
 } ABI_GUARD(c)
 
@@ -2421,7 +2438,7 @@ try {
     HIP_TRY(c, hipMemcpyAsync(prob, s + o_prob, (size_t)n * m.k * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(label, s + o_lab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (dec) HIP_TRY(c, hipMemcpyAsync(dec, s + o_dec, (size_t)n * np * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, wait_stream(c, st));
     return STR_ER_OK;
 } ABI_GUARD(c)
 
@@ -2489,7 +2506,7 @@ try {
     }
     HIP_TRY(c, hipGetLastError());
     if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, s + o_q, 1800 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, wait_stream(c, st));
     if (want_svm) {
         // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. assumes model->label[i] == i
         std::vector<int32_t> lab(m.k);
@@ -2550,7 +2567,7 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     HIP_TRY(c, hipMemcpyAsync(c->ka.box, box.data(), 8 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->ka.level, lev.data(), (size_t)n_nodes, hipMemcpyHostToDevice, s));
     if (plane) HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)cols, plane, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s)); // host vectors go out of scope after this call
+    HIP_TRY(c, wait_stream(c, s)); // host vectors go out of scope after this call
     BatchDev bd = make_batchdev(c, b);
     bd.n_seam_blocks = 0;
     const DetectParams dp = make_dp(c);
@@ -2558,15 +2575,15 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     if (plane) launch_nms_alt(s, bd, dp, c->d_alt_list);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(c, s));
     const uint32_t n_amb = c->h_ctr[0].n_amb;
     if (plane && c->prm.sibling_order == 0 && c->h_ctr[0].n_rel) {      // ties: the reference's flood order decides (k_flood_order)
         bool replayed = false;
         const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed, /*from_tree=*/true);
         if (rcr != STR_ER_OK) return rcr;
-        if (c->prio) HIP_TRY(c, hipStreamSynchronize(c->prio));       // the tie pass ran there
+        if (c->prio) HIP_TRY(c, wait_stream(c, c->prio));       // the tie pass ran there
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, wait_stream(c, s));
     }
     if (c->h_ctr[0].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
     const int np = (int)c->h_ctr[0].n_pool;
@@ -2575,7 +2592,7 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     const int ncopy = std::min(np, cap);
     if (ncopy > 0) {
         HIP_TRY(c, hipMemcpyAsync(pool_idx, c->d_pool, 4 * (size_t)ncopy, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, wait_stream(c, s));
     }
     return STR_ER_OK;
 }
@@ -2620,7 +2637,7 @@ try {
     launch_resize(c->stream, c->d_in, sw, sh, sw, 0, 0, c->d_pix, dw, dh, dw, 0, 0, 1, 1);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(dst, c->d_pix, nd, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c, c->stream));
     return STR_ER_OK;
 } ABI_GUARD(c)
 
@@ -2827,7 +2844,7 @@ try {
     HIP_TRY(c, hipGetLastError());
     std::vector<TrackRec> tr((size_t)n);
     HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, wait_stream(c, st));
     for (int i = 0; i < n; ++i) { colors[3 * (size_t)i] = tr[(size_t)i].color1; colors[3 * (size_t)i + 1] = tr[(size_t)i].color2; colors[3 * (size_t)i + 2] = tr[(size_t)i].color3; }
     return STR_ER_OK;
 } ABI_GUARD(c)
@@ -2858,7 +2875,7 @@ try {
                     reinterpret_cast<uint32_t *>(sc + o_list), reinterpret_cast<const uint32_t *>(sc + o_rng), 1);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, wait_stream(c, st));
     for (int i = 0; i < n; ++i) {
         tracked[i] = (uint8_t)tr[(size_t)i].tracked;
         if (cx) cx[i] = tr[(size_t)i].cx;
@@ -2876,7 +2893,7 @@ try {
     *n = (int32_t)r->cands.size();
     if (m > 0) {
         HIP_TRY(c, hipMemcpyAsync(dst_dev, r->cands.data(), sizeof(str_er_cand) * (size_t)m, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, wait_stream(c, c->stream));
     }
     return STR_ER_OK;
 } ABI_GUARD(c)
