@@ -403,13 +403,24 @@ def main():
             while st.pending():
                 st.next()
 
+        # what the host link of this box delivers: the same bytes, page-locked memory -> device, nothing else running
+        pin = torch.empty(frames.size, dtype=torch.uint8).pin_memory()
+        dst = torch.empty(frames.size, dtype=torch.uint8, device=device)
+        dst.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dst.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_gbs = 5 * frames.size / (time.perf_counter() - t1) / 1e9
+        del pin, dst
         filled = [False] * P
         stream_steps(max(P, args.warmup))
         t1 = time.perf_counter()
         stream_steps(args.steps)
         el = time.perf_counter() - t1
         pcie = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
-                "h2d_bytes_per_step": int(frames.size),
+                "h2d_bytes_per_step": int(frames.size), "h2d_gbs": round(frames.size * args.steps / el / 1e9, 2),
+                "h2d_gbs_link_alone": round(h2d_gbs, 2), "frames_per_s_at_link_rate": round(h2d_gbs * 1e9 / (frames.size / F), 1),
                 "note": "host BGR frames in page-locked memory -> str_er_stream (upload of one batch overlaps the kernels of the others)"}
         # ... and the same frames as a video decoder would deliver them: NV12, half the bytes (build-defined ingest, include/str_er.h)
         with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
@@ -433,7 +444,7 @@ def main():
         stream_steps_nv12(args.steps)
         el = time.perf_counter() - t1
         pcie_nv12 = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
-                     "h2d_bytes_per_step": int(nv.size),
+                     "h2d_bytes_per_step": int(nv.size), "h2d_gbs": round(nv.size * args.steps / el / 1e9, 2),
                      "note": "the same frames as NV12 (luma + interleaved Cb/Cr at half resolution: what a decoder delivers) through the same stream; "
                              "the NV12 -> Y/Cr/Cb step is build-defined (chroma replicated 2x2), so the planes -- and the candidates -- are not "
                              "those of the BGR frames"}

@@ -7,10 +7,20 @@
 // decodes / copies its frames straight into it, submits; the worker issues the H2D copy (true DMA, the buffer is pinned)
 // and the kernels on its context's stream while the other contexts compute; results come back in submission order.
 // Built on the public C ABI only (str_er_create / str_er_detect_bgr / ...).
+//
+// Round 4: the uploads take TURNS, in submission order, and a batch's kernels start only behind its own upload.  Before, every worker handed its
+// pinned buffer to str_er_detect_bgr (upload + kernels in one call): the `depth` uploads in flight shared the host link and the `depth` batches of
+// kernels shared the GPU -- jobs of two stages whose resources are both time-shared fall into step (all uploading, then all computing), and the
+// stream ran at 1 / (upload + compute) instead of 1 / max(upload, compute): NV12 frames, a third of the link's capacity, at 0.81 of the
+// device-resident rate.  Now one upload owns the link at a time (a batch's frames go into a device buffer of its slot, own copy stream), the
+// next one starts when it has landed, and the kernels of the batches before it run meanwhile.
 #include "../../include/str_er.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -24,6 +34,9 @@ struct str_er_stream {
     struct Slot {
         str_er_ctx *ctx = nullptr;
         uint8_t    *pinned = nullptr;
+        uint8_t    *d_in = nullptr;        // the batch's frames on the device (upload target)
+        hipStream_t copy = nullptr;        // the upload's stream
+        hipEvent_t  landed = nullptr;
         // job
         bool     busy = false, has_job = false, done = false;
         int32_t  w = 0, h = 0, n_frames = 0;
@@ -43,6 +56,8 @@ struct str_er_stream {
     std::condition_variable cv;
     std::deque<int> order;       // slots in submission order, oldest first
     uint64_t next_ticket = 1;
+    uint64_t upload_turn = 1;    // ticket of the batch whose upload may use the link now
+    size_t   upload_piece = (size_t)1 << 40;       // (developer knob STR_ER_UPLOAD_PIECE_MB: the upload in pieces; 4 / 16 MB made no difference that stands out of the run-to-run scatter)
     bool     stop = false;
     std::string err;
 };
@@ -60,13 +75,44 @@ void worker_main(str_er_stream *s, int idx)
             if (s->stop && !sl.has_job) return;
         }
         str_er_result *r = nullptr;
-        const int rc = sl.nv12 ? str_er_detect_nv12(sl.ctx, sl.pinned, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_HOST, sl.stages, &r)
-                               : str_er_detect_bgr(sl.ctx, sl.pinned, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_HOST, sl.stages, &r);
+        int rc = STR_ER_OK;
+        {
+            // the upload, when it is this batch's turn (submission order); the turn passes on when the bytes have landed
+            const int64_t rows = sl.nv12 ? (int64_t)sl.h + sl.h / 2 : (int64_t)sl.h;
+            const size_t bytes = (size_t)(sl.n_frames - 1) * (size_t)sl.pitch + (size_t)sl.stride * (size_t)rows;
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                s->cv.wait(lk, [&] { return s->upload_turn == sl.ticket; });
+            }
+            hipError_t e = hipSuccess;
+            const size_t piece = s->upload_piece;
+            for (size_t at = 0; at < bytes && e == hipSuccess; at += piece)
+                e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, bytes - at), hipMemcpyHostToDevice, sl.copy);
+            if (e == hipSuccess) e = hipEventRecord(sl.landed, sl.copy);
+            // (poll, then sleep between polls: a spinning wait per slot would keep `depth` host cores busy)
+            for (int spins = 0; e == hipSuccess;) {
+                const hipError_t q = hipEventQuery(sl.landed);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { e = q; break; }
+                if (++spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            {
+                std::lock_guard<std::mutex> lk(s->mu);
+                s->upload_turn = sl.ticket + 1;
+            }
+            s->cv.notify_all();
+            if (e != hipSuccess) { rc = STR_ER_EHIP; sl.err = std::string("upload: ") + hipGetErrorString(e); }
+        }
+        if (rc == STR_ER_OK)
+            rc = sl.nv12 ? str_er_detect_nv12(sl.ctx, sl.d_in, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_DEVICE, sl.stages, &r)
+                         : str_er_detect_bgr(sl.ctx, sl.d_in, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_DEVICE, sl.stages, &r);
+        else r = nullptr;
+        const bool upload_failed = rc != STR_ER_OK && r == nullptr && !sl.err.empty();
         {
             std::lock_guard<std::mutex> lk(s->mu);
             sl.rc = rc;
             sl.result = r;
-            if (rc != STR_ER_OK) sl.err = str_er_last_error(sl.ctx);
+            if (rc != STR_ER_OK && !upload_failed) sl.err = str_er_last_error(sl.ctx);
             sl.has_job = false;
             sl.done = true;
         }
@@ -90,6 +136,7 @@ try {
     str_er_stream *s = new (std::nothrow) str_er_stream();
     if (!s) return STR_ER_ENOMEM;
     s->device = p->device;
+    if (const char *e = std::getenv("STR_ER_UPLOAD_PIECE_MB")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) s->upload_piece = (size_t)v << 20; }
     s->slot_bytes = (size_t)p->max_frames * (size_t)p->max_width * (size_t)p->max_height * 3;
     s->slots.resize((size_t)depth);
     int rc = STR_ER_OK;
@@ -99,10 +146,18 @@ try {
         rc = str_er_create(&q, &s->slots[(size_t)i].ctx);
         if (rc == STR_ER_OK && hipHostMalloc(reinterpret_cast<void **>(&s->slots[(size_t)i].pinned), s->slot_bytes, hipHostMallocDefault) != hipSuccess)
             rc = STR_ER_ENOMEM;
+        if (rc == STR_ER_OK && (hipSetDevice(p->device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&s->slots[(size_t)i].d_in), s->slot_bytes) != hipSuccess))
+            rc = STR_ER_ENOMEM;
+        if (rc == STR_ER_OK && (hipStreamCreateWithFlags(&s->slots[(size_t)i].copy, hipStreamNonBlocking) != hipSuccess ||
+                                hipEventCreateWithFlags(&s->slots[(size_t)i].landed, hipEventDisableTiming) != hipSuccess))
+            rc = STR_ER_EHIP;
     }
     if (rc != STR_ER_OK) {
         for (auto &sl : s->slots) {
             if (sl.pinned) (void)hipHostFree(sl.pinned);
+            if (sl.d_in) (void)hipFree(sl.d_in);
+            if (sl.landed) (void)hipEventDestroy(sl.landed);
+            if (sl.copy) (void)hipStreamDestroy(sl.copy);
             if (sl.ctx) str_er_destroy(sl.ctx);
         }
         delete s;
@@ -125,6 +180,9 @@ void str_er_stream_destroy(str_er_stream *s)
     for (auto &sl : s->slots) {
         if (sl.result) str_er_result_free(sl.result);
         if (sl.pinned) (void)hipHostFree(sl.pinned);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.landed) (void)hipEventDestroy(sl.landed);
+        if (sl.copy) (void)hipStreamDestroy(sl.copy);
         if (sl.ctx) str_er_destroy(sl.ctx);
     }
     delete s;
