@@ -564,6 +564,19 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 // and inner vertical edges of its own 8-row band by itself (wave-wide scans, no workgroup barriers, nobody else on its words), the three row
 // pairs between bands in a workgroup-wide round afterwards: 3.22 / 8.4 against 2.99 / 8.07 -- the bands' edge counts differ; round 1's attempts -- fewer waves in the loop, two edges
 // per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
+#ifdef STR_ER_CONNECT_CNT
+// Developer aid (-DSTR_ER_CONNECT_CNT, tools/dev_connect_cnt.py): per-wave counts of the hand-written connect loop.  Round 4, text-like luma tile:
+// 201 edges, 17.4 iterations, 33 + 19 rounds of the two walking loops per wave -- a round is paid by the whole wave whenever one lane is not at
+// its level root yet, 2.5 rounds per iteration, about as many instructions as the passes themselves.  Naming the edges by RUN HEADS instead of
+// pixels (32-bit entries; the listing lane knows its pieces' heads, the run coming in from the left and the pieces of the lane below) brought that
+// to 27 + 17 and cost more in the listing loops than it saved: 1.832 against 1.812 ms per 32 text frames, noise 5.15 against 4.70 -- not adopted.
+__device__ unsigned long long g_connect_cnt[8];      // waves, loop iterations, walk rounds (a), (b), edges
+extern "C" void str_er_debug_connect_counts(unsigned long long *out8, int reset)
+{
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_connect_cnt), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_connect_cnt), z, sizeof(z)); }
+}
+#endif
 // LDS byte address of an object in shared memory (what a ds_* instruction takes)
 template <class T>
 __device__ __forceinline__ uint32_t lds_addr(const T *p)
@@ -592,11 +605,17 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
         uint32_t ka, kb, wa, wb, aa, ab, t0, t1, t2;
         unsigned long long busy, m1, m2, m3, m4, sx;
         uint32_t cur, tmp;
+#ifdef STR_ER_CONNECT_CNT
+        uint32_t n_it = 0, n_ha = 0, n_hb = 0;      // developer aid: loop iterations / rounds of the two walks, per wave (tools/dev_connect_cnt.py)
+#endif
         asm volatile(
             "s_mov_b64 %[sx], exec\n"
             "s_mov_b64 %[busy], 0\n"
             "s_mov_b32 %[cur], 0\n"
             "LOOP_%=:\n"
+#ifdef STR_ER_CONNECT_CNT
+            "s_add_u32 %[n_it], %[n_it], 1\n"
+#endif
             // ---- hand the next entries of the wave's share to its idle lanes (list order, ballot + mbcnt)
             "s_cmp_ge_u32 %[cur], %[m]\n"
             "s_cbranch_scc1 NOHAND_%=\n"
@@ -646,6 +665,9 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
             "s_mov_b64 exec, %[m1]\n"
             "s_cbranch_execz HOPB_%=\n"
             "HOPA_%=:\n"
+#ifdef STR_ER_CONNECT_CNT
+            "s_add_u32 %[n_ha], %[n_ha], 1\n"
+#endif
             "v_lshlrev_b32_sdwa %[t0], %[two], %[wa] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
             "ds_read_b32 %[t1], %[t0]\n"
             "v_mov_b32 %[ka], %[wa]\n"
@@ -661,6 +683,9 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
             "s_mov_b64 exec, %[m2]\n"
             "s_cbranch_execz HOPX_%=\n"
             "HOPBL_%=:\n"
+#ifdef STR_ER_CONNECT_CNT
+            "s_add_u32 %[n_hb], %[n_hb], 1\n"
+#endif
             "v_lshlrev_b32_sdwa %[t0], %[two], %[wb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
             "ds_read_b32 %[t1], %[t0]\n"
             "v_mov_b32 %[kb], %[wb]\n"
@@ -708,8 +733,15 @@ __device__ __forceinline__ void tile_connect_list(uint32_t *s_par, const uint16_
             "s_mov_b64 exec, %[sx]\n"
             : [ka] "=&v"(ka), [kb] "=&v"(kb), [wa] "=&v"(wa), [wb] "=&v"(wb), [aa] "=&v"(aa), [ab] "=&v"(ab), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
               [busy] "=&s"(busy), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [sx] "=&s"(sx), [cur] "=&s"(cur), [tmp] "=&s"(tmp)
+#ifdef STR_ER_CONNECT_CNT
+              , [n_it] "+s"(n_it), [n_ha] "+s"(n_ha), [n_hb] "+s"(n_hb)
+#endif
             : [m] "s"(m), [elist] "s"(lds_addr(s_elist) + 2u * w0), [lev] "s"(lds_addr(s_lev)), [two] "v"(2u), [c64k] "s"(0x10000u)
             : "vcc", "scc", "memory");
+#ifdef STR_ER_CONNECT_CNT
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&g_connect_cnt[0], 1ull); atomicAdd(&g_connect_cnt[1], (unsigned long long)n_it); atomicAdd(&g_connect_cnt[2], (unsigned long long)n_ha);
+                                        atomicAdd(&g_connect_cnt[3], (unsigned long long)n_hb); atomicAdd(&g_connect_cnt[4], (unsigned long long)m); }
+#endif
     }
 #else
     uint32_t       a = 0, b = 0, la = 0, lb = 0;
