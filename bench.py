@@ -194,7 +194,24 @@ def main():
             dist.broadcast(uid, 0)
             if backend != "nccl":
                 raise RuntimeError("not an RCCL run")
-            comm = S.Comm.rccl(dev_index, rank, world, uid.cpu().numpy().tobytes())
+            # (never executed on more than one GPU so far: the communicator is created on a helper thread with a time limit, so that a rank stuck inside
+            # ncclCommInitRank -- a collective: then every rank is -- falls back to torch.distributed with the others instead of hanging the run)
+            import threading
+            box = {}
+
+            def _mk():
+                try:
+                    box["comm"] = S.Comm.rccl(dev_index, rank, world, uid.cpu().numpy().tobytes())
+                except Exception as ee:                           # noqa: BLE001
+                    box["err"] = ee
+            th = threading.Thread(target=_mk, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("STR_ER_BENCH_COMM_TIMEOUT", "90")))
+            if th.is_alive():
+                raise RuntimeError("native RCCL communicator: no answer within the time limit")
+            if "err" in box:
+                raise box["err"]
+            comm = box["comm"]
         except Exception as e:                                    # noqa: BLE001
             print(f"[bench] rank {rank}: native RCCL gather not available ({e}); using torch.distributed", file=sys.stderr, flush=True)
             ok, comm = 0, None
