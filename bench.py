@@ -437,7 +437,9 @@ def main():
         el = time.perf_counter() - t1
         pcie = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
                 "h2d_bytes_per_step": int(frames.size), "h2d_gbs": round(frames.size * args.steps / el / 1e9, 2),
-                "h2d_gbs_link_alone": round(h2d_gbs, 2), "frames_per_s_at_link_rate": round(h2d_gbs * 1e9 / (frames.size / F), 1),
+                # (a torch copy of the same bytes from a torch-pinned tensor, nothing else running: 57 GB/s on most of the round's boxes, 26 on one where the
+                # stream itself -- hipHostMalloc'ed staging, several copies queued -- moved 43: the larger of the two is what the link is known to deliver)
+                "h2d_gbs_link_alone": round(h2d_gbs, 2), "frames_per_s_at_link_rate": round(max(h2d_gbs, frames.size * args.steps / el / 1e9) * 1e9 / (frames.size / F), 1),
                 "note": "host BGR frames in page-locked memory -> str_er_stream (upload of one batch overlaps the kernels of the others)"}
         # ... and the same frames as a video decoder would deliver them: NV12, half the bytes (build-defined ingest, include/str_er.h)
         with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
