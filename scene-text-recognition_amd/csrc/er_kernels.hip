@@ -484,14 +484,28 @@ __device__ unsigned long long g_tile_phase[16];
 #endif
 #else
 #define CNT(i, v) do { } while (0)
-#ifdef STR_ER_STOP_AFTER
+#if defined(STR_ER_WG_TRACE)
+// Developer aid: -DSTR_ER_WG_TRACE: every 997th workgroup of k_tile_tree notes s_memtime at its start (slot 15) and behind every phase, lane 0 only, straight
+// into g_wg_trace (one 8-byte store each, no atomics, nothing kept in registers or LDS: occupancy as in the product); tools/dev_wg_trace.py prints the phases'
+// share of a workgroup's LIFETIME -- which, the kernel needing every workgroup a CU can hold, is what its throughput follows.
+__device__ unsigned long long g_wg_trace[512][16];
+#define PHASE_INIT() const bool tr_on = threadIdx.x == 0 && blockIdx.x % 997u == 0u && blockIdx.x / 997u < 512u; \
+    if (tr_on) g_wg_trace[blockIdx.x / 997u][15] = __builtin_amdgcn_s_memtime()
+#define PHASE_MARK(i) do { if (tr_on) g_wg_trace[blockIdx.x / 997u][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" void str_er_debug_wg_trace(unsigned long long *out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_trace), sizeof(unsigned long long) * 512 * 16);
+    if (reset) { static unsigned long long z[512 * 16]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), z, sizeof(z)); }
+}
+#elif defined(STR_ER_STOP_AFTER)
 // Developer aid: -DSTR_ER_STOP_AFTER=n ends k_tile_tree after phase n (0 load .. 6 seam map) so that the cost of each
 // phase can be read off as a difference of kernel times; only meaningful with STR_ER_DEBUG_TILE_ONLY=1 (str_er_api.cpp).
 #define PHASE_MARK(i) do { if ((i) == STR_ER_STOP_AFTER) return; } while (0)
+#define PHASE_INIT() do { } while (0)
 #else
 #define PHASE_MARK(i) do { } while (0)
-#endif
 #define PHASE_INIT() do { } while (0)
+#endif
 #endif
 
 // Level root of pixel a (level la), with path halving: every same-level hop re-points the
@@ -1410,6 +1424,9 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         // nodes each (301 instructions per wave); here three waves go straight to the barrier behind the fold.  The wave's LDS operations
         // are carried out in the order it issues them, so a level sees the sums of the levels below without any barrier.
         if (tid < 64) {
+            // (measured in place, tools/dev_wg_trace.py: the fold is 13-14 % of a luma workgroup's LIFETIME for 3 % of its instructions -- a chain over the
+            // levels by one wave while three wait.  Raising the wave's priority for it (s_setprio 3, also for the scan of the level counts) shortened it by
+            // 6 % and the kernel not at all: not adopted.)
             uint32_t begin = 0;
             for (int base = 0; base < prm.hi; base += 64) {
                 const uint32_t end = s_hist[base + tid];                 // cursor of level base + lane = where its entries end
@@ -1420,14 +1437,18 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
                     pm &= pm - 1ull;
                     const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
                     for (uint32_t e = begin + (uint32_t)tid; e < e1; e += 64u) {
-                        const uint32_t a = e, pa = s_order[e] >> 20;
+                        // (everything a node needs is requested at once -- ONE trip to LDS per level instead of three dependent ones: the fold is a chain
+                        // over the levels, 14 % of a luma workgroup's lifetime, measured in place: tools/dev_wg_trace.py)
+                        const uint32_t           a = e, en = s_order[e], v = s_w0[a];
+                        const rowmask_t          rw = s_row[a];
+                        const unsigned long long cl = s_col[a];
+                        const uint32_t           pa = en >> 20;
                         if (pa == ORDER_NOPAR) continue;
-                        const uint32_t v = s_w0[a];
                         if (v >> 28) atomicOr(&s_w0[pa], v & 0xF0000000u);       // open: so is the parent, on the same sides
                         else {
                             atomicAdd(&s_w0[pa], v & ((1u << (2 * CNT_BITS)) - 1u));
-                            atomicOr(&s_row[pa], s_row[a]);
-                            atomicOr(&s_col[pa], s_col[a]);
+                            atomicOr(&s_row[pa], rw);
+                            atomicOr(&s_col[pa], cl);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
