@@ -132,6 +132,18 @@ def test_bgr_frame_all_six_planes(erf, oracle, oracle_cascades, S):
     assert res.times.shape == (7,) and res.times[0] > 0 and res.times[6] >= res.times[0]
 
 
+def test_last_tree_stats(erf, S):
+    """str_er_last_tree_stats (measurement aid for bench.py's tree_passes_roofline): tiles and border pairs follow from the plane sizes, the
+    record count is what the tile kernel exported."""
+    frame = S.synth.stext_bgr(S.synth.frame_seed(1), 640, 480)
+    erf.text_detect(frame)
+    st = erf.last_tree_stats()
+    tx, ty = (640 + 63) // 64, (480 + 31) // 32
+    assert st["tiles"] == 6 * tx * ty
+    assert st["seam_pairs"] == 6 * ((ty - 1) * 640 + (tx - 1) * 480)
+    assert 6 * tx * ty <= st["records"] < 6 * 640 * 480
+
+
 def test_compute_channels(erf, oracle, S):
     rng = np.random.default_rng(3)
     for shape in ((1, 1, 3), (7, 13, 3), (48, 64, 3), (33, 101, 3)):
