@@ -3334,26 +3334,35 @@ __device__ __forceinline__ double lane_stage_fast(const CascadeDev &c, int s, co
     const int n = c.stage_n[s];
     const int m = min(n, max(0, c.n_stumps - off));
     double    acc = 0;
+    // (round 4, measured in place with tools/dev_cls_trace.py: the stage sums were 55 % of a workgroup's 140 us -- 137 cycles per stump in the longest stage.
+    // Two dependent waits went: the packed (dim, T) words of the NEXT 64 stumps are requested while this block is summed -- a trip to memory per block had
+    // been waited for at its top --, and a stump's output pair (A, B) is read whole, at an address that does not depend on the histogram byte, and
+    // picked afterwards: one trip to LDS per batch of 8 stumps instead of two.  Same adds in the same order.)
+    int pw_next = (lane < m) ? (int)c.w[off + lane] : 0;
     for (int base = 0; base < m; base += 64) {
-        const int pw = (base + lane < m) ? (int)c.w[off + base + lane] : 0;
+        const int pw = pw_next;
+        if (base + 64 < m) pw_next = (base + 64 + lane < m) ? (int)c.w[off + base + 64 + lane] : 0;
         const int cnt = min(64, m - base);
-        const double *ab = s_ab + 2 * (size_t)(off + base);
+        const double2 *ab = reinterpret_cast<const double2 *>(s_ab + 2 * (size_t)(off + base));
         int j = 0;
         for (; j + 8 <= cnt; j += 8) {
-            double v[8];
+            double2  pr[8];
+            uint32_t hh[8], tt[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, j + u);
-                const uint32_t h = row[w & 1023u];
-                v[u] = ab[2 * (j + u) + (h < (w >> 10) ? 0 : 1)];
+                hh[u] = row[w & 1023u];
+                tt[u] = w >> 10;
+                pr[u] = ab[j + u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 8; ++u) acc += hh[u] < tt[u] ? pr[u].x : pr[u].y;
         }
         for (; j < cnt; ++j) {
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, j);
             const uint32_t h = row[w & 1023u];
-            acc += ab[2 * j + (h < (w >> 10) ? 0 : 1)];
+            const double2  p2 = ab[j];
+            acc += h < (w >> 10) ? p2.x : p2.y;
         }
     }
     return acc;
@@ -3378,7 +3387,13 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
     __shared__ Cls64Shared sh;
     const uint32_t total = list ? *n_list : *b.total_cands;
     const int      tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef STR_ER_WG_TRACE
+#define CLS_MARK(i) do { if (tid == 0 && blockIdx.x % 8u == 0u && blockIdx.x / 8u < 128u) g_wg_trace[384 + blockIdx.x / 8u][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CLS_MARK(i) do { } while (0)
+#endif
     for (uint32_t c0 = blockIdx.x * CLS_PER_BLOCK; c0 < total; c0 += gridDim.x * CLS_PER_BLOCK) {
+        CLS_MARK(0);
 #ifdef STR_ER_PHASE_PROF
         const unsigned long long tp0 = wall_clock64();
 #endif
@@ -3446,6 +3461,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
             }
             __syncthreads();            // every wave's rows are in place; the scratch (aliased by the tables below) is free
         }
+        CLS_MARK(1);
 #ifdef STR_ER_PHASE_PROF
         unsigned long long tp1 = wall_clock64();
         if (tid == 0) atomicAdd(&g_tile_phase[12], tp1 - tp0);
@@ -3457,6 +3473,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
             for (int i = tid; i < 2 * weak.n_stumps; i += CLS64_THREADS) sh.u.ab[2 * strong.n_stumps + i] = weak.ab[i];
             __syncthreads();
         }
+        CLS_MARK(2);
         // stage-parallel form: wave w < S + W sums stage w of the strong cascade or stage w - S of the weak one
         const bool par = fast && strong.n_stages + weak.n_stages <= CLS64_WAVES && strong.n_stages > 0 && weak.n_stages > 0;
         if (par) {
@@ -3467,6 +3484,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
             }
             __syncthreads();
         }
+        CLS_MARK(3);
         if (wv == 0) {
             const uint32_t cpos = c0 + lane;
             const bool     ok = cpos < total;
@@ -3506,6 +3524,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                 if (cls == 2) atomicAdd(&b.ctr[pi].n_weak, 1u);
             }
         }
+        CLS_MARK(4);
         __syncthreads();
     }
 }
