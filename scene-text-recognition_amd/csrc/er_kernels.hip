@@ -3345,6 +3345,30 @@ __device__ __forceinline__ double lane_stage_fast(const CascadeDev &c, int s, co
         const int cnt = min(64, m - base);
         const double2 *ab = reinterpret_cast<const double2 *>(s_ab + 2 * (size_t)(off + base));
         int j = 0;
+        if (cnt == 64) {
+            // a full block: the reads of batch q + 1 are on their way while batch q is summed (the wave of a long stage is soon alone on its SIMD:
+            // nobody else covers its trips to LDS)
+            double2  pr[2][8];
+            uint32_t hh[2][8], tt[2][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, u);
+                hh[0][u] = row[w & 1023u]; tt[0][u] = w >> 10; pr[0][u] = ab[u];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q < 7) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(pw, 8 * (q + 1) + u);
+                        hh[(q + 1) & 1][u] = row[w & 1023u]; tt[(q + 1) & 1][u] = w >> 10; pr[(q + 1) & 1][u] = ab[8 * (q + 1) + u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += hh[q & 1][u] < tt[q & 1][u] ? pr[q & 1][u].x : pr[q & 1][u].y;
+            }
+            j = 64;
+        }
         for (; j + 8 <= cnt; j += 8) {
             double2  pr[8];
             uint32_t hh[8], tt[8];
@@ -3416,11 +3440,15 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                     bx = b.ka.box[4 * ks]; by = b.ka.box[4 * ks + 1]; bw = b.ka.box[4 * ks + 2]; bh = b.ka.box[4 * ks + 3];
                     pix = pd.pix; stride = pd.stride; inv = pd.invert;
                 }
-                uint32_t *hist = sh.u.p1.hist[wv];
                 uint8_t  *tile = sh.u.p1.tile[wv];
-                for (int i = lane; i < 1024; i += 64) hist[i] = 0;
-                for (int i = lane; i < 26 * 26; i += 64) tile[i] = 0;
+                if (it == 0) CLS_MARK(5);
+                uint32_t *rowq = reinterpret_cast<uint32_t *>(sh.rows + (size_t)(it * CLS64_WAVES + wv) * CLS_ROW);
+                // The histogram is counted straight into the ER's packed row: a bin is a byte of it (a cell has 144 pixels, no count passes 255), so a pixel adds
+                // 1 << 8 * (bin & 3) to the dword of its bin -- no carry leaves a byte.
+                for (int k = 0; k < 4; ++k) rowq[lane + 64 * k] = 0;      // (a row starts on a dword, not on 16 bytes: CLS_ROW keeps the rows on different banks)
+                for (int i = lane; i < (26 * 26 + 4) / 4; i += 64) reinterpret_cast<uint32_t *>(tile)[i] = 0;
                 WAVE_SYNC();
+                if (it == 0) CLS_MARK(6);
                 if (ok) {
                     const double R1 = (bw > bh) ? (double)bh / bw : (double)bw / bh;
                     const int    k = (int)(26.0 * sqrt(R1));
@@ -3430,13 +3458,66 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                         const int offx = (dw > dh) ? 0 : (26 - dw) / 2;
                         const ResizeGeom g = resize_geom(bw, bh, dw, dh);
                         const uint8_t *roi = pix + (size_t)by * stride + bx;
-                        for (int i = lane; i < dw * dh; i += 64) {
-                            const int dy = i / dw, dx = i - dy * dw;
-                            tile[(dy + offy) * 26 + dx + offx] = (uint8_t)resize_px(g, roi, stride, inv, dx, dy);
+                        if (__builtin_amdgcn_readfirstlane(g.mode) == 2) {
+                            // The bilinear taps of the <= 26 x 26 tile are SEPARABLE: column dx fixes (sx, sx1, a0, a1), row dy fixes (y0, y1, b0, b1) -- cv::resize's own
+                            // tables.  Lane dx < 32 makes the column entry, lane 32 + dy the row entry, ONCE per ER (resize_px's f64 / f32 arithmetic, unchanged);
+                            // a pixel fetches its two entries by lane shuffle.  Round 4, measured in place (tools/dev_cls_trace.py): the resize was 14 k of an ER's
+                            // 22 k cycles with every pixel redoing that arithmetic, eleven rounds per lane.
+                            uint32_t tab0, tab1;
+                            {
+                                const bool isx = lane < 32;
+                                const int  d = isx ? min(lane, dw - 1) : min(lane - 32, dh - 1);
+                                float f = (float)((d + 0.5) * (isx ? g.scale_x : g.scale_y) - 0.5);
+                                int   q = (int)floorf(f);
+                                f -= (float)q;
+                                if (isx) {
+                                    if (q < 0) { f = 0.f; q = 0; }
+                                    if (q >= g.sw - 1) { f = 0.f; q = g.sw - 1; }
+                                }
+                                const int c0 = __float2int_rn((1.f - f) * 2048.f), c1 = __float2int_rn(f * 2048.f);
+                                const int p0 = isx ? q : min(max(q, 0), g.sh - 1);
+                                const int p1 = isx ? ((q + 1 < g.sw) ? q + 1 : q) : min(max(q + 1, 0), g.sh - 1);
+                                tab0 = (uint32_t)c1 | ((uint32_t)c0 << 16);
+                                tab1 = (uint32_t)p0 | ((uint32_t)p1 << 16);
+                            }
+                            const int      npx = dw * dh;
+                            const uint32_t rcp_dw = (65536u + (uint32_t)dw - 1u) / (uint32_t)dw;
+                            // (this step is bound by instruction issue, 16 waves a CU: moving the box to LDS first, or 16-bit loads of tap pairs, only made it slower)
+                            // four rounds of taps in flight per lane: a round alone waits a full trip to memory (~1300 cycles measured), eleven in a row
+                            for (int i0 = 0; i0 < npx; i0 += 256) {
+                                uint32_t xa[4], ya[4], t00[4], t01[4], t10[4], t11[4];
+                                int      dst[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int i = i0 + 64 * u + lane, ii = i < npx ? i : 0;
+                                    const int dy = (int)(((uint32_t)ii * rcp_dw) >> 16), dx = ii - dy * dw;     // ii / dw: exact while ii * dw < 65536
+                                    xa[u] = (uint32_t)__shfl((int)tab0, dx);
+                                    ya[u] = (uint32_t)__shfl((int)tab0, 32 + dy);
+                                    const uint32_t xb = (uint32_t)__shfl((int)tab1, dx), yb = (uint32_t)__shfl((int)tab1, 32 + dy);
+                                    const uint32_t o0 = (yb & 0xFFFFu) * (uint32_t)stride, o1 = (yb >> 16) * (uint32_t)stride;     // (32-bit offsets from the uniform base)
+                                    const uint32_t sx = xb & 0xFFFFu, sx1 = xb >> 16;
+                                    t00[u] = roi[o0 + sx], t01[u] = roi[o0 + sx1], t10[u] = roi[o1 + sx], t11[u] = roi[o1 + sx1];
+                                    dst[u] = i < npx ? (dy + offy) * 26 + dx + offx : -1;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int a0 = (int)(xa[u] >> 16), a1 = (int)(xa[u] & 0xFFFFu), b0 = (int)(ya[u] >> 16), b1 = (int)(ya[u] & 0xFFFFu);
+                                    const int r0 = (int)(t00[u] ^ inv) * a0 + (int)(t01[u] ^ inv) * a1;
+                                    const int r1 = (int)(t10[u] ^ inv) * a0 + (int)(t11[u] ^ inv) * a1;
+                                    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                                    if (dst[u] >= 0) tile[dst[u]] = (uint8_t)min(max(v, 0), 255);
+                                }
+                            }
+                        } else {
+                            for (int i = lane; i < dw * dh; i += 64) {
+                                const int dy = i / dw, dx = i - dy * dw;
+                                tile[(dy + offy) * 26 + dx + offx] = (uint8_t)resize_px(g, roi, stride, inv, dx, dy);
+                            }
                         }
                     }
                 }
                 WAVE_SYNC();
+                if (it == 0) CLS_MARK(7);
                 if (ok) {
                     for (int idx = lane; idx < 24 * 24; idx += 64) {
                         const int i = idx / 24, j = idx - i * 24;
@@ -3444,20 +3525,23 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                         const int v0 = tile[cpos - 25], v1 = tile[cpos - 24], v2 = tile[cpos - 23], v3 = tile[cpos + 1];
                         const int v4 = tile[cpos + 25], v5 = tile[cpos + 24], v6 = tile[cpos + 23], v7 = tile[cpos - 1];
                         const int sum = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
-                        const int code = (8 * v0 > sum) | ((8 * v1 > sum) << 1) | ((8 * v2 > sum) << 2) | ((8 * v3 > sum) << 3) |
-                                         ((8 * v4 > sum) << 4) | ((8 * v5 > sum) << 5) | ((8 * v6 > sum) << 6) | ((8 * v7 > sum) << 7);
-                        atomicAdd(&hist[(i / 12) * 512 + (j / 12) * 256 + code], 1u);
+                        // bit k = (8 * v_k > sum) = the sign of sum - 8 * v_k, shifted in from the right, v7 first (v_alignbit: one instruction a bit)
+                        uint32_t code = 0;
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v7), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v6), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v5), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v4), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v3), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v2), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v1), 31);
+                        code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v0), 31);
+                        const uint32_t bin = (uint32_t)((i / 12) * 512 + (j / 12) * 256) + code;
+                        atomicAdd(&rowq[bin >> 2], 1u << (8u * (bin & 3u)));
                     }
                 }
                 WAVE_SYNC();
-                if (ok) {
-                    uint8_t *row = sh.rows + (size_t)(it * CLS64_WAVES + wv) * CLS_ROW;
-                    for (int i = lane; i < 256; i += 64) {     // 4 bins per lane per step, one 32-bit store
-                        const uint32_t v = hist[4 * i] | (hist[4 * i + 1] << 8) | (hist[4 * i + 2] << 16) | (hist[4 * i + 3] << 24);
-                        *reinterpret_cast<uint32_t *>(row + 4 * i) = v;
-                    }
-                }
-                WAVE_SYNC();
+                if (it == 0) CLS_MARK(8);
+                if (it == 0) CLS_MARK(9);
             }
             __syncthreads();            // every wave's rows are in place; the scratch (aliased by the tables below) is free
         }

@@ -23,3 +23,13 @@ print(f"lifetime mean {life.mean():.0f} ticks")
 for i, n in enumerate(["phase 1 (LBP histograms)", "(A,B) tables into LDS", "stage sums", "cascade rule + records"]):
     dt = t[:, i + 1] - t[:, i]
     print(f"  {n:28s} {dt.mean():9.0f} ticks {100 * dt.mean() / life.mean():5.1f} %")
+for a, b, n in ((5, 6, "first ER: zero the scratch"), (6, 7, "first ER: ARAN resize"), (7, 8, "first ER: LBP + histogram"), (8, 9, "first ER: pack the row")):
+    dt = t[:, b] - t[:, a]
+    print(f"  {n:28s} {dt.mean():9.0f} ticks")
+try:
+    c = r.cands
+    a = (c["w"].astype(np.int64) * c["h"])
+    print("candidates", len(c), "box area percentiles 10/50/90/99:", np.percentile(a, [10, 50, 90, 99]).astype(int), " share with w*h <= 4096:", float((a <= 4096).mean()),
+          " w<=26&h<=26:", float(((c["w"] <= 26) & (c["h"] <= 26)).mean()))
+except Exception as e:
+    print("no cands:", type(r), [k for k in dir(r) if not k.startswith("_")][:20], e)
