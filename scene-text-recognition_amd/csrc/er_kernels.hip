@@ -3478,34 +3478,42 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                                 const int p0 = isx ? q : min(max(q, 0), g.sh - 1);
                                 const int p1 = isx ? ((q + 1 < g.sw) ? q + 1 : q) : min(max(q + 1, 0), g.sh - 1);
                                 tab0 = (uint32_t)c1 | ((uint32_t)c0 << 16);
-                                tab1 = (uint32_t)p0 | ((uint32_t)p1 << 16);
+                                // columns: (sx, sx1); rows: the byte offset of row y0 from the box's corner, bit 31: y1 is the next row (not clamped onto y0)
+                                tab1 = isx ? (uint32_t)p0 | ((uint32_t)p1 << 16) : (uint32_t)p0 * (uint32_t)stride | (p1 != p0 ? 0x80000000u : 0u);
                             }
                             const int      npx = dw * dh;
                             const uint32_t rcp_dw = (65536u + (uint32_t)dw - 1u) / (uint32_t)dw;
-                            // (this step is bound by instruction issue, 16 waves a CU: moving the box to LDS first, or 16-bit loads of tap pairs, only made it slower)
-                            // four rounds of taps in flight per lane: a round alone waits a full trip to memory (~1300 cycles measured), eleven in a row
+                            // the box's corner is the same for the whole wave: a scalar base, 32-bit lane offsets
+                            typedef const __attribute__((address_space(1))) uint8_t *gbytes_t;
+                            const uintptr_t roi_u = reinterpret_cast<uintptr_t>(roi);
+                            const gbytes_t  groi = (gbytes_t)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(roi_u >> 32)) << 32) |
+                                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)roi_u));
+                            // This step is bound by instruction issue, 16 waves a CU (moving the box to LDS first, or 16-bit loads of tap pairs, made it slower): every
+                            // product here fits 24 bits -- v_mul_u32_u24 is a full-rate instruction, the 32-bit multiply a quarter-rate one.
+                            // Four rounds of taps in flight per lane: a round alone waits a full trip to memory (~1300 cycles measured), eleven in a row.
                             for (int i0 = 0; i0 < npx; i0 += 256) {
                                 uint32_t xa[4], ya[4], t00[4], t01[4], t10[4], t11[4];
                                 int      dst[4];
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    const int i = i0 + 64 * u + lane, ii = i < npx ? i : 0;
-                                    const int dy = (int)(((uint32_t)ii * rcp_dw) >> 16), dx = ii - dy * dw;     // ii / dw: exact while ii * dw < 65536
-                                    xa[u] = (uint32_t)__shfl((int)tab0, dx);
-                                    ya[u] = (uint32_t)__shfl((int)tab0, 32 + dy);
-                                    const uint32_t xb = (uint32_t)__shfl((int)tab1, dx), yb = (uint32_t)__shfl((int)tab1, 32 + dy);
-                                    const uint32_t o0 = (yb & 0xFFFFu) * (uint32_t)stride, o1 = (yb >> 16) * (uint32_t)stride;     // (32-bit offsets from the uniform base)
+                                    const int      i = i0 + 64 * u + lane;
+                                    const uint32_t ii = i < npx ? (uint32_t)i : 0u;
+                                    const uint32_t dy = __umul24(ii, rcp_dw) >> 16, dx = ii - __umul24(dy, (uint32_t)dw);     // ii / dw: exact while ii * dw < 65536
+                                    xa[u] = (uint32_t)__shfl((int)tab0, (int)dx);
+                                    ya[u] = (uint32_t)__shfl((int)tab0, (int)(32u + dy));
+                                    const uint32_t xb = (uint32_t)__shfl((int)tab1, (int)dx), yb = (uint32_t)__shfl((int)tab1, (int)(32u + dy));
+                                    const uint32_t o0 = yb & 0x7FFFFFFFu, o1 = o0 + ((yb >> 31) ? (uint32_t)stride : 0u);
                                     const uint32_t sx = xb & 0xFFFFu, sx1 = xb >> 16;
-                                    t00[u] = roi[o0 + sx], t01[u] = roi[o0 + sx1], t10[u] = roi[o1 + sx], t11[u] = roi[o1 + sx1];
-                                    dst[u] = i < npx ? (dy + offy) * 26 + dx + offx : -1;
+                                    t00[u] = groi[o0 + sx], t01[u] = groi[o0 + sx1], t10[u] = groi[o1 + sx], t11[u] = groi[o1 + sx1];
+                                    dst[u] = i < npx ? (int)(__umul24(dy + (uint32_t)offy, 26u) + dx + (uint32_t)offx) : -1;
                                 }
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    const int a0 = (int)(xa[u] >> 16), a1 = (int)(xa[u] & 0xFFFFu), b0 = (int)(ya[u] >> 16), b1 = (int)(ya[u] & 0xFFFFu);
-                                    const int r0 = (int)(t00[u] ^ inv) * a0 + (int)(t01[u] ^ inv) * a1;
-                                    const int r1 = (int)(t10[u] ^ inv) * a0 + (int)(t11[u] ^ inv) * a1;
-                                    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                                    if (dst[u] >= 0) tile[dst[u]] = (uint8_t)min(max(v, 0), 255);
+                                    const uint32_t a0 = xa[u] >> 16, a1 = xa[u] & 0xFFFFu, b0 = ya[u] >> 16, b1 = ya[u] & 0xFFFFu;
+                                    const uint32_t r0 = __umul24(t00[u] ^ (uint32_t)inv, a0) + __umul24(t01[u] ^ (uint32_t)inv, a1);        // <= 255 * 2049
+                                    const uint32_t r1 = __umul24(t10[u] ^ (uint32_t)inv, a0) + __umul24(t11[u] ^ (uint32_t)inv, a1);
+                                    const uint32_t v = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2;           // (nothing is negative here)
+                                    if (dst[u] >= 0) tile[dst[u]] = (uint8_t)min(v, 255u);
                                 }
                             }
                         } else {
@@ -3520,8 +3528,8 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                 if (it == 0) CLS_MARK(7);
                 if (ok) {
                     for (int idx = lane; idx < 24 * 24; idx += 64) {
-                        const int i = idx / 24, j = idx - i * 24;
-                        const int cpos = (i + 1) * 26 + (j + 1);
+                        const int i = (int)(__umul24((uint32_t)idx, 2731u) >> 16), j = idx - (int)__umul24((uint32_t)i, 24u);      // idx / 24, exact below 576
+                        const int cpos = (int)__umul24((uint32_t)i + 1u, 26u) + (j + 1);
                         const int v0 = tile[cpos - 25], v1 = tile[cpos - 24], v2 = tile[cpos - 23], v3 = tile[cpos + 1];
                         const int v4 = tile[cpos + 25], v5 = tile[cpos + 24], v6 = tile[cpos + 23], v7 = tile[cpos - 1];
                         const int sum = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
@@ -3535,7 +3543,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
                         code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v2), 31);
                         code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v1), 31);
                         code = __builtin_amdgcn_alignbit(code, (uint32_t)(sum - 8 * v0), 31);
-                        const uint32_t bin = (uint32_t)((i / 12) * 512 + (j / 12) * 256) + code;
+                        const uint32_t bin = (i >= 12 ? 512u : 0u) + (j >= 12 ? 256u : 0u) + code;
                         atomicAdd(&rowq[bin >> 2], 1u << (8u * (bin & 3u)));
                     }
                 }
