@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
             const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)s0), hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)s0);
             const uint32_t L = __builtin_amdgcn_perm(hi, lo, selL), R = __builtin_amdgcn_perm(hi, lo, selR);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) h[k] = (int)((L >> (8 * k)) & 0xFFu) * a0[k] + (int)((R >> (8 * k)) & 0xFFu) * a1[k];
+            for (int k = 0; k < 4; ++k) h[k] = (int)(__umul24((L >> (8 * k)) & 0xFFu, (uint32_t)a0[k]) + __umul24((R >> (8 * k)) & 0xFFu, (uint32_t)a1[k]));
         };
         int ca = -1, cb = -1;               // source rows whose sums are in hA / hB (rows are >= 0)
         int hA[4] = {0, 0, 0, 0}, hB[4] = {0, 0, 0, 0};
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
             uint32_t v = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int o = min(max((((b0 * (hA[k] >> 4)) >> 16) + ((b1 * (hB[k] >> 4)) >> 16) + 2) >> 2, 0), 255);
+                const int o = min((int)(((__umul24((uint32_t)b0, (uint32_t)hA[k] >> 4) >> 16) + (__umul24((uint32_t)b1, (uint32_t)hB[k] >> 4) >> 16) + 2u) >> 2), 255);
                 v |= (uint32_t)o << (8 * k);
             }
             uint8_t *o = d + (size_t)dy * dstride + dx0;
@@ -388,18 +388,18 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
             const uint8_t *p0 = lds + (ya - y_lo) * (RS_WORDS * 4) - x_lo, *p1 = lds + (yb - y_lo) * (RS_WORDS * 4) - x_lo;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
-                const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
-                const int o = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+                const uint32_t r0 = __umul24(p0[sx[k]], (uint32_t)a0[k]) + __umul24(p0[sx1[k]], (uint32_t)a1[k]);
+                const uint32_t r1 = __umul24(p1[sx[k]], (uint32_t)a0[k]) + __umul24(p1[sx1[k]], (uint32_t)a1[k]);
+                const int o = min((int)(((__umul24((uint32_t)b0, r0 >> 4) >> 16) + (__umul24((uint32_t)b1, r1 >> 4) >> 16) + 2u) >> 2), 255);
                 v |= (uint32_t)o << (8 * k);
             }
         } else {
             const uint8_t *p0 = s + (size_t)ya * sstride, *p1 = s + (size_t)yb * sstride;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
-                const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
-                const int o = min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+                const uint32_t r0 = __umul24(p0[sx[k]], (uint32_t)a0[k]) + __umul24(p0[sx1[k]], (uint32_t)a1[k]);
+                const uint32_t r1 = __umul24(p1[sx[k]], (uint32_t)a0[k]) + __umul24(p1[sx1[k]], (uint32_t)a1[k]);
+                const int o = min((int)(((__umul24((uint32_t)b0, r0 >> 4) >> 16) + (__umul24((uint32_t)b1, r1 >> 4) >> 16) + 2u) >> 2), 255);
                 v |= (uint32_t)o << (8 * k);
             }
         }
@@ -2203,6 +2203,7 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
     const uint32_t  n = plane_nodes(b, pi);
     NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
     uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
+    uint32_t       *arr = b.na.arr + b.planes[pi].node_base;
     const int       lane = threadIdx.x & 63;
     for (uint32_t x0 = bi * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += nbp * blockDim.x) {
         const uint32_t  x = x0 + (uint32_t)lane;
@@ -2210,6 +2211,7 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
         uint32_t        hand_to = NONE;         // the surviving level root this (unified) node hands its own statistics to
         uint32_t        c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0, ky = 0xFFFFFFFFu;
         if (x < n) {
+            arr[x] = 0;                          // k_reduce's arrival counter (every record is visited exactly once here)
             const NodeRec   me = nr[x];          // (plain loads: k_seam's writes are visible since the kernel boundary, and a parent
             const uint32_t  l = me.key >> 24;    //  word rewritten by a lane of THIS kernel points to the same node either way)
             const uint32_t  w = me.par;
@@ -2285,16 +2287,15 @@ void launch_resolve(hipStream_t s, const BatchDev &b)
 }
 
 // er_merge's accumulation (src/ER.cpp:153-165): every live open node adds its (final) totals to its parent.  One launch for
-// the whole tree: aux[q] counts the children of q that still have to push (k_resolve).  A node may push once its counter is 0;
-// whoever CLAIMS it (CAS 0 -> CLAIMED) does: the lane that meets it in the node sweep, or the lane whose push just brought the
-// counter to 0 and that then carries on towards the root.  Every word involved -- totals, counters -- is only ever touched with
+// the whole tree: aux[q] is the number of children of q that push (k_resolve; constant here), arr[q] how many of them have.  A node nobody pushes into
+// is taken by the lane that meets it in the node sweep; a node with children belongs to the lane whose push completed the count, and that lane carries on
+// towards the root.  Every word that changes -- totals, arrival counters -- is only ever touched with
 // agent-scope atomics, which are performed at the device's coherence point (the per-XCD L2s are not coherent with each other), so
-// no cache has to be written back or invalidated: the ordering "my pushes, then my decrement" / "the claim, then my reads" only
+// no cache has to be written back or invalidated: the ordering "my pushes, then my arrival" / "the arrival, then my reads" only
 // needs the lane to wait for its own outstanding operations (a workgroup-scope fence = s_waitcnt; an agent-scope acquire /
 // release would write back and invalidate the whole L2 per node -- measured: 20 ms instead of 0.5 per batch).
 // (Round 1 launched once per level: ~32 dependent launches per batch -- the whole cost of the step on small batches and on noise.)
 #define RMW_AGENT(op, p, v) __hip_atomic_fetch_##op((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-constexpr uint32_t NODE_CLAIMED = 0xFFFFFFFFu;
 
 // The pushes are RETURNING atomics and node_arrive makes the counter decrement depend on what they returned: a returned value
 // comes from the coherence point, so the push has been performed there before the decrement is even issued.  (Waiting for the
@@ -2317,20 +2318,17 @@ __device__ __forceinline__ void node_totals(const NodeRec *n, uint32_t &c, uint3
     c = (uint32_t)cn; nodw = (uint32_t)(cn >> 32);
     bx0 = (uint32_t)a; by0 = (uint32_t)(a >> 32); bx1 = (uint32_t)z; by1 = (uint32_t)(z >> 32);
 }
-__device__ __forceinline__ bool node_claim(uint32_t *ctr)
-{
-    uint32_t expect = 0;
-    uint32_t won = __hip_atomic_compare_exchange_strong(ctr, &expect, NODE_CLAIMED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
-    asm volatile("" : "+v"(won) : : "memory");       // the reads of the node's totals are issued after the claim has returned
-    return won != 0;
-}
-// children done: `k` of them just pushed into the node with counter `ctr` (`pushed` = what node_push returned); true if the
-// caller now owns the node
-__device__ __forceinline__ bool node_arrive(uint32_t *ctr, uint32_t k, uint32_t pushed)
+// children done: `k` of them just pushed into a node (`pushed` = what node_push returned) that waits for `expect` of them in all; true if these were the
+// last ones: the caller now owns the node.  (Until round 4 the children counted the parent's counter DOWN and the one that reached 0 then had to CLAIM the
+// node with a compare-and-swap, against the sweep lane that might meet the 0 at the same moment: a fourth dependent trip to the coherence point per level of
+// every chain.  Counting the arrivals up in a word of their own leaves k_resolve's count untouched: a childless node is simply one whose count is 0 -- the
+// sweep takes it without any atomic --, and the arrival that completes the count owns the parent: totals, push, arrival -- three trips per level.)
+__device__ __forceinline__ bool node_arrive(uint32_t *arrived, uint32_t expect, uint32_t k, uint32_t pushed)
 {
     asm volatile("" : "+v"(k) : "v"(pushed) : "memory");
-    if (__hip_atomic_fetch_sub(ctr, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != k) return false;
-    return node_claim(ctr);
+    uint32_t won = __hip_atomic_fetch_add(arrived, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + k == expect ? 1u : 0u;
+    asm volatile("" : "+v"(won) : : "memory");       // the reads of the node's totals are issued after the arrival has returned
+    return won != 0;
 }
 
 __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
@@ -2339,7 +2337,8 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
     const uint32_t  bi = blockIdx.x - b.planes[pi].nb_base, nbp = b.planes[pi].nb_count;
     const uint32_t  n = plane_nodes(b, pi);
     NodeRec        *nr = b.na.rec + b.planes[pi].node_base;
-    uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
+    const uint32_t *aux = b.na.aux + b.planes[pi].node_base;       // (constant here: plain loads)
+    uint32_t       *arr = b.na.arr + b.planes[pi].node_base;
     const int       lane = threadIdx.x & 63;
     for (uint32_t x0 = bi * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += nbp * blockDim.x) {
         const uint32_t x = x0 + lane;
@@ -2347,8 +2346,8 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
         uint32_t q = NONE, c = 0, nd = 0, bx0 = 0xFFFFFFFFu, by0 = 0xFFFFFFFFu, bx1 = 0, by1 = 0;
         if (x < n) {
             const uint32_t w = nr[x].par, f = nr[x].nod;          // parent and flags are final since k_resolve
-            // (the claim itself tells whether the node is ready: a counter that is not 0 makes it fail)
-            act = w != NONE && !(f & (NODE_DEAD | NODE_CLOSED)) && node_claim(&aux[x]);
+            // (a node nobody pushes into is ready; the others are taken by their last child)
+            act = w != NONE && !(f & (NODE_DEAD | NODE_CLOSED)) && aux[x] == 0u;
             if (act) {
                 q = PAR_ID(w);
                 node_totals(nr + x, c, nd, bx0, by0, bx1, by1);
@@ -2366,12 +2365,12 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
             const unsigned long long m = __ballot(mine);
             const uint32_t k = (uint32_t)__popcll(m);
             if (k == 1) {
-                if (mine) cont = node_arrive(&aux[lq], 1u, node_push(nr + lq, c, nd, bx0, by0, bx1, by1));
+                if (mine) { const uint32_t ex = aux[lq]; cont = node_arrive(&arr[lq], ex, 1u, node_push(nr + lq, c, nd, bx0, by0, bx1, by1)); }
             } else {
                 const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
                 const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
                 const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
-                if (lane == leader) cont = node_arrive(&aux[lq], k, node_push(nr + lq, sc, sn, mx0, my0, mx1, my1));
+                if (lane == leader) { const uint32_t ex = aux[lq]; cont = node_arrive(&arr[lq], ex, k, node_push(nr + lq, sc, sn, mx0, my0, mx1, my1)); }
             }
             todo &= ~m;
         }
@@ -2383,7 +2382,8 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
             node_totals(nr + g, gc, gf, gx0, gy0, gx1, gy1);
             if (w == NONE || (gf & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
             const uint32_t p = PAR_ID(w);
-            cont = node_arrive(&aux[p], 1u, node_push(nr + p, gc, gf & NODE_CNT, gx0, gy0, gx1, gy1));
+            const uint32_t ex = aux[p];
+            cont = node_arrive(&arr[p], ex, 1u, node_push(nr + p, gc, gf & NODE_CNT, gx0, gy0, gx1, gy1));
             g = p;
         }
     }

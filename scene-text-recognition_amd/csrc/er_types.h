@@ -106,7 +106,8 @@ constexpr uint32_t NODE_SIDES = NODE_SIDE_T | NODE_SIDE_B | NODE_SIDE_L | NODE_S
 constexpr uint32_t NODE_CNT = 0xFFFFFFu;
 struct NodeArrays {
     NodeRec  *rec;
-    uint32_t *aux;          // per node: open pushing children not yet accumulated (k_resolve -> k_reduce), then node id -> kept slot (k_select -> k_kept)
+    uint32_t *aux;          // per node: its open children that push their totals (counted by k_resolve, constant through k_reduce), then node id -> kept slot (k_select -> k_kept)
+    uint32_t *arr;          // per node: how many of those children have pushed so far (zeroed by k_resolve, counted by k_reduce)
 };
 
 // Kept-node storage (index = PlaneDesc::kept_base + slot).

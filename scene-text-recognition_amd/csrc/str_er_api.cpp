@@ -208,18 +208,19 @@ template <typename T> int dev_alloc(str_er_ctx *c, T *&p, size_t n)
     return STR_ER_OK;
 }
 
-// The node records (32 B + 4 B per record) are the one part of the workspace whose need depends on the frames' content: they
+// The node records (32 B + 2 x 4 B per record) are the one part of the workspace whose need depends on the frames' content: they
 // are allocated for `node_share` records per pixel and re-allocated larger when a batch overflows them (run_batch).
 int alloc_node_records(str_er_ctx *c, size_t n)
 {
     if (c->na.rec) { (void)hipFree(c->na.rec); c->ws_bytes -= (int64_t)(c->node_slots * sizeof(NodeRec)); c->na.rec = nullptr; }
-    if (c->na.aux) { (void)hipFree(c->na.aux); c->ws_bytes -= (int64_t)(c->node_slots * 4); c->na.aux = nullptr; }
+    if (c->na.aux) { (void)hipFree(c->na.aux); c->ws_bytes -= (int64_t)(c->node_slots * 8); c->na.aux = nullptr; c->na.arr = nullptr; }
     c->node_slots = 0;
     if (hipMalloc(reinterpret_cast<void **>(&c->na.rec), n * sizeof(NodeRec)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->na.aux), n * 4) != hipSuccess)
-        return fail(c, STR_ER_ENOMEM, "hipMalloc (node records, " + std::to_string(n * 36) + " bytes)");
+        hipMalloc(reinterpret_cast<void **>(&c->na.aux), n * 8) != hipSuccess)
+        return fail(c, STR_ER_ENOMEM, "hipMalloc (node records, " + std::to_string(n * 40) + " bytes)");
+    c->na.arr = c->na.aux + n;
     c->node_slots = n;
-    c->ws_bytes += (int64_t)(n * 36);
+    c->ws_bytes += (int64_t)(n * 40);
     return STR_ER_OK;
 }
 
