@@ -2555,6 +2555,12 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
 {
     __shared__ uint32_t s_npool, s_alt_amb, s_alt_node, s_alt_nc, s_alt_diff;
     __shared__ uint32_t s_levels[8];
+#ifdef STR_ER_WG_TRACE
+#define NMS_MARK(i) do { if (threadIdx.x == 0 && pass == NMS_PASS_FIRST && blockIdx.x < 128u) g_wg_trace[128 + blockIdx.x][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NMS_MARK(i) do { } while (0)
+#endif
+    NMS_MARK(0);
     const bool       pass1 = pass != NMS_PASS_FIRST;          // a repeat: the plane's counters stay as the first pass left them
     const bool       alt = pass == NMS_PASS_ALT;
     // (the opposite-rule pass runs on the handful of planes k_alt_list found, `scratch` = its list: one workgroup per listed plane instead
@@ -2602,18 +2608,100 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     for (int i = tid; i < 8; i += NMS_THREADS) s_levels[i] = 0;
     if (tid == 0) { s_npool = 0; s_alt_amb = 0; s_alt_node = NONE; s_alt_nc = 0; s_alt_diff = 0; }
     __syncthreads();
+    // LDS planes (all but noise-like full-size ones): the static facts of the <= 4 nodes a thread owns -- level, parent, key, its box area and the
+    // parent's -- stay in registers, and the box area of every chain start sits beside the start.  Round 4, traced in place (tools/dev_nms_trace.py): the level
+    // loop was 70 % of the kernel -- 5.4 k cycles a level on the largest plane of a frame -- because every level re-read the levels of ALL nodes from memory
+    // and walked generic pointers; the chain evaluation, one thread per chain with a division per step, another 20 %.
+    constexpr int NPT = NMS_LDS_CAP / NMS_THREADS;
+    __shared__ int s_nsa[NMS_LDS_CAP];                   // box area of kstart[i]
+    int      lev_r[NPT], area_r[NPT], parea_r[NPT];
+    uint32_t par_r[NPT], key_r[NPT];
+    // (the nodes are handed out in level order -- a counting sort in LDS: the nodes of one level then sit in neighbouring lanes of one or two of a thread's
+    // four turns, and a level costs the waves that have nodes there one pass of the loop body instead of four)
+    __shared__ uint32_t s_lcur[256];
+    __shared__ uint16_t s_perm[NMS_LDS_CAP];
+    uint32_t node_r[NPT];
+    if (in_lds && tid < 256) s_lcur[tid] = 0;
+    if (in_lds) __syncthreads();
     for (uint32_t i = tid; i < K; i += NMS_THREADS) {
         kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull;
-        if (in_lds) { s_npar[i] = b.ka.parent[kb + i]; s_narea[i] = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]; }
+        if (in_lds) { s_npar[i] = b.ka.parent[kb + i]; s_nsa[i] = s_narea[i] = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]; atomicAdd(&s_lcur[klev[i]], 1u); }
         atomicOr(&s_levels[klev[i] >> 5], 1u << (klev[i] & 31));
     }
     __syncthreads();
+    if (in_lds) {
+        if (tid < 64) {              // counts -> first positions: four levels a lane, a scan over the wave
+            const uint32_t c0 = s_lcur[4 * tid], c1 = s_lcur[4 * tid + 1], c2 = s_lcur[4 * tid + 2], c3 = s_lcur[4 * tid + 3], tot = c0 + c1 + c2 + c3;
+            uint32_t incl = tot;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (tid >= d) incl += o; }
+            const uint32_t e = incl - tot;
+            s_lcur[4 * tid] = e; s_lcur[4 * tid + 1] = e + c0; s_lcur[4 * tid + 2] = e + c0 + c1; s_lcur[4 * tid + 3] = e + c0 + c1 + c2;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) s_perm[atomicAdd(&s_lcur[klev[i]], 1u)] = (uint16_t)i;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const uint32_t pos = (uint32_t)tid + (uint32_t)k * NMS_THREADS;
+            lev_r[k] = -1; node_r[k] = 0; par_r[k] = 0; key_r[k] = 0; area_r[k] = 1; parea_r[k] = 1;
+            if (pos < K) {
+                const uint32_t i = s_perm[pos];
+                node_r[k] = i; lev_r[k] = klev[i]; par_r[k] = (uint32_t)s_npar[i]; key_r[k] = kkey[i]; area_r[k] = s_narea[i]; parea_r[k] = s_narea[par_r[k]];
+            }
+        }
+    }
+    // (double)as / (double)ap > overlap_coef, the reference's test (src/ER.cpp:452), without the division unless the quotient is within 1e-9 of the coefficient
+    auto ratio_gt = [&](int as, int ap) -> bool {
+        const double x = (double)as, y = (double)ap, d = x - prm.overlap_coef * y;
+        if (fabs(d) > 1e-9 * y) return d > 0.0;
+        return x / y > prm.overlap_coef;
+    };
+    NMS_MARK(1);
 
     for (int t = 0; t <= maxl; ++t) {
         if (!((s_levels[t >> 5] >> (t & 31)) & 1)) continue;      // no kept node at this level
         // settle the nodes of level t (all their children, at lower levels, have proposed), then
         // let them propose to their parents; one barrier per level is enough because a node only
         // reads what lower levels wrote and only writes to higher levels
+        if (in_lds) {
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                if (lev_r[k] != t) continue;
+                const uint32_t i = node_r[k];
+                const uint32_t nc = s_nncand[i];
+                const uint32_t child = (uint32_t)(s_nbest[i] & 0xFFFFFFFFull);
+                uint32_t s = i;
+                int      as = area_r[k];
+                if (nc) {
+                    s = s_nstart[child]; as = s_nsa[child];
+                    s_nstart[i] = s; s_nsa[i] = as;
+                    if (nc > 1 && !pass1) {
+                        atomicAdd(&c.n_amb, 1u);
+                        c.tie_node = i; c.tie_nc = nc;
+                        if ((double)area_r[k] * prm.overlap_coef < rel_area) atomicAdd(&c.n_rel, 1u);
+                    }
+                    if (nc > 1 && alt) { atomicAdd(&s_alt_amb, 1u); s_alt_node = i; s_alt_nc = nc; }
+                }
+                if (i == root) continue;
+                const uint32_t P = par_r[k];
+                const int      ap = parea_r[k];
+                if (ratio_gt(as, ap)) {
+                    atomicAdd(&s_nncand[P], 1u);
+                    uint32_t ord;
+                    if (ord_mode == NMS_ORD_STAMP) {                             // entered last = first in the child list
+                        uint32_t st = 0;
+                        if (!sparse) st = stamp[key_r[k]];
+                        else if (ratio_gt(area_r[k], ap)) {                      // (only such children are watched)
+                            for (uint32_t j = 0; j < n_watch; ++j) if (s_wkey[j] == key_r[k]) { st = s_wstamp[j]; break; }
+                        }
+                        ord = ~st;
+                    }
+                    else if (ord_mode == NMS_ORD_INDEX) ord = i;
+                    else ord = ord_mode == NMS_ORD_KEY_MAX ? ~key_r[k] : key_r[k];
+                    atomicMin(&s_nbest[P], ((unsigned long long)ord << 32) | i);
+                }
+            }
+        } else
         for (uint32_t i = tid; i < K; i += NMS_THREADS) {
             if (klev[i] != t) continue;
             uint32_t s = i;
@@ -2653,6 +2741,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         __syncthreads();
     }
 
+    NMS_MARK(2);
     // planes with ties (exact mode only needs it): the key pixels the flood replay has to reach.  Which ties occur can depend
     // on how lower ties were decided, so the list holds every child that COULD compete whatever the order: a chain start
     // lies inside its child's box, so only children whose own box covers more than OVERLAP_COEF of the parent's can pass, and
@@ -2679,8 +2768,50 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         __syncthreads();
     }
 
+    NMS_MARK(3);
     // evaluate every chain from its start (src/ER.cpp:464-497)
     const int T = prm.stability_t;
+    if (in_lds) {
+        // Every member of a chain whose T-th ancestor is still in the chain has a stability of its own: all of them at once, a division each; the chain's
+        // winner -- largest stability, then smallest box, then lowest (src/ER.cpp:470-484 keeps the earlier one; along a chain the boxes only grow, so
+        // "lowest level" decides both) -- by two rounds of LDS atomics on the slot of the chain's start.  A stability is positive or +inf: 0 = "none yet".
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) { s_nbest[i] = 0ull; s_nncand[i] = 0xFFFFFFFFu; }
+        __syncthreads();
+        unsigned long long st_r[NPT];
+        uint32_t           X_r[NPT];
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const uint32_t i = node_r[k];
+            st_r[k] = 0ull; X_r[k] = 0;
+            if (lev_r[k] < 0) continue;
+            const uint32_t X = s_nstart[i];
+            uint32_t       anc = i;
+            bool           ok = true;
+            for (int j = 0; j < T; ++j) { if (anc == root) { ok = false; break; } anc = (uint32_t)s_npar[anc]; }
+            if (!ok || s_nstart[anc] != X) continue;
+            const int    a = area_r[k], bb = s_narea[anc];
+            const double st = (double)a / (double)(bb - a);   // 0 denominator -> +inf, as in the reference
+            st_r[k] = (unsigned long long)__double_as_longlong(st); X_r[k] = X;
+            atomicMax(&s_nbest[X], st_r[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            if (st_r[k] != 0ull && st_r[k] == s_nbest[X_r[k]]) atomicMin(&s_nncand[X_r[k]], ((uint32_t)lev_r[k] << 16) | node_r[k]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const uint32_t best = node_r[k];
+            if (st_r[k] == 0ull || st_r[k] != s_nbest[X_r[k]] || s_nncand[X_r[k]] != (((uint32_t)lev_r[k] << 16) | best)) continue;
+            const int    bw = kbox[4 * best + 2], bh = kbox[4 * best + 3];
+            const double ar = (double)bw / (double)bh;
+            const int    area = (int)b.ka.area[kb + best];
+            if (ar < 2.0 && ar > 0.10 && area < prm.max_area && area > prm.min_area && bh < pd.h * 0.8 && bw < pd.w * 0.8) {
+                const uint32_t slot = atomicAdd(&s_npool, 1u);
+                if (slot < pd.pool_cap) b.pool_tmp[pb + slot] = best;
+            }
+        }
+    } else
     for (uint32_t X = tid; X < K; X += NMS_THREADS) {
         if (kstart[X] != X) continue;
         int      len = 1;
@@ -2710,6 +2841,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         }
     }
     __syncthreads();
+    NMS_MARK(4);
     uint32_t np = s_npool;
     if (np > pd.pool_cap) {
         if (tid == 0) atomicOr(&c.overflow, 2u);
@@ -2751,6 +2883,11 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
         return;
     }
     if (cmp) __syncthreads();
+    NMS_MARK(5);
+    if (threadIdx.x == 0 && pass == NMS_PASS_FIRST && blockIdx.x < 128u) { NMS_MARK(6); }
+#ifdef STR_ER_WG_TRACE
+    if (threadIdx.x == 0 && pass == NMS_PASS_FIRST && blockIdx.x < 128u) { g_wg_trace[128 + blockIdx.x][7] = K; g_wg_trace[128 + blockIdx.x][8] = (unsigned long long)maxl; g_wg_trace[128 + blockIdx.x][9] = np; }
+#endif
     if (tid == 0) {
         c.n_pool = np;
         if (cmp) c.pool_changed = s_alt_diff;
