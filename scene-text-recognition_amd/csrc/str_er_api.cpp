@@ -97,6 +97,7 @@ struct str_er_ctx {
     bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
     uint64_t last_tree_records = 0, last_tree_pairs = 0, last_tree_tiles = 0;     // of the last batch (str_er_last_tree_stats)
     bool   spin_wait = false;          // STR_ER_SPIN_WAIT=1: always hipStreamSynchronize (busy-waits on a core), see wait_stream
+    int    wait_spin_us = 300;         // how long wait_stream polls before it sleeps between polls (run_batch: 2 ms for a call of a frame or two)
     bool   dbg_tile_only = false, dbg_stats = false;   // developer aids (STR_ER_DEBUG_TILE_ONLY / _STATS), read once at create
     int    tile_mode = 0;             // 0 auto (from the node density of the previous batch), 1 sparse, 2 dense (STR_ER_TILE_KERNEL)
     int64_t ws_bytes = 0;
@@ -154,6 +155,7 @@ struct str_er_ctx {
     PlaneDesc *h_planes = nullptr;
     PlaneCtr *h_ctr = nullptr;
     uint32_t *h_total = nullptr;
+    CandRec  *h_cands_spec = nullptr;                 // small calls: the first SPEC_CANDS candidate records come back WITH the counters (run_batch)
 
     HostCascade casc[2];
     bool svm_loaded = false;
@@ -176,7 +178,14 @@ int fail(str_er_ctx *c, int code, const std::string &msg)
 // Waiting for a stream.  hipStreamSynchronize busy-waits (so does hipEventSynchronize on a hipEventBlockingSync event, measured): with a batch in
 // flight on each of six contexts that is six host cores spinning -- and the GPU boxes grant a process 16 (cgroup quota), which the flood order walks
 // of the NMS ties need (round 4: the S-ties bench leg, 86 ms of walks per batch on 16 pool threads + 6 spinning waiters = throttled).  So: poll for
-// ~300 us -- a one-frame call's waits end inside that, its latency is as before -- then sleep between polls.
+// ~300 us, then sleep between polls.  A latency call (<= SPEC_PLANES planes: a frame or two, under a millisecond of GPU work, one wait at its end) polls
+// for 2 ms instead: the 100 us naps added 0.14 ms to most one-frame calls (0.80 ms when the wait happened to end inside the polling, 0.94 otherwise).
+// A call of a frame or two (<= SPEC_PLANES planes) is a latency call: its candidate records -- a thousand per 1920 x 1080 frame -- are copied to page-locked
+// memory right behind the counters, before the host knows how many there are; if they all fit (and no NMS tie pass re-made them) the second trip to the
+// device -- counters, THEN as many records as they say, into pageable memory -- is saved: about 0.1 of a 0.9 ms call.
+constexpr uint32_t SPEC_CANDS = 8192;
+constexpr int      SPEC_PLANES = 96;
+
 static hipError_t wait_stream(str_er_ctx *c, hipStream_t s)
 {
     if (!c || c->spin_wait) return hipStreamSynchronize(s);
@@ -184,7 +193,7 @@ static hipError_t wait_stream(str_er_ctx *c, hipStream_t s)
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->wait_spin_us)) std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
 }
 
@@ -1004,6 +1013,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     // share (or fails), and a share stops at one entry per pixel: the repeats end; `attempt` only guards against a slip in that argument.
     if (attempt > 24) return fail(c, STR_ER_ECAPACITY, "the batch was repeated 24 times with growing tables and still does not fit (internal error)");
     c->last_valid = false;             // (str_er_gather_last: the candidate array is being rewritten, or re-allocated)
+    c->wait_spin_us = (int)b_in.planes.size() <= SPEC_PLANES ? 2000 : 300;
     Batch b = b_in;
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
     // batches (small tile kernel: ~14 records per tile) take 4 x 4 tiles per group, noise-like ones (~250) 2 x 5.
@@ -1117,6 +1127,12 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    const CandRec *spec_src = nullptr;
+    uint32_t       spec_n = 0;
+    if ((stages & STR_ER_STAGE_NMS) && np <= SPEC_PLANES && c->pool_total) {
+        spec_src = c->d_cands; spec_n = (uint32_t)std::min<size_t>(SPEC_CANDS, c->pool_total);
+        HIP_TRY(c, hipMemcpyAsync(c->h_cands_spec, spec_src, sizeof(CandRec) * (size_t)spec_n, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(c, wait_stream(c, s));
     {   // what the tree passes of this batch worked on (str_er_last_tree_stats: bench.py prices them against the HBM roofline)
         uint64_t recs = 0, pairs = 0, tiles = 0;
@@ -1255,7 +1271,9 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     r->cands.resize(total);
     r->cand_off.assign(np + 1, 0);
     r->planes.resize(np);
-    if (total)
+    if (total && spec_src == c->d_cands && total <= spec_n)        // (same buffer as at the time of the copy: no tie pass re-made the records)
+        std::memcpy(r->cands.data(), c->h_cands_spec, sizeof(CandRec) * (size_t)total);
+    else if (total)
         if (hipMemcpyAsync(r->cands.data(), c->d_cands, sizeof(CandRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
             delete r; return fail(c, STR_ER_EHIP, "candidate copy failed");
         }
@@ -1532,6 +1550,7 @@ void str_er_destroy(str_er_ctx *c)
     if (c->h_planes) (void)hipHostFree(c->h_planes);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_cands_spec) (void)hipHostFree(c->h_cands_spec);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->prio) { (void)hipStreamSynchronize(c->prio); (void)hipStreamDestroy(c->prio); }
@@ -1651,7 +1670,8 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void **>(&c->h_total), 64) != hipSuccess)
+            hipHostMalloc(reinterpret_cast<void **>(&c->h_total), 64) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&c->h_cands_spec), sizeof(CandRec) * SPEC_CANDS) != hipSuccess)
             rc = fail(nullptr, STR_ER_ENOMEM, "hipHostMalloc failed");
     }
     if (rc != STR_ER_OK) { std::string keep = g_create_error.empty() ? c->err : g_create_error; str_er_destroy(c); g_create_error = keep; return rc; }
