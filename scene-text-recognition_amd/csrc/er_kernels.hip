@@ -1736,6 +1736,11 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     __shared__ uint32_t s_toff[GROUP_MAX_TILES + 1], s_tbase[GROUP_MAX_TILES];
     __shared__ uint32_t s_levels[8];
     const int       tid = threadIdx.x;
+#ifdef STR_ER_WG_TRACE
+#define GM_MARK(i) do { if (tid == 0 && blockIdx.x % 149u == 0u && blockIdx.x / 149u < 96u) g_wg_trace[288 + blockIdx.x / 149u][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GM_MARK(i) do { } while (0)
+#endif
     const int       GX = b.group_x, GY = b.group_y;
     const int       pi = b.group_plane[blockIdx.x];
     const PlaneDesc pd = b.planes[pi];
@@ -1763,6 +1768,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     __syncthreads();
     const uint32_t N = s_toff[nt];
     if (N == NONE || N == 0) return;
+    GM_MARK(1);
     NodeRec *const nr = b.na.rec + pd.node_base;
     auto tile_of = [&](uint32_t i) -> int {         // (records are grouped by tile: the tile whose range holds local index i)
         int lo = 0, hi = nt - 1;
@@ -1782,6 +1788,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         atomicOr(&s_levels[(a.y >> 24) >> 5], 1u << ((a.y >> 24) & 31u));
     }
     __syncthreads();
+    GM_MARK(2);
     // ---- the pixel pairs of the inner seams (same connect as node_connect, on LDS words) ----
     auto lfind = [&](uint32_t &a, uint32_t la) -> uint32_t {
         uint32_t wa = LD_WG(&s_par[a]);
@@ -1831,13 +1838,18 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
                     if (ea != 0xFFFFu && eb != 0xFFFFu) { a = s_toff[(yg / TILE_H) * gw + ix] + ea; bb = s_toff[(yg / TILE_H) * gw + ix + 1] + eb; }
                 }
             }
-            // (neighbouring lanes very often carry the same pair -- a flat region along the seam: the first lane of such a run connects)
+            // (neighbouring lanes very often carry the same pair -- a flat region along the seam: the first lane of such a run connects.
+            //  Round 4, traced in place -- tools/dev_group_trace.py: this step is half of a workgroup's 40 k cycles -- and tried: connecting only the pairs
+            //  that are a local minimum of max(level a, level b) along their tile's side -- the heavier of two neighbouring pairs is the heaviest edge of a
+            //  cycle whose other edges stay; parity green, ~20x fewer connects -- and fetching four rounds of seam entries ahead: neither moved it, here or
+            //  in k_seam.  The step is as long as its longest connects, the ones that merge two deep root paths; their number is not what costs.)
             const uint32_t pa = __shfl_up(a, 1), pb = __shfl_up(bb, 1);
             const bool dup = (tid & 63) != 0 && pa == a && pb == bb;
             if (a != NONE && !dup) lconnect(a, bb);
         }
     }
     __syncthreads();
+    GM_MARK(3);
     // ---- unified nodes hand their own statistics to the surviving level root; the others get a canonical parent (k_resolve) ----
     for (uint32_t i = tid; i < N; i += GROUP_THREADS) {
         const uint32_t l = s_key[i] >> 24, w = s_par[i];
@@ -1858,6 +1870,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         if (q != PAR_ID(w)) s_par[i] = PAR_MAKE(lq, q);
     }
     __syncthreads();
+    GM_MARK(4);
     // ---- bottom-up over the levels: a node whose component reaches the group's outer border passes its sides on to its parent; any
     // other node is complete -- it adds its totals to its parent (k_reduce) and is closed ----
     for (int wd = 0; wd < 8; ++wd) {
@@ -1881,6 +1894,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
             __syncthreads();
         }
     }
+    GM_MARK(5);
     // ---- back to the records, in place (ids global again) ----
     for (uint32_t i = tid; i < N; i += GROUP_THREADS) {
         const int      t = tile_of(i);
@@ -1892,6 +1906,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         dst[1] = make_uint4(s_x0[i], s_y0[i], s_x1[i], s_y1[i]);
     }
     if (tid == 0) b.group_done[blockIdx.x] = 1;
+    GM_MARK(6);
 }
 
 // variant: LDS for 512 / 1024 / 2048 / 3072 records per group, 256 / 512 / 1024 lanes
