@@ -8,7 +8,8 @@
 #include <algorithm>
 using namespace std;
 static const uint32_t NONE = 0xFFFFFFFFu;
-static const int TW = 64, TH = 32, TP = 2048, NT = 256;
+static const int TW = 64, TH = 32, TP = 2048, NTMAX = 256;
+static int NWV = 4, NT = 256;        // waves per tile (SIM_WAVES=1|2|4: round 4's question -- what would ONE or TWO waves per tile cost?), lanes
 struct Stats {
     double tiles = 0, edges[2] = {0, 0}, passes = 0, cas = 0, cas_lost = 0, iters[2] = {0, 0}, cost[2] = {0, 0}, pieces = 0, nodes = 0;
     double redundant2 = 0, lanepasses = 0, hops = 0;
@@ -83,18 +84,18 @@ static void run_rounds(Tile &t, vector<uint16_t> *elist_round, int nrounds, cons
         const vector<uint16_t> &el = elist_round[r];
         // entries: p | kind<<15?  we store kind separately: el_kind
         const uint32_t n = el.size();
-        Lane L[NT];
-        uint32_t next[NT], nend[NT];
+        Lane L[NTMAX];
+        uint32_t next[NTMAX], nend[NTMAX];
         uint32_t wcur[4], wend[4];
         for (int i = 0; i < NT; ++i) { L[i].active = false; next[i] = (uint32_t)((uint64_t)i * n / NT); nend[i] = (uint32_t)((uint64_t)(i + 1) * n / NT); }
-        for (int w = 0; w < 4; ++w) { wcur[w] = 0; wend[w] = nend[w * 64 + 63] - next[w * 64]; }
+        for (int w = 0; w < NWV; ++w) { wcur[w] = 0; wend[w] = nend[w * 64 + 63] - next[w * 64]; }
         bool done[4] = {false, false, false, false};
         int ndone = 0;
-        while (ndone < 4) {
+        while (ndone < NWV) {
             // phase 1: refill + finds for every wave
             bool any[4];
             int maxha[4], maxhb[4];
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NWV; ++w) {
                 any[w] = false; maxha[w] = maxhb[w] = 0;
                 if (done[w]) continue;
                 const uint32_t base = next[w * 64] - 0; (void)base;
@@ -131,7 +132,7 @@ static void run_rounds(Tile &t, vector<uint16_t> *elist_round, int nrounds, cons
                 }
             }
             // phase 2: CAS for every wave
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NWV; ++w) {
                 if (done[w]) continue;
                 if (!any[w]) { done[w] = true; ++ndone; continue; }
                 st.iters[r] += 1;
@@ -168,6 +169,7 @@ int main(int argc, char **argv)
     const char *fn = argv[1];
     const int W = atoi(argv[2]), H = atoi(argv[3]);
     VARIANT = argc > 4 ? atoi(argv[4]) : 0;
+    if (getenv("SIM_WAVES")) { NWV = atoi(getenv("SIM_WAVES")); if (NWV != 1 && NWV != 2 && NWV != 4) NWV = 4; NT = 64 * NWV; }
     vector<uint8_t> img((size_t)W * H);
     FILE *f = fopen(fn, "rb"); if (!f || fread(img.data(), 1, img.size(), f) != img.size()) { perror("read"); return 1; } fclose(f);
     Stats st;
@@ -207,7 +209,7 @@ int main(int argc, char **argv)
         if (VARIANT & 16) {
             vector<uint16_t> c0, c1;
             size_t i0 = 0, i1 = 0;
-            for (int tid = 0; tid < NT; ++tid) {
+            for (int tid = 0; tid < NTMAX; ++tid) {
                 const int p0 = tid * 8;
                 while (i0 < el[0].size() && (el[0][i0] & 0x7FFF) < p0 + 8) c1.push_back(el[0][i0++]);
                 while (i1 < el[1].size() && (el[1][i1] & 0x7FFF) < p0 + 8) { const int p = el[1][i1] & 0x7FFF; (t.lev[p] == t.lev[p + TW] ? c0 : c1).push_back(el[1][i1]); ++i1; }
@@ -219,7 +221,7 @@ int main(int argc, char **argv)
             // one combined list, interleaved by lane: H then V of each lane (tid order)
             vector<uint16_t> c;
             size_t i0 = 0, i1 = 0;
-            for (int tid = 0; tid < NT; ++tid) {
+            for (int tid = 0; tid < NTMAX; ++tid) {
                 const int p0 = tid * 8;
                 while (i0 < el[0].size() && (el[0][i0] & 0x7FFF) < p0 + 8) c.push_back(el[0][i0++]);
                 while (i1 < el[1].size() && (el[1][i1] & 0x7FFF) < p0 + 8) c.push_back(el[1][i1++]);
@@ -254,9 +256,9 @@ int main(int argc, char **argv)
         }
     }
     const double T = st.tiles;
-    printf("%s var %d: tiles %.0f pieces/tile %.0f nodes/tile %.0f edges H %.0f V %.0f | passes/connect %.2f cas lost %.1f%% hops/pass %.2f | wave-iters/wave: r0 %.2f r1 %.2f | cost/wave r0 %.0f r1 %.0f total %.0f | lane eff %.1f%% red2 %.0f/tile\n",
-           fn, VARIANT, T, st.pieces / T, st.nodes / T, st.edges[0] / T, st.edges[1] / T, st.passes / (st.edges[0] + st.edges[1]), 100.0 * st.cas_lost / max(1.0, st.cas), st.hops / st.passes,
-           st.iters[0] / T / 4, st.iters[1] / T / 4, st.cost[0] / T / 4, st.cost[1] / T / 4, (st.cost[0] + st.cost[1]) / T / 4,
+    printf("%s var %d waves %d: tiles %.0f pieces/tile %.0f nodes/tile %.0f edges H %.0f V %.0f | passes/connect %.2f cas lost %.1f%% hops/pass %.2f | wave-iters/wave: r0 %.2f r1 %.2f | cost/wave r0 %.0f r1 %.0f total %.0f (per TILE %.0f) | lane eff %.1f%% red2 %.0f/tile\n",
+           fn, VARIANT, NWV, T, st.pieces / T, st.nodes / T, st.edges[0] / T, st.edges[1] / T, st.passes / (st.edges[0] + st.edges[1]), 100.0 * st.cas_lost / max(1.0, st.cas), st.hops / st.passes,
+           st.iters[0] / T / NWV, st.iters[1] / T / NWV, st.cost[0] / T / NWV, st.cost[1] / T / NWV, (st.cost[0] + st.cost[1]) / T / NWV, (st.cost[0] + st.cost[1]) / T,
            100.0 * st.lanepasses / ((st.iters[0] + st.iters[1]) * 64), st.redundant2 / T);
     printf("  treehash %016llx\n", (unsigned long long)treehash);
     return 0;
