@@ -1819,6 +1819,10 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         const uint16_t *seam = b.seam + pd.seam_base;
         const uint32_t  n_hp = (uint32_t)((gh - 1) * gw * TILE_W), n_vp = (uint32_t)((gw - 1) * gh * TILE_H);
         const size_t    voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
+#ifdef STR_ER_GM_REDIST
+        __shared__ uint32_t s_gm_a[CAP <= 1024 ? GROUP_THREADS / 64 : 1][64], s_gm_b[CAP <= 1024 ? GROUP_THREADS / 64 : 1][64];
+        uint32_t gm_cnt = 0;          // survivors of this wave so far (the same in all its lanes)
+#endif
         for (uint32_t p0 = 0; p0 < n_hp + n_vp; p0 += GROUP_THREADS) {
             const uint32_t p = p0 + (uint32_t)tid;
             uint32_t a = NONE, bb = NONE;
@@ -1843,10 +1847,39 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
             //  that are a local minimum of max(level a, level b) along their tile's side -- the heavier of two neighbouring pairs is the heaviest edge of a
             //  cycle whose other edges stay; parity green, ~20x fewer connects -- and fetching four rounds of seam entries ahead: neither moved it, here or
             //  in k_seam.  The step is as long as its longest connects, the ones that merge two deep root paths; their number is not what costs.)
-            const uint32_t pa = __shfl_up(a, 1), pb = __shfl_up(bb, 1);
-            const bool dup = (tid & 63) != 0 && pa == a && pb == bb;
-            if (a != NONE && !dup) lconnect(a, bb);
+#ifdef STR_ER_GM_REDIST
+            // UNTESTED on a GPU (written when round 4's GPU minutes were spent; off unless -DSTR_ER_GM_REDIST): a wave runs its two or three rounds of connects one
+            // after the other and each round lasts as long as its longest connect.  Here the rounds only COLLECT: a pair survives if it is a local minimum of
+            // max(level a, level b) along its tile's side (see the note above: parity was green with this rule, alone it gave nothing), the survivors of all
+            // rounds are packed into the wave's 64 staging slots, and ONE round of connects follows the loop -- a survivor a lane.  (Small variants only: the
+            // staging is 8 bytes a lane, which the 2528-record variant's two-workgroups-a-CU budget does not have.)
+            if constexpr (CAP <= 1024) {
+                const uint32_t w = a != NONE ? max(s_key[a] >> 24, s_key[bb] >> 24) : 0xFFFFFFFFu;
+                const uint32_t wp = (uint32_t)__shfl_up((int)w, 1), wn = (uint32_t)__shfl_down((int)w, 1);
+                const bool     horiz = p0 + (uint32_t)(tid & ~63) < n_hp;          // (n_hp is a multiple of 64: a wave is all of one kind)
+                const int      ls = horiz ? (tid & 63) : (tid & 31), last = horiz ? 63 : 31;
+                const bool     keep = a != NONE && !((ls != 0 && wp <= w) || (ls != last && wn < w));
+                const unsigned long long m = __ballot(keep);
+                const uint32_t at = gm_cnt + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+                if (keep) {
+                    if (at < 64u) { s_gm_a[tid >> 6][at] = a; s_gm_b[tid >> 6][at] = bb; }
+                    else lconnect(a, bb);                                           // (more than 64 survivors in a wave: the rest at once, as before)
+                }
+                gm_cnt += (uint32_t)__popcll(m);
+            } else
+#endif
+            {
+                const uint32_t pa = __shfl_up(a, 1), pb = __shfl_up(bb, 1);
+                const bool dup = (tid & 63) != 0 && pa == a && pb == bb;
+                if (a != NONE && !dup) lconnect(a, bb);
+            }
         }
+#ifdef STR_ER_GM_REDIST
+        if constexpr (CAP <= 1024) {
+            WAVE_SYNC();
+            if ((uint32_t)(tid & 63) < min(gm_cnt, 64u)) lconnect(s_gm_a[tid >> 6][tid & 63], s_gm_b[tid >> 6][tid & 63]);
+        }
+#endif
     }
     __syncthreads();
     GM_MARK(3);
