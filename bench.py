@@ -1,38 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the ER hot path (extract + NMS + 2-stage classify) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu F]
-                    [--workload pyr3x8|native6] [--kind text|noise] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu F] [--size 1080p|4k]
+                    [--workload pyr3x8|native6|pyr3x12] [--kind text|noise|ties] [--no-cpu-baseline] ...
 
-A "step" is one pass of the hot path over one batch of F synthetic 1920x1080 BGR frames per
-GPU that are ALREADY RESIDENT IN HBM: compute_channels (+ pyramid) -> per-plane component
-tree -> NMS -> LBP + strong/weak cascades -> candidate records copied back to the host
-(and, for N > 1, gathered across ranks with RCCL).  Frames are dealt out to ranks, so per-GPU
-work is fixed as N grows ("weak" scaling) and `value` = all frames processed by all ranks
-per second.
+A "step" is one pass of the hot path over one batch of F synthetic BGR frames per GPU that are ALREADY
+RESIDENT IN HBM: compute_channels (+ pyramid) -> per-plane component tree -> NMS -> LBP + strong/weak
+cascades -> candidate records copied back to the host (and, for N > 1, gathered across ranks with RCCL).
+Frames are dealt out to ranks, so per-GPU work is fixed as N grows ("weak" scaling) and `value` = all
+frames processed by all ranks per second.  The timed region of K steps is run `--repeats` times (default 3),
+each bracketed by barrier + synchronize; `value` / `ms_per_step` are the median region, `value_min/max` the others.
 
 Workloads (BASELINE.json `configs`):
-  pyr3x8  : configs[1]/[2]: planes {Y,Cr,Cb} x 8 pyramid levels (24 planes, 12.40 Mpx/frame)
+  pyr3x8  : configs[1] -- the metric's: 1920x1080, planes {Y,Cr,Cb} x 8 pyramid levels (24 planes, 12.40 Mpx/frame)
   native6 : what the reference's text_detect really runs: {Y,Cr,Cb,255-Y,255-Cr,255-Cb} at
             native resolution (6 planes, 12.44 Mpx/frame; src/ER.cpp:114-128)
+  pyr3x12 : configs[4]: 3840x2160, {Y,Cr,Cb} x 12 pyramid levels (36 planes, 49.75 Mpx/frame); --size 4k
 
-Extra objects on the JSON line:
-  roofline       : HBM roofline of the dominant kernel (k_tile_tree): algorithmic bytes per launch over its ISOLATED
-                   launch duration (HIP events recorded by the library on the stream the kernel runs on, one batch in
-                   flight, mean of 3 launches after the timed region).  With several batches sharing the GPU an
-                   event-to-event time also contains the other batches' kernels (`overlapped_event_ms`).
-  cpu_baseline   : the oracle (a plain-C port of the reference's CPU algorithm) timed on this box's host cores on a
-                   bounded sample, threads over planes like the reference's `#pragma omp parallel for` (src/ER.cpp:50).
-  pcie_inclusive : the same step with the frames starting in page-locked HOST memory (ingest stream, uploads
-                   overlapping compute); never the reported `value`.
-  latency_1frame : one frame per call, one call in flight: call-to-return wall time.
+Extra objects on the JSON line (single-GPU default run):
+  roofline         : HBM roofline of the dominant kernel (k_tile_tree): algorithmic bytes per launch over its ISOLATED
+                     launch duration (HIP events recorded by the library on the stream the kernel runs on, one batch in
+                     flight, mean of 3 launches after the timed region).
+  cpu_baseline     : the oracle (a plain-C port of the reference's CPU algorithm) timed on this box's host cores on a
+                     bounded sample, threads over planes like the reference's `#pragma omp parallel for` (src/ER.cpp:50).
+  config3_ocr_leg  : BASELINE configs[2]: the same batches with the chain-code + SVM character scorer on every strong /
+                     weak ER (src/OCR.cpp:67-140): frames/s, ERs scored, per-kernel GPU ms, the MFMA roofline of the RBF
+                     kernel-matrix GEMM and its own CPU baseline.  `group_ocr_leg`: the reference's real call pattern
+                     (er_track + er_grouping, then the scorer on the members of the text lines, src/ER.cpp:695-747).
+  config5_4k_leg   : BASELINE configs[4] on this one GPU: 3840x2160 x 12 levels, frames/s, tile-kernel roofline, latency.
+  nms_ties_leg     : the same measurement on frames with NMS sibling ties (cost of exactness).
+  pcie_inclusive   : the same step with the frames starting in page-locked HOST memory; never the reported `value`.
+  latency_1frame   : one frame per call, one call in flight: call-to-return wall time.
 """
 import argparse
+import gzip
 import importlib
 import json
 import os
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -44,9 +51,11 @@ if ROOT not in sys.path:
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0    # ... and what a float4 copy reaches (same guide)
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense f32 matrix peak (v_mfma_f32_32x32x2_f32: 256 flop/cycle/CU x 256 CUs x 2.4 GHz)
 WORKLOADS = {
-    "pyr3x8": dict(n_pyr_levels=8, channel_mask=0x07, label="1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels (BASELINE configs[1]/[2])"),
+    "pyr3x8": dict(n_pyr_levels=8, channel_mask=0x07, label="1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels (BASELINE configs[1])"),
     "native6": dict(n_pyr_levels=1, channel_mask=0x3F, label="1920x1080 BGR, reference-native 6 planes x 1 level"),
+    "pyr3x12": dict(n_pyr_levels=12, channel_mask=0x07, label="3840x2160 BGR, {Y,Cr,Cb} x 12 pyramid levels (BASELINE configs[4])"),
 }
 
 
@@ -68,26 +77,29 @@ def effective_cpus() -> int:
     return n
 
 
-def plane_pixels(workload: str) -> int:
-    """Sum of plane pixels per frame (12 395 367 for pyr3x8, 12 441 600 for native6)."""
+def plane_pixels(workload: str, w: int = None, h: int = None) -> int:
+    """Sum of plane pixels per frame (12 395 367 for pyr3x8, 12 441 600 for native6, 49 752 702 for pyr3x12)."""
+    w, h = (W if w is None else w), (H if h is None else h)
     cfg = WORKLOADS[workload]
     nch = bin(cfg["channel_mask"]).count("1")
     tot = 0
     for k in range(cfg["n_pyr_levels"]):
         s = 2.0 ** (-0.5 * k)
-        tot += max(1, int(np.floor(W * s + 0.5))) * max(1, int(np.floor(H * s + 0.5))) * nch
+        tot += max(1, int(np.floor(w * s + 0.5))) * max(1, int(np.floor(h * s + 0.5))) * nch
     return tot
 
 
-def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
-    """Oracle on host cores: per frame compute_channels (+pyramid) then one thread per plane."""
+def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0, ocr_model: str = None):
+    """Oracle on host cores: per frame compute_channels (+pyramid) then one thread per plane.  With ocr_model: the chain-code
+    features + libsvm probability of every strong / weak ER as well (config 3)."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle, OracleSVM
 
     S = importlib.import_module("scene-text-recognition_amd")
     cfg = WORKLOADS[workload]
     o = Oracle()
     cs, cw = o.cascade_load(cascades[0]), o.cascade_load(cascades[1])
+    svm = OracleSVM(o, ocr_model) if ocr_model else None
     ncores = effective_cpus()
 
     def planes_of(frame):
@@ -100,9 +112,19 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
 
     def run_plane(p):
         r = o.detect_plane(p, cs, cw)
-        return len(r["pool"])
+        scored = 0
+        if svm is not None:
+            t = r["tree"].nodes
+            for j, i in enumerate(r["pool"]):
+                if int(r["cls"][j]) == 0:
+                    continue
+                x, y, w, h = int(t[i]["x"]), int(t[i]["y"]), int(t[i]["w"]), int(t[i]["h"])
+                q = o.chain_features(np.ascontiguousarray(p[y:y + h, x:x + w]))
+                svm.predict_probability(q / 255.0)
+                scored += 1
+        return len(r["pool"]), scored
 
-    frames_done, t_total, pooled = 0, 0.0, 0
+    frames_done, t_total, pooled, scored = 0, 0.0, 0, 0
     nthreads = 1
     while t_total < budget_s and frames_done < 64:
         frame = S.synth.KINDS[kind](S.synth.frame_seed(frames_done), W, H)
@@ -110,22 +132,148 @@ def cpu_baseline(kind: str, workload: str, cascades, budget_s: float = 12.0):
         planes = planes_of(frame)
         nthreads = max(1, min(len(planes), ncores))
         with ThreadPoolExecutor(nthreads) as ex:
-            pooled += sum(ex.map(run_plane, planes))
+            for a, b in ex.map(run_plane, planes):
+                pooled += a
+                scored += b
         t_total += time.perf_counter() - t0
         frames_done += 1
-    return {"value": round(frames_done / t_total, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
-            "sample": f"{frames_done} S-{kind} 1920x1080 frame(s), workload {workload}, {t_total:.1f} s of CPU wall time, "
-                      f"oracle/er_oracle.c -O2, one thread per plane ({nthreads} threads; the box reports {os.cpu_count()} cores, its CPU quota grants {ncores})"}
+    out = {"value": round(frames_done / t_total, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+           "sample": f"{frames_done} S-{kind} {W}x{H} frame(s), workload {workload}, {t_total:.1f} s of CPU wall time, "
+                     f"oracle/er_oracle.c -O2, one thread per plane ({nthreads} threads; the box reports {os.cpu_count()} cores, its CPU quota grants {ncores})"}
+    if svm is not None:
+        out["sample"] += f"; + oracle chain-code features and oracle/svm_oracle.c on the {scored} strong/weak ERs of those frames, inside the plane's thread"
+        out["ers_scored"] = scored
+    return out
+
+
+class Rig:
+    """P contexts of one geometry (each with its own stream and workspace), fed by P host threads."""
+
+    def __init__(self, S, P, w, h, F, cfg, dev_index, sibling_order, cascades, svm_text=None):
+        self.S, self.P, self.w, self.h, self.F, self.dev_index = S, P, w, h, F, dev_index
+        self.filters = []
+        for _ in range(P):
+            f = S.ERFilter(params=S.Params(max_width=w, max_height=h, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
+                                           channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=sibling_order))
+            f.load_cascade(0, cascades[0])
+            f.load_cascade(1, cascades[1])
+            if svm_text is not None:
+                f.load_svm_model_text(svm_text, 1800)
+            self.filters.append(f)
+
+    def close(self):
+        for f in self.filters:
+            f.close()
+        self.filters = []
+
+    def tie_totals(self):
+        st = [f.tie_stats() for f in self.filters]
+        return sum(x["planes_walked"] for x in st), sum(x["walk_ms_total"] for x in st), st[0]["host_threads"]
+
+    def run(self, n_batches, d_in, stages, comm=None, rank=0, world=1, gather_device=None):
+        """P batches are in flight at once: worker p runs batches p, p+P, p+2P, ... on its own context/stream (the C call
+        releases the GIL); the main thread consumes the results in batch order and does the cross-rank gather, so collectives
+        are issued in the same order on every rank."""
+        import torch
+        S, P, F = self.S, self.P, self.F
+        results = [None] * n_batches
+        done = [threading.Event() for _ in range(n_batches)]
+        turn = threading.Condition()
+        state = {"next": 0}
+
+        def worker(p):
+            torch.cuda.set_device(self.dev_index)
+            for i in range(p, n_batches, P):
+                results[i] = self.filters[p].detect_bgr_device(d_in.data_ptr(), self.w, self.h, F, stages)
+                if comm is not None:
+                    # the records are still in this context's device array: gather them before the context takes its next
+                    # batch, and in batch order -- every rank issues its collectives in the same order
+                    with turn:
+                        turn.wait_for(lambda: state["next"] == i)
+                    comm.gather_last(self.filters[p], frame_offset=rank * F)
+                    with turn:
+                        state["next"] = i + 1
+                        turn.notify_all()
+                done[i].set()
+
+        threads = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
+        for t in threads:
+            t.start()
+        prof, last = {}, None
+        for i in range(n_batches):
+            done[i].wait()
+            r = results[i]
+            results[i] = None
+            if world > 1 and comm is None:
+                S.dist.gather_candidates(r.cands, gather_device, frame_offset=rank * F)
+            for k, v in r.profile.items():
+                prof[k] = prof.get(k, 0.0) + v
+            last = r
+        for t in threads:
+            t.join()
+        return prof, last
+
+    def timed(self, n_batches, d_in, stages):
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prof, last = self.run(n_batches, d_in, stages)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, prof, last
+
+    def serial_profile(self, d_in, stages, n_cal=3):
+        """un-overlapped kernel durations: single-context steps (with P > 1 the events of a timed region include the time a
+        kernel spends sharing the GPU with the other batches)"""
+        sp, last = {}, None
+        for _ in range(n_cal):
+            last = self.filters[0].detect_bgr_device(d_in.data_ptr(), self.w, self.h, self.F, stages)
+            for k, v in last.profile.items():
+                sp[k] = sp.get(k, 0.0) + v / n_cal
+        return sp, last
+
+
+def make_frames(S, kind, w, h, F, first=0, ties_every=8):
+    from concurrent.futures import ThreadPoolExecutor
+    make = (lambda sd, ww, hh: S.synth.sties_bgr(sd, ww, hh, ties_every)) if kind == "ties" else S.synth.KINDS[kind]
+    with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
+        return np.stack(list(ex.map(lambda i: make(S.synth.frame_seed(first + i), w, h), range(F))))
+
+
+def tile_roofline(px, F, tile_ms, tile_ms_overlapped, workload):
+    tile_bytes = px * F
+    achieved = tile_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+    traffic, traffic_source = None, "not measured in this run (no rocprofv3 counter pass)"
+    pmc = os.path.join(ROOT, "profiles", "pmc_tile_tree.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as fh:
+                j = json.load(fh)
+            if j.get("workload") == workload and j.get("frames_per_launch"):
+                traffic = j["hbm_bytes_per_launch"] * F / j["frames_per_launch"]
+                traffic_source = ("STORED figure, not measured in this run: profiles/pmc_tile_tree.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                  f"passes of this command, collected {j.get('collected', 'earlier')}; FETCH doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to "
+                                  f"{F} frames per launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_peak": round(achieved / HBM_MEASURED_GBS, 5),
+            "measured_peak": HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "bytes_per_launch": tile_bytes, "avg_launch_ms": round(tile_ms, 4),
+            "timing": "isolated launch: HIP events on the library's stream, one batch in flight, mean of 3 launches after the timed region",
+            "overlapped_event_ms": round(tile_ms_overlapped, 4)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40, help="timed batches (one step = one batch of --frames-per-gpu frames per GPU; 40 steps = about a third of a second)")
+    ap.add_argument("--steps", type=int, default=40, help="timed batches per region (one step = one batch of --frames-per-gpu frames per GPU; 40 steps = about a fifth of a second)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=48,
-                    help="frames per batch (= per step) and GPU; 48-64 amortise the per-batch launch latencies best (32 or 96: about 7 %% slower)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pyr3x8")
+    ap.add_argument("--repeats", type=int, default=3, help="the timed region of --steps steps is run this many times; `value` is the median region")
+    ap.add_argument("--frames-per-gpu", type=int, default=None,
+                    help="frames per batch (= per step) and GPU; 48-64 amortise the per-batch launch latencies best (32 or 96: about 7 %% slower); default 48 (12 for --size 4k)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
+    ap.add_argument("--size", choices=["1080p", "4k"], default="1080p",
+                    help="frame size: 1080p = 1920x1080 (the metric's), 4k = 3840x2160 with the 12-level pyramid (BASELINE configs[4]; 12 frames per batch by default)")
     ap.add_argument("--kind", choices=["text", "noise", "ties"], default="text",
                     help="synthetic frames (SURVEY 8d): S-text (default), S-noise (stress), S-ties = S-text with a glyph in every third frame that "
                          "makes an NMS sibling tie whose outcome changes the pool (--ties-every 8: 1.2 %% of the planes need the reference's flood "
@@ -142,13 +290,22 @@ def main():
     ap.add_argument("--sibling-order", type=int, default=0, help="developer knob: 0 = exact NMS ties (default), 2 = largest-key rule (no flood order walk)")
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-frame-per-call latency leg (`latency_1frame`)")
     ap.add_argument("--ocr", action="store_true",
-                    help="BASELINE configs[2]: also run the chain-code + SVM character scorer on every strong/weak ER "
+                    help="BASELINE configs[2] as the MAIN timed region: also run the chain-code + SVM character scorer on every strong/weak ER "
                          "(synthetic stand-in for the missing classifier/OCR.model: scene-text-recognition_amd/data/ocr_synth.model.gz)")
+    ap.add_argument("--no-ocr-legs", action="store_true", help="skip `config3_ocr_leg` / `group_ocr_leg` of the default run")
+    ap.add_argument("--no-4k-leg", action="store_true", help="skip `config5_4k_leg` of the default run")
     ap.add_argument("--pipelines", type=int, default=6,
                     help="independent batches in flight per GPU (each has its own context, stream and workspace).  Three hide the "
                          "host-side result handling and the low-parallelism tails of a batch; the flood order walk that decides an NMS "
                          "sibling tie (about one plane per 48 S-text frames, 20-50 ms on a host core) needs a few more")
     args = ap.parse_args()
+    global W, H
+    if args.size == "4k":
+        W, H = 3840, 2160
+    if args.workload is None:
+        args.workload = "pyr3x12" if args.size == "4k" else "pyr3x8"
+    if args.frames_per_gpu is None:
+        args.frames_per_gpu = 12 if args.size == "4k" else 48
 
     # (torch first: it brings its own HIP runtime, which the library must share -- loaded the other way round the process has two)
     import torch
@@ -196,7 +353,6 @@ def main():
                 raise RuntimeError("not an RCCL run")
             # (never executed on more than one GPU so far: the communicator is created on a helper thread with a time limit, so that a rank stuck inside
             # ncclCommInitRank -- a collective: then every rank is -- falls back to torch.distributed with the others instead of hanging the run)
-            import threading
             box = {}
 
             def _mk():
@@ -226,197 +382,178 @@ def main():
     P = max(1, args.pipelines)
     tmp = tempfile.mkdtemp()
     cascades = S.cascade_io.write_golden(tmp)
-    filters = []
-    for _ in range(P):
-        f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
-                                       channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order))
-        f.load_cascade(0, cascades[0])
-        f.load_cascade(1, cascades[1])
-        if args.ocr:
-            import gzip
-            f.load_svm_model_text(gzip.open(S.cascade_io.ocr_model_path()).read(), 1800)
-        filters.append(f)
+    svm_text = gzip.open(S.cascade_io.ocr_model_path()).read()
+    svm_path = os.path.join(tmp, "ocr_synth.model")
+    with open(svm_path, "wb") as fh:
+        fh.write(svm_text)
+    single = world == 1 and rank == 0
+    ocr_legs = single and not args.no_ocr_legs and not args.ocr and not args.group and args.kind == "text" and args.size == "1080p" and args.workload == "pyr3x8"
+    rig = Rig(S, P, W, H, F, cfg, dev_index, args.sibling_order, cascades, svm_text if (args.ocr or ocr_legs) else None)
     # --ocr alone scores every strong/weak ER (slope 0); with --group the scorer runs where er_ocr runs it: on the members of the text lines
-    stages = S.STAGE_ALL | ((S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP) if args.group else 0)
+    st_group = S.STAGE_TRACK | S.STAGE_GROUP | S.GROUP_INNER_SUP
+    stages = S.STAGE_ALL | (st_group if args.group else 0)
     if args.ocr:
         stages |= S.STAGE_OCR_LINES if args.group else S.STAGE_OCR
 
-    ws_bytes = filters[0].workspace_bytes()
+    ws_bytes = rig.filters[0].workspace_bytes()
     # synthetic frames of this rank's shard: F DISTINCT frames, global frame index = rank*F + i, seed = 0x5EED0000 + index
     # (SURVEY 8(d)); generated on host threads (numpy releases the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
-        make = (lambda sd, w, h: S.synth.sties_bgr(sd, w, h, args.ties_every)) if args.kind == "ties" else S.synth.KINDS[args.kind]
-        frames = np.stack(list(ex.map(lambda i: make(S.synth.frame_seed(rank * F + i), W, H), range(F))))
+    frames = make_frames(S, args.kind, W, H, F, first=rank * F, ties_every=args.ties_every)
     d_frames = torch.from_numpy(frames).to(device)
     torch.cuda.synchronize()
 
-    # P batches are in flight at once: worker p runs batches p, p+P, p+2P, ... on its own context/stream
-    # (the C call releases the GIL); the main thread consumes the results in batch order and does the
-    # cross-rank gather, so collectives are issued in the same order on every rank.
-    import queue
-    import threading
-
-    def tie_totals():
-        st = [f.tie_stats() for f in filters]
-        return sum(x["planes_walked"] for x in st), sum(x["walk_ms_total"] for x in st), st[0]["host_threads"]
-
-    def run(n_batches, d_in=None):
-        d_in = d_frames if d_in is None else d_in
-        results = [None] * n_batches
-        done = [threading.Event() for _ in range(n_batches)]
-        turn = threading.Condition()
-        state = {"next": 0}
-
-        def worker(p):
-            torch.cuda.set_device(dev_index)
-            for i in range(p, n_batches, P):
-                results[i] = filters[p].detect_bgr_device(d_in.data_ptr(), W, H, F, stages)
-                if comm is not None:
-                    # the records are still in this context's device array: gather them before the context takes its next
-                    # batch, and in batch order -- every rank issues its collectives in the same order
-                    with turn:
-                        turn.wait_for(lambda: state["next"] == i)
-                    comm.gather_last(filters[p], frame_offset=rank * F)
-                    with turn:
-                        state["next"] = i + 1
-                        turn.notify_all()
-                done[i].set()
-
-        threads = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
-        for t in threads:
-            t.start()
-        prof, last = {}, None
-        for i in range(n_batches):
-            done[i].wait()
-            r = results[i]
-            results[i] = None
-            if world > 1 and comm is None:
-                S.dist.gather_candidates(r.cands, gather_device, frame_offset=rank * F)
-            for k, v in r.profile.items():
-                prof[k] = prof.get(k, 0.0) + v
-            last = r
-        for t in threads:
-            t.join()
-        return prof, last
-
     # W untimed warm-up steps -- on EVERY context: a context's first batch sizes its node records for the frames' content (and on
     # noise-like frames picks the large tile kernel), which must not happen inside the timed region of whichever contexts W did not reach
-    run(args.warmup * P)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ties0 = tie_totals()
-    cpu0 = time.process_time()
-    t0 = time.perf_counter()
-    prof_sum, r = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    host_cpu_per_wall = (time.process_time() - cpu0) / max(elapsed, 1e-9)      # host CPUs this process kept busy during the timed region
-    ties1 = tie_totals()
-    nms_ties = {"tie_planes_per_batch": round((ties1[0] - ties0[0]) / args.steps, 2),
-                "flood_walk_ms_per_batch": round((ties1[1] - ties0[1]) / args.steps, 2), "host_threads": ties1[2],
+    rig.run(args.warmup * P, d_frames, stages, comm, rank, world, gather_device)
+    regions = []
+    prof_sum, r = {}, None
+    ties0 = rig.tie_totals()
+    host_cpu = []
+    for _ in range(max(1, args.repeats)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        cpu0 = time.process_time()
+        t0 = time.perf_counter()
+        prof_sum, r = rig.run(args.steps, d_frames, stages, comm, rank, world, gather_device)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        host_cpu.append((time.process_time() - cpu0) / max(el, 1e-9))     # host CPUs this process kept busy during the timed region
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=gather_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        regions.append(el)
+    ties1 = rig.tie_totals()
+    n_reg = len(regions)
+    elapsed = float(np.median(regions))
+    host_cpu_per_wall = float(np.median(host_cpu))
+    nms_ties = {"tie_planes_per_batch": round((ties1[0] - ties0[0]) / (args.steps * n_reg), 2),
+                "flood_walk_ms_per_batch": round((ties1[1] - ties0[1]) / (args.steps * n_reg), 2), "host_threads": ties1[2],
                 "note": "planes of a batch whose NMS sibling tie changes the pool: the reference's flood order is walked on a host core for each "
                         "(host ms summed over planes), on the library's process-wide pool of at most host_threads threads"}
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # un-overlapped kernel durations: a few single-pipeline steps after the timed region (with P > 1 the
-    # events of the timed region include the time a kernel spends sharing the GPU with the other batch)
-    serial_prof = {}
     if P > 1:
-        n_cal = 3
-        for _ in range(n_cal):
-            rc = filters[0].detect_bgr_device(d_frames.data_ptr(), W, H, F, stages)
-            for k, v in rc.profile.items():
-                serial_prof[k] = serial_prof.get(k, 0.0) + v / n_cal
+        serial_prof, _ = rig.serial_profile(d_frames, stages)
     else:
         serial_prof = {k: v / max(args.steps, 1) for k, v in prof_sum.items()}
-    r_tree_stats = filters[0].last_tree_stats()
+    r_tree_stats = rig.filters[0].last_tree_stats()
+
+    # ---- config 3: the OCR scorer on every strong / weak ER of the same batches; then the reference's own call pattern (lines first)
+    ocr_leg = group_ocr_leg = None
+    if ocr_legs:
+        n_o = max(P, args.steps // 2)
+
+        def ocr_leg_run(st, label):
+            rig.run(P, d_frames, st)
+            el_o, prof_o, last_o = rig.timed(n_o, d_frames, st)
+            sp, last1 = rig.serial_profile(d_frames, st)
+            out = {"value": round(F * n_o / el_o, 2), "unit": "frames/s", "steps": n_o, "ms_per_step": round(1e3 * el_o / n_o, 3),
+                   "frac_of_value": round(F * n_o / el_o / (F * args.steps / elapsed), 4), "stages": label}
+            return out, sp, last1
+
+        ocr_leg, sp_o, last_o = ocr_leg_run(S.STAGE_ALL | S.STAGE_OCR, "STAGE_ALL | STAGE_OCR: chain_run (slope 0) on every strong / weak ER (src/OCR.cpp:67-140)")
+        n_sc = int((last_o.ocr_label >= 0).sum()) if last_o.ocr_label is not None else 0
+        k_cls, l_sv, _dim = rig.filters[0].svm_info()
+        l_pad, d_pad = -(-l_sv // 64) * 64, -(-1800 // 16) * 16
+        gemm_ms = sp_o.get("svm_kernel", 0.0)
+        flops = 2.0 * n_sc * d_pad * l_pad
+        tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ocr_leg.update({
+            "ers_scored_per_batch": n_sc, "svm_model": f"ocr_synth.model: {k_cls} classes, {l_sv} support vectors, 1800-d, RBF (stand-in for the missing OCR.model)",
+            "gpu_ms_per_batch_isolated": {k: round(sp_o.get(k, 0.0), 4) for k in ("ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")},
+            "gpu_ms_note": "ocr_features = k_ocr_list + k_ocr_hist + k_ocr_otsu + k_ocr_features; svm_kernel = k_svm_kernel (RBF kernel matrix, MFMA); svm_couple = "
+                           "k_svm_couple (decision values + sigmoid + pairwise coupling); ocr_host_gap = stream idle while the host reads the plane counters "
+                           "(the scorer's launch sizes), not GPU work",
+            "roofline_svm_kernel": {"bound": "mfma", "kernel": "k_svm_kernel", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flops_per_launch": int(flops), "avg_launch_ms": round(gemm_ms, 4),
+                                    "note": f"2 x N x {d_pad} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch; f32 in / f32 accumulate; the "
+                                            "launch also evaluates exp() in f64 for every kernel value"}})
+        if not args.no_cpu_baseline:
+            ocr_leg["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades, budget_s=8.0, ocr_model=svm_path)
+        group_ocr_leg, sp_g, last_g = ocr_leg_run(S.STAGE_ALL | st_group | S.STAGE_OCR_LINES,
+                                                  "STAGE_ALL | TRACK | GROUP(inner_sup) | OCR_LINES: calc_color, er_track, er_grouping, then chain_run on the members "
+                                                  "of the text lines with the line's slope (er_ocr, src/ER.cpp:695-747)")
+        group_ocr_leg["line_members_scored_per_batch"] = int(len(last_g.line_label)) if getattr(last_g, "line_label", None) is not None else None
+        group_ocr_leg["gpu_ms_per_batch_isolated"] = {k: round(sp_g.get(k, 0.0), 4) for k in ("track", "ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")}
 
     # ties leg: the same measurement on tie-rich frames (S-ties), so that the cost of exactness is on the line
     ties_leg = None
     if not args.no_ties_leg and args.kind == "text" and world == 1 and args.sibling_order == 0 and not args.ocr and not args.group:
-        with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
-            tf = np.stack(list(ex.map(lambda i: S.synth.sties_bgr(S.synth.frame_seed(i), W, H, args.ties_every), range(F))))
-        d_ties = torch.from_numpy(tf).to(device)
+        tf_ = make_frames(S, "ties", W, H, F, first=0, ties_every=args.ties_every)
+        d_ties = torch.from_numpy(tf_).to(device)
         torch.cuda.synchronize()
-        run(P, d_ties)
+        rig.run(P, d_ties, stages)
         n_t = max(P, args.steps // 2)
-        a0 = tie_totals()
+        a0 = rig.tie_totals()
         cpu1 = time.process_time()
-        t1 = time.perf_counter()
-        run(n_t, d_ties)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
+        el, _, _ = rig.timed(n_t, d_ties, stages)
         ties_cpu = (time.process_time() - cpu1) / max(el, 1e-9)
-        a1 = tie_totals()
+        a1 = rig.tie_totals()
         ties_leg = {"value": round(F * n_t / el, 2), "unit": "frames/s", "steps": n_t, "ms_per_step": round(1e3 * el / n_t, 3),
+                    "frac_of_value": round(F * n_t / el / (F * args.steps / elapsed), 4),
                     "tie_planes_per_batch": round((a1[0] - a0[0]) / n_t, 2), "tie_plane_share": round((a1[0] - a0[0]) / n_t / (F * bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels']), 4),
                     "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(), "host_cpu_quota": effective_cpus(), "host_cpus_busy": round(ties_cpu, 2),
                     "note": f"S-ties frames (S-text + one double-L glyph in every {args.ties_every}th frame: an NMS sibling tie with two different outcomes); same "
                             "batches in flight as `value`; flood_walk_ms = host time of the reference-order walks, summed over planes.  The walks are "
-                            "bound by host memory latency (~6 ms per 1920x1080 plane): once tie planes per batch x 6 ms / host_threads exceeds the "
-                            "GPU's time per batch the leg is host-bound (measured with a glyph in every 3rd frame, 3.1 % of the planes: 0.47 of `value`)"}
+                            "bound by host memory latency: once tie planes per batch x walk time / host_threads exceeds the "
+                            "GPU's time per batch the leg is host-bound"}
         del d_ties
 
     # latency leg: ONE frame per call, one batch in flight (north_star: ">= 500 fps end-to-end on 1920x1080" is a
-    # per-frame statement; the headline `value` needs 48-frame batches x 3 in flight)
-    latency = None
-    if not args.no_latency and rank == 0:
-        for f in filters[1:]:
-            f.close()
-        filters = filters[:1]
-        f1 = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, n_pyr_levels=cfg["n_pyr_levels"],
-                                        channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order))
+    # per-frame statement; the headline `value` needs 48-frame batches x 6 in flight)
+    def latency_leg(w, h, lcfg, frs, d_frs, lstages, with_svm):
+        f1 = S.ERFilter(params=S.Params(max_width=w, max_height=h, max_frames=1, n_pyr_levels=lcfg["n_pyr_levels"],
+                                        channel_mask=lcfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order))
         f1.load_cascade(0, cascades[0]); f1.load_cascade(1, cascades[1])
-        if args.ocr:
-            import gzip
-            f1.load_svm_model_text(gzip.open(S.cascade_io.ocr_model_path()).read(), 1800)
-        fb = frames[0].nbytes
+        if with_svm:
+            f1.load_svm_model_text(svm_text, 1800)
+        fb, nF = frs[0].nbytes, len(frs)
         for i in range(3):
-            f1.detect_bgr_device(d_frames.data_ptr() + (i % F) * fb, W, H, 1, stages)
+            f1.detect_bgr_device(d_frs.data_ptr() + (i % nF) * fb, w, h, 1, lstages)
         n_lat = 40
         dev_ms, host_ms = [], []
         for i in range(n_lat):
             t1 = time.perf_counter()
-            f1.detect_bgr_device(d_frames.data_ptr() + (i % F) * fb, W, H, 1, stages)
+            f1.detect_bgr_device(d_frs.data_ptr() + (i % nF) * fb, w, h, 1, lstages)
             dev_ms.append(1e3 * (time.perf_counter() - t1))
         for i in range(n_lat):
             t1 = time.perf_counter()
-            f1.text_detect(frames[i % F], stages)          # pageable host frame: H2D copy inside the call
+            f1.text_detect(frs[i % nF], lstages)          # pageable host frame: H2D copy inside the call
             host_ms.append(1e3 * (time.perf_counter() - t1))
         f1.close()
-        latency = {"ms_per_frame": round(float(np.median(dev_ms)), 3), "frames_per_s": round(1e3 / float(np.median(dev_ms)), 1),
-                   "ms_per_frame_p90": round(float(np.percentile(dev_ms, 90)), 3),
-                   "ms_per_frame_host_input": round(float(np.median(host_ms)), 3),
-                   "frames_per_s_host_input": round(1e3 / float(np.median(host_ms)), 1),
-                   "note": f"1 frame per call, 1 call in flight, call-to-return wall time incl. the candidate copy to the host; median of {n_lat}; "
-                           "host_input = the frame starts in pageable host memory (H2D inside the call)"}
+        return {"ms_per_frame": round(float(np.median(dev_ms)), 3), "frames_per_s": round(1e3 / float(np.median(dev_ms)), 1),
+                "ms_per_frame_p90": round(float(np.percentile(dev_ms, 90)), 3),
+                "ms_per_frame_host_input": round(float(np.median(host_ms)), 3),
+                "frames_per_s_host_input": round(1e3 / float(np.median(host_ms)), 1),
+                "note": f"1 frame per call, 1 call in flight, call-to-return wall time incl. the candidate copy to the host; median of {n_lat}; "
+                        "host_input = the frame starts in pageable host memory (H2D inside the call)"}
+
+    latency = None
+    rig.close()
+    if not args.no_latency and rank == 0:
+        latency = latency_leg(W, H, cfg, frames, d_frames, stages, args.ocr)
 
     pcie = pcie_nv12 = None
     if not args.no_host_frames and not args.ocr and rank == 0:
         # "a frame = BGR upload excluded and included (both reported)".  The frames sit in the stream's page-locked
         # staging buffers (where a decoder would put them); every step uploads its 3*W*H*F bytes again.
-        for f in filters:
-            f.close()
+        from concurrent.futures import ThreadPoolExecutor
         st = S.FrameStream(S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=cfg["n_pyr_levels"],
                                     channel_mask=cfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order), depth=P)
         st.load_cascade(0, cascades[0]); st.load_cascade(1, cascades[1])
 
-        def stream_steps(n):
+        def stream_steps(n, data, submit):
             for _ in range(n):
                 if st.pending() == P:
                     st.next()
                 slot, buf = st.acquire()
                 if not filled[slot]:
-                    buf[: frames.size] = frames.reshape(-1)
+                    buf[: data.size] = data.reshape(-1)
                     filled[slot] = True
-                st.submit(slot, W, H, F, stages)
+                submit(slot, W, H, F, stages)
             while st.pending():
                 st.next()
 
@@ -431,11 +568,12 @@ def main():
         h2d_gbs = 5 * frames.size / (time.perf_counter() - t1) / 1e9
         del pin, dst
         filled = [False] * P
-        stream_steps(max(P, args.warmup))
+        stream_steps(max(P, args.warmup), frames, st.submit)
         t1 = time.perf_counter()
-        stream_steps(args.steps)
+        stream_steps(args.steps, frames, st.submit)
         el = time.perf_counter() - t1
         pcie = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
+                "frac_of_value": round(F * args.steps / el / (F * args.steps / elapsed), 4),
                 "h2d_bytes_per_step": int(frames.size), "h2d_gbs": round(frames.size * args.steps / el / 1e9, 2),
                 # (a torch copy of the same bytes from a torch-pinned tensor, nothing else running: 57 GB/s on most of the round's boxes, 26 on one where the
                 # stream itself -- hipHostMalloc'ed staging, several copies queued -- moved 43: the larger of the two is what the link is known to deliver)
@@ -444,30 +582,57 @@ def main():
         # ... and the same frames as a video decoder would deliver them: NV12, half the bytes (build-defined ingest, include/str_er.h)
         with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
             nv = np.stack(list(ex.map(S.synth.nv12_from_bgr, frames)))
-
-        def stream_steps_nv12(n):
-            for _ in range(n):
-                if st.pending() == P:
-                    st.next()
-                slot, buf = st.acquire()
-                if not filled[slot]:
-                    buf[: nv.size] = nv.reshape(-1)
-                    filled[slot] = True
-                st.submit_nv12(slot, W, H, F, stages)
-            while st.pending():
-                st.next()
-
         filled = [False] * P
-        stream_steps_nv12(max(P, args.warmup))
+        stream_steps(max(P, args.warmup), nv, st.submit_nv12)
         t1 = time.perf_counter()
-        stream_steps_nv12(args.steps)
+        stream_steps(args.steps, nv, st.submit_nv12)
         el = time.perf_counter() - t1
         pcie_nv12 = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
+                     "frac_of_value": round(F * args.steps / el / (F * args.steps / elapsed), 4),
                      "h2d_bytes_per_step": int(nv.size), "h2d_gbs": round(nv.size * args.steps / el / 1e9, 2),
                      "note": "the same frames as NV12 (luma + interleaved Cb/Cr at half resolution: what a decoder delivers) through the same stream; "
                              "the NV12 -> Y/Cr/Cb step is build-defined (chroma replicated 2x2), so the planes -- and the candidates -- are not "
                              "those of the BGR frames"}
         st.close()
+        del nv
+
+    # ---- config 5 on this one GPU: 3840x2160, 12 levels (the 8-GPU plane / strip sharding of configs[4] is covered by tests; this is the single-GPU rate)
+    k4_leg = None
+    if single and not args.no_4k_leg and args.size == "1080p" and args.workload == "pyr3x8" and args.kind == "text" and not args.ocr and not args.group:
+        del d_frames
+        torch.cuda.empty_cache()
+        w4, h4, F4, cfg4 = 3840, 2160, 12, WORKLOADS["pyr3x12"]
+        fr4 = make_frames(S, "text", w4, h4, F4)
+        d4 = torch.from_numpy(fr4).to(device)
+        rig4 = Rig(S, P, w4, h4, F4, cfg4, dev_index, args.sibling_order, cascades)
+        rig4.run(2 * P, d4, S.STAGE_ALL)
+        n4 = max(P, args.steps // 2)
+        el4, prof4, _ = rig4.timed(n4, d4, S.STAGE_ALL)
+        sp4, _ = rig4.serial_profile(d4, S.STAGE_ALL)
+        px4 = plane_pixels("pyr3x12", w4, h4)
+        k4_leg = {"value": round(F4 * n4 / el4, 2), "unit": "frames/s", "steps": n4, "frames_per_step": F4, "ms_per_step": round(1e3 * el4 / n4, 3),
+                  "plane_pixels_per_frame": px4, "mpx_per_s": round(px4 * F4 * n4 / el4 / 1e6, 1),
+                  "mpx_per_s_of_value": round(plane_pixels(args.workload) * F * args.steps / elapsed / 1e6, 1),
+                  "workload": WORKLOADS["pyr3x12"]["label"] + "; S-text frames; one GPU",
+                  "roofline": tile_roofline(px4, F4, sp4.get("tile_tree", 0.0), prof4.get("tile_tree", 0.0) / n4, "pyr3x12"),
+                  "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in sp4.items()}}
+        # the cost of exact NMS ties at this size: the host walk of one 8.3 Mpx plane
+        if args.sibling_order == 0 and not args.no_ties_leg:
+            t4 = make_frames(S, "ties", w4, h4, F4, ties_every=args.ties_every)
+            d4t = torch.from_numpy(t4).to(device)
+            rig4.run(P, d4t, S.STAGE_ALL)
+            a0 = rig4.tie_totals()
+            n4t = max(P, n4 // 2)
+            el4t, _, _ = rig4.timed(n4t, d4t, S.STAGE_ALL)
+            a1 = rig4.tie_totals()
+            walked = a1[0] - a0[0]
+            k4_leg["nms_ties"] = {"value": round(F4 * n4t / el4t, 2), "frac_of_4k_value": round(F4 * n4t / el4t / (F4 * n4 / el4), 4),
+                                  "tie_planes_per_batch": round(walked / n4t, 2), "flood_walk_ms_per_plane": round((a1[1] - a0[1]) / max(walked, 1), 2)}
+            del d4t, t4
+        rig4.close()
+        if not args.no_latency:
+            k4_leg["latency_1frame"] = latency_leg(w4, h4, cfg4, fr4, d4, S.STAGE_ALL, False)
+        del d4
 
     if rank == 0:
         total_frames = F * world * args.steps
@@ -482,21 +647,9 @@ def main():
         # event-to-event time also contains the other batches' kernels and is not a per-launch cost.
         tile_ms_overlapped = prof_sum.get("tile_tree", 0.0) / max(args.steps, 1)
         tile_ms = serial_prof.get("tile_tree", 0.0) or tile_ms_overlapped
-        tile_bytes = px * F
-        achieved = tile_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        traffic, traffic_source = None, "not measured in this run (no rocprofv3 counter pass)"
-        pmc = os.path.join(ROOT, "profiles", "pmc_tile_tree.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as fh:
-                    j = json.load(fh)
-                if j.get("workload") == args.workload and j.get("frames_per_launch"):
-                    traffic = j["hbm_bytes_per_launch"] * F / j["frames_per_launch"]
-                    traffic_source = ("STORED figure, not measured in this run: profiles/pmc_tile_tree.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                      f"passes of this command, collected {j.get('collected', 'earlier')}; FETCH doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to "
-                                      f"{F} frames per launch")
-            except Exception:
-                traffic = None
+        roof = tile_roofline(px, F, tile_ms, tile_ms_overlapped, args.workload)
+        roof["path_bytes_per_frame"] = int(b_alg)
+        roof["path_frac"] = round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)
         # the other passes of the component tree, priced the same way: algorithmic bytes = what the pass has to read and write once
         # (32-byte node records + their 4-byte counters, two 16-bit seam entries per pixel pair across a tile border) over the pass's isolated time
         ts = r_tree_stats
@@ -510,10 +663,11 @@ def main():
         tree_roof["note"] = (f"k_group_merge / k_seam / k_resolve / k_reduce of one batch ({ts['records']} exported node records, {ts['seam_pairs']} border pixel pairs, "
                              f"{ts['tiles']} tiles): isolated times as for k_tile_tree; bound by LDS / device-scope atomic latency, not by HBM (DESIGN 3.2)")
         out = {
-            "metric": "frames/sec (ER extract + 2-stage classify), 1920x1080",
+            "metric": f"frames/sec (ER extract + 2-stage classify), {W}x{H}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "repeats": n_reg, "value_min": round(total_frames / max(regions), 2), "value_max": round(total_frames / min(regions), 2),
             "config": {"workload": f"{args.workload}: {cfg['label']}; S-{args.kind} frames" +
                                    ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr and not args.group else "") +
                                    ("; + calc_color, er_track, er_grouping (text lines)" if args.group else "") +
@@ -523,25 +677,23 @@ def main():
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
                        "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P, "host_cpus_busy": round(host_cpu_per_wall, 2),
                        "workspace_bytes_per_batch_in_flight": ws_bytes, "nms_sibling_ties": "exact (reference flood order)" if args.sibling_order == 0 else "key rule",
+                       "cu_partition": os.environ.get("STR_ER_CU_PARTITION", "none"),
                        **({"gather": "RCCL through the C ABI (str_er_gather_last)" if comm is not None else "torch.distributed all_gather"} if world > 1 else {})},
             "nms_ties": nms_ties,
+            **({"config3_ocr_leg": ocr_leg} if ocr_leg else {}),
+            **({"group_ocr_leg": group_ocr_leg} if group_ocr_leg else {}),
+            **({"config5_4k_leg": k4_leg} if k4_leg else {}),
             **({"nms_ties_leg": ties_leg} if ties_leg else {}),
             **({"pcie_inclusive": pcie} if pcie else {}),
             **({"pcie_inclusive_nv12": pcie_nv12} if pcie_nv12 else {}),
             **({"latency_1frame": latency} if latency else {}),
-            "roofline": {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_peak": round(achieved / HBM_MEASURED_GBS, 5),
-                         "measured_peak": HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "bytes_per_launch": tile_bytes, "avg_launch_ms": round(tile_ms, 4),
-                         "timing": "isolated launch: HIP events on the library's stream, one batch in flight, mean of 3 launches after the timed region",
-                         "overlapped_event_ms": round(tile_ms_overlapped, 4),
-                         "path_bytes_per_frame": int(b_alg), "path_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)},
+            "roofline": roof,
             "tree_passes_roofline": tree_roof,
             "gpu_ms_per_step_by_kernel_group": {k: round(v / args.steps, 4) for k, v in prof_sum.items()},
             "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in serial_prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades)
+            out["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades, ocr_model=svm_path if args.ocr and not args.group else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -31,4 +31,24 @@ __device__ __forceinline__ int otsu_from_hist(const uint32_t *hist, double n)
     return (int)max_val;
 }
 
+// cv::resize INTER_LINEAR 8UC1 geometry (OpenCV 4.x semantics; the CPU restatement the tests compare with follows the same statement)
+struct ResizeGeom {
+    int    sw, sh, dw, dh;
+    int    mode;          // 0 copy, 1 exact 2x2 area, 2 fixed-point bilinear
+    double scale_x, scale_y;
+};
+
+__device__ __forceinline__ ResizeGeom resize_geom(int sw, int sh, int dw, int dh)
+{
+    ResizeGeom g;
+    g.sw = sw; g.sh = sh; g.dw = dw; g.dh = dh;
+    g.scale_x = 1.0 / ((double)dw / sw);
+    g.scale_y = 1.0 / ((double)dh / sh);
+    if (dw == sw && dh == sh) { g.mode = 0; return g; }
+    const int isx = (int)rint(g.scale_x), isy = (int)rint(g.scale_y);
+    const bool fast = fabs(g.scale_x - isx) < DBL_EPSILON && fabs(g.scale_y - isy) < DBL_EPSILON;
+    g.mode = (fast && isx == 2 && isy == 2) ? 1 : 2;
+    return g;
+}
+
 } // namespace str_er

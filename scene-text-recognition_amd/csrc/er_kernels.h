@@ -99,15 +99,4 @@ void launch_lbp_boxes(hipStream_t s, const uint8_t *plane, int w, int h, int str
 // CascadeBoost::predict on explicit feature vectors (n x 1024 doubles).
 void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, CascadeDev c);
 
-// OCR::chain_run feature extraction (slope 0) for n boxes of one device plane: q_out [n x 1800] u8 and/or x_out [n x xdim] f64 (= q/255).
-void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
-                           double *x_out, int xdim, const RotGeom *rot);
-
-// Batch form: list the strong/weak candidates (n = their number, known on the host from the plane counters) and
-// extract their chain-code features straight from the device planes into x_out [n x xdim] (f64, q/255).
-void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out, int n, double *x_out, int xdim);
-// chain-code features of n records (plane = recs[list[i]].plane, box = its x,y,w,h), optionally rotated per record
-void launch_chain_features_members(hipStream_t s, const CandRec *recs, const uint32_t *list, const PlaneDesc *planes, int n, double *x_out, int xdim,
-                                   const RotGeom *rot);
-
 } // namespace str_er

@@ -192,25 +192,6 @@ void launch_invert(hipStream_t s, const uint8_t *src, uint8_t *dst, size_t n)
 // statement this follows).  `inv` is xor-ed into every tap so an inverted channel is
 // resized exactly like the materialised 255-x plane would be.
 // ------------------------------------------------------------------------------------
-struct ResizeGeom {
-    int    sw, sh, dw, dh;
-    int    mode;          // 0 copy, 1 exact 2x2 area, 2 fixed-point bilinear
-    double scale_x, scale_y;
-};
-
-__device__ __forceinline__ ResizeGeom resize_geom(int sw, int sh, int dw, int dh)
-{
-    ResizeGeom g;
-    g.sw = sw; g.sh = sh; g.dw = dw; g.dh = dh;
-    g.scale_x = 1.0 / ((double)dw / sw);
-    g.scale_y = 1.0 / ((double)dh / sh);
-    if (dw == sw && dh == sh) { g.mode = 0; return g; }
-    const int isx = (int)rint(g.scale_x), isy = (int)rint(g.scale_y);
-    const bool fast = fabs(g.scale_x - isx) < DBL_EPSILON && fabs(g.scale_y - isy) < DBL_EPSILON;
-    g.mode = (fast && isx == 2 && isy == 2) ? 1 : 2;
-    return g;
-}
-
 __device__ __forceinline__ int resize_px(const ResizeGeom &g, const uint8_t *__restrict__ src, int sstride, int inv,
                                          int dx, int dy)
 {
@@ -1819,10 +1800,6 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         const uint16_t *seam = b.seam + pd.seam_base;
         const uint32_t  n_hp = (uint32_t)((gh - 1) * gw * TILE_W), n_vp = (uint32_t)((gw - 1) * gh * TILE_H);
         const size_t    voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
-#ifdef STR_ER_GM_REDIST
-        __shared__ uint32_t s_gm_a[CAP <= 1024 ? GROUP_THREADS / 64 : 1][64], s_gm_b[CAP <= 1024 ? GROUP_THREADS / 64 : 1][64];
-        uint32_t gm_cnt = 0;          // survivors of this wave so far (the same in all its lanes)
-#endif
         for (uint32_t p0 = 0; p0 < n_hp + n_vp; p0 += GROUP_THREADS) {
             const uint32_t p = p0 + (uint32_t)tid;
             uint32_t a = NONE, bb = NONE;
@@ -1847,39 +1824,12 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
             //  that are a local minimum of max(level a, level b) along their tile's side -- the heavier of two neighbouring pairs is the heaviest edge of a
             //  cycle whose other edges stay; parity green, ~20x fewer connects -- and fetching four rounds of seam entries ahead: neither moved it, here or
             //  in k_seam.  The step is as long as its longest connects, the ones that merge two deep root paths; their number is not what costs.)
-#ifdef STR_ER_GM_REDIST
-            // UNTESTED on a GPU (written when round 4's GPU minutes were spent; off unless -DSTR_ER_GM_REDIST): a wave runs its two or three rounds of connects one
-            // after the other and each round lasts as long as its longest connect.  Here the rounds only COLLECT: a pair survives if it is a local minimum of
-            // max(level a, level b) along its tile's side (see the note above: parity was green with this rule, alone it gave nothing), the survivors of all
-            // rounds are packed into the wave's 64 staging slots, and ONE round of connects follows the loop -- a survivor a lane.  (Small variants only: the
-            // staging is 8 bytes a lane, which the 2528-record variant's two-workgroups-a-CU budget does not have.)
-            if constexpr (CAP <= 1024) {
-                const uint32_t w = a != NONE ? max(s_key[a] >> 24, s_key[bb] >> 24) : 0xFFFFFFFFu;
-                const uint32_t wp = (uint32_t)__shfl_up((int)w, 1), wn = (uint32_t)__shfl_down((int)w, 1);
-                const bool     horiz = p0 + (uint32_t)(tid & ~63) < n_hp;          // (n_hp is a multiple of 64: a wave is all of one kind)
-                const int      ls = horiz ? (tid & 63) : (tid & 31), last = horiz ? 63 : 31;
-                const bool     keep = a != NONE && !((ls != 0 && wp <= w) || (ls != last && wn < w));
-                const unsigned long long m = __ballot(keep);
-                const uint32_t at = gm_cnt + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
-                if (keep) {
-                    if (at < 64u) { s_gm_a[tid >> 6][at] = a; s_gm_b[tid >> 6][at] = bb; }
-                    else lconnect(a, bb);                                           // (more than 64 survivors in a wave: the rest at once, as before)
-                }
-                gm_cnt += (uint32_t)__popcll(m);
-            } else
-#endif
             {
                 const uint32_t pa = __shfl_up(a, 1), pb = __shfl_up(bb, 1);
                 const bool dup = (tid & 63) != 0 && pa == a && pb == bb;
                 if (a != NONE && !dup) lconnect(a, bb);
             }
         }
-#ifdef STR_ER_GM_REDIST
-        if constexpr (CAP <= 1024) {
-            WAVE_SYNC();
-            if ((uint32_t)(tid & 63) < min(gm_cnt, 64u)) lconnect(s_gm_a[tid >> 6][tid & 63], s_gm_b[tid >> 6][tid & 63]);
-        }
-#endif
     }
     __syncthreads();
     GM_MARK(3);
@@ -3900,281 +3850,6 @@ void launch_cascade_fv(hipStream_t s, const double *fv, int n, double *out, Casc
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_cascade_fv, dim3(n < 2048 ? n : 2048), dim3(CLS_THREADS), 0, s, fv, n, out, c);
-}
-
-// ------------------------------------------------------------------------------------
-// OCR scorer, feature half (config 3): OCR::chain_run up to the svm call
-// (src/OCR.cpp:67-91) with slope == 0, one workgroup per ER:
-//   Otsu threshold of 255 - roi  ->  ARAN(30) of the binarised image  ->  extract_feature
-//   (src/OCR.cpp:144-218): border following, 8 direction bitmaps, 7x7 Gaussian (8-bit fixed point),
-//   min-max normalisation, 2x2 area decimation  ->  q[1800] (feature = q / 255.0).
-// The OpenCV primitives involved (Otsu, findContours, GaussianBlur, normalize) are restated from OpenCV 4.x.
-// ------------------------------------------------------------------------------------
-struct ChainShared {
-    uint32_t    hist[256];
-    int         thresh;
-    uint8_t     img[30 * 30 + 4];
-    signed char f[32 * 32];
-    uint8_t     maps[8 * 900];
-    uint16_t    hrow[8 * 900];
-    uint32_t    mn[8], mx[8];
-};
-
-// Source of ARAN(30): the Otsu-binarised ROI, tap = (255 - (p ^ inv)) > thresh ? 255 : 0 ...
-__device__ __forceinline__ int bin_tap(const uint8_t *p, int inv, int th) { return (255 - (*p ^ inv)) > th ? 255 : 0; }
-
-struct BinSrc {
-    const uint8_t *roi; int stride, inv, th;
-    __device__ __forceinline__ int operator()(int x, int y) const { return bin_tap(roi + (size_t)y * stride + x, inv, th); }
-};
-// ... or that image seen through OCR::rotate_mat (src/OCR.cpp:282-352): canvas pixel (x, y) is rebuilt
-// from its four binarised source taps with the reference's own f64 expression, in its order.
-struct RotSrc {
-    BinSrc b; int bw, bh; RotGeom r;
-    __device__ __forceinline__ int operator()(int x, int y) const
-    {
-        const int i = y + r.min_y + r.ch, j = x + r.min_x;
-        if (i >= r.max_y - r.ch || j >= r.max_x) return 0;                   // the loops are exclusive
-        const double new_j = r.c * (double)j - r.s * (double)(i - r.ch) + (double)r.x0;
-        const double new_i = r.s * (double)j + r.c * (double)(i - r.ch) + (double)r.y0;
-        if (!(new_i > 0 && new_j > 0 && new_i < (double)(bh - 1) && new_j < (double)(bw - 1))) return 0;
-        if (r.crop && !(i > r.min_y + r.ch && i < r.max_y - r.ch)) return 0;
-        const int    sy = (int)new_i, sx = (int)new_j;
-        const double fi = floor(new_i), fj = floor(new_j);
-        if (new_i == fi && new_j == fj) return b(sx, sy);
-        const double alpha = new_i - fi, beta = new_j - fj;
-        const double A = (double)b(sx, sy), B = (double)b(sx + 1, sy), C = (double)b(sx, sy + 1), D = (double)b(sx + 1, sy + 1);
-        const double v = (1 - alpha) * (1 - beta) * A + (1 - alpha) * beta * B + alpha * (1 - beta) * C + alpha * beta * D;
-        return (int)(uint8_t)round(v);
-    }
-};
-
-// resize_px over an arbitrary source (same arithmetic as resize_px)
-template <class Src>
-__device__ __forceinline__ int resize_px_src(const ResizeGeom &g, const Src &src, int dx, int dy)
-{
-    if (g.mode == 0) return src(dx, dy);
-    if (g.mode == 1) return (src(2 * dx, 2 * dy) + src(2 * dx + 1, 2 * dy) + src(2 * dx, 2 * dy + 1) + src(2 * dx + 1, 2 * dy + 1) + 2) >> 2;
-    float fx = (float)((dx + 0.5) * g.scale_x - 0.5);
-    int   sx = (int)floorf(fx);
-    fx -= (float)sx;
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= g.sw - 1) { fx = 0.f; sx = g.sw - 1; }
-    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
-    float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
-    int   sy = (int)floorf(fy);
-    fy -= (float)sy;
-    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
-    const int y0 = min(max(sy, 0), g.sh - 1), y1 = min(max(sy + 1, 0), g.sh - 1);
-    const int sx1 = (sx + 1 < g.sw) ? sx + 1 : sx;
-    const int r0 = src(sx, y0) * a0 + src(sx1, y0) * a1;
-    const int r1 = src(sx, y1) * a0 + src(sx1, y1) * a1;
-    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-    return min(max(v, 0), 255);
-}
-
-__device__ __forceinline__ int reflect101_30(int i) { return i < 0 ? -i : (i >= 30 ? 58 - i : i); }
-
-// Box source: either explicit boxes on one plane (single-stage API), or the batch's classified
-// candidates: ocr_list[i] = index into cands[], whose plane says which channel / pyramid level / polarity.
-__global__ __launch_bounds__(256) void k_chain_features(const uint8_t *__restrict__ plane, int stride, int inv,
-                                                        const int32_t *__restrict__ boxes, int n, uint8_t *__restrict__ q_out,
-                                                        double *__restrict__ x_out, int xdim, const CandRec *__restrict__ cands,
-                                                        const uint32_t *__restrict__ ocr_list, const PlaneDesc *__restrict__ planes,
-                                                        const RotGeom *__restrict__ rot)
-{
-    __shared__ ChainShared sh;
-    const int tid = threadIdx.x;
-    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-        int bx, by, bw, bh;
-        if (cands) {
-            const CandRec   &cd = cands[ocr_list[bi]];
-            const PlaneDesc &pd = planes[cd.plane];
-            bx = cd.x; by = cd.y; bw = cd.w; bh = cd.h;
-            plane = pd.pix; stride = pd.stride; inv = pd.invert;
-        } else {
-            bx = boxes[4 * bi]; by = boxes[4 * bi + 1]; bw = boxes[4 * bi + 2]; bh = boxes[4 * bi + 3];
-        }
-        const uint8_t *roi = plane + (size_t)by * stride + bx;
-        // ---- Otsu (getThreshVal_Otsu_8u) on 255 - roi
-        sh.hist[tid] = 0;
-        for (int i = tid; i < 8; i += 256) { sh.mn[i] = 255; sh.mx[i] = 0; }
-        for (int i = tid; i < 900; i += 256) sh.img[i] = 0;
-        for (int i = tid; i < 32 * 32; i += 256) sh.f[i] = 0;
-        for (int i = tid; i < 8 * 900; i += 256) sh.maps[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < bw * bh; i += 256) {
-            const int y = i / bw, x = i - y * bw;
-            atomicAdd(&sh.hist[255 - (roi[(size_t)y * stride + x] ^ inv)], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) sh.thresh = otsu_from_hist(sh.hist, (double)bw * bh);
-        __syncthreads();
-        // ---- ARAN(30) of the binarised (and, for a slanted text line, rotated) ROI
-        {
-            const BinSrc bsrc{roi, stride, inv, sh.thresh};
-            const bool   ron = rot != nullptr && rot[bi].on != 0;
-            const int    sw = ron ? rot[bi].rw : bw, shh = ron ? rot[bi].rh : bh;
-            const double R1 = (sw > shh) ? (double)shh / sw : (double)sw / shh;
-            const int    k = (int)(30.0 * sqrt(R1));
-            const int    dw = (sw > shh) ? 30 : k, dh = (sw > shh) ? k : 30;
-            if (dw > 0 && dh > 0) {
-                const int offy = (dw > dh) ? (30 - dh) / 2 : 0, offx = (dw > dh) ? 0 : (30 - dw) / 2;
-                const ResizeGeom g = resize_geom(sw, shh, dw, dh);
-                if (ron) {
-                    const RotSrc rsrc{bsrc, bw, bh, rot[bi]};
-                    for (int i = tid; i < dw * dh; i += 256) {
-                        const int dy = i / dw, dx = i - dy * dw;
-                        const int v = resize_px_src(g, rsrc, dx, dy);
-                        sh.img[(dy + offy) * 30 + dx + offx] = (uint8_t)v;
-                        sh.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
-                    }
-                } else {
-                    for (int i = tid; i < dw * dh; i += 256) {
-                        const int dy = i / dw, dx = i - dy * dw;
-                        const int v = resize_px_src(g, bsrc, dx, dy);
-                        sh.img[(dy + offy) * 30 + dx + offx] = (uint8_t)v;
-                        sh.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- border following (cv::findContours RETR_LIST / CHAIN_APPROX_NONE) + direction bitmaps: one lane
-        if (tid == 0) {
-            const int ddx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, ddy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-            for (int y = 1; y <= 30; ++y) {
-                int prev = 0;
-                for (int x = 1; x <= 31; ++x) {
-                    int p = sh.f[y * 32 + x];
-                    if (p == prev) continue;
-                    int is_hole = 0;
-                    if (!(prev == 0 && p == 1)) {
-                        if (p != 0 || prev < 1) { prev = p; continue; }
-                        is_hole = 1;
-                    }
-                    const int i0 = y * 32 + x - is_hole;
-                    int s_end = is_hole ? 0 : 4, s = s_end, i1 = i0;
-                    do { s = (s - 1) & 7; i1 = i0 + ddy[s] * 32 + ddx[s]; } while (sh.f[i1] == 0 && s != s_end);
-                    int cx = x - is_hole, cy = y;
-                    if (s == s_end) {
-                        sh.f[i0] = (signed char)(2 | -128);          // isolated pixel: a one-point contour, skipped (:160)
-                    } else {
-                        int i3 = i0;
-                        for (;;) {
-                            int i4;
-                            s_end = s;
-                            for (;;) { ++s; i4 = i3 + ddy[s & 7] * 32 + ddx[s & 7]; if (sh.f[i4] != 0) break; }
-                            s &= 7;
-                            if ((unsigned)(s - 1) < (unsigned)s_end) sh.f[i3] = (signed char)(2 | -128);
-                            else if (sh.f[i3] == 1) sh.f[i3] = 2;
-                            // next point relative to the current one (OCR::chain_code_direction, :602-622)
-                            const int sx = ddx[s], sy = ddy[s];
-                            int d;
-                            if (sx < 0 && sy == 0) d = 0; else if (sx < 0 && sy < 0) d = 1; else if (sx == 0 && sy < 0) d = 2;
-                            else if (sx > 0 && sy < 0) d = 3; else if (sx > 0 && sy == 0) d = 4; else if (sx > 0 && sy > 0) d = 5;
-                            else if (sx == 0 && sy > 0) d = 6; else d = 7;
-                            sh.maps[d * 900 + (cy - 1) * 30 + (cx - 1)] = 255;
-                            cx += sx; cy += sy;
-                            if (i4 == i0 && i3 == i1) break;
-                            i3 = i4;
-                            s = (s + 4) & 7;
-                        }
-                    }
-                    p = sh.f[y * 32 + x];
-                    prev = p;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- GaussianBlur 7x7 (kernel 8,28,56,72,56,28,8 / 256, BORDER_REFLECT_101), fixed point
-        for (int i = tid; i < 8 * 900; i += 256) {
-            const int c = i / 900, r = i - c * 900, y = r / 30, x = r - y * 30;
-            const uint8_t *m = sh.maps + c * 900 + y * 30;
-            const int s = 8 * (m[reflect101_30(x - 3)] + m[reflect101_30(x + 3)]) + 28 * (m[reflect101_30(x - 2)] + m[reflect101_30(x + 2)]) +
-                          56 * (m[reflect101_30(x - 1)] + m[reflect101_30(x + 1)]) + 72 * m[x];
-            sh.hrow[i] = (uint16_t)s;
-        }
-        __syncthreads();
-        for (int i = tid; i < 8 * 900; i += 256) {
-            const int c = i / 900, r = i - c * 900, y = r / 30, x = r - y * 30;
-            const uint16_t *hc = sh.hrow + c * 900 + x;
-            const int s = 8 * (hc[reflect101_30(y - 3) * 30] + hc[reflect101_30(y + 3) * 30]) +
-                          28 * (hc[reflect101_30(y - 2) * 30] + hc[reflect101_30(y + 2) * 30]) +
-                          56 * (hc[reflect101_30(y - 1) * 30] + hc[reflect101_30(y + 1) * 30]) + 72 * hc[y * 30];
-            const int v = min((s + (1 << 15)) >> 16, 255);
-            sh.maps[i] = (uint8_t)v;                     // each lane overwrites only its own element; hrow is the source
-            atomicMin(&sh.mn[c], (uint32_t)v);
-            atomicMax(&sh.mx[c], (uint32_t)v);
-        }
-        __syncthreads();
-        // ---- normalize(0, 255, NORM_MINMAX) in float, then resize 30 -> 15 (exact 2x: area)
-        for (int i = tid; i < 8 * 900; i += 256) {
-            const int    c = i / 900;
-            const int    mn = (int)sh.mn[c], mx = (int)sh.mx[c];
-            const double scale = (mx - mn) > 0 ? 255.0 / (mx - mn) : 0.0, shift = 0.0 - mn * scale;
-            const float  v = (float)sh.maps[i] * (float)scale + (float)shift;
-            sh.hrow[i] = (uint16_t)min(max(__float2int_rn(v), 0), 255);
-        }
-        __syncthreads();
-        for (int i = tid; i < 1800; i += 256) {
-            const int c = i / 225, r = i - c * 225, y = r / 15, x = r - y * 15;
-            const uint16_t *m = sh.hrow + c * 900 + (2 * y) * 30 + 2 * x;
-            const int v = (m[0] + m[1] + m[30] + m[31] + 2) >> 2;
-            if (q_out) q_out[(size_t)bi * 1800 + i] = (uint8_t)v;
-            if (x_out) x_out[(size_t)bi * xdim + i] = v / 255.0;       // fv.value = ptr[p] / 255.0 (src/OCR.cpp:211)
-        }
-        __syncthreads();
-    }
-}
-
-void launch_chain_features(hipStream_t s, const uint8_t *plane, int stride, int inv, const int32_t *boxes, int n, uint8_t *q_out,
-                           double *x_out, int xdim, const RotGeom *rot)
-{
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, plane, stride, inv, boxes, n, q_out, x_out, xdim,
-                       (const CandRec *)nullptr, (const uint32_t *)nullptr, (const PlaneDesc *)nullptr, rot);
-}
-
-// indices of the strong / weak candidates of the batch, in candidate order (deterministic)
-__global__ __launch_bounds__(1024) void k_ocr_list(BatchDev b, uint32_t *__restrict__ list, uint32_t *__restrict__ n_out)
-{
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x;
-    const uint32_t total = *b.total_cands;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < total; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = (i < total && b.cands[i].cls != 0) ? 1u : 0u;
-        const uint32_t incl = wave_incl_scan(v);
-        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t off = s_carry, tot = 0;
-        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-        if (v) list[off + incl - 1] = i;
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
-    }
-    if (tid == 0) *n_out = s_carry;
-}
-
-void launch_ocr_features(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out, int n, double *x_out, int xdim)
-{
-    hipLaunchKernelGGL(k_ocr_list, dim3(1), dim3(1024), 0, s, b, list, n_out);
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, (const uint8_t *)nullptr, 0, 0, (const int32_t *)nullptr, n,
-                       (uint8_t *)nullptr, x_out, xdim, (const CandRec *)b.cands, (const uint32_t *)list, b.planes, (const RotGeom *)nullptr);
-}
-
-void launch_chain_features_members(hipStream_t s, const CandRec *recs, const uint32_t *list, const PlaneDesc *planes, int n, double *x_out, int xdim,
-                                   const RotGeom *rot)
-{
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_chain_features, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, (const uint8_t *)nullptr, 0, 0, (const int32_t *)nullptr, n,
-                       (uint8_t *)nullptr, x_out, xdim, recs, list, planes, rot);
 }
 
 } // namespace str_er

@@ -1,0 +1,71 @@
+// ocr_kernels.h -- device model + launchers of the OCR scorer of config 3 (ocr_kernels.hip):
+// OCR::chain_run (src/OCR.cpp:67-140) = chain-code features + svm_predict_probability (src/svm.cpp:2592-2629).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "er_kernels.h"
+
+namespace str_er {
+
+struct SvmDev {
+    int32_t k, l, l_pad, dim, dpad;
+    int32_t kc;             // row length of coef_t: k - 1 rounded up to 64 (64 or 128)
+    double  gamma;
+    const float  *sv;       // [l_pad x dpad] dense, zero padded
+    const double *svnorm;   // [l_pad]
+    const double *coef;     // [(k-1) x l]            sv_coef as libsvm stores it (kept for the layout tests)
+    const double *coef_t;   // [l_pad x kc]              coef_t[q][b] = sv_coef[b][q], zero padded: one coalesced row per support vector
+    const double *rho, *probA, *probB;   // [k(k-1)/2]
+    const int32_t *label, *nsv, *start;  // [k]
+};
+
+// Where the boxes of a call come from: explicit boxes on one device plane (single-stage API), or records
+// (box = recs[list[i]].x,y,w,h on plane planes[recs[list[i]].plane]); rot (optional) = OCR::rotate_mat per box.
+struct OcrSrc {
+    const uint8_t   *plane;
+    int32_t          stride, inv;
+    const int32_t   *boxes;
+    const CandRec   *recs;
+    const uint32_t  *list;
+    const PlaneDesc *planes;
+    const RotGeom   *rot;
+};
+
+// Scratch of one scoring call (all device pointers; carve them out of one allocation with ocr_layout()).
+struct OcrBuf {
+    uint32_t *hist;      // [n x 256]       histogram of 255 - roi                       (features)
+    int32_t  *thresh;    // [n]             Otsu threshold                               (features)
+    uint32_t *big;       // [1 + 4095]      count, then the boxes whose histogram is spread over many workgroups (features)
+    uint8_t  *q;         // [n x 1800] or null: the features as the reference's 8-bit image (q / 255.0 = the svm input)
+    float    *xf;        // [n_pad x dpad]  svm input, f32, zero padded                  (svm)
+    double   *xnorm;     // [n_pad]         |x|^2                                        (svm)
+    double   *kv;        // [n_pad x l_pad] RBF kernel values                            (svm)
+    double   *dec;       // [n x k(k-1)/2] or null: decision values
+    double   *prob;      // [n x k] or null: class probabilities
+    int32_t  *label;     // [n]
+    double   *pbest;     // [n]             probability of the predicted label (pv[label], src/OCR.cpp:92-93)
+    size_t    bytes;     // total size of the carve-up
+};
+
+// Offsets are applied to `base` (may be null to size the allocation only: read .bytes).
+OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m /* null: features only */, bool want_q, bool want_dec, bool want_prob);
+
+// indices of the strong / weak candidates of the batch, in candidate order (deterministic): list[0 .. *n_out)
+void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out);
+
+// chain-code features of n boxes: Otsu of 255 - roi, ARAN(30), direction bitmaps, 7x7 Gaussian, min-max, 2x2 decimation
+// -> buf.q (if not null) and buf.xf / buf.xnorm (if m is not null)
+void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m);
+
+// svm_predict_probability for the n rows of buf.xf / buf.xnorm -> buf.label, buf.pbest (+ buf.prob, buf.dec if not null)
+void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
+// ... its two halves: the RBF kernel matrix buf.kv; decision values + coupling from buf.kv
+void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
+void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
+
+// f64 feature vectors (API entry str_er_svm_predict_probability) -> buf.xf / buf.xnorm
+void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBuf &buf, const SvmDev &m);
+
+} // namespace str_er

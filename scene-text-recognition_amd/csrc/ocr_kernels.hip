@@ -1,0 +1,790 @@
+// ocr_kernels.hip -- the OCR scorer of config 3 for N boxes at once:
+// OCR::chain_run (src/OCR.cpp:67-140) = chain-code features (extract_feature, :144-218) + svm_predict_probability
+// (src/svm.cpp:2592-2629).  Launch chain of one call:
+//
+//   k_ocr_hist      one wave per box: histogram of 255 - roi                              (HBM: the ROI bytes, once)
+//   k_ocr_otsu      one LANE per box: getThreshVal_Otsu_8u's sequential f64 scan -- 64 boxes per wave instead of one
+//   k_ocr_features  one wave per box: ARAN(30) of the binarised (optionally rotated) ROI, direction bitmaps, 7x7 Gaussian,
+//                   min-max normalisation, 2x2 decimation -> q[1800]; written as the svm's f32 row + |x|^2
+//   k_svm_kernel    K[n][i] = exp(-gamma |x_n - sv_i|^2): the x.sv part is a dense [N x 1808] x [1808 x l] contraction on
+//                   the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate), the exp in f64 in the epilogue
+//   k_svm_couple    one wave per box: the k(k-1)/2 decision values (svm_predict_values, src/svm.cpp:2539-2566) from one
+//                   coalesced coefficient row per support vector, Platt sigmoid (:1818-1826), Wu-Lin-Weng coupling
+//                   (multiclass_probability, :1829-1890), arg max -- all in f64, pairwise values never leave LDS
+//
+// The OpenCV primitives involved (Otsu, findContours, GaussianBlur, normalize, resize) are restated from OpenCV 4.x and
+// checked against the CPU restatement the tests use ("parity unpinned").
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <stdint.h>
+
+#include "er_device.h"
+#include "ocr_kernels.h"
+
+namespace str_er {
+
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------
+// boxes
+// ---------------------------------------------------------------------------------------------------------
+struct OcrBox { const uint8_t *roi; int stride, inv, bw, bh; };
+
+__device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)
+{
+    OcrBox b;
+    if (s.recs) {
+        const CandRec   &cd = s.recs[s.list[bi]];
+        const PlaneDesc &pd = s.planes[cd.plane];
+        b.bw = cd.w; b.bh = cd.h; b.stride = pd.stride; b.inv = pd.invert;
+        b.roi = pd.pix + (size_t)cd.y * pd.stride + cd.x;
+    } else {
+        const int32_t *q = s.boxes + 4 * (size_t)bi;
+        b.bw = q[2]; b.bh = q[3]; b.stride = s.stride; b.inv = s.inv;
+        b.roi = s.plane + (size_t)q[1] * s.stride + q[0];
+    }
+    return b;
+}
+
+// indices of the strong / weak candidates of the batch, in candidate order
+__global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ cands, const uint32_t *__restrict__ total_cands,
+                                                   uint32_t *__restrict__ list, uint32_t *__restrict__ n_out)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t total = *total_cands;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 1024) {
+        const uint32_t i = base + tid;
+        const bool     v = i < total && cands[i].cls != 0;
+        const unsigned long long m = __ballot(v);
+        const uint32_t excl = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[tid >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+        if (v) list[off + excl] = i;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = s_carry;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Otsu, part 1: the histogram of 255 - roi.  One wave per box; eight interleaved sub-histograms (a binarisable
+// ROI has two dominant grey values: with one copy most lanes of a wave would queue on the same LDS word).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int OCR_WAVES = 4;          // boxes in flight per workgroup
+
+constexpr int OCR_BIG_PX = 4096;       // boxes above this many pixels are spread over many workgroups (k_ocr_hist_big): a launch lasts as long as its longest wave,
+constexpr int OCR_BIG_CAP = 4095;      // and one wave needs ~7 us per 1000 pixels -- the largest boxes of a batch are 50 times the average one
+constexpr int OCR_BIG_PARTS = 32;      // row ranges a big box is cut into
+
+__global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist(OcrSrc src, int n, uint32_t *__restrict__ hist, uint32_t *__restrict__ big)
+{
+    __shared__ uint32_t s_h[OCR_WAVES][256 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *h = s_h[w];
+    for (int bi = blockIdx.x * OCR_WAVES + w; bi < n; bi += gridDim.x * OCR_WAVES) {
+        const OcrBox b = ocr_box(src, bi);
+        if (b.bw * b.bh > OCR_BIG_PX) {
+            // queued for k_ocr_hist_big, which adds into the (zeroed) row; a full queue: the box is counted here after all
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(big, 1u);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (at < (uint32_t)OCR_BIG_CAP) {
+                if (lane == 0) big[1 + at] = (uint32_t)bi;
+                for (int v = lane; v < 256; v += 64) hist[(size_t)bi * 256 + v] = 0;
+                continue;
+            }
+        }
+        for (int i = lane; i < 256 * 8 / 4; i += 64) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+        const int sub = lane & 7;
+        // four loads in flight per lane (a load per pass would pay a memory round trip per row of the box)
+        auto bin = [&](int y, int x) -> uint32_t { return ((255u - ((uint32_t)b.roi[(size_t)y * b.stride + x] ^ (uint32_t)b.inv)) << 3) | (uint32_t)sub; };
+        if (b.bw <= 64) {
+            // several rows per pass: lane -> (row in the pass, column)
+            const int rpp = 64 / b.bw, ry = lane / b.bw, x = lane - ry * b.bw;
+            const bool on = ry < rpp;
+            for (int y0 = 0; y0 < b.bh; y0 += 4 * rpp) {
+                uint32_t e[4];
+                bool     ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int y = y0 + u * rpp + ry; ok[u] = on && y < b.bh; e[u] = ok[u] ? bin(y, x) : 0u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (ok[u]) atomicAdd(&h[e[u]], 1u);
+            }
+        } else {
+            for (int y0 = 0; y0 < b.bh; y0 += 4)
+                for (int x = lane; x < b.bw; x += 64) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = y0 + u < b.bh ? bin(y0 + u, x) : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (e[u] != 0xFFFFFFFFu) atomicAdd(&h[e[u]], 1u);
+                }
+        }
+        for (int v = lane; v < 256; v += 64) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(h + 8 * v), c = *reinterpret_cast<const uint4 *>(h + 8 * v + 4);
+            hist[(size_t)bi * 256 + v] = a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w;
+        }
+    }
+}
+
+// The queued boxes: workgroup (part, slot) counts rows [part bh / 32, (part + 1) bh / 32) of queue entry slot, slot + gridDim.y, ...; its four
+// waves take every fourth row of the range, and the non-empty bins are added to the box's row of `hist` with device atomics.
+__global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist_big(OcrSrc src, uint32_t *__restrict__ hist, const uint32_t *__restrict__ big)
+{
+    __shared__ uint32_t s_h[OCR_WAVES][256 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, part = blockIdx.x;
+    uint32_t *h = s_h[w];
+    const int nq = (int)min(big[0], (uint32_t)OCR_BIG_CAP), sub = lane & 7;
+    for (int qi = blockIdx.y; qi < nq; qi += gridDim.y) {
+        const int    bi = (int)big[1 + qi];
+        const OcrBox b = ocr_box(src, bi);
+        const int    y_lo = (int)((long long)part * b.bh / OCR_BIG_PARTS), y_hi = (int)((long long)(part + 1) * b.bh / OCR_BIG_PARTS);
+        if (y_lo + w >= y_hi) continue;
+        for (int i = lane; i < 256 * 8 / 4; i += 64) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+        for (int y = y_lo + w; y < y_hi; y += OCR_WAVES)
+            for (int x0 = 0; x0 < b.bw; x0 += 256) {
+                uint32_t e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + 64 * u + lane;
+                    e[u] = x < b.bw ? (((255u - ((uint32_t)b.roi[(size_t)y * b.stride + x] ^ (uint32_t)b.inv)) << 3) | (uint32_t)sub) : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (e[u] != 0xFFFFFFFFu) atomicAdd(&h[e[u]], 1u);
+            }
+        for (int v = lane; v < 256; v += 64) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(h + 8 * v), c = *reinterpret_cast<const uint4 *>(h + 8 * v + 4);
+            const uint32_t t = a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w;
+            if (t) atomicAdd(&hist[(size_t)bi * 256 + v], t);
+        }
+    }
+}
+
+// Otsu, part 2: the scan is a chain of 256 dependent f64 steps (two divisions each) whose rounding must be the
+// reference's: it cannot be spread over lanes, so every lane runs the scan of its own box.  The histograms of the
+// wave's 64 boxes are transposed through LDS (row stride 257 words: conflict-free for both access patterns).
+__global__ __launch_bounds__(64) void k_ocr_otsu(OcrSrc src, int n, const uint32_t *__restrict__ hist, int32_t *__restrict__ thresh)
+{
+    __shared__ uint32_t s_h[64 * 257];
+    const int lane = threadIdx.x, b0 = blockIdx.x * 64;
+    const int nb = min(64, n - b0);
+    for (int e = 0; e < nb; ++e)
+        for (int v = lane; v < 256; v += 64) s_h[e * 257 + v] = hist[(size_t)(b0 + e) * 256 + v];
+    __syncthreads();
+    if (lane < nb) {
+        const OcrBox b = ocr_box(src, b0 + lane);
+        thresh[b0 + lane] = otsu_from_hist(s_h + lane * 257, (double)b.bw * b.bh);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// features
+// ---------------------------------------------------------------------------------------------------------
+// Source of ARAN(30): the Otsu-binarised ROI, tap = (255 - (p ^ inv)) > thresh ? 255 : 0 ...
+struct BinSrc {
+    const uint8_t *roi; int stride, inv, th;
+    __device__ __forceinline__ int operator()(int x, int y) const { return (255 - (roi[(size_t)y * stride + x] ^ inv)) > th ? 255 : 0; }
+};
+// ... or that image seen through OCR::rotate_mat (src/OCR.cpp:282-352): canvas pixel (x, y) is rebuilt
+// from its four binarised source taps with the reference's own f64 expression, in its order.
+struct RotSrc {
+    BinSrc b; int bw, bh; RotGeom r;
+    __device__ __forceinline__ int operator()(int x, int y) const
+    {
+        const int i = y + r.min_y + r.ch, j = x + r.min_x;
+        if (i >= r.max_y - r.ch || j >= r.max_x) return 0;                   // the loops are exclusive
+        const double new_j = r.c * (double)j - r.s * (double)(i - r.ch) + (double)r.x0;
+        const double new_i = r.s * (double)j + r.c * (double)(i - r.ch) + (double)r.y0;
+        if (!(new_i > 0 && new_j > 0 && new_i < (double)(bh - 1) && new_j < (double)(bw - 1))) return 0;
+        if (r.crop && !(i > r.min_y + r.ch && i < r.max_y - r.ch)) return 0;
+        const int    sy = (int)new_i, sx = (int)new_j;
+        const double fi = floor(new_i), fj = floor(new_j);
+        if (new_i == fi && new_j == fj) return b(sx, sy);
+        const double alpha = new_i - fi, beta = new_j - fj;
+        const double A = (double)b(sx, sy), B = (double)b(sx + 1, sy), C = (double)b(sx, sy + 1), D = (double)b(sx + 1, sy + 1);
+        const double v = (1 - alpha) * (1 - beta) * A + (1 - alpha) * beta * B + alpha * (1 - beta) * C + alpha * beta * D;
+        return (int)(uint8_t)round(v);
+    }
+};
+
+// cv::resize INTER_LINEAR 8UC1 over an arbitrary source (same arithmetic as resize_px, er_kernels.hip)
+template <class Src>
+__device__ __forceinline__ int resize_px_src(const ResizeGeom &g, const Src &src, int dx, int dy)
+{
+    if (g.mode == 0) return src(dx, dy);
+    if (g.mode == 1) return (src(2 * dx, 2 * dy) + src(2 * dx + 1, 2 * dy) + src(2 * dx, 2 * dy + 1) + src(2 * dx + 1, 2 * dy + 1) + 2) >> 2;
+    float fx = (float)((dx + 0.5) * g.scale_x - 0.5);
+    int   sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= g.sw - 1) { fx = 0.f; sx = g.sw - 1; }
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+    int   sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+    const int y0 = min(max(sy, 0), g.sh - 1), y1 = min(max(sy + 1, 0), g.sh - 1);
+    const int sx1 = (sx + 1 < g.sw) ? sx + 1 : sx;
+    const int r0 = src(sx, y0) * a0 + src(sx1, y0) * a1;
+    const int r1 = src(sx, y1) * a0 + src(sx1, y1) * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return min(max(v, 0), 255);
+}
+
+__device__ __forceinline__ int reflect101_30(int i) { return i < 0 ? -i : (i >= 30 ? 58 - i : i); }
+
+// Direction bitmaps without following borders.  cv::findContours (RETR_LIST, CHAIN_APPROX_NONE) walks every outer and
+// hole border of the 8-connected foreground once; extract_feature (src/OCR.cpp:144-197) then marks, for each contour
+// point, the direction code of the step to the next point.  A step of the walk is a function of the state (pixel P,
+// direction b of the previous border pixel): the next pixel is the first foreground neighbour counter-clockwise from
+// b + 1.  That map is a bijection on the states whose neighbour b is foreground, so the states fall into disjoint
+// cycles; the cycles the tracer follows are exactly those whose steps sweep over a 4-adjacent background pixel, and
+// every step of such a cycle does (a step that sweeps over nothing, or over one diagonal background pixel only, lies
+// on a 3- or 4-cycle around an inner corner that no border passes through).  Hence the set of (pixel, code) marks is a
+// function of each pixel's 8-neighbour mask alone: bit c of chain_lut(nb) = "code c is marked at a foreground pixel
+// whose neighbours are nb" (bit d of nb = neighbour d, d counter-clockwise from east).  Checked against the serial
+// tracer of the CPU restatement on every mask and on random 30 x 30 images (tests/test_svm.py).
+__device__ __forceinline__ uint32_t chain_lut(uint32_t nb)
+{
+    uint32_t out = 0;
+    for (int b = 0; b < 8; ++b) {
+        if (!((nb >> b) & 1u)) continue;
+        bool swept4 = false;
+        int  dn = b;
+        for (int s = b + 1; s <= b + 8; ++s) {
+            if ((nb >> (s & 7)) & 1u) { dn = s & 7; break; }
+            if (!(s & 1)) swept4 = true;            // even directions are the 4-neighbours
+        }
+        // OCR::chain_code_direction (src/OCR.cpp:602-622) of the step east = 4, north-east = 3, ... : (4 - s) mod 8
+        if (swept4) out |= 1u << ((4 - dn) & 7);
+    }
+    return out;
+}
+
+struct FeatWave {
+    uint8_t  f[32 * 32];          // ARAN(30) image != 0, one pixel of border
+    uint8_t  om[30 * 32];         // per pixel: the direction codes marked there (bit c)
+    uint64_t rows[8 * 30];        // per code and row: the marks as bits 3 .. 32, with BORDER_REFLECT_101 columns at 0 .. 2 and 33 .. 35
+    uint8_t  v[8 * 900];          // blurred maps
+    uint32_t mn[8], mx[8];
+    float    scale[8], shift[8];
+};
+
+template <bool ROT>
+__device__ __forceinline__ void feat_aran(FeatWave &L, const OcrBox &b, int th, const RotGeom *rg, int lane)
+{
+    const BinSrc bsrc{b.roi, b.stride, b.inv, th};
+    const int    sw = ROT ? rg->rw : b.bw, shh = ROT ? rg->rh : b.bh;
+    const double R1 = (sw > shh) ? (double)shh / sw : (double)sw / shh;
+    const int    k = (int)(30.0 * sqrt(R1));
+    const int    dw = (sw > shh) ? 30 : k, dh = (sw > shh) ? k : 30;
+    if (dw <= 0 || dh <= 0) return;
+    const int offy = (dw > dh) ? (30 - dh) / 2 : 0, offx = (dw > dh) ? 0 : (30 - dw) / 2;
+    const ResizeGeom g = resize_geom(sw, shh, dw, dh);
+    const float inv_dw = 1.0f / (float)dw;
+    for (int i = lane; i < dw * dh; i += 64) {
+        const int dy = (int)(((float)i + 0.5f) * inv_dw), dx = i - dy * dw;      // exact for i < 900, dw <= 30
+        int v;
+        if (ROT) { const RotSrc rsrc{bsrc, b.bw, b.bh, *rg}; v = resize_px_src(g, rsrc, dx, dy); }
+        else v = resize_px_src(g, bsrc, dx, dy);
+        L.f[(dy + offy + 1) * 32 + dx + offx + 1] = v ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int n, const int32_t *__restrict__ thresh, uint8_t *__restrict__ q_out,
+                                                                float *__restrict__ xf, double *__restrict__ xnorm, int dpad)
+{
+    __shared__ FeatWave s_w[OCR_WAVES];
+    __shared__ uint8_t  s_lut[256];
+    __shared__ uint16_t s_g7[128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    FeatWave &L = s_w[w];
+    // tables: direction marks by neighbour mask; one row pass of the 7-tap Gaussian (8, 28, 56, 72, 56, 28, 8) over 7 mark bits (a mark is 255)
+    s_lut[threadIdx.x] = (uint8_t)chain_lut(threadIdx.x);
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x;
+        s_g7[t] = (uint16_t)(255 * (8 * ((t & 1) + ((t >> 6) & 1)) + 28 * (((t >> 1) & 1) + ((t >> 5) & 1)) + 56 * (((t >> 2) & 1) + ((t >> 4) & 1)) + 72 * ((t >> 3) & 1)));
+    }
+    __syncthreads();
+    // (from here on the waves of the workgroup are independent: every wave owns its part of LDS; the wave is the synchronisation unit)
+    for (int bi = blockIdx.x * OCR_WAVES + w; bi < n; bi += gridDim.x * OCR_WAVES) {
+        const OcrBox b = ocr_box(src, bi);
+        const int    th = thresh[bi];
+        for (int i = lane; i < 32 * 32 / 4; i += 64) reinterpret_cast<uint32_t *>(L.f)[i] = 0;
+        if (lane < 8) { L.mn[lane] = 255; L.mx[lane] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        // ---- ARAN(30) of the binarised (and, for a slanted text line, rotated) ROI
+        if (src.rot != nullptr && src.rot[bi].on != 0) feat_aran<true>(L, b, th, src.rot + bi, lane);
+        else feat_aran<false>(L, b, th, nullptr, lane);
+        __builtin_amdgcn_wave_barrier();
+        // ---- direction marks of every pixel from its neighbour mask
+        for (int i = lane; i < 30 * 32; i += 64) {
+            const int y = i >> 5, x = i & 31;
+            uint32_t  o = 0;
+            if (x < 30) {
+                const uint8_t *p = L.f + (y + 1) * 32 + x + 1;
+                if (p[0]) {
+                    const uint32_t nb = (uint32_t)p[1] | ((uint32_t)p[-31] << 1) | ((uint32_t)p[-32] << 2) | ((uint32_t)p[-33] << 3) | ((uint32_t)p[-1] << 4) |
+                                        ((uint32_t)p[31] << 5) | ((uint32_t)p[32] << 6) | ((uint32_t)p[33] << 7);
+                    o = s_lut[nb];
+                }
+            }
+            L.om[i] = (uint8_t)o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- per code and row: the 30 marks as a bit row, reflect-padded by 3 on both sides
+        for (int i = lane; i < 8 * 30; i += 64) {
+            const int c = i / 30, y = i - c * 30;
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(L.om + y * 32);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) bits |= ((((row[d] >> c) & 0x01010101u) * 0x00204081u >> 21) & 0xFu) << (4 * d);
+            bits &= 0x3FFFFFFFu;
+            uint64_t p = (uint64_t)bits << 3;
+            p |= (uint64_t)((bits >> 3) & 1u) | (uint64_t)((bits >> 2) & 1u) << 1 | (uint64_t)((bits >> 1) & 1u) << 2;                 // x = -3, -2, -1 -> 3, 2, 1
+            p |= (uint64_t)((bits >> 28) & 1u) << 33 | (uint64_t)((bits >> 27) & 1u) << 34 | (uint64_t)((bits >> 26) & 1u) << 35;       // x = 30, 31, 32 -> 28, 27, 26
+            L.rows[i] = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- GaussianBlur 7x7 (BORDER_REFLECT_101), 8-bit fixed point: a lane owns a column of one map and slides down it
+        for (int i = lane; i < 8 * 30; i += 64) {
+            const int c = i / 30, x = i - c * 30;
+            const uint64_t *rw = L.rows + c * 30;
+            uint32_t h0, h1, h2, h3, h4, h5, h6;
+            auto hrow = [&](int y) -> uint32_t { return s_g7[(uint32_t)(rw[reflect101_30(y)] >> x) & 127u]; };
+            h0 = hrow(-3); h1 = hrow(-2); h2 = hrow(-1); h3 = hrow(0); h4 = hrow(1); h5 = hrow(2);
+            uint32_t lo = 255, hi = 0;
+            for (int y = 0; y < 30; ++y) {
+                h6 = hrow(y + 3);
+                const uint32_t s = 8 * (h0 + h6) + 28 * (h1 + h5) + 56 * (h2 + h4) + 72 * h3;
+                const uint32_t v = min((s + (1u << 15)) >> 16, 255u);
+                L.v[c * 900 + y * 30 + x] = (uint8_t)v;
+                lo = min(lo, v); hi = max(hi, v);
+                h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = h5; h5 = h6;
+            }
+            atomicMin(&L.mn[c], lo);
+            atomicMax(&L.mx[c], hi);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- normalize(0, 255, NORM_MINMAX) in float, then resize 30 -> 15 (exact 2x: area)
+        if (lane < 8) {
+            const int    mn = (int)L.mn[lane], mx = (int)L.mx[lane];
+            const double scale = (mx - mn) > 0 ? 255.0 / (mx - mn) : 0.0, shift = 0.0 - mn * scale;
+            L.scale[lane] = (float)scale; L.shift[lane] = (float)shift;
+        }
+        __builtin_amdgcn_wave_barrier();
+        double nrm = 0;
+        for (int i = lane; i < 1800; i += 64) {
+            const int c = i / 225, r = i - c * 225, y = r / 15, x = r - y * 15;
+            const uint8_t *m = L.v + c * 900 + (2 * y) * 30 + 2 * x;
+            const float   sc = L.scale[c], sf = L.shift[c];
+            auto nz = [&](uint8_t e) -> int { return min(max(__float2int_rn((float)e * sc + sf), 0), 255); };
+            const int v = (nz(m[0]) + nz(m[1]) + nz(m[30]) + nz(m[31]) + 2) >> 2;
+            if (q_out) q_out[(size_t)bi * 1800 + i] = (uint8_t)v;
+            if (xf) {
+                const double d = v / 255.0;                         // fv.value = ptr[p] / 255.0 (src/OCR.cpp:211)
+                xf[(size_t)bi * dpad + i] = (float)d;
+                nrm += d * d;
+            }
+        }
+        if (xf) {
+            for (int i = 1800 + lane; i < dpad; i += 64) xf[(size_t)bi * dpad + i] = 0.f;
+            for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o);
+            if (lane == 0) xnorm[bi] = nrm;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// libsvm inference
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_svm_prep(const double *__restrict__ x, int n, int dim, float *__restrict__ xf, int dpad,
+                                                  double *__restrict__ xnorm)
+{
+    // one wave per vector
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n) return;
+    double s = 0;
+    for (int i = lane; i < dpad; i += 64) {
+        const double d = i < dim ? x[(size_t)v * dim + i] : 0.0;
+        xf[(size_t)v * dpad + i] = (float)d;
+        s += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) xnorm[v] = s;
+}
+
+// K = exp(-gamma (|x|^2 + |sv|^2 - 2 x.sv)).  Workgroup tile 128 (vectors) x 64 (support vectors), four waves, each a 64 x 32
+// sub-tile = two 32x32 accumulators sharing the B operand; K step 16, both operand tiles double-buffered in LDS as [k][row]
+// (row stride padded to 132 / 68 words) so that an MFMA operand is one conflict-free ds_read_b32 per lane and a staging
+// store is one ds_write_b32 per k -- the global side stays float4 along k.
+constexpr int GM = 128, GN = 64, GK = 16;
+
+__global__ __launch_bounds__(256) void k_svm_kernel(const float *__restrict__ xf, const double *__restrict__ xnorm, int n_rows,
+                                                    const float *__restrict__ sv, const double *__restrict__ svnorm, int l_pad,
+                                                    int dpad, double gamma, double *__restrict__ kv)
+{
+    __shared__ float As[2][GK][GM + 4];
+    __shared__ float Bs[2][GK][GN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
+    // staging: A = 128 rows x 16 k = 512 float4 (2 per thread), B = 64 rows x 16 k = 256 float4 (1 per thread)
+    const int arow0 = tid >> 2, arow1 = arow0 + 64, ak = (tid & 3) * 4;
+    const float *pa0 = xf + (size_t)min(m0 + arow0, n_rows - 1) * dpad + ak;
+    const float *pa1 = xf + (size_t)min(m0 + arow1, n_rows - 1) * dpad + ak;
+    const float *pb = sv + (size_t)(n0 + arow0) * dpad + ak;
+    float16v acc0 = {0}, acc1 = {0};
+    float4 a0 = *reinterpret_cast<const float4 *>(pa0), a1 = *reinterpret_cast<const float4 *>(pa1), b0 = *reinterpret_cast<const float4 *>(pb);
+    auto stage = [&](int buf) {
+        As[buf][ak][arow0] = a0.x; As[buf][ak + 1][arow0] = a0.y; As[buf][ak + 2][arow0] = a0.z; As[buf][ak + 3][arow0] = a0.w;
+        As[buf][ak][arow1] = a1.x; As[buf][ak + 1][arow1] = a1.y; As[buf][ak + 2][arow1] = a1.z; As[buf][ak + 3][arow1] = a1.w;
+        Bs[buf][ak][arow0] = b0.x; Bs[buf][ak + 1][arow0] = b0.y; Bs[buf][ak + 2][arow0] = b0.z; Bs[buf][ak + 3][arow0] = b0.w;
+    };
+    stage(0);
+    __syncthreads();
+    const int nk = dpad / GK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const int ko = (kt + 1) * GK;
+            a0 = *reinterpret_cast<const float4 *>(pa0 + ko); a1 = *reinterpret_cast<const float4 *>(pa1 + ko); b0 = *reinterpret_cast<const float4 *>(pb + ko);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const int   kr = kk + (lane >> 5), c = lane & 31;
+            const float bv = Bs[cur][kr][wn + c];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][kr][wm + c], bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][kr][wm + 32 + c], bv, acc1, 0, 0, 0);
+        }
+        if (kt + 1 < nk) stage(cur ^ 1);
+        __syncthreads();
+    }
+    // 32x32 accumulator layout: element i of lane L is row 8*(i/4) + 4*(L/32) + i%4, column L%32
+    const int    col = n0 + wn + (lane & 31);
+    const double sn = svnorm[col];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + wm + 32 * h + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+            if (row < n_rows) {
+                double d2 = xnorm[row] + sn - 2.0 * (double)(h ? acc1[i] : acc0[i]);
+                d2 = d2 > 0 ? d2 : 0;
+                kv[(size_t)row * l_pad + col] = exp(-gamma * d2);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double bcast(double v, int src)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// 1 / x for the coupling's step (x = a sum of probabilities, far from 0 and from the ends of the exponent range): the
+// hardware estimate plus two Newton steps -- full f64 accuracy without the scaling and fix-up of a general division
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// svm_predict_values + sigmoid_predict + multiclass_probability for one vector per wave.  Class-indexed vectors (p, Qp,
+// Q's diagonal) live in registers: lane L holds classes L and L + 64 (k <= 128).  The pairwise table V (k(k-1)/2 f64 in
+// LDS, pair (i < j) at rb(i) + j, rb(i) = i k - i (i + 1) / 2 - i - 1) first collects the decision values, then the
+// pairwise probabilities r_ij, then Q's off-diagonal entries -r_ji r_ij.
+//
+// Decision values: libsvm sums, for the pair (i, j), coef[j-1][q] K[q] over class i's support vectors and coef[i][q] K[q]
+// over class j's.  Walking the support vectors in their (class-sorted) order with lane b holding the column b of the
+// transposed coefficient table gives, per class a, the 64 (128) partial sums S[a][b] from one coalesced row per support
+// vector; S[a][b] is the class-a half of the pair (a, b' = b < a ? b : b + 1).  The two halves of a pair are added class i
+// first like the reference, each half summed in the reference's order (the grouping of the final addition differs: 1 ulp).
+//
+// Coupling: the reference's Gauss-Seidel sweep divides p and Qp by (1 + diff) after every coordinate step (5 divisions
+// per step, 2 of them on every lane).  Here the sweep runs on the unnormalised iterate -- p~ = p / sigma, B = Q p~,
+// A = p~ Q p~, S = sum p~ = 1 / sigma -- for which a step is d = (A / S - B_t) / Q_tt; p~_t += d; B += d Q_t; A += d (d Q_tt + 2 B_t);
+// S += d: one reciprocal on the critical path and one fused multiply-add per lane; the iterate is renormalised at the end
+// of a sweep, where the reference's stopping test (max_t |Qp_t - pQp| < 0.005 / k, on the same quantities up to rounding)
+// is evaluated.  The same fixed point, the same sweeps: probabilities agree with the reference's to ~1e-16.
+template <bool TWO, bool TWOC>       // TWO: k > 64 (two class registers per lane); TWOC: k - 1 > 64 (two coefficient columns per lane)
+__global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv, int l_pad, SvmDev m, double *__restrict__ dec_out,
+                                                   double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest)
+{
+    // LDS: V[np] pairwise table; QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps
+    extern __shared__ __attribute__((aligned(16))) double V[];
+    const int k = m.k, np = k * (k - 1) / 2, kc = m.kc;
+    double *QI = V + ((np + 1) & ~1), *D = QI + 2 * k;
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const double *kr = kv + (size_t)v * l_pad;
+    auto rb = [k](int i) -> int { return i * k - i * (i + 1) / 2 - i - 1; };
+    const int  t0 = lane, t1 = lane + 64;
+    const bool on0 = t0 < k, on1 = TWO && t1 < k;
+    const int  rb0 = rb(t0), rb1 = rb(t1);
+    // ---- decision values.  The support vectors are walked in their stored (class-sorted) order, eight coefficient rows in flight at a time
+    // (a row per iteration would pay a memory round trip per support vector); the kernel values come 64 at a time into a register and are
+    // broadcast by v_readlane; a class ends where its last support vector does (empty classes end at once).
+    {
+        constexpr bool two_c = TWOC;                       // (k = 65: two class registers, but 64 coefficient columns)
+        // where every class's support vectors end, a class per lane (a scalar load per class end would be a memory round trip each)
+        const int cend0 = t0 < k ? m.start[t0] + m.nsv[t0] : 0x7FFFFFFF, cend1 = (TWO && t1 < k) ? m.start[t1] + m.nsv[t1] : 0x7FFFFFFF;
+        auto class_end = [&](int a) -> int { return a < 64 ? __builtin_amdgcn_readlane(cend0, a) : (TWO && a < k ? __builtin_amdgcn_readlane(cend1, a - 64) : 0x7FFFFFFF); };
+        int    a = 0, q_end = class_end(0);
+        double s0 = 0, s1 = 0;
+        auto flush = [&]() {
+            const int rba = rb(a);
+            // lane b: other class b' = b < a ? b : b + 1
+            if (t0 < k - 1) { if (t0 >= a) V[rba + t0 + 1] = s0; else V[rb0 + a] += s0; }
+            if (two_c && t1 < k - 1) { if (t1 >= a) V[rba + t1 + 1] = s1; else V[rb1 + a] += s1; }
+            __builtin_amdgcn_wave_barrier();
+            s0 = 0; s1 = 0;
+            ++a;
+            q_end = a < k ? class_end(a) : 0x7FFFFFFF;
+        };
+        constexpr int CH = 16;                               // rows per chunk; the next chunk is requested before this one is used
+        const int l = m.l;
+        double cur0[CH], cur1[CH], nxt0[CH], nxt1[CH];
+        auto load = [&](double (&d0)[CH], double (&d1)[CH], int q0) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {                             // coef_t has l_pad rows (zero beyond l); l_pad is a multiple of 64
+                d0[u] = m.coef_t[(size_t)(q0 + u) * kc + lane];
+                d1[u] = two_c ? m.coef_t[(size_t)(q0 + u) * kc + lane + 64] : 0.0;
+            }
+        };
+        load(cur0, cur1, 0);
+        double kreg = kr[lane], knext = 0;
+        for (int q0 = 0; q0 < l; q0 += CH) {
+            const bool more = q0 + CH < l;
+            if (more) load(nxt0, nxt1, q0 + CH);
+            if ((q0 & 63) == 0 && q0 + 64 < l_pad) knext = kr[q0 + 64 + lane];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int q = q0 + u;
+                while (q == q_end) flush();
+                const double kq = bcast(kreg, q & 63);
+                s0 += cur0[u] * kq;
+                if (two_c) s1 += cur1[u] * kq;
+            }
+            if (((q0 + CH) & 63) == 0) kreg = knext;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { cur0[u] = nxt0[u]; cur1[u] = nxt1[u]; }
+        }
+        while (a < k) flush();
+    }
+    // ---- dec = sum - rho; r_ij = sigmoid_predict(dec, A, B) clamped to [1e-7, 1 - 1e-7] (src/svm.cpp:2603-2611)
+    const double min_prob = 1e-7;
+    for (int pb = lane; pb < np; pb += 256) {           // four pairs per pass: their model constants are requested together
+        double rho[4], pA[4], pB[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = min(pb + 64 * u, np - 1);
+            rho[u] = m.rho[p]; pA[u] = m.probA[p]; pB[u] = m.probB[p];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = pb + 64 * u;
+            if (p >= np) break;
+            const double d = V[p] - rho[u];
+            if (dec_out) dec_out[(size_t)v * np + p] = d;
+            const double fApB = d * pA[u] + pB[u];
+            // sigmoid_predict (src/svm.cpp:1818-1826): exp(-f) / (1 + exp(-f)) for f >= 0, 1 / (1 + exp(f)) otherwise -- one exp of -|f| serves both
+            const double ex = exp(-fabs(fApB));
+            double sg = fApB >= 0 ? ex / (1.0 + ex) : 1.0 / (1 + ex);
+            sg = sg > min_prob ? sg : min_prob;
+            sg = sg < 1 - min_prob ? sg : 1 - min_prob;
+            V[p] = sg;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- one walk over j for every class t of this lane: Q_tt = sum_{j != t} r_jt^2 and B_t = sum_j Q_tj / k for p = 1 / k, j ascending
+    // (r_jt = V(j, t) for j < t, 1 - V(t, j) for j > t; Q_tj = -r_jt r_tj).  Branch-free: the address is clamped, the term masked.
+    const double ik = 1.0 / k;
+    double qd0 = 0, qd1 = 0, B0 = 0, B1 = 0;
+    for (int j = 0; j < k; ++j) {
+        const int rbj = rb(j);
+        {
+            const int    idx = j < t0 ? rbj + t0 : rb0 + j;
+            const double e = V[min(max(idx, 0), np - 1)], r = j < t0 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
+            const bool   on = on0 && j != t0;
+            qd0 += on ? r * r : 0.0;
+            B0 += on ? w * ik : 0.0;
+        }
+        if (TWO) {
+            const int    idx = j < t1 ? rbj + t1 : rb1 + j;
+            const double e = V[min(max(idx, 0), np - 1)], r = j < t1 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
+            const bool   on = on1 && j != t1;
+            qd1 += on ? r * r : 0.0;
+            B1 += on ? w * ik : 0.0;
+        }
+    }
+    B0 += on0 ? qd0 * ik : 0.0;
+    B1 += on1 ? qd1 * ik : 0.0;
+    if (on0) { QI[2 * t0] = qd0; QI[2 * t0 + 1] = 1.0 / qd0; }
+    if (on1) { QI[2 * t1] = qd1; QI[2 * t1 + 1] = 1.0 / qd1; }
+    __builtin_amdgcn_wave_barrier();
+    // ---- Q_tj = -r_jt r_tj = -(1 - V) V
+    for (int p = lane; p < np; p += 64) { const double s = V[p]; V[p] = (-(1.0 - s)) * s; }
+    __builtin_amdgcn_wave_barrier();
+    double p0 = on0 ? ik : 0.0, p1 = on1 ? ik : 0.0;
+    double A = wave_sum(p0 * B0 + p1 * B1);
+    const int    max_iter = k > 100 ? k : 100;
+    const double eps = 0.005 / k;
+    for (int iter = 0; iter < max_iter; ++iter) {
+        double err = on0 ? fabs(B0 - A) : 0.0;
+        if (on1) err = fmax(err, fabs(B1 - A));
+        for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+        if (err < eps) break;
+        double S = 1.0;
+        // one coordinate step; HI: t is one of the classes 64 ..
+        auto step = [&](int t, double Bt) {
+            const double2 qi = *reinterpret_cast<const double2 *>(QI + 2 * t);
+            const double  d = (rcp_nr(S) * A - Bt) * qi.y;
+            A = A + d * (d * qi.x + 2.0 * Bt);
+            S += d;
+            D[t] = d;                                              // (every lane writes the same word)
+            const int rbt = rb(t);
+            {
+                const int    idx = t0 > t ? rbt + t0 : rb0 + t;
+                const double e = V[min(max(idx, 0), np - 1)];
+                B0 = __builtin_fma(d, t0 == t ? qi.x : (on0 ? e : 0.0), B0);
+            }
+            if (TWO) {
+                const int    idx = t1 > t ? rbt + t1 : rb1 + t;
+                const double e = V[min(max(idx, 0), np - 1)];
+                B1 = __builtin_fma(d, t1 == t ? qi.x : (on1 ? e : 0.0), B1);
+            }
+        };
+        const int klo = k < 64 ? k : 64;
+        for (int t = 0; t < klo; ++t) step(t, bcast(B0, t));
+        if (TWO) for (int t = 64; t < k; ++t) step(t, bcast(B1, t - 64));
+        __builtin_amdgcn_wave_barrier();
+        const double sg = rcp_nr(S);
+        if (on0) p0 += D[t0];
+        if (on1) p1 += D[t1];
+        p0 *= sg; p1 *= sg; B0 *= sg; B1 *= sg; A *= sg * sg;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (prob) {
+        if (on0) prob[(size_t)v * k + t0] = p0;
+        if (on1) prob[(size_t)v * k + t1] = p1;
+    }
+    // arg max with the reference's tie rule (first maximum, src/svm.cpp:2614-2617)
+    double best = on0 ? p0 : -1.0;
+    int    bi = t0;
+    if (on1 && p1 > best) { best = p1; bi = t1; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int    oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    // prob of the result = pv[label]: the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. takes the entry
+    // of the first class carrying that label
+    const int lab = m.label[bi];
+    int first = (on0 && m.label[t0] == lab) ? t0 : ((on1 && m.label[t1] == lab) ? t1 : 1 << 20);
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    const double pf = first < 64 ? bcast(p0, first & 63) : bcast(p1, (first - 64) & 63);
+    if (lane == 0) { label[v] = lab; pbest[v] = pf; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m, bool want_q, bool want_dec, bool want_prob)
+{
+    OcrBuf b{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> uint8_t * { uint8_t *p = base ? base + off : nullptr; off = up256(off + bytes); return p; };
+    auto skip = [](uint8_t *p, bool on) -> uint8_t * { return on ? p : nullptr; };
+    const size_t n_pad = (n + 127) / 128 * 128;
+    b.hist = reinterpret_cast<uint32_t *>(take(n * 256 * 4));
+    b.thresh = reinterpret_cast<int32_t *>(take(n * 4));
+    b.big = reinterpret_cast<uint32_t *>(take(4 * (size_t)(OCR_BIG_CAP + 1)));
+    uint8_t *q = take(want_q ? n * 1800 : 0);
+    b.q = base ? skip(q, want_q) : nullptr;
+    if (m) {
+        const size_t np = (size_t)m->k * (m->k - 1) / 2;
+        b.xf = reinterpret_cast<float *>(take(n_pad * m->dpad * 4));
+        b.xnorm = reinterpret_cast<double *>(take(n_pad * 8));
+        b.kv = reinterpret_cast<double *>(take(n_pad * m->l_pad * 8));
+        uint8_t *d = take(want_dec ? n * np * 8 : 0), *p = take(want_prob ? n * m->k * 8 : 0);
+        b.dec = reinterpret_cast<double *>(base ? skip(d, want_dec) : nullptr);
+        b.prob = reinterpret_cast<double *>(base ? skip(p, want_prob) : nullptr);
+        b.label = reinterpret_cast<int32_t *>(take(n * 4));
+        b.pbest = reinterpret_cast<double *>(take(n * 8));
+    }
+    b.bytes = off;
+    return b;
+}
+
+void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out)
+{
+    hipLaunchKernelGGL(k_ocr_list, dim3(1), dim3(1024), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, list, n_out);
+}
+
+void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m)
+{
+    if (n <= 0) return;
+    const int wg = (n + OCR_WAVES - 1) / OCR_WAVES;
+    (void)hipMemsetAsync(buf.big, 0, 4, s);
+    hipLaunchKernelGGL(k_ocr_hist, dim3(wg < 2048 ? wg : 2048), dim3(64 * OCR_WAVES), 0, s, src, n, buf.hist, buf.big);
+    hipLaunchKernelGGL(k_ocr_hist_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, src, buf.hist, (const uint32_t *)buf.big);
+    hipLaunchKernelGGL(k_ocr_otsu, dim3((n + 63) / 64), dim3(64), 0, s, src, n, (const uint32_t *)buf.hist, buf.thresh);
+    hipLaunchKernelGGL(k_ocr_features, dim3(wg < 1024 ? wg : 1024), dim3(64 * OCR_WAVES), 0, s, src, n, (const int32_t *)buf.thresh, buf.q,
+                       m ? buf.xf : (float *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dpad : 0);
+}
+
+void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBuf &buf, const SvmDev &m)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_svm_prep, dim3((n + 3) / 4), dim3(256), 0, s, x, n, dim, buf.xf, m.dpad, buf.xnorm);
+}
+
+void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_svm_kernel, dim3(m.l_pad / GN, (n + GM - 1) / GM), dim3(256), 0, s, (const float *)buf.xf, (const double *)buf.xnorm, n, m.sv,
+                       m.svnorm, m.l_pad, m.dpad, m.gamma, buf.kv);
+}
+
+void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
+{
+    if (n <= 0) return;
+    const size_t np = (size_t)m.k * (m.k - 1) / 2, lds = sizeof(double) * (((np + 1) & ~(size_t)1) + 3 * (size_t)m.k);
+    if (m.kc > 64)
+        hipLaunchKernelGGL((k_svm_couple<true, true>), dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+    else if (m.k > 64)
+        hipLaunchKernelGGL((k_svm_couple<true, false>), dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+    else
+        hipLaunchKernelGGL((k_svm_couple<false, false>), dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+}
+
+void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
+{
+    launch_svm_kernel(s, n, buf, m);
+    launch_svm_couple(s, n, buf, m);
+}
+
+} // namespace str_er

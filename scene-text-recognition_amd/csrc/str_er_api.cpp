@@ -21,7 +21,7 @@
 #include <vector>
 
 #include "er_kernels.h"
-#include "svm_kernels.h"
+#include "ocr_kernels.h"
 #include "track_kernels.h"
 #include "er_group.h"
 #include "flood_order.h"
@@ -83,6 +83,10 @@ struct str_er_ctx {
     hipStream_t side = nullptr;          // the opposite-rule NMS pass runs here, beside classify
     hipStream_t prio = nullptr;          // high priority: the few small operations that settle an NMS tie (they would queue behind other contexts' big kernels)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // experiment (STR_ER_CU_PARTITION=N): the bandwidth / issue-bound kernels (channels, pyramid, tile trees) on a stream restricted to
+    // 256 - N compute units, everything else on the N others, so that one context's latency-bound passes run BESIDE another context's tile kernel
+    hipStream_t wide = nullptr;
+    hipEvent_t ev_wf = nullptr, ev_wj = nullptr;
     bool own_stream = false;
     int ppf = 0;                     // logical planes per frame
     std::vector<int> chans;          // channel indices selected by the mask
@@ -161,7 +165,7 @@ struct str_er_ctx {
     bool svm_loaded = false;
     SvmDev svm{};
     void *d_svm_blob = nullptr;
-    hipEvent_t ev[16]{};
+    hipEvent_t ev[24]{};
     int n_ev = 0;
     bool profiling = false;
     std::vector<std::pair<const char *, double>> profile;
@@ -519,10 +523,24 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     return d;
 }
 
-void rec(str_er_ctx *c, const char *name)
+// the wide stream takes over after everything queued on the main stream so far / the main stream continues after the wide one
+static void wide_fork(str_er_ctx *c)
 {
-    if (c->n_ev < 16) {
-        (void)hipEventRecord(c->ev[c->n_ev], c->stream);
+    if (!c->wide) return;
+    (void)hipEventRecord(c->ev_wf, c->stream);
+    (void)hipStreamWaitEvent(c->wide, c->ev_wf, 0);
+}
+static void wide_join(str_er_ctx *c)
+{
+    if (!c->wide) return;
+    (void)hipEventRecord(c->ev_wj, c->wide);
+    (void)hipStreamWaitEvent(c->stream, c->ev_wj, 0);
+}
+
+void rec(str_er_ctx *c, const char *name, hipStream_t on = nullptr)
+{
+    if (c->n_ev < 24) {
+        (void)hipEventRecord(c->ev[c->n_ev], on ? on : c->stream);
         c->profile.emplace_back(name, 0.0);
         ++c->n_ev;
     }
@@ -591,38 +609,30 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
         }
     }
     hipStream_t s = c->stream;
-    const size_t n_pad = align_up(n_m, 64), npairs = (size_t)m.k * (m.k - 1) / 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_rec = take(sizeof(CandRec) * n_m), o_rot = take(sizeof(RotGeom) * n_m), o_list = take(4 * n_m), o_x = take(n_m * 1800 * 8),
-                 o_xf = take(n_pad * m.dpad * 4 + 256), o_xn = take(n_pad * 8), o_kv = take(n_pad * m.l_pad * 8), o_dec = take(n_m * npairs * 8),
-                 o_prob = take(n_m * m.k * 8), o_lab = take(n_m * 4);
-    int rc2 = ensure_scratch(c, off);
+    const size_t o_rec = take(sizeof(CandRec) * n_m), o_rot = take(sizeof(RotGeom) * n_m), o_list = take(4 * n_m), o_buf = take(0);
+    int rc2 = ensure_scratch(c, o_buf + ocr_layout(nullptr, n_m, &m, false, false, false).bytes);
     if (rc2 != STR_ER_OK) return rc2;
     uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+    const OcrBuf buf = ocr_layout(sc + o_buf, n_m, &m, false, false, false);
     HIP_TRY(c, hipMemcpyAsync(sc + o_rec, recs.data(), sizeof(CandRec) * n_m, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(sc + o_rot, rot.data(), sizeof(RotGeom) * n_m, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(sc + o_list, ident.data(), 4 * n_m, hipMemcpyHostToDevice, s));
-    launch_chain_features_members(s, reinterpret_cast<const CandRec *>(sc + o_rec), reinterpret_cast<const uint32_t *>(sc + o_list), d_planes, (int)n_m,
-                                  reinterpret_cast<double *>(sc + o_x), 1800, reinterpret_cast<const RotGeom *>(sc + o_rot));
-    HIP_TRY(c, hipMemsetAsync(sc + o_xf, 0, n_pad * m.dpad * 4 + 256, s));
-    HIP_TRY(c, hipMemsetAsync(sc + o_xn, 0, n_pad * 8, s));
-    launch_svm_predict(s, reinterpret_cast<const double *>(sc + o_x), (int)n_m, 1800, reinterpret_cast<float *>(sc + o_xf),
-                       reinterpret_cast<double *>(sc + o_xn), (int)n_pad, reinterpret_cast<double *>(sc + o_kv),
-                       reinterpret_cast<double *>(sc + o_dec), reinterpret_cast<double *>(sc + o_prob), reinterpret_cast<int32_t *>(sc + o_lab), m);
+    OcrSrc src{};
+    src.recs = reinterpret_cast<const CandRec *>(sc + o_rec); src.list = reinterpret_cast<const uint32_t *>(sc + o_list); src.planes = d_planes;
+    src.rot = reinterpret_cast<const RotGeom *>(sc + o_rot);
+    rec(c, "ocr_host_gap");
+    launch_ocr_features(s, src, (int)n_m, buf, &m);
+    rec(c, "ocr_features");
+    launch_svm_kernel(s, (int)n_m, buf, m);
+    rec(c, "svm_kernel");
+    launch_svm_couple(s, (int)n_m, buf, m);
+    rec(c, "svm_couple");
     HIP_TRY(c, hipGetLastError());
-    std::vector<int32_t> lab(n_m), mlab((size_t)m.k);
-    std::vector<double>  pall(n_m * (size_t)m.k);
-    HIP_TRY(c, hipMemcpyAsync(lab.data(), sc + o_lab, 4 * n_m, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(pall.data(), sc + o_prob, 8 * pall.size(), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(mlab.data(), m.label, 4 * (size_t)m.k, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(r->line_label.data(), buf.label, 4 * n_m, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(r->line_prob.data(), buf.pbest, 8 * n_m, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, wait_stream(c, s));
-    for (size_t j = 0; j < n_m; ++j) {
-        int idx = -1;
-        for (int k = 0; k < m.k; ++k) if (mlab[(size_t)k] == lab[j]) { idx = k; break; }
-        r->line_label[j] = lab[j];
-        r->line_prob[j] = idx >= 0 ? pall[j * (size_t)m.k + (size_t)idx] : 0.0;
-    }
     for (size_t t = r->texts.size(); t-- > 0;) {
         const str_er_text &tx = r->texts[t];
         const size_t       f = (size_t)tx.first, n = (size_t)tx.count;
@@ -1013,7 +1023,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     // share (or fails), and a share stops at one entry per pixel: the repeats end; `attempt` only guards against a slip in that argument.
     if (attempt > 24) return fail(c, STR_ER_ECAPACITY, "the batch was repeated 24 times with growing tables and still does not fit (internal error)");
     c->last_valid = false;             // (str_er_gather_last: the candidate array is being rewritten, or re-allocated)
-    c->wait_spin_us = (int)b_in.planes.size() <= SPEC_PLANES ? 2000 : 300;
+    struct SpinGuard { str_er_ctx *c; int old; ~SpinGuard() { c->wait_spin_us = old; } } spin_guard{c, c->wait_spin_us};
+    c->wait_spin_us = (int)b_in.planes.size() <= SPEC_PLANES ? 2000 : 300;      // (for this call only: the guard puts the default back)
     Batch b = b_in;
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
     // batches (small tile kernel: ~14 records per tile) take 4 x 4 tiles per group, noise-like ones (~250) 2 x 5.
@@ -1067,8 +1078,13 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     if (import_trees) {
         const int rci = (*import_trees)(b, bd);
         if (rci != STR_ER_OK) return rci;
-    } else launch_tile_tree(s, bd, dp, c->tile_sparse);
-    rec(c, "tile_tree");
+        rec(c, "tile_tree");
+    } else {
+        wide_fork(c);                   // (the layout upload above is on the main stream)
+        launch_tile_tree(c->wide ? c->wide : s, bd, dp, c->tile_sparse);
+        rec(c, "tile_tree", c->wide);
+        wide_join(c);
+    }
     if (c->dbg_tile_only) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
         (void)wait_stream(c, s);
@@ -1129,7 +1145,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     const CandRec *spec_src = nullptr;
     uint32_t       spec_n = 0;
-    if ((stages & STR_ER_STAGE_NMS) && np <= SPEC_PLANES && c->pool_total) {
+    if ((stages & STR_ER_STAGE_NMS) && np <= SPEC_PLANES && c->pool_total && c->last_total <= SPEC_CANDS) {
         spec_src = c->d_cands; spec_n = (uint32_t)std::min<size_t>(SPEC_CANDS, c->pool_total);
         HIP_TRY(c, hipMemcpyAsync(c->h_cands_spec, spec_src, sizeof(CandRec) * (size_t)spec_n, hipMemcpyDeviceToHost, s));
     }
@@ -1317,38 +1333,37 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         r->have_ocr = true;
         if (n_ocr) {
             const SvmDev &m = c->svm;
-            const size_t n_pad = align_up(n_ocr, 64), npairs = (size_t)m.k * (m.k - 1) / 2;
             size_t off = 0;
             auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-            const size_t o_list = take(4 * (size_t)total + 64), o_x = take(n_ocr * 1800 * 8), o_xf = take(n_pad * m.dpad * 4 + 256), o_xn = take(n_pad * 8),
-                         o_kv = take(n_pad * m.l_pad * 8), o_dec = take(n_ocr * npairs * 8), o_prob = take(n_ocr * m.k * 8), o_lab = take(n_ocr * 4);
-            int rc2 = ensure_scratch(c, off);
+            const size_t o_list = take(4 * (size_t)total + 64), o_buf = take(0);
+            int rc2 = ensure_scratch(c, o_buf + ocr_layout(nullptr, n_ocr, &m, false, false, false).bytes);
             if (rc2 != STR_ER_OK) { delete r; return rc2; }
             uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
+            const OcrBuf buf = ocr_layout(sc + o_buf, n_ocr, &m, false, false, false);
             uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
-            launch_ocr_features(s, bd, d_list + 16, d_list, (int)n_ocr, reinterpret_cast<double *>(sc + o_x), 1800);
-            hipError_t e = hipMemsetAsync(sc + o_xf, 0, n_pad * m.dpad * 4 + 256, s);
-            if (e == hipSuccess) e = hipMemsetAsync(sc + o_xn, 0, n_pad * 8, s);
-            launch_svm_predict(s, reinterpret_cast<const double *>(sc + o_x), (int)n_ocr, 1800, reinterpret_cast<float *>(sc + o_xf),
-                               reinterpret_cast<double *>(sc + o_xn), (int)n_pad, reinterpret_cast<double *>(sc + o_kv),
-                               reinterpret_cast<double *>(sc + o_dec), reinterpret_cast<double *>(sc + o_prob),
-                               reinterpret_cast<int32_t *>(sc + o_lab), m);
+            rec(c, "ocr_host_gap");          // (the host read the counters first: this interval is the round trip, not GPU work)
+            launch_ocr_list(s, bd, d_list + 16, d_list);
+            OcrSrc src{};
+            src.recs = bd.cands; src.list = d_list + 16; src.planes = bd.planes;
+            launch_ocr_features(s, src, (int)n_ocr, buf, &m);
+            rec(c, "ocr_features");
+            launch_svm_kernel(s, (int)n_ocr, buf, m);
+            rec(c, "svm_kernel");
+            launch_svm_couple(s, (int)n_ocr, buf, m);
+            rec(c, "svm_couple");
             std::vector<uint32_t> list(n_ocr);
-            std::vector<int32_t> lab(n_ocr), mlab(m.k);
-            std::vector<double> pall(n_ocr * m.k);
-            if (e == hipSuccess) e = hipGetLastError();
+            std::vector<int32_t> lab(n_ocr);
+            std::vector<double> pb(n_ocr);
+            hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(list.data(), d_list + 16, 4 * n_ocr, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), sc + o_lab, 4 * n_ocr, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(pall.data(), sc + o_prob, 8 * pall.size(), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(mlab.data(), m.label, 4 * (size_t)m.k, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), buf.label, 4 * n_ocr, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(pb.data(), buf.pbest, 8 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = wait_stream(c, s);
             if (e != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, std::string("OCR stage: ") + hipGetErrorString(e)); }
             for (size_t i = 0; i < n_ocr; ++i) {
                 if (list[i] >= total) continue;
-                int idx = -1;
-                for (int k = 0; k < m.k; ++k) if (mlab[k] == lab[i]) { idx = k; break; }
                 r->ocr_label[list[i]] = lab[i];
-                r->ocr_prob[list[i]] = idx >= 0 ? pall[i * m.k + idx] : 0.0;
+                r->ocr_prob[list[i]] = pb[i];
             }
         }
     }
@@ -1554,6 +1569,9 @@ void str_er_destroy(str_er_ctx *c)
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->prio) { (void)hipStreamSynchronize(c->prio); (void)hipStreamDestroy(c->prio); }
+    if (c->wide) { (void)hipStreamSynchronize(c->wide); (void)hipStreamDestroy(c->wide); }
+    if (c->ev_wf) (void)hipEventDestroy(c->ev_wf);
+    if (c->ev_wj) (void)hipEventDestroy(c->ev_wj);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1634,6 +1652,36 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
         else {
             c->h_tie_plane = reinterpret_cast<uint32_t *>(c->h_tie + (size_t)c->n_tie_slots * c->tie_slot_bytes);
             c->h_tie_count = c->h_tie_plane + TIE_SLOTS;
+        }
+    }
+    if (const char *e = std::getenv("STR_ER_CU_PARTITION")) {
+        // Mask bits are dealt round-robin over the 8 XCDs (bit i -> XCD i % 8), so a prefix of N bits takes N / 8 compute units of every XCD.
+        const int n = std::atoi(e);
+        hipDeviceProp_t prop{};
+        if (n >= 8 && c->own_stream && hipGetDeviceProperties(&prop, p->device) == hipSuccess && n <= prop.multiProcessorCount - 8) {
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> small((size_t)words, 0u), big((size_t)words, 0u);
+            // STR_ER_CU_PARTITION_MODE: "spread" (default) = n / 8 compute units of every XCD; "xcd" = whole XCDs (n / 32 of them);
+            // "full" = both streams on every compute unit (the two-stream structure alone)
+            const char *mode = std::getenv("STR_ER_CU_PARTITION_MODE");
+            const bool by_xcd = mode && std::strcmp(mode, "xcd") == 0, full = mode && std::strcmp(mode, "full") == 0;
+            for (int i = 0; i < ncu; ++i) {
+                const bool in_small = by_xcd ? (i % 8) < n / (ncu / 8) : i < n;
+                if (full || in_small) small[(size_t)(i / 32)] |= 1u << (i % 32);
+                if (full || !in_small) big[(size_t)(i / 32)] |= 1u << (i % 32);
+            }
+            // "prio": no masks -- the passes' stream at the highest priority, the tile kernels' at the lowest, so that a pass's few workgroups are
+            // dispatched ahead of another context's tile kernel backlog as slots free up
+            const bool prio = mode && std::strcmp(mode, "prio") == 0;
+            int plo = 0, phi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+            hipStream_t narrow = nullptr;
+            if ((prio ? hipStreamCreateWithPriority(&narrow, hipStreamNonBlocking, phi) : hipExtStreamCreateWithCUMask(&narrow, (uint32_t)words, small.data())) == hipSuccess &&
+                (prio ? hipStreamCreateWithPriority(&c->wide, hipStreamNonBlocking, plo) : hipExtStreamCreateWithCUMask(&c->wide, (uint32_t)words, big.data())) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_wf, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_wj, hipEventDisableTiming) == hipSuccess) {
+                (void)hipStreamDestroy(c->stream);
+                c->stream = narrow;
+            } else A(fail(nullptr, STR_ER_EHIP, "STR_ER_CU_PARTITION: masked stream creation failed"));
         }
     }
     c->spin_wait = std::getenv("STR_ER_SPIN_WAIT") != nullptr;
@@ -1804,18 +1852,20 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
     if (frame_bytes * n_frames > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
     auto plane_sz = [&](int l) { return align_up((size_t)geo[l].stride * geo[l].h, 256); };
     c->n_ev = 0; c->profile.clear(); rec(c, "begin");
+    wide_fork(c);
+    const hipStream_t ws = c->wide ? c->wide : c->stream;
     if (nv12)
-        launch_nv12_to_ycrcb(c->stream, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
+        launch_nv12_to_ycrcb(ws, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
                              c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);
     else
-        launch_bgr_to_ycrcb(c->stream, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
+        launch_bgr_to_ycrcb(ws, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
                             c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);
-    rec(c, "channels");
+    rec(c, "channels", ws);
     for (int l = 1; l < nl; ++l)
-        launch_resize(c->stream, c->d_pix + geo[l - 1].off, geo[l - 1].w, geo[l - 1].h, geo[l - 1].stride, (int64_t)plane_sz(l - 1),
+        launch_resize(ws, c->d_pix + geo[l - 1].off, geo[l - 1].w, geo[l - 1].h, geo[l - 1].stride, (int64_t)plane_sz(l - 1),
                       (int64_t)frame_bytes, c->d_pix + geo[l].off, geo[l].w, geo[l].h, geo[l].stride, (int64_t)plane_sz(l),
                       (int64_t)frame_bytes, 3, n_frames);
-    rec(c, "pyramid");
+    rec(c, "pyramid", ws);
 
     Batch b;
     for (int f = 0; f < n_frames; ++f)
@@ -2333,7 +2383,7 @@ try {
         if (key == "svm_type") ok_type = line.find("c_svc") != std::string::npos;
         else if (key == "kernel_type") ok_kernel = line.find("rbf") != std::string::npos;
         else if (key == "gamma") gamma = std::strtod(line.c_str() + from, nullptr);
-        else if (key == "nr_class") { const long v = std::strtol(line.c_str() + from, nullptr, 10); k = v < 0 || v > 128 ? -1 : (int)v; }
+        else if (key == "nr_class") { const long v = std::strtol(line.c_str() + from, nullptr, 10); k = v < 0 || v > 125 ? -1 : (int)v; }      // (k_svm_couple keeps k (k - 1) / 2 + 3 k doubles in 64 KB of LDS)
         // (every support vector is a line of the text: a count beyond the text's length is a damaged header, not a table to allocate)
         else if (key == "total_sv") { const long v = std::strtol(line.c_str() + from, nullptr, 10); l = v < 0 || (unsigned long)v > len || v > (1L << 28) ? -1 : (int)v; }
         else if (key == "rho") numbers(line, from, rho);
@@ -2345,9 +2395,9 @@ try {
     }
     if (!ok_type || !ok_kernel) return fail(c, STR_ER_EFORMAT, "svm model: only svm_type c_svc with kernel_type rbf is supported");
     const int np = k * (k - 1) / 2;
-    if (!have_sv || k < 2 || k > 128 || l < 1 || (int)rho.size() != np || (int)pa.size() != np || (int)pb.size() != np ||
+    if (!have_sv || k < 2 || k > 125 || l < 1 || (int)rho.size() != np || (int)pa.size() != np || (int)pb.size() != np ||
         (int)lab.size() != k || (int)nsv.size() != k)
-        return fail(c, STR_ER_EFORMAT, "svm model: incomplete header (need nr_class<=128, rho, label, probA, probB, nr_sv)");
+        return fail(c, STR_ER_EFORMAT, "svm model: incomplete header (need nr_class<=125, rho, label, probA, probB, nr_sv)");
     const int dpad = (int)align_up((size_t)dim, 16), l_pad = (int)align_up((size_t)l, 64);
     std::vector<float> sv((size_t)l_pad * dpad, 0.f);
     std::vector<double> svnorm(l_pad, 0.0), coef((size_t)(k - 1) * l, 0.0);
@@ -2369,25 +2419,26 @@ try {
         }
         svnorm[i] = nrm;
     }
-    std::vector<int32_t> ilab(k), insv(k), start(k), pi(np), pj(np);
+    std::vector<int32_t> ilab(k), insv(k), start(k);
     int tot = 0;
     for (int i = 0; i < k; ++i) {
         if (!to_int(lab[i], ilab[i]) || !to_int(nsv[i], insv[i]) || insv[i] < 0 || insv[i] > l) return fail(c, STR_ER_EFORMAT, "svm model: label / nr_sv entries are not counts");
         start[i] = tot; tot += insv[i];
     }
     if (tot != l) return fail(c, STR_ER_EFORMAT, "svm model: nr_sv does not add up to total_sv");
-    for (int i = 0, p = 0; i < k; ++i) for (int j = i + 1; j < k; ++j, ++p) { pi[p] = i; pj[p] = j; }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_rho = take(np * 8),
-                 o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4), o_pi = take(np * 4),
-                 o_pj = take(np * 4);
+    // coef_t[q][b] = sv_coef[b][q]: the decision values read one coalesced row per support vector (k_svm_couple)
+    const int kc = (int)align_up((size_t)(k - 1), 64);
+    std::vector<double> coef_t((size_t)l_pad * kc, 0.0);      // (l_pad rows: the walk reads eight rows at a time)
+    for (int j = 0; j < k - 1; ++j) for (int i = 0; i < l; ++i) coef_t[(size_t)i * kc + j] = coef[(size_t)j * l + i];
+    const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
+                 o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);
     std::vector<uint8_t> blob(off);
     std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
-    std::memcpy(&blob[o_coef], coef.data(), coef.size() * 8); std::memcpy(&blob[o_rho], rho.data(), np * 8);
+    std::memcpy(&blob[o_coef], coef.data(), coef.size() * 8); std::memcpy(&blob[o_coeft], coef_t.data(), coef_t.size() * 8); std::memcpy(&blob[o_rho], rho.data(), np * 8);
     std::memcpy(&blob[o_pa], pa.data(), np * 8); std::memcpy(&blob[o_pb], pb.data(), np * 8);
     std::memcpy(&blob[o_lab], ilab.data(), k * 4); std::memcpy(&blob[o_nsv], insv.data(), k * 4); std::memcpy(&blob[o_start], start.data(), k * 4);
-    std::memcpy(&blob[o_pi], pi.data(), np * 4); std::memcpy(&blob[o_pj], pj.data(), np * 4);
     void *d = nullptr;
     HIP_TRY(c, hipMalloc(&d, blob.size()));
     hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
@@ -2398,11 +2449,11 @@ try {
     SvmDev m{};
     m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
     m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
+    m.kc = kc; m.coef_t = reinterpret_cast<const double *>(b + o_coeft);
     m.coef = reinterpret_cast<const double *>(b + o_coef); m.rho = reinterpret_cast<const double *>(b + o_rho);
     m.probA = reinterpret_cast<const double *>(b + o_pa); m.probB = reinterpret_cast<const double *>(b + o_pb);
     m.label = reinterpret_cast<const int32_t *>(b + o_lab); m.nsv = reinterpret_cast<const int32_t *>(b + o_nsv);
-    m.start = reinterpret_cast<const int32_t *>(b + o_start); m.pair_i = reinterpret_cast<const int32_t *>(b + o_pi);
-    m.pair_j = reinterpret_cast<const int32_t *>(b + o_pj);
+    m.start = reinterpret_cast<const int32_t *>(b + o_start);
     c->svm = m;
     c->svm_loaded = true;
     return STR_ER_OK;
@@ -2440,25 +2491,20 @@ try {
     if (n == 0) return STR_ER_OK;
     HIP_TRY(c, hipSetDevice(c->prm.device));
     const SvmDev &m = c->svm;
-    const size_t n_pad = align_up((size_t)n, 64), np = (size_t)m.k * (m.k - 1) / 2;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_x = take((size_t)n * dim * 8), o_xf = take(n_pad * m.dpad * 4), o_xn = take(n_pad * 8), o_kv = take(n_pad * m.l_pad * 8),
-                 o_dec = take((size_t)n * np * 8), o_prob = take((size_t)n * m.k * 8), o_lab = take((size_t)n * 4);
-    int rc = ensure_scratch(c, off);
+    const size_t np = (size_t)m.k * (m.k - 1) / 2;
+    const size_t o_x = 0, o_buf = align_up((size_t)n * dim * 8, 256);
+    int rc = ensure_scratch(c, o_buf + ocr_layout(nullptr, (size_t)n, &m, false, dec != nullptr, true).bytes);
     if (rc != STR_ER_OK) return rc;
     uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
+    const OcrBuf buf = ocr_layout(s + o_buf, (size_t)n, &m, false, dec != nullptr, true);
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemsetAsync(s + o_xf, 0, n_pad * m.dpad * 4 + 256, st));
-    HIP_TRY(c, hipMemsetAsync(s + o_xn, 0, n_pad * 8, st));
     HIP_TRY(c, hipMemcpyAsync(s + o_x, x, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
-    launch_svm_predict(st, reinterpret_cast<const double *>(s + o_x), n, dim, reinterpret_cast<float *>(s + o_xf),
-                       reinterpret_cast<double *>(s + o_xn), (int)n_pad, reinterpret_cast<double *>(s + o_kv),
-                       reinterpret_cast<double *>(s + o_dec), reinterpret_cast<double *>(s + o_prob), reinterpret_cast<int32_t *>(s + o_lab), m);
+    launch_svm_prep(st, reinterpret_cast<const double *>(s + o_x), n, dim, buf, m);
+    launch_svm_score(st, n, buf, m);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(prob, s + o_prob, (size_t)n * m.k * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(label, s + o_lab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (dec) HIP_TRY(c, hipMemcpyAsync(dec, s + o_dec, (size_t)n * np * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(prob, buf.prob, (size_t)n * m.k * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (dec) HIP_TRY(c, hipMemcpyAsync(dec, buf.dec, (size_t)n * np * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, wait_stream(c, st));
     return STR_ER_OK;
 } ABI_GUARD(c)
@@ -2488,18 +2534,14 @@ try {
     if ((size_t)w * h > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
-    const SvmDev &m = c->svm;
-    const size_t n_pad = align_up((size_t)n, 64), np = want_svm ? (size_t)m.k * (m.k - 1) / 2 : 0;
+    const SvmDev *m = want_svm ? &c->svm : nullptr;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_rot = take(slope ? sizeof(RotGeom) * (size_t)n : 0);
-    const size_t o_box = take(16 * (size_t)n), o_q = take(1800 * (size_t)n), o_x = take(want_svm ? (size_t)n * 1800 * 8 : 0),
-                 o_xf = take(want_svm ? n_pad * m.dpad * 4 + 256 : 0), o_xn = take(want_svm ? n_pad * 8 : 0),
-                 o_kv = take(want_svm ? n_pad * m.l_pad * 8 : 0), o_dec = take((size_t)n * np * 8),
-                 o_prob = take(want_svm ? (size_t)n * m.k * 8 : 0), o_lab = take((size_t)n * 4);
-    int rc = ensure_scratch(c, off);
+    const size_t o_rot = take(slope ? sizeof(RotGeom) * (size_t)n : 0), o_box = take(16 * (size_t)n), o_buf = take(0);
+    int rc = ensure_scratch(c, o_buf + ocr_layout(nullptr, (size_t)n, m, true, false, false).bytes);
     if (rc != STR_ER_OK) return rc;
     uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
+    const OcrBuf buf = ocr_layout(s + o_buf, (size_t)n, m, true, false, false);
     HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
     std::vector<RotGeom> rot;
     if (slope) {
@@ -2510,34 +2552,19 @@ try {
         }
         HIP_TRY(c, hipMemcpyAsync(s + o_rot, rot.data(), sizeof(RotGeom) * (size_t)n, hipMemcpyHostToDevice, st));
     }
-    launch_chain_features(st, c->d_pix, w, 0, reinterpret_cast<const int32_t *>(s + o_box), n, s + o_q,
-                          want_svm ? reinterpret_cast<double *>(s + o_x) : nullptr, 1800,
-                          slope ? reinterpret_cast<const RotGeom *>(s + o_rot) : nullptr);
-    std::vector<double> pall;
-    if (want_svm) {
-        HIP_TRY(c, hipMemsetAsync(s + o_xf, 0, n_pad * m.dpad * 4 + 256, st));
-        HIP_TRY(c, hipMemsetAsync(s + o_xn, 0, n_pad * 8, st));
-        launch_svm_predict(st, reinterpret_cast<const double *>(s + o_x), n, 1800, reinterpret_cast<float *>(s + o_xf),
-                           reinterpret_cast<double *>(s + o_xn), (int)n_pad, reinterpret_cast<double *>(s + o_kv),
-                           reinterpret_cast<double *>(s + o_dec), reinterpret_cast<double *>(s + o_prob),
-                           reinterpret_cast<int32_t *>(s + o_lab), m);
-        pall.resize((size_t)n * m.k);
-        HIP_TRY(c, hipMemcpyAsync(pall.data(), s + o_prob, pall.size() * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(label, s + o_lab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(c, hipGetLastError());
-    if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, s + o_q, 1800 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, wait_stream(c, st));
+    OcrSrc src{};
+    src.plane = c->d_pix; src.stride = w; src.inv = 0; src.boxes = reinterpret_cast<const int32_t *>(s + o_box);
+    src.rot = slope ? reinterpret_cast<const RotGeom *>(s + o_rot) : nullptr;
+    launch_ocr_features(st, src, n, buf, m);
     if (want_svm) {
         // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. assumes model->label[i] == i
-        std::vector<int32_t> lab(m.k);
-        HIP_TRY(c, hipMemcpy(lab.data(), m.label, (size_t)m.k * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) {
-            int idx = -1;
-            for (int k = 0; k < m.k; ++k) if (lab[k] == label[i]) { idx = k; break; }
-            prob[i] = idx >= 0 ? pall[(size_t)i * m.k + idx] : 0.0;
-        }
+        launch_svm_score(st, n, buf, *m);
+        HIP_TRY(c, hipMemcpyAsync(prob, buf.pbest, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     }
+    HIP_TRY(c, hipGetLastError());
+    if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, buf.q, 1800 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, wait_stream(c, st));
     return STR_ER_OK;
 } ABI_GUARD(c)
 

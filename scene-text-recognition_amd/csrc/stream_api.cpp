@@ -76,7 +76,9 @@ void worker_main(str_er_stream *s, int idx)
         }
         str_er_result *r = nullptr;
         int rc = STR_ER_OK;
-        {
+        bool upload_failed = false;
+        // (nothing may leave this thread as an exception -- std::terminate -- and the upload turn must pass on whatever happens: every later ticket waits for it)
+        try {
             // the upload, when it is this batch's turn (submission order); the turn passes on when the bytes have landed
             const int64_t rows = sl.nv12 ? (int64_t)sl.h + sl.h / 2 : (int64_t)sl.h;
             const size_t bytes = (size_t)(sl.n_frames - 1) * (size_t)sl.pitch + (size_t)sl.stride * (size_t)rows;
@@ -85,34 +87,36 @@ void worker_main(str_er_stream *s, int idx)
                 s->cv.wait(lk, [&] { return s->upload_turn == sl.ticket; });
             }
             hipError_t e = hipSuccess;
-            const size_t piece = s->upload_piece;
-            for (size_t at = 0; at < bytes && e == hipSuccess; at += piece)
-                e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, bytes - at), hipMemcpyHostToDevice, sl.copy);
-            if (e == hipSuccess) e = hipEventRecord(sl.landed, sl.copy);
-            // (poll, then sleep between polls: a spinning wait per slot would keep `depth` host cores busy)
-            for (int spins = 0; e == hipSuccess;) {
-                const hipError_t q = hipEventQuery(sl.landed);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) { e = q; break; }
-                if (++spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(50));
-            }
             {
-                std::lock_guard<std::mutex> lk(s->mu);
-                s->upload_turn = sl.ticket + 1;
+                struct TurnGuard {
+                    str_er_stream *s; uint64_t next;
+                    ~TurnGuard() { { std::lock_guard<std::mutex> lk(s->mu); s->upload_turn = next; } s->cv.notify_all(); }
+                } pass_on{s, sl.ticket + 1};
+                const size_t piece = s->upload_piece;
+                for (size_t at = 0; at < bytes && e == hipSuccess; at += piece)
+                    e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, bytes - at), hipMemcpyHostToDevice, sl.copy);
+                if (e == hipSuccess) e = hipEventRecord(sl.landed, sl.copy);
+                // (poll, then sleep between polls: a spinning wait per slot would keep `depth` host cores busy)
+                for (int spins = 0; e == hipSuccess;) {
+                    const hipError_t q = hipEventQuery(sl.landed);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) { e = q; break; }
+                    if (++spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
             }
-            s->cv.notify_all();
-            if (e != hipSuccess) { rc = STR_ER_EHIP; sl.err = std::string("upload: ") + hipGetErrorString(e); }
+            if (e != hipSuccess) { rc = STR_ER_EHIP; upload_failed = true; sl.err = std::string("upload: ") + hipGetErrorString(e); }
+            if (rc == STR_ER_OK)
+                rc = sl.nv12 ? str_er_detect_nv12(sl.ctx, sl.d_in, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_DEVICE, sl.stages, &r)
+                             : str_er_detect_bgr(sl.ctx, sl.d_in, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_DEVICE, sl.stages, &r);
+        } catch (...) {
+            rc = STR_ER_ENOMEM; r = nullptr; upload_failed = true;
+            try { sl.err = "stream worker: out of host memory"; } catch (...) { }
         }
-        if (rc == STR_ER_OK)
-            rc = sl.nv12 ? str_er_detect_nv12(sl.ctx, sl.d_in, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_DEVICE, sl.stages, &r)
-                         : str_er_detect_bgr(sl.ctx, sl.d_in, sl.w, sl.h, sl.stride, sl.pitch, sl.n_frames, STR_ER_MEM_DEVICE, sl.stages, &r);
-        else r = nullptr;
-        const bool upload_failed = rc != STR_ER_OK && r == nullptr && !sl.err.empty();
         {
             std::lock_guard<std::mutex> lk(s->mu);
             sl.rc = rc;
             sl.result = r;
-            if (rc != STR_ER_OK && !upload_failed) sl.err = str_er_last_error(sl.ctx);
+            if (rc != STR_ER_OK && !upload_failed) { try { sl.err = str_er_last_error(sl.ctx); } catch (...) { } }
             sl.has_job = false;
             sl.done = true;
         }

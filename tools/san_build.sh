@@ -24,6 +24,6 @@ for src in er_group flood_order gather str_er_api stream_api; do
         -c $ROOT/csrc/$src.cpp -o $OUT/${src}_$kind.o
     objs="$objs $OUT/${src}_$kind.o"
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o $OUT/libstr_er_hip_$kind.so $objs $ROOT/lib/{er_kernels,svm_kernels,track_kernels}.o -ldl -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o $OUT/libstr_er_hip_$kind.so $objs $ROOT/lib/{er_kernels,ocr_kernels,track_kernels}.o -ldl -lpthread
 rm -f $objs
 echo $OUT/libstr_er_hip_$kind.so
