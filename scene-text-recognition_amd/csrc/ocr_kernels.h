@@ -19,6 +19,7 @@ struct SvmDev {
     const double *coef_t;   // [l_pad x kc]              coef_t[q][b] = sv_coef[b][q], zero padded: one coalesced row per support vector
     const double *rho, *probA, *probB;   // [k(k-1)/2]
     const int32_t *label, *nsv, *start;  // [k]
+    const uint16_t *pair_ij;             // [k(k-1)/2]  (i << 8) | j of every class pair i < j, in libsvm's order
 };
 
 // Where the boxes of a call come from: explicit boxes on one device plane (single-stage API), or records

@@ -47,7 +47,8 @@ __device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)
     return b;
 }
 
-// indices of the strong / weak candidates of the batch, in candidate order
+// indices of the strong / weak candidates of the batch, in candidate order.  One workgroup; a thread takes four consecutive candidates per
+// pass (the four class bytes are requested together: the scan is a chain of memory round trips otherwise).
 __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ cands, const uint32_t *__restrict__ total_cands,
                                                    uint32_t *__restrict__ list, uint32_t *__restrict__ n_out)
 {
@@ -57,16 +58,21 @@ __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ c
     const uint32_t total = *total_cands;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < total; base += 1024) {
-        const uint32_t i = base + tid;
-        const bool     v = i < total && cands[i].cls != 0;
-        const unsigned long long m = __ballot(v);
-        const uint32_t excl = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_w[tid >> 6] = (uint32_t)__popcll(m);
+    for (uint32_t base = 0; base < total; base += 4096) {
+        const uint32_t i0 = base + 4u * (uint32_t)tid;
+        uint32_t       m4 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m4 |= (i0 + u < total && cands[i0 + u].cls != 0) ? 1u << u : 0u;
+        const uint32_t cnt = (uint32_t)__popc(m4);
+        uint32_t       incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) s_w[tid >> 6] = incl;
         __syncthreads();
-        uint32_t off = s_carry, tot = 0;
+        uint32_t off = s_carry + incl - cnt, tot = 0;
         for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-        if (v) list[off + excl] = i;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if ((m4 >> u) & 1u) list[off++] = i0 + u;
         __syncthreads();
         if (tid == 0) s_carry += tot;
         __syncthreads();
@@ -512,108 +518,91 @@ __device__ __forceinline__ double rcp_nr(double x)
 }
 
 // svm_predict_values + sigmoid_predict + multiclass_probability for one vector per wave.  Class-indexed vectors (p, Qp,
-// Q's diagonal) live in registers: lane L holds classes L and L + 64 (k <= 128).  The pairwise table V (k(k-1)/2 f64 in
-// LDS, pair (i < j) at rb(i) + j, rb(i) = i k - i (i + 1) / 2 - i - 1) first collects the decision values, then the
-// pairwise probabilities r_ij, then Q's off-diagonal entries -r_ji r_ij.
+// Q's diagonal) live in registers: lane L holds classes L and L + 64.  The pairwise table V (k(k-1)/2 entries in LDS, pair
+// (i < j) at rb(i) + j, rb(i) = i k - i (i + 1) / 2 - i - 1) holds the pairwise probabilities r_ij, then Q's off-diagonal
+// entries -r_ji r_ij -- as f32: 8 KB instead of 16, which is what lets 16 waves share a compute unit's LDS (the kernel is a
+// chain of dependent f64 operations per wave: what it needs is waves).  An entry's rounding (6e-8 relative) moves a
+// probability by ~1e-8: Q is strongly diagonally dominant (Q_tt = sum of k - 1 squares, |Q_tj| <= 1/4).
 //
-// Decision values: libsvm sums, for the pair (i, j), coef[j-1][q] K[q] over class i's support vectors and coef[i][q] K[q]
-// over class j's.  Walking the support vectors in their (class-sorted) order with lane b holding the column b of the
-// transposed coefficient table gives, per class a, the 64 (128) partial sums S[a][b] from one coalesced row per support
-// vector; S[a][b] is the class-a half of the pair (a, b' = b < a ? b : b + 1).  The two halves of a pair are added class i
-// first like the reference, each half summed in the reference's order (the grouping of the final addition differs: 1 ulp).
+// Decision values: a lane per class pair, eight pairs of a lane at a time, summed exactly as libsvm does (coef[j-1][q] K[q]
+// over class i's support vectors, then coef[i][q] K[q] over class j's, then - rho: src/svm.cpp:2539-2566) -- the first half
+// from the transposed coefficient table (lanes = consecutive j: one row segment per support vector), the second from the
+// table as libsvm stores it (lanes = consecutive j again: neighbouring columns of row i).  The loops run over the support
+// vector's rank inside its class with all eight pairs' loads in flight.
 //
 // Coupling: the reference's Gauss-Seidel sweep divides p and Qp by (1 + diff) after every coordinate step (5 divisions
 // per step, 2 of them on every lane).  Here the sweep runs on the unnormalised iterate -- p~ = p / sigma, B = Q p~,
 // A = p~ Q p~, S = sum p~ = 1 / sigma -- for which a step is d = (A / S - B_t) / Q_tt; p~_t += d; B += d Q_t; A += d (d Q_tt + 2 B_t);
 // S += d: one reciprocal on the critical path and one fused multiply-add per lane; the iterate is renormalised at the end
 // of a sweep, where the reference's stopping test (max_t |Qp_t - pQp| < 0.005 / k, on the same quantities up to rounding)
-// is evaluated.  The same fixed point, the same sweeps: probabilities agree with the reference's to ~1e-16.
-template <bool TWO, bool TWOC>       // TWO: k > 64 (two class registers per lane); TWOC: k - 1 > 64 (two coefficient columns per lane)
+// is evaluated.  The same fixed point, the same sweeps.
+// MODE 0: k <= 64.  MODE 1: k = 65 (the reference's 65 characters): the one class beyond the 64 lanes is carried as a wave-uniform value in
+// every lane -- a second class register per lane would double the vector work of every step for one useful lane.  MODE 2: 66 <= k <= 125.
+template <int MODE>
 __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv, int l_pad, SvmDev m, double *__restrict__ dec_out,
                                                    double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest)
 {
-    // LDS: V[np] pairwise table; QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps
-    extern __shared__ __attribute__((aligned(16))) double V[];
-    const int k = m.k, np = k * (k - 1) / 2, kc = m.kc;
-    double *QI = V + ((np + 1) & ~1), *D = QI + 2 * k;
+    constexpr bool TWO = MODE == 2, TAIL = MODE == 1;
+    // LDS: QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps; V[np] pairwise table (f32)
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int k = m.k, np = k * (k - 1) / 2, kc = m.kc, l = m.l;
+    double *QI = lds_d, *D = QI + 2 * k;
+    float  *V = reinterpret_cast<float *>(D + k);
     const int v = blockIdx.x, lane = threadIdx.x;
     const double *kr = kv + (size_t)v * l_pad;
     auto rb = [k](int i) -> int { return i * k - i * (i + 1) / 2 - i - 1; };
     const int  t0 = lane, t1 = lane + 64;
-    const bool on0 = t0 < k, on1 = TWO && t1 < k;
+    const bool on0 = MODE != 0 || t0 < k, on1 = TWO && t1 < k;         // (k >= 64: every lane has a class)
     const int  rb0 = rb(t0), rb1 = rb(t1);
-    // ---- decision values.  The support vectors are walked in their stored (class-sorted) order, eight coefficient rows in flight at a time
-    // (a row per iteration would pay a memory round trip per support vector); the kernel values come 64 at a time into a register and are
-    // broadcast by v_readlane; a class ends where its last support vector does (empty classes end at once).
-    {
-        constexpr bool two_c = TWOC;                       // (k = 65: two class registers, but 64 coefficient columns)
-        // where every class's support vectors end, a class per lane (a scalar load per class end would be a memory round trip each)
-        const int cend0 = t0 < k ? m.start[t0] + m.nsv[t0] : 0x7FFFFFFF, cend1 = (TWO && t1 < k) ? m.start[t1] + m.nsv[t1] : 0x7FFFFFFF;
-        auto class_end = [&](int a) -> int { return a < 64 ? __builtin_amdgcn_readlane(cend0, a) : (TWO && a < k ? __builtin_amdgcn_readlane(cend1, a - 64) : 0x7FFFFFFF); };
-        int    a = 0, q_end = class_end(0);
-        double s0 = 0, s1 = 0;
-        auto flush = [&]() {
-            const int rba = rb(a);
-            // lane b: other class b' = b < a ? b : b + 1
-            if (t0 < k - 1) { if (t0 >= a) V[rba + t0 + 1] = s0; else V[rb0 + a] += s0; }
-            if (two_c && t1 < k - 1) { if (t1 >= a) V[rba + t1 + 1] = s1; else V[rb1 + a] += s1; }
-            __builtin_amdgcn_wave_barrier();
-            s0 = 0; s1 = 0;
-            ++a;
-            q_end = a < k ? class_end(a) : 0x7FFFFFFF;
-        };
-        constexpr int CH = 16;                               // rows per chunk; the next chunk is requested before this one is used
-        const int l = m.l;
-        double cur0[CH], cur1[CH], nxt0[CH], nxt1[CH];
-        auto load = [&](double (&d0)[CH], double (&d1)[CH], int q0) {
+    // ---- decision values, r_ij = sigmoid_predict(dec, A, B) clamped to [1e-7, 1 - 1e-7] (src/svm.cpp:2603-2611)
+    constexpr int PC = 8;
+    const double  min_prob = 1e-7;
+    for (int c0 = 0; c0 < np; c0 += 64 * PC) {
+        int    ci[PC], cj[PC], sa[PC], na[PC], sb[PC], nb[PC];
+        double sum[PC];
+        int    qa = 0, qb = 0;
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {                             // coef_t has l_pad rows (zero beyond l); l_pad is a multiple of 64
-                d0[u] = m.coef_t[(size_t)(q0 + u) * kc + lane];
-                d1[u] = two_c ? m.coef_t[(size_t)(q0 + u) * kc + lane + 64] : 0.0;
-            }
-        };
-        load(cur0, cur1, 0);
-        double kreg = kr[lane], knext = 0;
-        for (int q0 = 0; q0 < l; q0 += CH) {
-            const bool more = q0 + CH < l;
-            if (more) load(nxt0, nxt1, q0 + CH);
-            if ((q0 & 63) == 0 && q0 + 64 < l_pad) knext = kr[q0 + 64 + lane];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int q = q0 + u;
-                while (q == q_end) flush();
-                const double kq = bcast(kreg, q & 63);
-                s0 += cur0[u] * kq;
-                if (two_c) s1 += cur1[u] * kq;
-            }
-            if (((q0 + CH) & 63) == 0) kreg = knext;
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { cur0[u] = nxt0[u]; cur1[u] = nxt1[u]; }
+        for (int u = 0; u < PC; ++u) {
+            const int  p = c0 + 64 * u + lane;
+            const bool ok = p < np;
+            const int  ij = ok ? (int)m.pair_ij[p] : 0;
+            ci[u] = ij >> 8; cj[u] = ij & 255;
+            sa[u] = m.start[ci[u]]; na[u] = ok ? m.nsv[ci[u]] : 0;
+            sb[u] = m.start[cj[u]]; nb[u] = ok ? m.nsv[cj[u]] : 0;
+            sum[u] = 0;
+            qa = max(qa, na[u]); qb = max(qb, nb[u]);
         }
-        while (a < k) flush();
-    }
-    // ---- dec = sum - rho; r_ij = sigmoid_predict(dec, A, B) clamped to [1e-7, 1 - 1e-7] (src/svm.cpp:2603-2611)
-    const double min_prob = 1e-7;
-    for (int pb = lane; pb < np; pb += 256) {           // four pairs per pass: their model constants are requested together
-        double rho[4], pA[4], pB[4];
+        for (int o = 32; o > 0; o >>= 1) { qa = max(qa, __shfl_xor(qa, o)); qb = max(qb, __shfl_xor(qb, o)); }
+        for (int q = 0; q < qa; ++q) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = min(pb + 64 * u, np - 1);
+            for (int u = 0; u < PC; ++u)
+                if (q < na[u]) sum[u] += m.coef_t[(size_t)(sa[u] + q) * kc + cj[u] - 1] * kr[sa[u] + q];
+        }
+        for (int q = 0; q < qb; ++q) {
+#pragma unroll
+            for (int u = 0; u < PC; ++u)
+                if (q < nb[u]) sum[u] += m.coef[(size_t)ci[u] * l + sb[u] + q] * kr[sb[u] + q];
+        }
+        double rho[PC], pA[PC], pB[PC];
+#pragma unroll
+        for (int u = 0; u < PC; ++u) {
+            const int p = min(c0 + 64 * u + lane, np - 1);
             rho[u] = m.rho[p]; pA[u] = m.probA[p]; pB[u] = m.probB[p];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = pb + 64 * u;
-            if (p >= np) break;
-            const double d = V[p] - rho[u];
-            if (dec_out) dec_out[(size_t)v * np + p] = d;
-            const double fApB = d * pA[u] + pB[u];
-            // sigmoid_predict (src/svm.cpp:1818-1826): exp(-f) / (1 + exp(-f)) for f >= 0, 1 / (1 + exp(f)) otherwise -- one exp of -|f| serves both
-            const double ex = exp(-fabs(fApB));
-            double sg = fApB >= 0 ? ex / (1.0 + ex) : 1.0 / (1 + ex);
-            sg = sg > min_prob ? sg : min_prob;
-            sg = sg < 1 - min_prob ? sg : 1 - min_prob;
-            V[p] = sg;
+        for (int u = 0; u < PC; ++u) {
+            const int p = c0 + 64 * u + lane;
+            if (p < np) {
+                const double d = sum[u] - rho[u];
+                if (dec_out) dec_out[(size_t)v * np + p] = d;
+                const double fApB = d * pA[u] + pB[u];
+                // sigmoid_predict (src/svm.cpp:1818-1826): exp(-f) / (1 + exp(-f)) for f >= 0, 1 / (1 + exp(f)) otherwise -- one exp of -|f| serves both
+                const double ex = exp(-fabs(fApB));
+                double sg = fApB >= 0 ? ex / (1.0 + ex) : 1.0 / (1 + ex);
+                sg = sg > min_prob ? sg : min_prob;
+                sg = sg < 1 - min_prob ? sg : 1 - min_prob;
+                V[p] = (float)sg;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -625,14 +614,14 @@ __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv
         const int rbj = rb(j);
         {
             const int    idx = j < t0 ? rbj + t0 : rb0 + j;
-            const double e = V[min(max(idx, 0), np - 1)], r = j < t0 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
+            const double e = (double)V[min(max(idx, 0), np - 1)], r = j < t0 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
             const bool   on = on0 && j != t0;
             qd0 += on ? r * r : 0.0;
             B0 += on ? w * ik : 0.0;
         }
         if (TWO) {
             const int    idx = j < t1 ? rbj + t1 : rb1 + j;
-            const double e = V[min(max(idx, 0), np - 1)], r = j < t1 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
+            const double e = (double)V[min(max(idx, 0), np - 1)], r = j < t1 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
             const bool   on = on1 && j != t1;
             qd1 += on ? r * r : 0.0;
             B1 += on ? w * ik : 0.0;
@@ -640,23 +629,33 @@ __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv
     }
     B0 += on0 ? qd0 * ik : 0.0;
     B1 += on1 ? qd1 * ik : 0.0;
+    // the uniform class 64 (MODE 1): lane j holds its pair (j, 64); sums over the wave (the order of the additions differs from the reference's: 1 ulp)
+    double qdT = 0, BT = 0, pT = 0;
+    if (TAIL) {
+        const double e = (double)V[rb0 + 64];
+        qdT = wave_sum(e * e);
+        BT = wave_sum(((-(1.0 - e)) * e) * ik) + qdT * ik;
+        pT = ik;
+    }
     if (on0) { QI[2 * t0] = qd0; QI[2 * t0 + 1] = 1.0 / qd0; }
     if (on1) { QI[2 * t1] = qd1; QI[2 * t1 + 1] = 1.0 / qd1; }
+    if (TAIL) { QI[128] = qdT; QI[129] = 1.0 / qdT; }                  // (every lane writes the same words)
     __builtin_amdgcn_wave_barrier();
     // ---- Q_tj = -r_jt r_tj = -(1 - V) V
-    for (int p = lane; p < np; p += 64) { const double s = V[p]; V[p] = (-(1.0 - s)) * s; }
+    for (int p = lane; p < np; p += 64) { const double e = (double)V[p]; V[p] = (float)((-(1.0 - e)) * e); }
     __builtin_amdgcn_wave_barrier();
     double p0 = on0 ? ik : 0.0, p1 = on1 ? ik : 0.0;
-    double A = wave_sum(p0 * B0 + p1 * B1);
+    double A = wave_sum(p0 * B0 + p1 * B1) + pT * BT;
     const int    max_iter = k > 100 ? k : 100;
     const double eps = 0.005 / k;
     for (int iter = 0; iter < max_iter; ++iter) {
         double err = on0 ? fabs(B0 - A) : 0.0;
         if (on1) err = fmax(err, fabs(B1 - A));
         for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+        if (TAIL) err = fmax(err, fabs(BT - A));
         if (err < eps) break;
         double S = 1.0;
-        // one coordinate step; HI: t is one of the classes 64 ..
+        // one coordinate step (the step of class t on its own B_t -- the diagonal -- is applied after the sweep: nothing reads B_t again before)
         auto step = [&](int t, double Bt) {
             const double2 qi = *reinterpret_cast<const double2 *>(QI + 2 * t);
             const double  d = (rcp_nr(S) * A - Bt) * qi.y;
@@ -665,29 +664,33 @@ __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv
             D[t] = d;                                              // (every lane writes the same word)
             const int rbt = rb(t);
             {
-                const int    idx = t0 > t ? rbt + t0 : rb0 + t;
-                const double e = V[min(max(idx, 0), np - 1)];
-                B0 = __builtin_fma(d, t0 == t ? qi.x : (on0 ? e : 0.0), B0);
+                const int idx = t0 > t ? rbt + t0 : rb0 + t;
+                const float e = V[min(max(idx, 0), np - 1)];
+                B0 = __builtin_fma(d, (double)((on0 && t0 != t) ? e : 0.f), B0);
             }
             if (TWO) {
-                const int    idx = t1 > t ? rbt + t1 : rb1 + t;
-                const double e = V[min(max(idx, 0), np - 1)];
-                B1 = __builtin_fma(d, t1 == t ? qi.x : (on1 ? e : 0.0), B1);
+                const int idx = t1 > t ? rbt + t1 : rb1 + t;
+                const float e = V[min(max(idx, 0), np - 1)];
+                B1 = __builtin_fma(d, (double)((on1 && t1 != t) ? e : 0.f), B1);
             }
+            if (TAIL && t < 64) BT = __builtin_fma(d, (double)V[rbt + 64], BT);      // (one address for the whole wave)
         };
         const int klo = k < 64 ? k : 64;
         for (int t = 0; t < klo; ++t) step(t, bcast(B0, t));
         if (TWO) for (int t = 64; t < k; ++t) step(t, bcast(B1, t - 64));
+        if (TAIL) step(64, BT);
         __builtin_amdgcn_wave_barrier();
         const double sg = rcp_nr(S);
-        if (on0) p0 += D[t0];
-        if (on1) p1 += D[t1];
-        p0 *= sg; p1 *= sg; B0 *= sg; B1 *= sg; A *= sg * sg;
+        if (on0) { const double d = D[t0]; p0 += d; B0 = __builtin_fma(d, qd0, B0); }
+        if (on1) { const double d = D[t1]; p1 += d; B1 = __builtin_fma(d, qd1, B1); }
+        if (TAIL) { const double d = D[64]; pT += d; BT = __builtin_fma(d, qdT, BT); }
+        p0 *= sg; p1 *= sg; B0 *= sg; B1 *= sg; A *= sg * sg; pT *= sg; BT *= sg;
         __builtin_amdgcn_wave_barrier();
     }
     if (prob) {
         if (on0) prob[(size_t)v * k + t0] = p0;
         if (on1) prob[(size_t)v * k + t1] = p1;
+        if (TAIL && lane == 0) prob[(size_t)v * k + 64] = pT;
     }
     // arg max with the reference's tie rule (first maximum, src/svm.cpp:2614-2617)
     double best = on0 ? p0 : -1.0;
@@ -698,12 +701,14 @@ __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv
         const int    oi = __shfl_xor(bi, o);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
+    if (TAIL && pT > best) { best = pT; bi = 64; }
     // prob of the result = pv[label]: the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. takes the entry
     // of the first class carrying that label
     const int lab = m.label[bi];
     int first = (on0 && m.label[t0] == lab) ? t0 : ((on1 && m.label[t1] == lab) ? t1 : 1 << 20);
     for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-    const double pf = first < 64 ? bcast(p0, first & 63) : bcast(p1, (first - 64) & 63);
+    if (TAIL && first > 64 && m.label[64] == lab) first = 64;
+    const double pf = first < 64 ? bcast(p0, first & 63) : (TAIL ? pT : bcast(p1, (first - 64) & 63));
     if (lane == 0) { label[v] = lab; pbest[v] = pf; }
 }
 
@@ -747,12 +752,16 @@ void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t 
 void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m)
 {
     if (n <= 0) return;
+    // grids of one round of resident workgroups (k_ocr_hist: 32 KB of LDS -> 5 per compute unit, k_ocr_features: 45 KB -> 3): a second, partly
+    // filled round would cost as much as a full one
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop{}; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
     const int wg = (n + OCR_WAVES - 1) / OCR_WAVES;
     (void)hipMemsetAsync(buf.big, 0, 4, s);
-    hipLaunchKernelGGL(k_ocr_hist, dim3(wg < 2048 ? wg : 2048), dim3(64 * OCR_WAVES), 0, s, src, n, buf.hist, buf.big);
+    hipLaunchKernelGGL(k_ocr_hist, dim3(wg < 5 * n_cu ? wg : 5 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, buf.hist, buf.big);
     hipLaunchKernelGGL(k_ocr_hist_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, src, buf.hist, (const uint32_t *)buf.big);
     hipLaunchKernelGGL(k_ocr_otsu, dim3((n + 63) / 64), dim3(64), 0, s, src, n, (const uint32_t *)buf.hist, buf.thresh);
-    hipLaunchKernelGGL(k_ocr_features, dim3(wg < 1024 ? wg : 1024), dim3(64 * OCR_WAVES), 0, s, src, n, (const int32_t *)buf.thresh, buf.q,
+    hipLaunchKernelGGL(k_ocr_features, dim3(wg < 3 * n_cu ? wg : 3 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, (const int32_t *)buf.thresh, buf.q,
                        m ? buf.xf : (float *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dpad : 0);
 }
 
@@ -772,13 +781,13 @@ void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
 void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
 {
     if (n <= 0) return;
-    const size_t np = (size_t)m.k * (m.k - 1) / 2, lds = sizeof(double) * (((np + 1) & ~(size_t)1) + 3 * (size_t)m.k);
-    if (m.kc > 64)
-        hipLaunchKernelGGL((k_svm_couple<true, true>), dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
-    else if (m.k > 64)
-        hipLaunchKernelGGL((k_svm_couple<true, false>), dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+    const size_t np = (size_t)m.k * (m.k - 1) / 2, lds = sizeof(double) * 3 * (size_t)m.k + sizeof(float) * np;
+    if (m.k > 65)
+        hipLaunchKernelGGL(k_svm_couple<2>, dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+    else if (m.k == 65)
+        hipLaunchKernelGGL(k_svm_couple<1>, dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
     else
-        hipLaunchKernelGGL((k_svm_couple<false, false>), dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+        hipLaunchKernelGGL(k_svm_couple<0>, dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
 }
 
 void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)

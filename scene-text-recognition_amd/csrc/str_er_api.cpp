@@ -2432,10 +2432,14 @@ try {
     const int kc = (int)align_up((size_t)(k - 1), 64);
     std::vector<double> coef_t((size_t)l_pad * kc, 0.0);      // (l_pad rows: the walk reads eight rows at a time)
     for (int j = 0; j < k - 1; ++j) for (int i = 0; i < l; ++i) coef_t[(size_t)i * kc + j] = coef[(size_t)j * l + i];
+    std::vector<uint16_t> pair_ij((size_t)np);
+    for (int i = 0, p = 0; i < k; ++i) for (int j = i + 1; j < k; ++j, ++p) pair_ij[(size_t)p] = (uint16_t)((i << 8) | j);
+    const size_t o_pij = take((size_t)np * 2);
     const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
                  o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);
     std::vector<uint8_t> blob(off);
     std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
+    std::memcpy(&blob[o_pij], pair_ij.data(), (size_t)np * 2);
     std::memcpy(&blob[o_coef], coef.data(), coef.size() * 8); std::memcpy(&blob[o_coeft], coef_t.data(), coef_t.size() * 8); std::memcpy(&blob[o_rho], rho.data(), np * 8);
     std::memcpy(&blob[o_pa], pa.data(), np * 8); std::memcpy(&blob[o_pb], pb.data(), np * 8);
     std::memcpy(&blob[o_lab], ilab.data(), k * 4); std::memcpy(&blob[o_nsv], insv.data(), k * 4); std::memcpy(&blob[o_start], start.data(), k * 4);
@@ -2449,6 +2453,7 @@ try {
     SvmDev m{};
     m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
     m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
+    m.pair_ij = reinterpret_cast<const uint16_t *>(b + o_pij);
     m.kc = kc; m.coef_t = reinterpret_cast<const double *>(b + o_coeft);
     m.coef = reinterpret_cast<const double *>(b + o_coef); m.rho = reinterpret_cast<const double *>(b + o_rho);
     m.probA = reinterpret_cast<const double *>(b + o_pa); m.probB = reinterpret_cast<const double *>(b + o_pb);
