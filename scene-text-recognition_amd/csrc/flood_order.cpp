@@ -22,6 +22,7 @@
 #include <deque>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -43,13 +44,14 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
     // looked up from the plane when the walk first touches a pixel -- no pass over the whole plane in front of a walk that stops early -- is 11 %
     // SLOWER on the boxes' EPYC 9575F (16.0 -> 17.9 ms for a whole 1920 x 1080 plane, tools/walk_bench.cpp): two dependent loads per new pixel
     // instead of one, and the walk is a chain of mispredicted branches and dependent loads, ~8 ns per pixel, whatever the bytes)
-    // Kept for the planes a video stream brings again and again, up to 1920 x 1080 x 2 pixels; the scratch of a larger plane (one 4K plane: 50 MB)
-    // is handed back when its walk ends, so that up to 64 pool threads and every caller thread do not hold it for the life of the process.
+    // Kept for the planes a video stream brings again and again, up to one 1920 x 1080 plane (12.4 MB a thread: 0.8 GB for a pool of 64); the scratch
+    // of a larger plane (one 4K plane: 50 MB) is handed back when its walk ends, so that up to 64 pool threads and every caller thread do not hold it
+    // for the life of the process.
     thread_local std::vector<uint16_t> st_buf;
     thread_local std::vector<uint32_t> link_buf;
     struct Shrink {
         std::vector<uint16_t> &a; std::vector<uint32_t> &b;
-        ~Shrink() { if (a.size() > ((size_t)1 << 22)) { std::vector<uint16_t>().swap(a); std::vector<uint32_t>().swap(b); } }
+        ~Shrink() { if (a.size() > ((size_t)1 << 21) + ((size_t)1 << 16)) { std::vector<uint16_t>().swap(a); std::vector<uint32_t>().swap(b); } }
     } shrink{st_buf, link_buf};
     if (st_buf.size() < n) st_buf.resize(n);
     if (link_buf.size() < n) link_buf.resize(n);
@@ -165,7 +167,24 @@ int flood_host_cpus()
         return got == 2 && a > 0 && b > 0;
     };
     long long quota = 0, period = 0;
-    bool have = read2("/sys/fs/cgroup/cpu.max", quota, period);
+    // cgroup v2: the process's own group ("0::/path" in /proc/self/cgroup) and every ancestor up to the root may carry a quota: the tightest one counts
+    bool have = false;
+    {
+        char line[512] = {0}, path[640];
+        std::FILE *f = std::fopen("/proc/self/cgroup", "r");
+        std::string own;
+        while (f && std::fgets(line, sizeof line, f))
+            if (std::strncmp(line, "0::", 3) == 0) { own = line + 3; while (!own.empty() && (own.back() == '\n' || own.back() == '/')) own.pop_back(); }
+        if (f) std::fclose(f);
+        for (;;) {
+            std::snprintf(path, sizeof path, "/sys/fs/cgroup%s/cpu.max", own.c_str());
+            long long q = 0, pr = 0;
+            if (read2(path, q, pr) && (!have || q * period < quota * pr)) { quota = q; period = pr; have = true; }
+            const size_t cut = own.rfind('/');
+            if (own.empty()) break;
+            own.erase(cut == std::string::npos ? 0 : cut);
+        }
+    }
     if (!have) {
         long long dummy = 0;
         std::FILE *f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");

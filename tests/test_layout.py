@@ -10,7 +10,7 @@ def _product_files():
     for base in (PKG, os.path.join(ROOT, "include")):
         for dp, _, fns in os.walk(base):
             for fn in fns:
-                if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                if fn.endswith((".py", ".cpp", ".hip", ".inl", ".h", ".hpp")):
                     yield os.path.join(dp, fn)
     yield os.path.join(ROOT, "str_er_amd.py")
 
