@@ -127,23 +127,7 @@ __device__ __forceinline__ bool connect_pass(uint32_t *s_par, uint32_t &a, uint3
 // takes anything from one to a dozen passes, so a lane takes its next edge as soon as it is done with one.  Every WAVE owns a contiguous
 // quarter of the list and hands its entries, in list order, to whichever of its lanes are idle (ballot + mbcnt: no LDS traffic, no
 // barrier): a wave leaves after ~(passes of its quarter) / 64 iterations instead of after the passes of its unluckiest lane.
-// (Measured, 32 frames text / noise, and not adopted.  Round 3: a static contiguous deal per lane -- round 2's form, 2.62 against 2.27 once the
-// list was one; the k-th batch of 64 entries spread over the wave's whole share: no difference; the two ends carried as KEYS, (level << 16) |
-// slot -- one compare orders them, the CAS value is the other key, a lane without an edge holds two equal keys and runs the pass as a
-// no-op: 19 vector instructions per pass instead of 34 in the listing, but the compiler's loop has more branches: vector -0.8 %, scalar
-// +6.7 %, branch +23 % per wave, 2.31 / 5.59 against 2.25 / 5.38 (masked idle lanes: 2.34 / 5.71) -- the kernel's time follows the TOTAL
-// number of instructions its waves issue, of whatever kind; handing out only when 8 / 16 / 24 lanes are idle: no difference.
-// Round 2: a workgroup-wide cursor that hands the next entries to whichever lanes are idle -- round 1's form -- 3.19 / 9.8 ms against
-// 3.11 / 8.5: the ballots and the LDS atomic per refill cost more than the balance gains;
-// lane i takes entries i, i + 256, ...: 3.28 / 10.2; both finds of a pass in one loop so that their loads are in flight together:
-// 3.62 / 11.5, the loop runs as long as the longer chain with both halves' instructions; walking up a's chain to b's level in a loop of
-// finds inside the pass: 3.67 / 12.3; the vertical round first: 3.21 / 10.8; three rounds with the vertical edges between equal levels first
-// (plain unions while no node has a parent): 3.27 / 9.4 against 2.98 / 8.0; runs that start right below a pixel of their own level linked
-// upwards in the load phase (a fifth of the vertical edges gone, but long same-level chains): 3.03 / 8.8 against 2.99 / 8.1; a lost CAS judged
-// again on the spot with the word it returned instead of in the next pass: 3.22 / 9.9 against 2.98 / 8.05; every wave joining the horizontal
-// and inner vertical edges of its own 8-row band by itself (wave-wide scans, no workgroup barriers, nobody else on its words), the three row
-// pairs between bands in a workgroup-wide round afterwards: 3.22 / 8.4 against 2.99 / 8.07 -- the bands' edge counts differ; round 1's attempts -- fewer waves in the loop, two edges
-// per lane in flight, a level-ordered form with a barrier per level, one combined round -- all lost as well.)
+// (Other hand-out schemes and pass orders, measured and not adopted: NOTES.md "Connect loop")
 #ifdef STR_ER_CONNECT_CNT
 // Developer aid (-DSTR_ER_CONNECT_CNT, tools/dev_connect_cnt.py): per-wave counts of the hand-written connect loop.  Round 4, text-like luma tile:
 // 201 edges, 17.4 iterations, 33 + 19 rounds of the two walking loops per wave -- a round is paid by the whole wave whenever one lane is not at
@@ -453,16 +437,7 @@ constexpr int FOLD_CAP_SPARSE = TILE_H > 32 ? 1024 : 480;   // 16 (32) granules:
 // The kernel is bound by instruction issue (vector AND scalar: every divergent branch is scalar bookkeeping), not by HBM (1 byte per
 // pixel) nor by LDS bandwidth: what made it faster in round 2 was fewer instructions per wave, 4435 -> 3270 (vector 2105 -> 1749, scalar
 // 1960 -> 1213, LDS 370 -> 308), for 3.73 -> 3.03 ms per 32 text frames.
-// (Measured and not adopted: one compacted list of all pieces of the tile, processed by all lanes evenly -- fewer instructions, but the
-// two extra barriers and the dependent LDS reads of the list cost what they save; round 3: the parent word of a lane's NEXT piece fetched
-// while the current one is walked / added up, in the flatten and the statistics loops -- 2.11 against 2.08 ms: the four instructions per
-// round cost more than the latency they hide; a launch of resident workgroups that walk through the tiles -- the next tile's pixels requested
-// a tile ahead, tiles handed out by a batch-wide cursor read two tiles ahead: 2.33 against 1.93 ms; 2 / 4 / 8 / 16 tiles per workgroup in a
-// plain launch: 2.05 / 2.11 / 2.23 / 2.44 -- the loop costs ~150 instructions per wave and tile (descriptors, spills, a barrier), HBM latency
-// was hidden by the seven other workgroups of the CU all along, and the hardware's dispatcher balances better than a cursor; a short cut for
-// UNIFORM tiles (one level, no wall: a sixth of the chroma tiles of text-like and of natural frames), whose single record can be written down after
-// the load phase: 1.899 against 1.903 ms -- such a tile was cheap already, and every other tile pays for the test; one barrier less between the
-// ids and the statistics (zeroes earlier, the list's parent ids behind the statistics loop): no difference.)
+// (Launch shapes, prefetching and the uniform-tile short cut, measured and not adopted: NOTES.md "Tile kernel as a whole")
 // Per channel (32 frames, pyr3x8): luma 0.98 ms, Cr 0.50, Cb 0.50 -- a chroma tile has a sixth of a luma tile's nodes and costs half: what a
 // tile costs is mostly what EVERY tile costs (load phase 22 % of a chroma tile, building the edge list, the reductions of the statistics pass).
 // ------------------------------------------------------------------------------------

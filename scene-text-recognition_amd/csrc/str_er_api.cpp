@@ -5,431 +5,11 @@
 // one HIP stream with no host synchronisation in between, then copies back the per-plane
 // counters and the packed candidate records.  No computation of the path happens on the
 // host; if the device or a kernel fails the call fails (there is no CPU fallback).
-#include "../../include/str_er.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "er_kernels.h"
-#include "ocr_kernels.h"
-#include "track_kernels.h"
-#include "er_group.h"
-#include "flood_order.h"
-#include <functional>
-#include <thread>
-
-using namespace str_er;
-
-namespace {
+#include "str_er_ctx.h"
 
 thread_local std::string g_create_error;
-constexpr int TIE_SLOTS = 16;      // at most so many planes per batch the device hands to the host for the flood order walk without a round trip
-                                   // (a context has as many slots as fit 64 MB of page-locked memory, at least 4: str_er_ctx::n_tie_slots)
 
-struct HostCascade {
-    bool loaded = false;
-    bool real = true;
-    std::vector<int32_t> stage_n, stage_thresh;
-    std::vector<uint16_t> dim;
-    std::vector<double> thr, dir, vp, vn;
-    void *d_blob = nullptr;
-    CascadeDev dev{};
-};
-
-static_assert(sizeof(str_er_node) == 24, "node layout");
-static_assert(sizeof(CandRec) == sizeof(str_er_cand), "cand layout");
-
-struct PlaneGeom { int w, h, stride; size_t off; }; // physical planes of one pyramid level
-
-} // namespace
-
-struct str_er_result {
-    std::vector<str_er_plane_info> planes;
-    std::vector<str_er_cand> cands;
-    std::vector<uint32_t> cand_off;          // n_planes + 1
-    std::vector<std::vector<str_er_node>> nodes;
-    bool have_nodes = false;
-    std::vector<int32_t> ocr_label;
-    std::vector<double> ocr_prob;
-    bool have_ocr = false;
-    std::vector<str_er_track> tracks;
-    bool have_tracks = false;
-    std::vector<str_er_text> texts;
-    std::vector<int32_t> text_ers;
-    std::vector<str_er_gbound> gbounds;
-    std::vector<int32_t> group_all;
-    std::vector<int32_t> line_label;
-    std::vector<double> line_prob;
-    std::vector<uint8_t> line_kept, text_alive;
-    bool have_line_ocr = false;
-    bool have_texts = false;
-    double times[7] = {0, 0, 0, 0, 0, 0, 0};
-};
-
-struct str_er_ctx {
-    str_er_params prm{};
-    std::string err;
-    hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;          // the opposite-rule NMS pass runs here, beside classify
-    hipStream_t prio = nullptr;          // high priority: the few small operations that settle an NMS tie (they would queue behind other contexts' big kernels)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // experiment (STR_ER_CU_PARTITION=N): the bandwidth / issue-bound kernels (channels, pyramid, tile trees) on a stream restricted to
-    // 256 - N compute units, everything else on the N others, so that one context's latency-bound passes run BESIDE another context's tile kernel
-    hipStream_t wide = nullptr;
-    hipEvent_t ev_wf = nullptr, ev_wj = nullptr;
-    bool own_stream = false;
-    int ppf = 0;                     // logical planes per frame
-    std::vector<int> chans;          // channel indices selected by the mask
-    size_t slots = 0;                // node slots (== plane pixels) the workspace can hold
-    int max_planes = 0;
-    int kept_cap = 0, pool_cap = 0;   // per plane: the most a plane may get
-    bool auto_caps = true;            // (neither was given: every plane gets a share of the tables by its pixel count)
-    double kept_share = 1.0 / 64, pool_share = 1.0 / 256;   // ... kept nodes / pooled ERs per padded pixel; grown -- and the batch repeated -- on overflow
-    size_t kept_total = 0, pool_total = 0;      // entries of the kept-node / pool arrays
-    int64_t table_bytes = 0;
-    double min_ocr_prob = 0.15;       // MIN_OCR_PROBABILITY (inc/utils.h), the ERFilter constructor's last argument
-    bool   tile_sparse = true;        // which size of k_tile_tree the next batch uses (er_kernels.hip: FOLD_CAP_SPARSE / _DENSE)
-    uint64_t last_tree_records = 0, last_tree_pairs = 0, last_tree_tiles = 0;     // of the last batch (str_er_last_tree_stats)
-    bool   spin_wait = false;          // STR_ER_SPIN_WAIT=1: always hipStreamSynchronize (busy-waits on a core), see wait_stream
-    int    wait_spin_us = 300;         // how long wait_stream polls before it sleeps between polls (run_batch: 2 ms for a call of a frame or two)
-    bool   dbg_tile_only = false, dbg_stats = false;   // developer aids (STR_ER_DEBUG_TILE_ONLY / _STATS), read once at create
-    int    tile_mode = 0;             // 0 auto (from the node density of the previous batch), 1 sparse, 2 dense (STR_ER_TILE_KERNEL)
-    int64_t ws_bytes = 0;
-
-    // device workspace
-    uint8_t *d_in = nullptr;  size_t in_bytes = 0;    // staging for host inputs
-    uint8_t *d_pix = nullptr; size_t pix_bytes = 0;   // physical planes (Y,Cr,Cb per level)
-    PlaneDesc *d_planes = nullptr;
-    PlaneCtr *d_ctr = nullptr;
-    NodeArrays na{};
-    KeptArrays ka{};
-    uint16_t *d_seam = nullptr; size_t seam_slots = 0;
-    size_t node_slots = 0;            // node records allocated (NodeArrays::rec / aux)
-    uint32_t node_blocks_cap = 0;     // workgroups per plane in k_resolve / k_reduce; 0 = by the frames' content (STR_ER_NODE_BLOCKS sets it)
-    uint32_t node_blocks = 12;        // workgroups per plane of the per-record kernels: from the record counts of the previous batch
-    double node_share = 0.06;         // records per padded plane pixel (S-text needs 0.006, S-noise 0.09); grown -- and the batch repeated -- when a plane runs out
-    uint16_t *d_tile_plane = nullptr, *d_sb_plane = nullptr; uint32_t *d_sb_first = nullptr; size_t sb_slots = 0;
-    std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
-    std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
-    uint32_t *d_tile_nbase = nullptr; size_t tile_slots = 0;
-    uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
-    CandRec *d_cands = nullptr, *d_cands2 = nullptr;      // (second set: the layout after an NMS tie pass changed pools, then swapped)
-    uint32_t *d_redo = nullptr;                          // candidates to classify again + their count (last word)
-    TrackRec *d_track = nullptr; uint32_t *d_track_list = nullptr, *d_ranges = nullptr;   // STR_ER_STAGE_TRACK
-    uint32_t *d_group = nullptr, *d_group_pairs = nullptr; size_t group_words = 0, group_pair_cap = 0;   // STR_ER_STAGE_GROUP, grown on demand
-    uint32_t *d_total = nullptr;
-    uint32_t *d_wparent = nullptr;
-    // tie planes exported by the device itself (k_export_tie_planes): TIE_SLOTS x tie_slot_bytes of page-locked, device-addressable memory,
-    // then the slot -> plane table and the slot counter
-    uint8_t *h_tie = nullptr; size_t tie_slot_bytes = 0; int n_tie_slots = 0; uint32_t *h_tie_plane = nullptr, *h_tie_count = nullptr;
-    uint8_t *h_replay = nullptr; size_t h_replay_bytes = 0;   // page-locked: the planes (and watch lists) the flood order walk reads
-    uint32_t *d_watch = nullptr, *d_wstamp = nullptr; // NMS: watched key pixels per plane (k_nms -> flood order walk) and their stamps (-> k_nms)
-    ReplayItem *d_replay_items = nullptr;
-    uint32_t *d_alt_list = nullptr;                   // planes of the opposite-rule NMS pass (k_alt_list)
-    uint32_t *d_tie_slot_plane = nullptr;             // plane of every tie slot of the batch (k_tie_slots -> k_export_tie_planes)
-    uint8_t *d_replay = nullptr; size_t replay_bytes = 0;   // flood-replay scratch, allocated the first time a plane has sibling ties
-    uint32_t last_total = 0; bool last_valid = false;   // candidates of the last detect call, still in d_cands (str_er_gather_last)
-    uint64_t n_replayed = 0;                          // planes whose NMS ties were decided by a flood replay (statistics)
-    double   walk_ms_total = 0;                       // host time those walks took, summed over planes (statistics)
-    uint64_t n_batches = 0;
-    bool replay_on_gpu = false;                       // STR_ER_REPLAY=gpu: walk the flood with k_flood_order instead of a host core
-    uint16_t *d_cand_plane = nullptr, *d_cand_plane2 = nullptr;
-    void *d_scratch = nullptr; size_t scratch_bytes = 0;
-    uint8_t *d_strip_out = nullptr, *d_strip_in = nullptr; size_t strip_out_cap = 0, strip_in_cap = 0;   // strip blobs: made here / uploaded for a merge
-    uint32_t *d_strip_flag = nullptr;                 // a strip blob named a node outside its records
-    uint16_t *d_nb_plane = nullptr; std::vector<uint16_t> h_nb_plane; uint32_t n_node_blocks = 0;      // plane of every workgroup of the per-record kernels
-    uint16_t *d_tile_nrec = nullptr;                  // records per tile (k_tile_tree -> k_group_merge)
-    uint16_t *d_group_plane = nullptr; std::vector<uint16_t> h_group_plane;      // plane of every group of tiles
-    uint8_t  *d_group_done = nullptr;                 // per group of tiles: joined in LDS (k_group_merge -> k_seam)
-    int       dbg_group[3] = {0, 0, -1};              // developer knobs STR_ER_GROUP_X / _Y / _KERNEL
-    int       group_mode = -1;                        // STR_ER_GROUPS: -1 automatic (4 x 4 tiles with the small tile kernel, 2 x 5 with the big one), 0 off
-    std::vector<void *> allocs;
-
-    // pinned host mirrors
-    PlaneDesc *h_planes = nullptr;
-    PlaneCtr *h_ctr = nullptr;
-    uint32_t *h_total = nullptr;
-    CandRec  *h_cands_spec = nullptr;                 // small calls: the first SPEC_CANDS candidate records come back WITH the counters (run_batch)
-
-    HostCascade casc[2];
-    bool svm_loaded = false;
-    SvmDev svm{};
-    void *d_svm_blob = nullptr;
-    hipEvent_t ev[24]{};
-    int n_ev = 0;
-    bool profiling = false;
-    std::vector<std::pair<const char *, double>> profile;
-};
-
-namespace {
-
-int fail(str_er_ctx *c, int code, const std::string &msg)
-{
-    if (c) c->err = msg; else g_create_error = msg;
-    return code;
-}
-
-// Waiting for a stream.  hipStreamSynchronize busy-waits (so does hipEventSynchronize on a hipEventBlockingSync event, measured): with a batch in
-// flight on each of six contexts that is six host cores spinning -- and the GPU boxes grant a process 16 (cgroup quota), which the flood order walks
-// of the NMS ties need (round 4: the S-ties bench leg, 86 ms of walks per batch on 16 pool threads + 6 spinning waiters = throttled).  So: poll for
-// ~300 us, then sleep between polls.  A latency call (<= SPEC_PLANES planes: a frame or two, under a millisecond of GPU work, one wait at its end) polls
-// for 2 ms instead: the 100 us naps added 0.14 ms to most one-frame calls (0.80 ms when the wait happened to end inside the polling, 0.94 otherwise).
-// A call of a frame or two (<= SPEC_PLANES planes) is a latency call: its candidate records -- a thousand per 1920 x 1080 frame -- are copied to page-locked
-// memory right behind the counters, before the host knows how many there are; if they all fit (and no NMS tie pass re-made them) the second trip to the
-// device -- counters, THEN as many records as they say, into pageable memory -- is saved: about 0.1 of a 0.9 ms call.
-constexpr uint32_t SPEC_CANDS = 8192;
-constexpr int      SPEC_PLANES = 96;
-
-static hipError_t wait_stream(str_er_ctx *c, hipStream_t s)
-{
-    if (!c || c->spin_wait) return hipStreamSynchronize(s);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->wait_spin_us)) std::this_thread::sleep_for(std::chrono::microseconds(100));
-    }
-}
-
-#define HIP_TRY(ctx, expr)                                                                         \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail((ctx), (e_ == hipErrorOutOfMemory) ? STR_ER_ENOMEM : STR_ER_EHIP,          \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
-    } while (0)
-
-template <typename T> int dev_alloc(str_er_ctx *c, T *&p, size_t n)
-{
-    void *v = nullptr;
-    const size_t bytes = std::max<size_t>(n * sizeof(T), 256);
-    hipError_t e = hipMalloc(&v, bytes);
-    if (e != hipSuccess) return fail(c, STR_ER_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
-    c->allocs.push_back(v);
-    c->ws_bytes += (int64_t)bytes;
-    p = static_cast<T *>(v);
-    return STR_ER_OK;
-}
-
-// The node records (32 B + 2 x 4 B per record) are the one part of the workspace whose need depends on the frames' content: they
-// are allocated for `node_share` records per pixel and re-allocated larger when a batch overflows them (run_batch).
-int alloc_node_records(str_er_ctx *c, size_t n)
-{
-    if (c->na.rec) { (void)hipFree(c->na.rec); c->ws_bytes -= (int64_t)(c->node_slots * sizeof(NodeRec)); c->na.rec = nullptr; }
-    if (c->na.aux) { (void)hipFree(c->na.aux); c->ws_bytes -= (int64_t)(c->node_slots * 8); c->na.aux = nullptr; c->na.arr = nullptr; }
-    c->node_slots = 0;
-    if (hipMalloc(reinterpret_cast<void **>(&c->na.rec), n * sizeof(NodeRec)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->na.aux), n * 8) != hipSuccess)
-        return fail(c, STR_ER_ENOMEM, "hipMalloc (node records, " + std::to_string(n * 40) + " bytes)");
-    c->na.arr = c->na.aux + n;
-    c->node_slots = n;
-    c->ws_bytes += (int64_t)(n * 40);
-    return STR_ER_OK;
-}
-
-int ensure_scratch(str_er_ctx *c, size_t bytes)
-{
-    if (bytes <= c->scratch_bytes) return STR_ER_OK;
-    if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
-    hipError_t e = hipMalloc(&c->d_scratch, bytes);
-    if (e != hipSuccess) return fail(c, STR_ER_ENOMEM, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
-    c->scratch_bytes = bytes;
-    return STR_ER_OK;
-}
-
-void pyr_dims(int w0, int h0, int level, int &w, int &h)
-{
-    const double s = std::pow(2.0, -0.5 * level);
-    w = std::max(1, (int)std::floor(w0 * s + 0.5));
-    h = std::max(1, (int)std::floor(h0 * s + 0.5));
-}
-
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-DetectParams make_dp(const str_er_ctx *c)
-{
-    DetectParams d{};
-    d.thresh_step = c->prm.thresh_step; d.min_area = c->prm.min_area; d.max_area = c->prm.max_area;
-    d.stability_t = c->prm.stability_t; d.overlap_coef = c->prm.overlap_coef;
-    d.hi = 255 / c->prm.thresh_step + 1;
-    d.qscale = (float)(1.0 / (double)c->prm.thresh_step);
-    d.kept_cap = c->kept_cap; d.pool_cap = c->pool_cap; d.sibling_order = c->prm.sibling_order;
-    return d;
-}
-
-// ---- cascade text (format: SURVEY.md Appendix C; CascadeBoost::load_classifier,
-// ---- src/adaboost.cpp:873-951) ---------------------------------------------------------------
-bool parse_number(const std::string &t, double &v)
-{
-    if (t.empty()) return false;
-    char *end = nullptr;
-    v = std::strtod(t.c_str(), &end);
-    return end != t.c_str();
-}
-
-// (int) of a parsed number, as the reference's (int)stod(...) -- but a value an int cannot hold (inf, nan, 1e99: undefined behaviour in the
-// reference, found by the fuzz loop under UBSan) is a format error here
-bool to_int(double v, int32_t &out)
-{
-    if (!(v > -2147483649.0 && v < 2147483648.0)) return false;
-    out = (int32_t)v;
-    return true;
-}
-
-int parse_cascade(str_er_ctx *c, HostCascade &hc, const char *text, size_t len)
-{
-    std::vector<std::string> tok;
-    {
-        size_t i = 0;
-        while (i < len) {
-            while (i < len && (text[i] == ' ' || text[i] == '\t' || text[i] == '\r' || text[i] == '\n')) ++i;
-            size_t j = i;
-            while (j < len && !(text[j] == ' ' || text[j] == '\t' || text[j] == '\r' || text[j] == '\n')) ++j;
-            if (j > i) tok.emplace_back(text + i, j - i);
-            i = j;
-        }
-    }
-    size_t k = 0;
-    auto next = [&]() -> const std::string * { return k < tok.size() ? &tok[k++] : nullptr; };
-    HostCascade n;
-    const std::string *t = next();
-    if (!t || *t != "boost_type") return fail(c, STR_ER_EFORMAT, "cascade: missing boost_type");
-    t = next();
-    if (!t) return fail(c, STR_ER_EFORMAT, "cascade: truncated header");
-    n.real = (*t != "DISCRETE");
-    t = next();
-    if (!t || *t != "base_type") return fail(c, STR_ER_EFORMAT, "cascade: missing base_type");
-    t = next();
-    t = next();
-    if (!t || *t != "num_of_iter") return fail(c, STR_ER_EFORMAT, "cascade: missing num_of_iter");
-    for (;;) {
-        t = next();
-        double v;
-        if (!t || !parse_number(*t, v)) break;
-        int32_t iv;
-        if (!to_int(v, iv)) return fail(c, STR_ER_EFORMAT, "cascade: stage size is not an integer");
-        n.stage_n.push_back(iv);
-    }
-    if (!t || *t != "threshold" || n.stage_n.empty()) return fail(c, STR_ER_EFORMAT, "cascade: missing threshold");
-    for (size_t j = 0; j < n.stage_n.size(); ++j) {
-        t = next();
-        double v;
-        if (!t || !parse_number(*t, v)) return fail(c, STR_ER_EFORMAT, "cascade: short threshold list");
-        int32_t iv;
-        if (!to_int(v, iv)) return fail(c, STR_ER_EFORMAT, "cascade: stage threshold outside the range of int");
-        n.stage_thresh.push_back(iv); // (int)stod(...), src/adaboost.cpp:919
-    }
-    const int per = n.real ? 5 : 4;
-    for (;;) {
-        double v[5];
-        int got = 0;
-        for (; got < per; ++got) {
-            t = next();
-            if (!t || !parse_number(*t, v[got])) break;
-        }
-        if (got == 0) break;
-        if (got < per) return fail(c, STR_ER_EFORMAT, "cascade: incomplete stump row");
-        int32_t d;
-        if (!to_int(v[1], d) || d < 0 || d >= 1024) return fail(c, STR_ER_EFORMAT, "cascade: feature index outside the 1024-bin histogram");
-        n.dim.push_back((uint16_t)d);
-        if (n.real) { n.thr.push_back(v[2]); n.dir.push_back(1.0); n.vp.push_back(v[3]); n.vn.push_back(v[4]); }
-        else {
-            int32_t dr;
-            if (!to_int(v[2], dr)) return fail(c, STR_ER_EFORMAT, "cascade: stump direction is not an integer");
-            n.dir.push_back((double)dr); n.thr.push_back(v[3]); n.vp.push_back(1.0 * v[0]); n.vn.push_back(-1.0 * v[0]);
-        }
-    }
-    long long total = 0;
-    for (int32_t s : n.stage_n) { if (s < 0) return fail(c, STR_ER_EFORMAT, "cascade: negative stage size"); total += s; }
-    if (total > (long long)n.dim.size()) return fail(c, STR_ER_EFORMAT, "cascade: fewer stump rows than num_of_iter announces");
-    // upload: one blob
-    const size_t ns = n.dim.size(), nst = n.stage_n.size();
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return o; };
-    const size_t o_thr = take(ns * 8), o_dir = take(ns * 8), o_vp = take(ns * 8), o_vn = take(ns * 8), o_dim = take(ns * 2),
-                 o_sn = take(nst * 4), o_st = take(nst * 4), o_rec = take(ns * sizeof(StumpRec)), o_w = take(ns * 4), o_ab = take(ns * 16);
-    std::vector<uint8_t> blob(off ? off : 16);
-    std::memcpy(&blob[o_thr], n.thr.data(), ns * 8); std::memcpy(&blob[o_dir], n.dir.data(), ns * 8);
-    std::memcpy(&blob[o_vp], n.vp.data(), ns * 8); std::memcpy(&blob[o_vn], n.vn.data(), ns * 8);
-    std::memcpy(&blob[o_dim], n.dim.data(), ns * 2); std::memcpy(&blob[o_sn], n.stage_n.data(), nst * 4);
-    std::memcpy(&blob[o_st], n.stage_thresh.data(), nst * 4);
-    int32_t all_unit = 1;
-    for (size_t i = 0; i < ns; ++i) {
-        StumpRec r;
-        r.dim = n.dim[i]; r.thr = n.thr[i]; r.vp = n.vp[i]; r.vn = n.vn[i];
-        r.mode = n.dir[i] == 1.0 ? 0 : (n.dir[i] == -1.0 ? 1 : 2);
-        std::memcpy(&blob[o_rec + i * sizeof(StumpRec)], &r, sizeof(r));
-        // integer form for 8-bit counts: (h < T) ? A : B
-        double T = 0, A = n.vn[i], B = n.vn[i];
-        if (r.mode == 0) {            // h < thr  <=>  h < ceil(thr)
-            A = n.vp[i]; B = n.vn[i];
-            T = std::isnan(n.thr[i]) ? 0.0 : std::ceil(n.thr[i]);
-        } else if (r.mode == 1) {     // h > thr  <=>  !(h < floor(thr)+1)
-            A = n.vn[i]; B = n.vp[i];
-            T = std::isnan(n.thr[i]) ? 1e9 : std::floor(n.thr[i]) + 1.0;   // NaN: h > NaN is false -> always vn = A
-        } else all_unit = 0;
-        const uint32_t Ti = (uint32_t)std::min(std::max(T, 0.0), 300.0);
-        const uint32_t wv = (uint32_t)n.dim[i] | (Ti << 10);
-        std::memcpy(&blob[o_w + i * 4], &wv, 4);
-        std::memcpy(&blob[o_ab + i * 16], &A, 8); std::memcpy(&blob[o_ab + i * 16 + 8], &B, 8);
-    }
-    void *d = nullptr;
-    HIP_TRY(c, hipMalloc(&d, blob.size()));
-    hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); return fail(c, STR_ER_EHIP, std::string("cascade upload: ") + hipGetErrorString(e)); }
-    if (hc.d_blob) (void)hipFree(hc.d_blob);
-    n.d_blob = d;
-    const uint8_t *b = static_cast<const uint8_t *>(d);
-    n.dev.thr = reinterpret_cast<const double *>(b + o_thr); n.dev.dir = reinterpret_cast<const double *>(b + o_dir);
-    n.dev.vp = reinterpret_cast<const double *>(b + o_vp); n.dev.vn = reinterpret_cast<const double *>(b + o_vn);
-    n.dev.dim = reinterpret_cast<const uint16_t *>(b + o_dim);
-    n.dev.rec = reinterpret_cast<const StumpRec *>(b + o_rec);
-    n.dev.w = reinterpret_cast<const uint32_t *>(b + o_w); n.dev.ab = reinterpret_cast<const double *>(b + o_ab);
-    n.dev.all_unit = all_unit;
-    n.dev.stage_n = reinterpret_cast<const int32_t *>(b + o_sn); n.dev.stage_thresh = reinterpret_cast<const int32_t *>(b + o_st);
-    n.dev.n_stages = (int32_t)nst; n.dev.n_stumps = (int32_t)ns;
-    n.dev.max_stage = 0;
-    for (int32_t s : n.stage_n) n.dev.max_stage = std::max(n.dev.max_stage, s);
-    n.loaded = true;
-    hc = std::move(n);
-    return STR_ER_OK;
-}
-
-// ---- batch layout -------------------------------------------------------------------------------
-struct Batch {
-    std::vector<PlaneDesc> planes;
-    uint32_t n_tiles = 0, n_pairs = 0;
-    size_t slots = 0, seam = 0, nodes = 0;      // padded pixels, seam entries, node records
-    size_t kept = 0, pool = 0;                  // entries of the kept-node / pool arrays handed to the planes
-    uint32_t kept_floor = 0, pool_floor = 0;    // str_er_nms_tree: the plane's tables must hold the imported tree
-    int planes_per_image = 0;       // BGR frames: planes of one (frame, pyramid level), consecutive in `planes`; 0 = no colour image
-    uint32_t n_groups = 0; int group_x = 0, group_y = 0;       // k_group_merge: groups of group_x x group_y tiles (0: none); assign_groups()
-};
-
-void add_plane(Batch &b, const uint8_t *pix, int w, int h, int stride, int invert, uint32_t frame, int ch, int pyr)
-{
-    PlaneDesc d{};
-    d.pix = pix; d.w = w; d.h = h; d.stride = stride; d.invert = invert ? 0xFF : 0;
-    d.tiles_x = (w + TILE_W - 1) / TILE_W; d.tiles_y = (h + TILE_H - 1) / TILE_H;
-    d.tile_base = b.n_tiles; b.n_tiles += (uint32_t)d.tiles_x * d.tiles_y;
-    d.n_hpairs = (uint32_t)w * (d.tiles_y - 1);
-    d.n_pairs = d.n_hpairs + (uint32_t)h * (d.tiles_x - 1);
-    d.pair_base = b.n_pairs; b.n_pairs += d.n_pairs;
-    b.slots += (size_t)d.tiles_x * d.tiles_y * TILE_PX;      // (node records are laid out by assign_node_records)
-    d.seam_base = (uint32_t)b.seam; b.seam += 2 * (size_t)d.n_pairs;
-    d.frame = frame; d.ch = (uint8_t)ch; d.pyr = (uint8_t)pyr;
-    b.planes.push_back(d);
-}
+namespace str_er_host {
 
 // Node records: every plane gets `share` records per padded pixel (+ a floor for tiny planes), never more than one per pixel.
 size_t plane_node_cap(int tiles, double share)
@@ -537,7 +117,7 @@ static void wide_join(str_er_ctx *c)
     (void)hipStreamWaitEvent(c->stream, c->ev_wj, 0);
 }
 
-void rec(str_er_ctx *c, const char *name, hipStream_t on = nullptr)
+void rec(str_er_ctx *c, const char *name, hipStream_t on)
 {
     if (c->n_ev < 24) {
         (void)hipEventRecord(c->ev[c->n_ev], on ? on : c->stream);
@@ -666,7 +246,7 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
 // hold the same records the host has in r->cands / r->tracks).  GPU: sort ranks, inner_suppression flags, pair list;
 // host: the greedy line assignment and the per-line steps (er_group.cpp).
 int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, const std::vector<uint32_t> &img, bool inner_sup,
-                str_er_result *r, bool presorted = false)
+                str_er_result *r, bool presorted)
 {
     const int    G = (int)(img.size() / 2);
     const size_t n_c = r->cands.size();
@@ -755,7 +335,7 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
 // Exact NMS where the reference's answer depends on its flood's sibling order (DetectParams::sibling_order == 0): for every plane
 // whose first NMS pass met a tie, replay the reference's flood on the GPU (k_flood_order) and repeat the plane's NMS with the ties
 // decided by the replayed order.  h_ctr holds the counters of the first pass.  Planes go in rounds that fit the scratch buffer.
-int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, const DetectParams &dp, bool &replayed, bool from_tree = false)
+int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, const DetectParams &dp, bool &replayed, bool from_tree)
 {
     // (from_tree: str_er_nms_tree_plane -- no batch ran, nothing was exported)
     replayed = false;
@@ -1015,9 +595,8 @@ int upload_layout(str_er_ctx *c, Batch &b)
 // Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
 // import_trees (optional): the tile trees were built elsewhere (strips of a plane extracted by other GPUs) -- instead of running
 // k_tile_tree / k_seam the hook puts node records and counters in place on the context's stream.
-using ImportHook = std::function<int(const Batch &, const BatchDev &)>;
 int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result **out,
-              std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees = nullptr, int attempt = 0)
+              std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees, int attempt)
 {
     // A batch whose planes outgrow their shares of the tables is laid out again with larger shares and repeated.  Every repeat raises a
     // share (or fails), and a share stops at one entry per pixel: the repeats end; `attempt` only guards against a slip in that argument.
@@ -1461,23 +1040,7 @@ int stage_input(str_er_ctx *c, const uint8_t *src, size_t bytes, int mem_kind, c
     return STR_ER_OK;
 }
 
-} // namespace
-
-// =================================================================================================
-// C ABI
-// =================================================================================================
-// Nothing is thrown across the C ABI: every entry point that takes a context is a function-try-block (the std::vector / std::string work behind
-// them -- parsers of untrusted bytes, per-batch tables -- can run out of memory).
-static int abi_caught(str_er_ctx *c, int code, const char *what)
-{
-    if (!c) return code;
-    try { c->err = what; } catch (...) { }
-    return code;
-}
-#define ABI_GUARD(ctx)                                                                                   \
-    catch (const std::bad_alloc &) { return abi_caught((ctx), STR_ER_ENOMEM, "out of host memory"); }      \
-    catch (const std::length_error &) { return abi_caught((ctx), STR_ER_ENOMEM, "out of host memory (container size)"); } \
-    catch (...) { return abi_caught((ctx), STR_ER_EHIP, "internal error (exception)"); }
+} // namespace str_er_host
 
 extern "C" {
 
@@ -1742,36 +1305,6 @@ try {
     return STR_ER_OK;
 } ABI_GUARD(c)
 
-int str_er_load_cascade_mem(str_er_ctx *c, int which, const char *text, size_t len)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!text || (which != STR_ER_CASCADE_STRONG && which != STR_ER_CASCADE_WEAK)) return fail(c, STR_ER_EINVAL, "bad cascade argument");
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    return parse_cascade(c, c->casc[which], text, len);
-} ABI_GUARD(c)
-
-int str_er_load_cascade(str_er_ctx *c, int which, const char *path)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!path) return fail(c, STR_ER_EINVAL, "null path");
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(c, STR_ER_EIO, std::string("cannot open ") + path);
-    std::string buf;
-    char tmp[65536];
-    size_t n;
-    while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n);
-    std::fclose(f);
-    return str_er_load_cascade_mem(c, which, buf.data(), buf.size());
-} ABI_GUARD(c)
-
-int str_er_cascade_info(const str_er_ctx *c, int which, int32_t *n_stages, int32_t *n_stumps)
-try {
-    if (!c || (which != 0 && which != 1)) return STR_ER_EINVAL;
-    if (n_stages) *n_stages = c->casc[which].loaded ? c->casc[which].dev.n_stages : 0;
-    if (n_stumps) *n_stumps = c->casc[which].loaded ? c->casc[which].dev.n_stumps : 0;
-    return STR_ER_OK;
-} ABI_GUARD(const_cast<str_er_ctx *>(c))
-
 static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int64_t frame_pitch, int32_t n_frames,
                            int mem_kind, uint32_t stages, const uint8_t *plane_select, str_er_result **out, bool nv12 = false);
 
@@ -1881,349 +1414,6 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
     return run_batch(c, b, stages, out, t0, true);
 }
 
-// =================================================================================================
-// one plane in horizontal strips over several GPUs.
-//
-// Whole planes are the unit the path shards by (8(e)); one large frame has few of them and the three level-0 planes bound the
-// speed-up (3840x2160, 12 levels: 6.0x on 8 GPUs).  The tile kernel is the largest part of the work and has no data flow between
-// tiles, so a plane can be cut into strips of tile rows: every GPU builds the tile trees of its strip and joins the seams INSIDE the
-// strip (str_er_strip_extract); what crosses the wire is the strip's node records (32 bytes per exported node: about a quarter of
-// the strip's pixel bytes on text-like frames) and the node of every pixel of its first / last row.  The owner of the plane puts the
-// strips' records behind one another, makes the ids plane-wide, joins the pixel pairs across every cut with the same connect as any
-// other seam and carries on with the usual passes -- resolve, accumulate, prune, NMS, classify (str_er_strip_merge).  The node
-// set of a component tree does not depend on the order in which tiles are joined, so the result is that of the unsplit plane.
-// Strips are cut from the level-0 planes (in a pyramid context too: its smaller planes are dealt out whole, str_er_detect_bgr_planes).
-// The blob is assembled ON THE DEVICE and can stay there: with an RCCL communicator (str_er_comm_allgather_bytes) it goes from the
-// extracting GPU's memory into the owner's without touching a host; the host-memory entry points copy it once.
-//
-//   blob = StripHeader | StripPlane x n_planes | per plane: records | per plane: node of every pixel of the first row (if the plane
-//          goes on above), of the last row (if it goes on below) -- sections start on 256-byte boundaries
-// =================================================================================================
-extern "C++" {          // (helpers with C++ types, inside the file's extern "C" block)
-namespace {
-
-constexpr uint32_t STRIP_MAGIC = 0x50525453u;      // "STRP"
-constexpr uint32_t STRIP_VERSION = 2;
-struct StripHeader { uint32_t magic, version, w, h, strip, n_strips, row0 /* plane row of the records' row 0 */, rows, n_planes, thresh_step, channel_mask, reserved; };
-struct StripPlane { uint32_t ch, n_nodes, n_walls, start_node, has_top, has_bot; };      // (records: ids, keys and rows local to the strip)
-struct StripLayout { size_t head = 0, total = 0; std::vector<size_t> rec, top, bot; };
-
-StripLayout strip_layout(const std::vector<StripPlane> &sp, uint32_t w)
-{
-    StripLayout L;
-    const size_t n = sp.size();
-    L.head = sizeof(StripHeader) + n * sizeof(StripPlane);
-    size_t at = align_up(L.head, 256);
-    L.rec.resize(n); L.top.resize(n); L.bot.resize(n);
-    for (size_t k = 0; k < n; ++k) { L.rec[k] = at; at = align_up(at + (size_t)sp[k].n_nodes * sizeof(NodeRec), 256); }
-    for (size_t k = 0; k < n; ++k) {
-        L.top[k] = at; if (sp[k].has_top) at = align_up(at + 4 * (size_t)w, 256);
-        L.bot[k] = at; if (sp[k].has_bot) at = align_up(at + 4 * (size_t)w, 256);
-    }
-    L.total = at;
-    return L;
-}
-
-// channels of one BGR frame into the level-0 planes of the pixel pool (what str_er_detect_bgr does for level 0)
-int frame_to_planes(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int &pstride, size_t &psize)
-{
-    const uint8_t *dbgr = nullptr;
-    int64_t dstride = stride;
-    if (mem_kind == STR_ER_MEM_HOST) {
-        dstride = (int64_t)w * 3;
-        if ((size_t)dstride * h > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "staging buffer too small");
-        HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)dstride, bgr, (size_t)stride, (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
-        dbgr = c->d_in;
-    } else if (mem_kind == STR_ER_MEM_DEVICE) dbgr = bgr;
-    else return fail(c, STR_ER_EINVAL, "bad mem_kind");
-    pstride = (int)align_up((size_t)w, 64);
-    psize = align_up((size_t)pstride * h, 256);
-    if (3 * psize > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
-    launch_bgr_to_ycrcb(c->stream, dbgr, w, h, dstride, dstride * h, 1, c->d_pix, c->d_pix + psize, c->d_pix + 2 * psize, pstride, (int64_t)(3 * psize));
-    return STR_ER_OK;
-}
-
-int ensure_strip_buf(str_er_ctx *c, uint8_t *&p, size_t &cap, size_t need)
-{
-    if (need <= cap) return STR_ER_OK;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    need += need / 4;
-    if (hipMalloc(reinterpret_cast<void **>(&p), need) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (strip blob)");
-    cap = need;
-    return STR_ER_OK;
-}
-
-} // namespace
-} // extern "C++"
-
-int str_er_strip_extract_dev(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
-                             const void **d_blob, int64_t *blob_bytes)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!bgr || !d_blob || !blob_bytes || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 || strip < 0 || strip >= n_strips)
-        return fail(c, STR_ER_EINVAL, "bad strip arguments");
-    if (w > c->prm.max_width || h > c->prm.max_height) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
-    *d_blob = nullptr; *blob_bytes = 0;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    c->last_valid = false;
-    int pstride = 0; size_t psize = 0;
-    int rc = frame_to_planes(c, bgr, w, h, stride, mem_kind, pstride, psize);
-    if (rc != STR_ER_OK) return rc;
-    const int ty_all = (h + TILE_H - 1) / TILE_H;
-    const int t0 = (int)((int64_t)strip * ty_all / n_strips), t1 = (int)((int64_t)(strip + 1) * ty_all / n_strips);
-    const int r0 = t0 * TILE_H, r1 = std::min(h, t1 * TILE_H), rows = std::max(0, r1 - r0);
-    const size_t npl = c->chans.size();
-    std::vector<StripPlane> sp(npl);
-    for (size_t k = 0; k < npl; ++k) { sp[k] = StripPlane{}; sp[k].ch = (uint32_t)c->chans[k]; sp[k].start_node = NONE; }
-    hipStream_t s = c->stream;
-    Batch b;
-    const bool ptop = rows > 0 && r0 > 0, pbot = rows > 0 && r1 < h;
-    if (rows > 0) {
-        // A strip is laid out as a plane with a PHANTOM tile row above and / or below wherever the plane goes on: the strip's first /
-        // last row is then an ordinary tile seam -- its nodes stay open and their ids are in the seam map -- and the tile kernel needs to
-        // know nothing about strips (no strip flags, no second code path in the largest kernel of the step).  Below, the phantom row is simply
-        // past the image (one tile row more than the height needs).  Above, the strip is copied behind TILE_H rows of pixels at the
-        // sentinel level, which the flood never enters -- hence the restriction to thresh_steps that have such a level.
-        const size_t pad_plane = align_up((size_t)pstride * (size_t)(rows + TILE_H), 256);
-        if (ptop) {
-            if ((int)std::lrintf(255.0f * (float)(1.0 / (double)c->prm.thresh_step)) != 255 / c->prm.thresh_step + 1)
-                return fail(c, STR_ER_EINVAL, "strips need a thresh_step whose top level is the sentinel level (2, 4, 8, 16 ...: round(255/step) = 255/step + 1)");
-            rc = ensure_scratch(c, pad_plane * npl);
-            if (rc != STR_ER_OK) return rc;
-        }
-        for (size_t k = 0; k < npl; ++k) {
-            const int ch = c->chans[k];
-            const uint8_t *src = c->d_pix + (size_t)(ch % 3) * psize + (size_t)r0 * pstride;
-            const uint8_t *lay = src;
-            if (ptop) {
-                uint8_t *dst = static_cast<uint8_t *>(c->d_scratch) + k * pad_plane;
-                HIP_TRY(c, hipMemsetAsync(dst, ch >= 3 ? 0x00 : 0xFF, (size_t)TILE_H * pstride, s));      // (inverted channels read pixel ^ 0xFF)
-                HIP_TRY(c, hipMemcpyAsync(dst + (size_t)TILE_H * pstride, src, (size_t)rows * pstride, hipMemcpyDeviceToDevice, s));
-                lay = dst;
-            }
-            add_plane(b, lay, w, rows + (ptop ? TILE_H : 0) + (pbot ? TILE_H : 0), pstride, ch >= 3, 0, ch, 0);
-            PlaneDesc &pd = b.planes.back();
-            pd.h = rows + (ptop ? TILE_H : 0);                   // (the phantom row below is simply past the image)
-            pd.n_pairs = pd.n_hpairs + (uint32_t)pd.h * (uint32_t)(pd.tiles_x - 1);
-        }
-        const DetectParams dp = make_dp(c);
-        for (int attempt = 0;; ++attempt) {
-            assign_node_records(b, c->node_share);
-            if (b.nodes > c->node_slots) { rc = alloc_node_records(c, b.nodes + b.nodes / 8); if (rc != STR_ER_OK) return rc; }
-            if (b.seam > c->seam_slots || b.n_tiles > c->tile_slots || b.slots > c->slots) return fail(c, STR_ER_ECAPACITY, "strip exceeds the context capacity");
-            c->layout_key.clear();                 // (a strip's layout is not a frame's: never reuse the cached tables for it)
-            rc = upload_layout(c, b);
-            c->layout_key.clear();
-            if (rc != STR_ER_OK) return rc;
-            const BatchDev bd = make_batchdev(c, b);
-            // the seam row of the phantom tile row below lies past the image: no tile writes it, so it is blanked here ("wall")
-            if (pbot)
-                for (const PlaneDesc &pd : b.planes)
-                    HIP_TRY(c, hipMemsetAsync(c->d_seam + pd.seam_base + (size_t)(2 * (pd.tiles_y - 2) + 1) * w, 0xFF, 2 * (size_t)w, s));
-            launch_tile_tree(s, bd, dp, c->tile_sparse);
-            launch_seam(s, bd, !c->tile_sparse);
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * npl, hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, wait_stream(c, s));
-            double need = 0;
-            for (size_t k = 0; k < npl; ++k)
-                if (c->h_ctr[k].overflow & 8u) need = std::max(need, (double)c->h_ctr[k].n_nodes / (double)((size_t)b.planes[k].tiles_x * b.planes[k].tiles_y * TILE_PX));
-            if (need == 0) break;
-            if (c->node_share >= 1.0 || attempt > 24) return fail(c, STR_ER_ECAPACITY, "node records exhausted at one record per pixel (internal error)");
-            c->node_share = std::min(1.0, std::max(c->node_share * 1.5, need * 1.25));
-        }
-        for (size_t k = 0; k < npl; ++k) {
-            const PlaneCtr &pc = c->h_ctr[k];
-            sp[k].n_nodes = pc.n_nodes; sp[k].n_walls = pc.n_walls; sp[k].start_node = r0 == 0 ? pc.start_node : NONE;
-            sp[k].has_top = ptop; sp[k].has_bot = pbot;
-        }
-    }
-    // what leaves the GPU, put together on the GPU: the records, and the node of every pixel of the first / last row (seam map:
-    // index in the tile's records; tile_nbase: the tile's first record)
-    const StripLayout L = strip_layout(sp, (uint32_t)w);
-    rc = ensure_strip_buf(c, c->d_strip_out, c->strip_out_cap, L.total);
-    if (rc != STR_ER_OK) return rc;
-    std::vector<uint8_t> head(L.head);
-    const StripHeader hd{STRIP_MAGIC, STRIP_VERSION, (uint32_t)w, (uint32_t)h, (uint32_t)strip, (uint32_t)n_strips, (uint32_t)std::max(0, r0 - (r0 > 0 ? TILE_H : 0)), (uint32_t)rows,
-                         (uint32_t)npl, (uint32_t)c->prm.thresh_step, c->prm.channel_mask, 0u};
-    std::memcpy(head.data(), &hd, sizeof(hd));
-    std::memcpy(head.data() + sizeof(hd), sp.data(), npl * sizeof(StripPlane));
-    HIP_TRY(c, hipMemcpyAsync(c->d_strip_out, head.data(), L.head, hipMemcpyHostToDevice, s));
-    for (size_t k = 0; k < npl && rows > 0; ++k) {
-        const PlaneDesc &pd = b.planes[k];
-        if (sp[k].n_nodes) HIP_TRY(c, hipMemcpyAsync(c->d_strip_out + L.rec[k], c->na.rec + pd.node_base, (size_t)sp[k].n_nodes * sizeof(NodeRec), hipMemcpyDeviceToDevice, s));
-        // seam map: boundary j holds pixel row (j+1)*TILE_H - 1 at [2j * w, +w) and pixel row (j+1)*TILE_H at [(2j+1) * w, +w)
-        const int jt = 0, jb = pd.tiles_y - 2;               // the seams under the phantom row above / over the phantom row below
-        if (ptop) launch_strip_border_ids(s, c->d_seam + pd.seam_base + (size_t)(2 * jt + 1) * w, c->d_tile_nbase + pd.tile_base + (size_t)(jt + 1) * pd.tiles_x, w,
-                                          reinterpret_cast<uint32_t *>(c->d_strip_out + L.top[k]));
-        if (pbot) launch_strip_border_ids(s, c->d_seam + pd.seam_base + (size_t)(2 * jb) * w, c->d_tile_nbase + pd.tile_base + (size_t)jb * pd.tiles_x, w,
-                                          reinterpret_cast<uint32_t *>(c->d_strip_out + L.bot[k]));
-    }
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, wait_stream(c, s));        // (also: `head` is pageable memory)
-    *d_blob = c->d_strip_out; *blob_bytes = (int64_t)L.total;
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-int str_er_strip_extract(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, int32_t strip, int32_t n_strips,
-                         void **blob, int64_t *blob_bytes)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!blob || !blob_bytes) return fail(c, STR_ER_EINVAL, "bad strip arguments");
-    *blob = nullptr; *blob_bytes = 0;
-    const void *d = nullptr;
-    int64_t n = 0;
-    const int rc = str_er_strip_extract_dev(c, bgr, w, h, stride, mem_kind, strip, n_strips, &d, &n);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *out = static_cast<uint8_t *>(std::malloc((size_t)n));
-    if (!out) return fail(c, STR_ER_ENOMEM, "strip blob allocation");
-    if (hipMemcpy(out, d, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { std::free(out); return fail(c, STR_ER_EHIP, "strip blob download"); }
-    *blob = out; *blob_bytes = n;
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-void str_er_strip_free(void *blob) { std::free(blob); }
-
-int str_er_strip_merge_ex(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
-                          const int64_t *blob_bytes, int blob_kind, int32_t n_strips, const uint8_t *plane_select, uint32_t stages, str_er_result **out)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!bgr || !blobs || !blob_bytes || !out || w < 1 || h < 1 || stride < (int64_t)w * 3 || n_strips < 1 ||
-        (blob_kind != STR_ER_MEM_HOST && blob_kind != STR_ER_MEM_DEVICE))
-        return fail(c, STR_ER_EINVAL, "bad strip arguments");
-    if (w > c->prm.max_width || h > c->prm.max_height) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
-    *out = nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    const size_t npl = c->chans.size();
-    // the planes this call puts together (the others' strips are skipped: another owner merges them)
-    std::vector<size_t> sel;
-    for (size_t k = 0; k < npl; ++k) if (!plane_select || plane_select[k]) sel.push_back(k);
-    if (sel.empty()) return fail(c, STR_ER_EINVAL, "plane_select selects no plane");
-    // ---- the blobs: on the device (as they are, or uploaded once); their headers on the host, checked before anything is trusted ----
-    const size_t head_bytes = sizeof(StripHeader) + npl * sizeof(StripPlane);
-    struct View { StripHeader hd; std::vector<StripPlane> sp; StripLayout L; const uint8_t *d; };
-    std::vector<View> view((size_t)n_strips);
-    size_t up_total = 0;
-    for (int i = 0; i < n_strips; ++i) {
-        if (!blobs[i] || blob_bytes[i] < (int64_t)head_bytes) return fail(c, STR_ER_EFORMAT, "strip blob too short");
-        up_total += align_up((size_t)blob_bytes[i], 256);
-    }
-    if (blob_kind == STR_ER_MEM_HOST) {
-        const int rcb = ensure_strip_buf(c, c->d_strip_in, c->strip_in_cap, up_total);
-        if (rcb != STR_ER_OK) return rcb;
-    }
-    size_t up_at = 0;
-    const int ty_all = (h + TILE_H - 1) / TILE_H;
-    for (int i = 0; i < n_strips; ++i) {
-        View &v = view[(size_t)i];
-        std::vector<uint8_t> head(head_bytes);
-        if (blob_kind == STR_ER_MEM_HOST) {
-            std::memcpy(head.data(), blobs[i], head_bytes);
-            HIP_TRY(c, hipMemcpyAsync(c->d_strip_in + up_at, blobs[i], (size_t)blob_bytes[i], hipMemcpyHostToDevice, c->stream));
-            v.d = c->d_strip_in + up_at;
-            up_at += align_up((size_t)blob_bytes[i], 256);
-        } else {
-            HIP_TRY(c, hipMemcpy(head.data(), blobs[i], head_bytes, hipMemcpyDeviceToHost));
-            v.d = static_cast<const uint8_t *>(blobs[i]);
-        }
-        std::memcpy(&v.hd, head.data(), sizeof(StripHeader));
-        const StripHeader &hd = v.hd;
-        if (hd.magic != STRIP_MAGIC || hd.version != STRIP_VERSION || hd.w != (uint32_t)w || hd.h != (uint32_t)h || hd.n_strips != (uint32_t)n_strips ||
-            hd.strip != (uint32_t)i || hd.n_planes != npl || hd.thresh_step != (uint32_t)c->prm.thresh_step || hd.channel_mask != c->prm.channel_mask)
-            return fail(c, STR_ER_EFORMAT, "strip blob does not belong to this frame / context (strip " + std::to_string(i) + ")");
-        // the rows the strip claims are the rows this cut gives it
-        const int s0 = (int)((int64_t)i * ty_all / n_strips), s1 = (int)((int64_t)(i + 1) * ty_all / n_strips);
-        const int r0 = s0 * TILE_H, r1 = std::min(h, s1 * TILE_H), rows = std::max(0, r1 - r0);
-        if (hd.rows != (uint32_t)rows || hd.row0 != (uint32_t)std::max(0, r0 - (r0 > 0 ? TILE_H : 0)))
-            return fail(c, STR_ER_EFORMAT, "strip blob: rows do not match the cut of the frame (strip " + std::to_string(i) + ")");
-        v.sp.resize(npl);
-        std::memcpy(v.sp.data(), head.data() + sizeof(StripHeader), npl * sizeof(StripPlane));
-        for (size_t k = 0; k < npl; ++k) {
-            const StripPlane &p = v.sp[k];
-            const bool top = rows > 0 && r0 > 0, bot = rows > 0 && r1 < h;
-            if (p.ch != (uint32_t)c->chans[k] || p.n_nodes >= (1u << 24) || (p.start_node != NONE && p.start_node >= p.n_nodes) ||
-                (p.has_top != 0) != top || (p.has_bot != 0) != bot || (rows == 0 && p.n_nodes != 0))
-                return fail(c, STR_ER_EFORMAT, "strip blob: inconsistent plane header (strip " + std::to_string(i) + ", plane " + std::to_string(k) + ")");
-        }
-        v.L = strip_layout(v.sp, (uint32_t)w);
-        if ((size_t)blob_bytes[i] != v.L.total) return fail(c, STR_ER_EFORMAT, "strip blob: size does not match its headers (strip " + std::to_string(i) + ")");
-    }
-    int pstride = 0; size_t psize = 0;
-    c->n_ev = 0; c->profile.clear(); rec(c, "begin");
-    int rc = frame_to_planes(c, bgr, w, h, stride, mem_kind, pstride, psize);
-    if (rc != STR_ER_OK) return rc;
-    rec(c, "channels");
-    Batch b;
-    for (size_t k : sel) {
-        const int ch = c->chans[k];
-        add_plane(b, c->d_pix + (size_t)(ch % 3) * psize, w, h, pstride, ch >= 3, 0, ch, 0);
-        b.planes.back().color_pitch = (uint32_t)psize;
-    }
-    b.planes_per_image = sel.size() == npl ? (int)npl : 0;       // (er_track / calc_color need all channels of the frame)
-    // the records of all strips of a plane must fit the plane's share
-    const size_t ns = sel.size();
-    std::vector<std::vector<uint32_t>> base(ns, std::vector<uint32_t>((size_t)n_strips + 1, 0));
-    double need = 0;
-    for (size_t j = 0; j < ns; ++j) {
-        for (int i = 0; i < n_strips; ++i) base[j][(size_t)i + 1] = base[j][(size_t)i] + view[(size_t)i].sp[sel[j]].n_nodes;
-        need = std::max(need, (double)base[j][(size_t)n_strips] / (double)((size_t)b.planes[j].tiles_x * b.planes[j].tiles_y * TILE_PX));
-        if (base[j][(size_t)n_strips] >= (1u << 24)) return fail(c, STR_ER_ECAPACITY, "more than 2^24 node records in one plane");
-    }
-    if (need > c->node_share) c->node_share = std::min(1.0, need * 1.05);
-    HIP_TRY(c, hipMemsetAsync(c->d_strip_flag, 0, sizeof(uint32_t), c->stream));
-    const ImportHook hook = [&](const Batch &bb, const BatchDev &bd) -> int {
-        hipStream_t s = c->stream;
-        for (size_t j = 0; j < ns; ++j) {
-            const size_t k = sel[j];
-            const PlaneDesc &pd = bb.planes[j];
-            if (base[j][(size_t)n_strips] > pd.node_cap) return fail(c, STR_ER_ECAPACITY, "strip records exceed the plane's share (internal error)");
-            PlaneCtr pc{};
-            pc.n_nodes = base[j][(size_t)n_strips];
-            pc.start_node = NONE;
-            for (int i = 0; i < n_strips; ++i) {
-                const View &v = view[(size_t)i];
-                const StripPlane &p = v.sp[k];
-                pc.n_walls += p.n_walls;
-                if (p.start_node != NONE) pc.start_node = p.start_node + base[j][(size_t)i];
-                if (!p.n_nodes) continue;
-                NodeRec *dst = bd.na.rec + pd.node_base + base[j][(size_t)i];
-                HIP_TRY(c, hipMemcpyAsync(dst, v.d + v.L.rec[k], (size_t)p.n_nodes * sizeof(NodeRec), hipMemcpyDeviceToDevice, s));
-                // (ids, keys and rows from strip-local to plane-wide; a parent id outside the strip's records raises the flag)
-                launch_rebase_records(s, dst, bd.na.aux + pd.node_base + base[j][(size_t)i], p.n_nodes, base[j][(size_t)i], v.hd.row0 * (uint32_t)w, v.hd.row0, (uint32_t)w, (uint32_t)h,
-                                      c->d_strip_flag);
-            }
-            c->h_ctr[j] = pc;
-            HIP_TRY(c, hipMemcpyAsync(c->d_ctr + j, c->h_ctr + j, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
-            // (before anything walks the parent chains: levels consistent, no cycles -- a damaged blob must end in EFORMAT, not in a hang)
-            launch_check_forest(s, bd.na.rec + pd.node_base, pc.n_nodes, c->d_strip_flag);
-            // pixel pairs across the cuts (strips without rows have no borders: the cut is between the nearest strips that have)
-            for (int lo = 0; lo + 1 < n_strips; ++lo) {
-                if (!view[(size_t)lo].sp[k].has_bot) continue;
-                int hi = lo + 1;
-                while (hi < n_strips && !view[(size_t)hi].sp[k].has_top) ++hi;
-                if (hi >= n_strips) continue;
-                launch_connect_cut(s, bd.na.rec + pd.node_base, reinterpret_cast<const uint32_t *>(view[(size_t)lo].d + view[(size_t)lo].L.bot[k]),
-                                   reinterpret_cast<const uint32_t *>(view[(size_t)hi].d + view[(size_t)hi].L.top[k]), (uint32_t)w, base[j][(size_t)lo],
-                                   view[(size_t)lo].sp[k].n_nodes, base[j][(size_t)hi], view[(size_t)hi].sp[k].n_nodes, c->d_strip_flag);
-            }
-        }
-        HIP_TRY(c, hipGetLastError());
-        uint32_t flag = 0;
-        HIP_TRY(c, hipMemcpyAsync(&flag, c->d_strip_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, wait_stream(c, s));       // h_ctr is about to be reused for the counters coming back
-        if (flag) return fail(c, STR_ER_EFORMAT, "strip blob: damaged node records (an id outside its strip's records, a box or key outside the plane, inconsistent levels or a cycle of parents)");
-        return STR_ER_OK;
-    };
-    return run_batch(c, b, stages, out, t0, true, &hook);
-} ABI_GUARD(c)
-
-int str_er_strip_merge(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, int mem_kind, const void *const *blobs,
-                       const int64_t *blob_bytes, int32_t n_strips, uint32_t stages, str_er_result **out)
-try {
-    return str_er_strip_merge_ex(c, bgr, w, h, stride, mem_kind, blobs, blob_bytes, STR_ER_MEM_HOST, n_strips, nullptr, stages, out);
-} ABI_GUARD(c)
-
 int str_er_detect_planes(str_er_ctx *c, const uint8_t *planes, int32_t w, int32_t h, int64_t stride, int64_t plane_pitch,
                          int32_t n_planes, int mem_kind, uint32_t stages, str_er_result **out)
 try {
@@ -2254,448 +1444,12 @@ try {
     return run_batch(c, b, stages, out, t0, false);
 } ABI_GUARD(c)
 
-int str_er_compute_channels(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t h, int64_t stride, uint8_t *planes6)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!bgr || !planes6 || w < 1 || h < 1 || stride < (int64_t)w * 3) return fail(c, STR_ER_EINVAL, "bad arguments");
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    const size_t n = (size_t)w * h;
-    if (n * 3 > c->in_bytes || n * 6 > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "frame larger than the context capacity");
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)w * 3, bgr, (size_t)stride, (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, c->stream));
-    uint8_t *d = c->d_pix;
-    launch_bgr_to_ycrcb(c->stream, c->d_in, w, h, (int64_t)w * 3, 0, 1, d, d + n, d + 2 * n, w, 0);
-    launch_invert(c->stream, d, d + 3 * n, 3 * n);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(planes6, d, 6 * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, wait_stream(c, c->stream));
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-static int boxes_call(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
-                      double *hist, uint8_t *tiles, uint8_t *cls, double *ss, double *sw, bool cascades, uint8_t *codes = nullptr)
-{
-    if (!c) return STR_ER_EINVAL;
-    if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
-    if (cascades && !(c->casc[0].loaded && c->casc[1].loaded)) return fail(c, STR_ER_ESTATE, "classify needs both cascades");
-    if (cascades && (!cls || !ss || !sw)) return fail(c, STR_ER_EINVAL, "null output");
-    for (int i = 0; i < n; ++i) {
-        const int32_t *b = boxes + 4 * (size_t)i;
-        if (b[2] < 1 || b[3] < 1 || b[0] < 0 || b[1] < 0 || (int64_t)b[0] + b[2] > w || (int64_t)b[1] + b[3] > h)
-            return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " outside the plane");
-    }
-    if (n == 0) return STR_ER_OK;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    const size_t np = (size_t)w * h;
-    if (np > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
-    const size_t o_box = 0, o_hist = align_up(16 * (size_t)n, 256), o_tile = o_hist + 8192 * (size_t)n,
-                 o_cls = align_up(o_tile + 676 * (size_t)n, 256), o_ss = align_up(o_cls + (size_t)n, 256), o_sw = o_ss + 8 * (size_t)n,
-                 o_code = align_up(o_sw + 8 * (size_t)n, 256), total = o_code + 576 * (size_t)n;
-    int rc = ensure_scratch(c, total);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
-    HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    launch_lbp_boxes(c->stream, c->d_pix, w, h, w, reinterpret_cast<const int32_t *>(s + o_box), n,
-                     hist ? reinterpret_cast<double *>(s + o_hist) : nullptr, tiles ? s + o_tile : nullptr, codes ? s + o_code : nullptr, s + o_cls,
-                     reinterpret_cast<double *>(s + o_ss), reinterpret_cast<double *>(s + o_sw), c->casc[0].dev, c->casc[1].dev,
-                     cascades ? 1 : 0);
-    HIP_TRY(c, hipGetLastError());
-    if (hist) HIP_TRY(c, hipMemcpyAsync(hist, s + o_hist, 8192 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (tiles) HIP_TRY(c, hipMemcpyAsync(tiles, s + o_tile, 676 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (codes) HIP_TRY(c, hipMemcpyAsync(codes, s + o_code, 576 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (cascades) {
-        HIP_TRY(c, hipMemcpyAsync(cls, s + o_cls, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(ss, s + o_ss, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(sw, s + o_sw, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(c, wait_stream(c, c->stream));
-    return STR_ER_OK;
-}
-
-int str_er_classify_boxes(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes,
-                          int32_t n, uint8_t *cls, double *score_strong, double *score_weak)
-try {
-    return boxes_call(c, plane, w, h, stride, boxes, n, nullptr, nullptr, cls, score_strong, score_weak, true);
-} ABI_GUARD(c)
-
-int str_er_lbp_hist(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
-                    double *hist, uint8_t *tiles26)
-try {
-    if (c && !hist) return fail(c, STR_ER_EINVAL, "null hist");
-    return boxes_call(c, plane, w, h, stride, boxes, n, hist, tiles26, nullptr, nullptr, nullptr, false);
-} ABI_GUARD(c)
-
-int str_er_calc_lbp(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n, uint8_t *lbp24)
-try {
-    if (c && !lbp24) return fail(c, STR_ER_EINVAL, "null lbp24");
-    return boxes_call(c, plane, w, h, stride, boxes, n, nullptr, nullptr, nullptr, nullptr, nullptr, false, lbp24);
-} ABI_GUARD(c)
-
-int str_er_cascade_predict(str_er_ctx *c, int which, const double *fv, int32_t n, double *out)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if ((which != 0 && which != 1) || n < 0 || (n > 0 && (!fv || !out))) return fail(c, STR_ER_EINVAL, "bad arguments");
-    if (!c->casc[which].loaded) return fail(c, STR_ER_ESTATE, "cascade not loaded");
-    if (n == 0) return STR_ER_OK;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    const size_t in_b = 8192 * (size_t)n, total = in_b + 8 * (size_t)n;
-    int rc = ensure_scratch(c, total);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
-    HIP_TRY(c, hipMemcpyAsync(s, fv, in_b, hipMemcpyHostToDevice, c->stream));
-    launch_cascade_fv(c->stream, reinterpret_cast<const double *>(s), n, reinterpret_cast<double *>(s + in_b), c->casc[which].dev);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(out, s + in_b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, wait_stream(c, c->stream));
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-// ---- libsvm text model (svm_save_model format, src/svm.cpp:2641-2736; reader :2767-2982) -------------
-int str_er_load_svm_model_mem(str_er_ctx *c, const char *text, size_t len, int32_t dim)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!text || dim < 1) return fail(c, STR_ER_EINVAL, "bad arguments");
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    std::string buf(text, len);
-    size_t pos = 0;
-    auto next_line = [&](std::string &out) -> bool {
-        if (pos >= buf.size()) return false;
-        size_t e = buf.find('\n', pos);
-        if (e == std::string::npos) e = buf.size();
-        out.assign(buf, pos, e - pos);
-        pos = e + 1;
-        return true;
-    };
-    auto numbers = [](const std::string &s, size_t from, std::vector<double> &out) {
-        const char *p = s.c_str() + from;
-        char *end;
-        for (;;) { double v = std::strtod(p, &end); if (end == p) break; out.push_back(v); p = end; }
-    };
-    int k = 0, l = 0;
-    double gamma = 0;
-    bool ok_type = false, ok_kernel = false, have_sv = false;
-    std::vector<double> rho, pa, pb, lab, nsv;
-    std::string line;
-    while (next_line(line)) {
-        const size_t sp = line.find(' ');
-        const std::string key = line.substr(0, sp);
-        const size_t from = sp == std::string::npos ? line.size() : sp;
-        if (key == "svm_type") ok_type = line.find("c_svc") != std::string::npos;
-        else if (key == "kernel_type") ok_kernel = line.find("rbf") != std::string::npos;
-        else if (key == "gamma") gamma = std::strtod(line.c_str() + from, nullptr);
-        else if (key == "nr_class") { const long v = std::strtol(line.c_str() + from, nullptr, 10); k = v < 0 || v > 125 ? -1 : (int)v; }      // (k_svm_couple keeps k (k - 1) / 2 + 3 k doubles in 64 KB of LDS)
-        // (every support vector is a line of the text: a count beyond the text's length is a damaged header, not a table to allocate)
-        else if (key == "total_sv") { const long v = std::strtol(line.c_str() + from, nullptr, 10); l = v < 0 || (unsigned long)v > len || v > (1L << 28) ? -1 : (int)v; }
-        else if (key == "rho") numbers(line, from, rho);
-        else if (key == "probA") numbers(line, from, pa);
-        else if (key == "probB") numbers(line, from, pb);
-        else if (key == "label") numbers(line, from, lab);
-        else if (key == "nr_sv") numbers(line, from, nsv);
-        else if (key == "SV") { have_sv = true; break; }
-    }
-    if (!ok_type || !ok_kernel) return fail(c, STR_ER_EFORMAT, "svm model: only svm_type c_svc with kernel_type rbf is supported");
-    const int np = k * (k - 1) / 2;
-    if (!have_sv || k < 2 || k > 125 || l < 1 || (int)rho.size() != np || (int)pa.size() != np || (int)pb.size() != np ||
-        (int)lab.size() != k || (int)nsv.size() != k)
-        return fail(c, STR_ER_EFORMAT, "svm model: incomplete header (need nr_class<=125, rho, label, probA, probB, nr_sv)");
-    const int dpad = (int)align_up((size_t)dim, 16), l_pad = (int)align_up((size_t)l, 64);
-    std::vector<float> sv((size_t)l_pad * dpad, 0.f);
-    std::vector<double> svnorm(l_pad, 0.0), coef((size_t)(k - 1) * l, 0.0);
-    for (int i = 0; i < l; ++i) {
-        if (!next_line(line)) return fail(c, STR_ER_EFORMAT, "svm model: fewer SV lines than total_sv");
-        const char *p = line.c_str();
-        char *end;
-        for (int j = 0; j < k - 1; ++j) { coef[(size_t)j * l + i] = std::strtod(p, &end); if (end == p) return fail(c, STR_ER_EFORMAT, "svm model: bad SV line"); p = end; }
-        double nrm = 0;
-        for (;;) {
-            const long idx = std::strtol(p, &end, 10);
-            if (end == p || *end != ':') break;
-            p = end + 1;
-            const double v = std::strtod(p, &end);
-            p = end;
-            if (idx < 0 || idx >= dim) return fail(c, STR_ER_EFORMAT, "svm model: SV feature index outside [0, dim)");
-            sv[(size_t)i * dpad + idx] = (float)v;
-            nrm += v * v;
-        }
-        svnorm[i] = nrm;
-    }
-    std::vector<int32_t> ilab(k), insv(k), start(k);
-    int tot = 0;
-    for (int i = 0; i < k; ++i) {
-        if (!to_int(lab[i], ilab[i]) || !to_int(nsv[i], insv[i]) || insv[i] < 0 || insv[i] > l) return fail(c, STR_ER_EFORMAT, "svm model: label / nr_sv entries are not counts");
-        start[i] = tot; tot += insv[i];
-    }
-    if (tot != l) return fail(c, STR_ER_EFORMAT, "svm model: nr_sv does not add up to total_sv");
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    // coef_t[q][b] = sv_coef[b][q]: the decision values read one coalesced row per support vector (k_svm_couple)
-    const int kc = (int)align_up((size_t)(k - 1), 64);
-    std::vector<double> coef_t((size_t)l_pad * kc, 0.0);      // (l_pad rows: the walk reads eight rows at a time)
-    for (int j = 0; j < k - 1; ++j) for (int i = 0; i < l; ++i) coef_t[(size_t)i * kc + j] = coef[(size_t)j * l + i];
-    std::vector<uint16_t> pair_ij((size_t)np);
-    for (int i = 0, p = 0; i < k; ++i) for (int j = i + 1; j < k; ++j, ++p) pair_ij[(size_t)p] = (uint16_t)((i << 8) | j);
-    const size_t o_pij = take((size_t)np * 2);
-    const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
-                 o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);
-    std::vector<uint8_t> blob(off);
-    std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
-    std::memcpy(&blob[o_pij], pair_ij.data(), (size_t)np * 2);
-    std::memcpy(&blob[o_coef], coef.data(), coef.size() * 8); std::memcpy(&blob[o_coeft], coef_t.data(), coef_t.size() * 8); std::memcpy(&blob[o_rho], rho.data(), np * 8);
-    std::memcpy(&blob[o_pa], pa.data(), np * 8); std::memcpy(&blob[o_pb], pb.data(), np * 8);
-    std::memcpy(&blob[o_lab], ilab.data(), k * 4); std::memcpy(&blob[o_nsv], insv.data(), k * 4); std::memcpy(&blob[o_start], start.data(), k * 4);
-    void *d = nullptr;
-    HIP_TRY(c, hipMalloc(&d, blob.size()));
-    hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); return fail(c, STR_ER_EHIP, std::string("svm upload: ") + hipGetErrorString(e)); }
-    if (c->d_svm_blob) (void)hipFree(c->d_svm_blob);
-    c->d_svm_blob = d;
-    const uint8_t *b = static_cast<const uint8_t *>(d);
-    SvmDev m{};
-    m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
-    m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
-    m.pair_ij = reinterpret_cast<const uint16_t *>(b + o_pij);
-    m.kc = kc; m.coef_t = reinterpret_cast<const double *>(b + o_coeft);
-    m.coef = reinterpret_cast<const double *>(b + o_coef); m.rho = reinterpret_cast<const double *>(b + o_rho);
-    m.probA = reinterpret_cast<const double *>(b + o_pa); m.probB = reinterpret_cast<const double *>(b + o_pb);
-    m.label = reinterpret_cast<const int32_t *>(b + o_lab); m.nsv = reinterpret_cast<const int32_t *>(b + o_nsv);
-    m.start = reinterpret_cast<const int32_t *>(b + o_start);
-    c->svm = m;
-    c->svm_loaded = true;
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-int str_er_load_svm_model(str_er_ctx *c, const char *path, int32_t dim)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!path) return fail(c, STR_ER_EINVAL, "null path");
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(c, STR_ER_EIO, std::string("cannot open ") + path);      // reference: svm_load_model returns NULL (src/svm.cpp:2878-2879)
-    std::string buf;
-    char tmp[65536];
-    size_t n;
-    while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n);
-    std::fclose(f);
-    return str_er_load_svm_model_mem(c, buf.data(), buf.size(), dim);
-} ABI_GUARD(c)
-
-int str_er_svm_info(const str_er_ctx *c, int32_t *nr_class, int32_t *total_sv, int32_t *dim)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (nr_class) *nr_class = c->svm_loaded ? c->svm.k : 0;
-    if (total_sv) *total_sv = c->svm_loaded ? c->svm.l : 0;
-    if (dim) *dim = c->svm_loaded ? c->svm.dim : 0;
-    return STR_ER_OK;
-} ABI_GUARD(const_cast<str_er_ctx *>(c))
-
-int str_er_svm_predict_probability(str_er_ctx *c, const double *x, int32_t n, int32_t dim, int32_t *label, double *prob, double *dec)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (n < 0 || (n > 0 && (!x || !label || !prob))) return fail(c, STR_ER_EINVAL, "bad arguments");
-    if (!c->svm_loaded) return fail(c, STR_ER_ESTATE, "svm model not loaded");
-    if (dim != c->svm.dim) return fail(c, STR_ER_EINVAL, "feature dimension differs from the one the model was loaded with");
-    if (n == 0) return STR_ER_OK;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    const SvmDev &m = c->svm;
-    const size_t np = (size_t)m.k * (m.k - 1) / 2;
-    const size_t o_x = 0, o_buf = align_up((size_t)n * dim * 8, 256);
-    int rc = ensure_scratch(c, o_buf + ocr_layout(nullptr, (size_t)n, &m, false, dec != nullptr, true).bytes);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
-    const OcrBuf buf = ocr_layout(s + o_buf, (size_t)n, &m, false, dec != nullptr, true);
-    hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(s + o_x, x, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
-    launch_svm_prep(st, reinterpret_cast<const double *>(s + o_x), n, dim, buf, m);
-    launch_svm_score(st, n, buf, m);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(prob, buf.prob, (size_t)n * m.k * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (dec) HIP_TRY(c, hipMemcpyAsync(dec, buf.dec, (size_t)n * np * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, wait_stream(c, st));
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-int str_er_ocr_chain_run(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes, int32_t n,
-                         int32_t *label, double *prob, uint8_t *q_out)
-try {
-    return str_er_ocr_chain_run_slope(c, plane, w, h, stride, boxes, nullptr, n, label, prob, q_out);
-} ABI_GUARD(c)
-
-int str_er_ocr_chain_run_slope(str_er_ctx *c, const uint8_t *plane, int32_t w, int32_t h, int64_t stride, const int32_t *boxes,
-                               const double *slope, int32_t n, int32_t *label, double *prob, uint8_t *q_out)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!plane || w < 1 || h < 1 || stride < w || n < 0 || (n > 0 && !boxes)) return fail(c, STR_ER_EINVAL, "bad arguments");
-    const bool want_svm = label != nullptr || prob != nullptr;
-    if (want_svm && (!label || !prob)) return fail(c, STR_ER_EINVAL, "label and prob must be given together");
-    if (want_svm && !c->svm_loaded) return fail(c, STR_ER_ESTATE, "svm model not loaded");
-    if (want_svm && c->svm.dim != 1800) return fail(c, STR_ER_ESTATE, "chain_run needs a model loaded with dim = 1800 (8 x 15 x 15)");
-    for (int i = 0; i < n; ++i) {
-        const int32_t *b = boxes + 4 * (size_t)i;
-        if (b[2] < 1 || b[3] < 1 || b[0] < 0 || b[1] < 0 || (int64_t)b[0] + b[2] > w || (int64_t)b[1] + b[3] > h)
-            return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " outside the plane");
-    }
-    if (n == 0) return STR_ER_OK;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    if ((size_t)w * h > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
-    hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
-    const SvmDev *m = want_svm ? &c->svm : nullptr;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_rot = take(slope ? sizeof(RotGeom) * (size_t)n : 0), o_box = take(16 * (size_t)n), o_buf = take(0);
-    int rc = ensure_scratch(c, o_buf + ocr_layout(nullptr, (size_t)n, m, true, false, false).bytes);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *s = static_cast<uint8_t *>(c->d_scratch);
-    const OcrBuf buf = ocr_layout(s + o_buf, (size_t)n, m, true, false, false);
-    HIP_TRY(c, hipMemcpyAsync(s + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
-    std::vector<RotGeom> rot;
-    if (slope) {
-        rot.resize((size_t)n);
-        for (int i = 0; i < n; ++i) {
-            if (!std::isfinite(slope[i])) return fail(c, STR_ER_EINVAL, "slope " + std::to_string(i) + " is not finite");
-            rot[(size_t)i] = make_rot_geom(boxes[4 * (size_t)i + 2], boxes[4 * (size_t)i + 3], slope[i]);
-        }
-        HIP_TRY(c, hipMemcpyAsync(s + o_rot, rot.data(), sizeof(RotGeom) * (size_t)n, hipMemcpyHostToDevice, st));
-    }
-    OcrSrc src{};
-    src.plane = c->d_pix; src.stride = w; src.inv = 0; src.boxes = reinterpret_cast<const int32_t *>(s + o_box);
-    src.rot = slope ? reinterpret_cast<const RotGeom *>(s + o_rot) : nullptr;
-    launch_ocr_features(st, src, n, buf, m);
-    if (want_svm) {
-        // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. assumes model->label[i] == i
-        launch_svm_score(st, n, buf, *m);
-        HIP_TRY(c, hipMemcpyAsync(prob, buf.pbest, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(c, hipGetLastError());
-    if (q_out) HIP_TRY(c, hipMemcpyAsync(q_out, buf.q, 1800 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, wait_stream(c, st));
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, const uint8_t *plane, int64_t stride, int32_t rows, int32_t cols,
-                         int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous)
-{
-    if (!c) return STR_ER_EINVAL;
-    if (!nodes || n_nodes < 1 || rows < 1 || cols < 1 || !n_pool || (cap > 0 && !pool_idx) || cap < 0 || (plane && stride < cols))
-        return fail(c, STR_ER_EINVAL, "bad arguments");
-    if (plane && (size_t)rows * (size_t)cols > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
-    if (!c->auto_caps && n_nodes > c->kept_cap) return fail(c, STR_ER_ECAPACITY, "tree larger than kept_cap");
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    std::vector<uint32_t> key(n_nodes), area(n_nodes); std::vector<int32_t> par(n_nodes);
-    std::vector<uint16_t> box(4 * (size_t)n_nodes); std::vector<uint8_t> lev(n_nodes);
-    int root = -1, maxl = 0;
-    for (int i = 0; i < n_nodes; ++i) {
-        const str_er_node &n = nodes[i];
-        int p = n.parent;
-        if (p < 0 || p == i) { if (root >= 0) return fail(c, STR_ER_EINVAL, "tree has more than one root"); root = i; p = i; }
-        if (p >= n_nodes) return fail(c, STR_ER_EINVAL, "parent index out of range");
-        if (n.w < 1 || n.h < 1) return fail(c, STR_ER_EINVAL, "empty box");
-        if (plane && n.key >= (uint32_t)rows * (uint32_t)cols) return fail(c, STR_ER_EINVAL, "node key outside the plane");
-        key[i] = n.key; area[i] = (uint32_t)n.area; par[i] = p; lev[i] = n.level;
-        box[4 * (size_t)i] = n.x; box[4 * (size_t)i + 1] = n.y; box[4 * (size_t)i + 2] = n.w; box[4 * (size_t)i + 3] = n.h;
-        maxl = std::max(maxl, (int)n.level);
-    }
-    if (root < 0) return fail(c, STR_ER_EINVAL, "tree has no root");
-    for (int i = 0; i < n_nodes; ++i)
-        if (i != root && lev[par[i]] <= lev[i]) return fail(c, STR_ER_EINVAL, "parent level must exceed child level");
-    hipStream_t s = c->stream;
-    Batch b;
-    add_plane(b, c->d_pix, cols, rows, cols, 0, 0, 0, 0);
-    b.kept_floor = b.pool_floor = (uint32_t)n_nodes;        // (the imported tree is the plane's kept-node table)
-    assign_tables(b, c);
-    if (b.kept > c->kept_total || b.pool > c->pool_total) {
-        const int rct = alloc_tables(c, std::max(c->kept_total, b.kept), std::max(c->pool_total, b.pool));
-        if (rct != STR_ER_OK) return rct;
-    }
-    std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc));
-    PlaneCtr pc{};
-    pc.n_kept = (uint32_t)n_nodes; pc.root_slot = (uint32_t)root; pc.max_level = (uint32_t)maxl;
-    c->h_ctr[0] = pc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_ctr, c->h_ctr, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->ka.key, key.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->ka.area, area.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->ka.parent, par.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->ka.box, box.data(), 8 * (size_t)n_nodes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->ka.level, lev.data(), (size_t)n_nodes, hipMemcpyHostToDevice, s));
-    if (plane) HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)cols, plane, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, wait_stream(c, s)); // host vectors go out of scope after this call
-    BatchDev bd = make_batchdev(c, b);
-    bd.n_seam_blocks = 0;
-    const DetectParams dp = make_dp(c);
-    launch_nms(s, bd, dp, /*use_index_order=*/plane == nullptr);
-    if (plane) launch_nms_alt(s, bd, dp, c->d_alt_list);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, wait_stream(c, s));
-    const uint32_t n_amb = c->h_ctr[0].n_amb;
-    if (plane && c->prm.sibling_order == 0 && c->h_ctr[0].n_rel) {      // ties: the reference's flood order decides (k_flood_order)
-        bool replayed = false;
-        const int rcr = resolve_sibling_ties(c, b, bd, dp, replayed, /*from_tree=*/true);
-        if (rcr != STR_ER_OK) return rcr;
-        if (c->prio) HIP_TRY(c, wait_stream(c, c->prio));       // the tie pass ran there
-        HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, wait_stream(c, s));
-    }
-    if (c->h_ctr[0].overflow & 2u) return fail(c, STR_ER_ECAPACITY, "NMS pool overflow: raise pool_cap");
-    const int np = (int)c->h_ctr[0].n_pool;
-    *n_pool = np;
-    if (ambiguous) *ambiguous = (int32_t)n_amb;
-    const int ncopy = std::min(np, cap);
-    if (ncopy > 0) {
-        HIP_TRY(c, hipMemcpyAsync(pool_idx, c->d_pool, 4 * (size_t)ncopy, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, wait_stream(c, s));
-    }
-    return STR_ER_OK;
-}
-
-int str_er_nms_tree(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, int32_t rows, int32_t cols, int32_t *pool_idx,
-                    int32_t cap, int32_t *n_pool, int32_t *ambiguous)
-try {
-    return nms_tree_impl(c, nodes, n_nodes, nullptr, 0, rows, cols, pool_idx, cap, n_pool, ambiguous);
-} ABI_GUARD(c)
-
-int str_er_nms_tree_plane(str_er_ctx *c, const str_er_node *nodes, int32_t n_nodes, const uint8_t *plane, int32_t cols, int32_t rows,
-                          int64_t stride, int32_t *pool_idx, int32_t cap, int32_t *n_pool, int32_t *ambiguous)
-try {
-    if (!plane) return c ? fail(c, STR_ER_EINVAL, "null plane") : STR_ER_EINVAL;
-    return nms_tree_impl(c, nodes, n_nodes, plane, stride, rows, cols, pool_idx, cap, n_pool, ambiguous);
-} ABI_GUARD(c)
-
-int str_er_flood_order(const uint8_t *plane, int32_t w, int32_t h, int64_t stride, int32_t thresh_step, uint32_t *stamp)
-{
-    if (!plane || !stamp || w < 1 || h < 1 || stride < w || thresh_step < 1 || thresh_step > 255 || (int64_t)w * h > (1 << 24)) return STR_ER_EINVAL;
-    std::memset(stamp, 0, 4 * (size_t)w * h);
-    flood_order_host(plane, w, h, stride, 0, (float)(1.0 / (double)thresh_step), 255 / thresh_step + 1, nullptr, 0xFFFFFFFFu, stamp);
-    return STR_ER_OK;
-}
-
 int str_er_internal_last_cands(str_er_ctx *c, const void **d_cands, uint32_t *n, int *device)
 try {
     if (!c || !c->last_valid) return STR_ER_ESTATE;
     *d_cands = c->d_cands; *n = c->last_total; *device = c->prm.device;
     return STR_ER_OK;
 } ABI_GUARD(c)
-
-int str_er_resize_plane(str_er_ctx *c, const uint8_t *src, int32_t sw, int32_t sh, int64_t sstride, uint8_t *dst, int32_t dw,
-                        int32_t dh)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw) return fail(c, STR_ER_EINVAL, "bad arguments");
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    const size_t ns = (size_t)sw * sh, nd = (size_t)dw * dh;
-    if (ns > c->in_bytes || nd > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane larger than the context capacity");
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)sw, src, (size_t)sstride, (size_t)sw, (size_t)sh, hipMemcpyHostToDevice, c->stream));
-    launch_resize(c->stream, c->d_in, sw, sh, sw, 0, 0, c->d_pix, dw, dh, dw, 0, 0, 1, 1);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(dst, c->d_pix, nd, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, wait_stream(c, c->stream));
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-// ---- results ---------------------------------------------------------------------------------
-int32_t str_er_result_n_planes(const str_er_result *r) { return r ? (int32_t)r->planes.size() : 0; }
 
 int str_er_result_plane_info(const str_er_result *r, int32_t plane, str_er_plane_info *info)
 {
@@ -2812,14 +1566,6 @@ const uint8_t *str_er_result_text_alive(const str_er_result *r, int32_t *n)
     return r->text_alive.empty() ? &none : r->text_alive.data();
 }
 
-int str_er_set_min_ocr_prob(str_er_ctx *c, double p)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!(p >= 0.0 && p <= 1.0)) return fail(c, STR_ER_EINVAL, "min_ocr_prob must be in [0, 1]");
-    c->min_ocr_prob = p;
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
 const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t *n)
 {
     if (!r || !r->have_texts) { if (n) *n = 0; return nullptr; }
@@ -2828,114 +1574,7 @@ const str_er_gbound *str_er_result_group_bounds(const str_er_result *r, int32_t 
     return r->gbounds.empty() ? &none : r->gbounds.data();
 }
 
-int str_er_er_grouping(str_er_ctx *c, const str_er_cand *cands, const str_er_track *tracks, int32_t n, int overlap_sup, int inner_sup,
-                       str_er_result **out)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!out || n < 0 || (n > 0 && (!cands || !tracks))) return fail(c, STR_ER_EINVAL, "bad arguments");
-    *out = nullptr;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    str_er_result *r = new (std::nothrow) str_er_result();
-    if (!r) return fail(c, STR_ER_ENOMEM, "result allocation");
-    r->cands.assign(cands, cands + n);
-    r->tracks.assign(tracks, tracks + n);
-    r->have_tracks = true;
-    r->cand_off.assign(2, 0); r->cand_off[1] = (uint32_t)n;
-    r->planes.resize(1);
-    std::memset(&r->planes[0], 0, sizeof(str_er_plane_info));
-    r->planes[0].n_pool = n; r->planes[0].root = -1;
-    int rc = STR_ER_OK;
-    if (n > 0 && overlap_sup) {
-        rc = group_phase_overlap(c, std::vector<uint32_t>{0u, (uint32_t)n}, inner_sup != 0, r);
-    } else if (n > 0) {
-        const size_t o_c = 0, o_tr = align_up(sizeof(CandRec) * (size_t)n, 256);
-        rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * (size_t)n);
-        if (rc == STR_ER_OK) {
-            uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
-            hipError_t e = hipMemcpyAsync(sc + o_c, cands, sizeof(CandRec) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(sc + o_tr, tracks, sizeof(TrackRec) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) rc = fail(c, STR_ER_EHIP, hipGetErrorString(e));
-            else rc = group_phase(c, reinterpret_cast<const CandRec *>(sc + o_c), reinterpret_cast<const TrackRec *>(sc + o_tr),
-                                  std::vector<uint32_t>{0u, (uint32_t)n}, inner_sup != 0, r);
-        }
-    } else {
-        r->have_texts = true;
-    }
-    if (rc != STR_ER_OK) { delete r; return rc; }
-    *out = r;
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
 const double *str_er_result_times(const str_er_result *r) { return r ? r->times : nullptr; }
-
-int str_er_calc_color(str_er_ctx *c, const uint8_t *mask_plane, int32_t w, int32_t h, int64_t stride, const uint8_t *color_img, int32_t cw,
-                      int32_t ch, int64_t cstride, const int32_t *boxes, int32_t n, double *colors)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (!mask_plane || !color_img || w < 1 || h < 1 || stride < w || cw < 1 || ch < 1 || cstride < (int64_t)cw * 3 || n < 0 ||
-        (n > 0 && (!boxes || !colors)))
-        return fail(c, STR_ER_EINVAL, "bad arguments");
-    for (int i = 0; i < n; ++i) {
-        const int32_t *b = boxes + 4 * (size_t)i;
-        if (b[2] < 1 || b[3] < 1 || b[0] < 0 || b[1] < 0 || (int64_t)b[0] + b[2] > w || (int64_t)b[1] + b[3] > h)
-            return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " outside the plane");
-        if (b[2] > cw || b[3] > ch) return fail(c, STR_ER_EINVAL, "box " + std::to_string(i) + " larger than the colour image");
-    }
-    if (n == 0) return STR_ER_OK;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    if ((size_t)w * h > c->pix_bytes || (size_t)cw * 3 * ch > c->in_bytes) return fail(c, STR_ER_ECAPACITY, "image larger than the context capacity");
-    hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, mask_plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)cw * 3, color_img, (size_t)cstride, (size_t)cw * 3, (size_t)ch, hipMemcpyHostToDevice, st));
-    const size_t o_box = 0, o_tr = align_up(16 * (size_t)n, 256);
-    int rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * (size_t)n);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
-    HIP_TRY(c, hipMemcpyAsync(sc + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
-    ColorSrc col{c->d_in, c->d_in + 1, c->d_in + 2, 3, (int64_t)cw * 3};
-    launch_calc_color_boxes(st, c->d_pix, w, col, reinterpret_cast<const int32_t *>(sc + o_box), n, reinterpret_cast<TrackRec *>(sc + o_tr));
-    HIP_TRY(c, hipGetLastError());
-    std::vector<TrackRec> tr((size_t)n);
-    HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, wait_stream(c, st));
-    for (int i = 0; i < n; ++i) { colors[3 * (size_t)i] = tr[(size_t)i].color1; colors[3 * (size_t)i + 1] = tr[(size_t)i].color2; colors[3 * (size_t)i + 2] = tr[(size_t)i].color3; }
-    return STR_ER_OK;
-} ABI_GUARD(c)
-
-int str_er_er_track(str_er_ctx *c, const str_er_cand *cands, const double *colors, int32_t n, uint8_t *tracked, int32_t *cx, int32_t *cy)
-try {
-    if (!c) return STR_ER_EINVAL;
-    if (n < 0 || (n > 0 && (!cands || !colors || !tracked))) return fail(c, STR_ER_EINVAL, "bad arguments");
-    if (n == 0) return STR_ER_OK;
-    HIP_TRY(c, hipSetDevice(c->prm.device));
-    hipStream_t st = c->stream;
-    const size_t o_c = 0, o_tr = align_up(sizeof(CandRec) * (size_t)n, 256), o_list = align_up(o_tr + sizeof(TrackRec) * (size_t)n, 256),
-                 o_rng = align_up(o_list + 4 * (size_t)n, 256);
-    int rc = ensure_scratch(c, o_rng + 64);
-    if (rc != STR_ER_OK) return rc;
-    uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
-    std::vector<TrackRec> tr((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        TrackRec t{};
-        t.color1 = colors[3 * (size_t)i]; t.color2 = colors[3 * (size_t)i + 1]; t.color3 = colors[3 * (size_t)i + 2];
-        tr[(size_t)i] = t;
-    }
-    const uint32_t rng[2] = {0u, (uint32_t)n};
-    HIP_TRY(c, hipMemcpyAsync(sc + o_c, cands, sizeof(CandRec) * (size_t)n, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(sc + o_tr, tr.data(), sizeof(TrackRec) * (size_t)n, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(sc + o_rng, rng, sizeof(rng), hipMemcpyHostToDevice, st));
-    launch_er_track(st, reinterpret_cast<const CandRec *>(sc + o_c), reinterpret_cast<TrackRec *>(sc + o_tr),
-                    reinterpret_cast<uint32_t *>(sc + o_list), reinterpret_cast<const uint32_t *>(sc + o_rng), 1);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, wait_stream(c, st));
-    for (int i = 0; i < n; ++i) {
-        tracked[i] = (uint8_t)tr[(size_t)i].tracked;
-        if (cx) cx[i] = tr[(size_t)i].cx;
-        if (cy) cy[i] = tr[(size_t)i].cy;
-    }
-    return STR_ER_OK;
-} ABI_GUARD(c)
 
 int str_er_result_cands_to_device(str_er_ctx *c, const str_er_result *r, void *dst_dev, int32_t cap, int32_t *n)
 try {

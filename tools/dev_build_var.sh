@@ -9,4 +9,4 @@ mkdir -p $ROOT/lib/var
     grep -A10 "Name: _ZN6str_er11k_tile_treeILi" | grep "Name\|Spill\|VGPRs:\|LDS\|Occupancy\|Scratch" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | tr '\n' ' '
 echo
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/lib/var/$name.so $ROOT/lib/var/$name.o \
-    $ROOT/lib/{ocr_kernels,track_kernels,er_group,flood_order,gather,str_er_api,stream_api}.o -ldl -lpthread && rm -f $ROOT/lib/var/$name.o
+    $ROOT/lib/{ocr_kernels,track_kernels,er_group,flood_order,gather,str_er_api,api_models,api_strips,api_stages,stream_api}.o -ldl -lpthread && rm -f $ROOT/lib/var/$name.o

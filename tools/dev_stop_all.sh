@@ -15,7 +15,7 @@ if [ "${1:-build}" = "build" ]; then
     done
     wait
     for n in $PHASES; do
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libstop_$n.so $OUT/er_kernels_$n.o $ROOT/scene-text-recognition_amd/lib/{ocr_kernels,track_kernels,er_group,flood_order,gather,str_er_api,stream_api}.o -ldl -lpthread
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libstop_$n.so $OUT/er_kernels_$n.o $ROOT/scene-text-recognition_amd/lib/{ocr_kernels,track_kernels,er_group,flood_order,gather,str_er_api,api_models,api_strips,api_stages,stream_api}.o -ldl -lpthread
         rm -f $OUT/er_kernels_$n.o
     done
     ls -la $OUT

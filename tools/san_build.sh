@@ -19,7 +19,7 @@ esac
 python $ROOT/build.py > /dev/null          # the kernels' objects
 OUT=$ROOT/lib/san; mkdir -p $OUT
 objs=""
-for src in er_group flood_order gather str_er_api stream_api; do
+for src in er_group flood_order gather str_er_api api_models api_strips api_stages stream_api; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -fno-omit-frame-pointer -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $SAN -x hip \
         -c $ROOT/csrc/$src.cpp -o $OUT/${src}_$kind.o
     objs="$objs $OUT/${src}_$kind.o"
