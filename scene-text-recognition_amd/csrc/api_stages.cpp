@@ -254,13 +254,15 @@ try {
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemcpy2DAsync(c->d_pix, (size_t)w, mask_plane, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpy2DAsync(c->d_in, (size_t)cw * 3, color_img, (size_t)cstride, (size_t)cw * 3, (size_t)ch, hipMemcpyHostToDevice, st));
-    const size_t o_box = 0, o_tr = align_up(16 * (size_t)n, 256);
-    int rc = ensure_scratch(c, o_tr + sizeof(TrackRec) * (size_t)n);
+    const size_t o_box = 0, o_tr = align_up(16 * (size_t)n, 256), o_cs = align_up(o_tr + sizeof(TrackRec) * (size_t)n, 256);
+    int rc = ensure_scratch(c, o_cs + calc_color_scratch_bytes((size_t)n));
     if (rc != STR_ER_OK) return rc;
     uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(sc + o_box, boxes, 16 * (size_t)n, hipMemcpyHostToDevice, st));
     ColorSrc col{c->d_in, c->d_in + 1, c->d_in + 2, 3, (int64_t)cw * 3};
-    launch_calc_color_boxes(st, c->d_pix, w, col, reinterpret_cast<const int32_t *>(sc + o_box), n, reinterpret_cast<TrackRec *>(sc + o_tr));
+    OcrSrc src{};
+    src.plane = c->d_pix; src.stride = w; src.inv = 0; src.boxes = reinterpret_cast<const int32_t *>(sc + o_box);
+    launch_calc_color(st, src, col, n, reinterpret_cast<TrackRec *>(sc + o_tr), sc + o_cs);
     HIP_TRY(c, hipGetLastError());
     std::vector<TrackRec> tr((size_t)n);
     HIP_TRY(c, hipMemcpyAsync(tr.data(), sc + o_tr, sizeof(TrackRec) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -1,0 +1,32 @@
+// ocr_device.h -- device helpers shared by ocr_kernels.hip and track_kernels.hip: where a box of a scoring / colour call lies.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ocr_kernels.h"
+
+namespace str_er {
+
+constexpr int OCR_WAVES = 4;           // boxes in flight per workgroup (a wave per box)
+constexpr int OCR_BIG_PX = 4096;       // boxes above this many pixels are spread over many workgroups: a launch lasts as long as its longest wave,
+constexpr int OCR_BIG_CAP = 4095;      // and one wave needs ~7 us per 1000 pixels -- the largest boxes of a batch are 50 times the average one
+constexpr int OCR_BIG_PARTS = 32;      // row ranges a big box is cut into
+
+struct OcrBox { const uint8_t *roi; int stride, inv, bw, bh; };
+
+__device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)
+{
+    OcrBox b;
+    if (s.recs) {
+        const CandRec   &cd = s.recs[s.list[bi]];
+        const PlaneDesc &pd = s.planes[cd.plane];
+        b.bw = cd.w; b.bh = cd.h; b.stride = pd.stride; b.inv = pd.invert;
+        b.roi = pd.pix + (size_t)cd.y * pd.stride + cd.x;
+    } else {
+        const int32_t *q = s.boxes + 4 * (size_t)bi;
+        b.bw = q[2]; b.bh = q[3]; b.stride = s.stride; b.inv = s.inv;
+        b.roi = s.plane + (size_t)q[1] * s.stride + q[0];
+    }
+    return b;
+}
+
+} // namespace str_er

@@ -56,6 +56,9 @@ OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m /* null: features onl
 // indices of the strong / weak candidates of the batch, in candidate order (deterministic): list[0 .. *n_out)
 void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out);
 
+// Otsu threshold of 255 - roi for n boxes (cv::threshold(..., THRESH_OTSU)): hist [n x 256], big [1 + 4095] (scratch), thresh [n]
+void launch_box_thresholds(hipStream_t s, const OcrSrc &src, int n, uint32_t *hist, uint32_t *big, int32_t *thresh);
+
 // chain-code features of n boxes: Otsu of 255 - roi, ARAN(30), direction bitmaps, 7x7 Gaussian, min-max, 2x2 decimation
 // -> buf.q (if not null) and buf.xf / buf.xnorm (if m is not null)
 void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m);

@@ -21,6 +21,7 @@
 
 #include "er_device.h"
 #include "ocr_kernels.h"
+#include "ocr_device.h"
 
 namespace str_er {
 
@@ -29,24 +30,6 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------------
 // boxes
 // ---------------------------------------------------------------------------------------------------------
-struct OcrBox { const uint8_t *roi; int stride, inv, bw, bh; };
-
-__device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)
-{
-    OcrBox b;
-    if (s.recs) {
-        const CandRec   &cd = s.recs[s.list[bi]];
-        const PlaneDesc &pd = s.planes[cd.plane];
-        b.bw = cd.w; b.bh = cd.h; b.stride = pd.stride; b.inv = pd.invert;
-        b.roi = pd.pix + (size_t)cd.y * pd.stride + cd.x;
-    } else {
-        const int32_t *q = s.boxes + 4 * (size_t)bi;
-        b.bw = q[2]; b.bh = q[3]; b.stride = s.stride; b.inv = s.inv;
-        b.roi = s.plane + (size_t)q[1] * s.stride + q[0];
-    }
-    return b;
-}
-
 // indices of the strong / weak candidates of the batch, in candidate order.  One workgroup; a thread takes four consecutive candidates per
 // pass (the four class bytes are requested together: the scan is a chain of memory round trips otherwise).
 __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ cands, const uint32_t *__restrict__ total_cands,
@@ -84,11 +67,6 @@ __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ c
 // Otsu, part 1: the histogram of 255 - roi.  One wave per box; eight interleaved sub-histograms (a binarisable
 // ROI has two dominant grey values: with one copy most lanes of a wave would queue on the same LDS word).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int OCR_WAVES = 4;          // boxes in flight per workgroup
-
-constexpr int OCR_BIG_PX = 4096;       // boxes above this many pixels are spread over many workgroups (k_ocr_hist_big): a launch lasts as long as its longest wave,
-constexpr int OCR_BIG_CAP = 4095;      // and one wave needs ~7 us per 1000 pixels -- the largest boxes of a batch are 50 times the average one
-constexpr int OCR_BIG_PARTS = 32;      // row ranges a big box is cut into
 
 __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist(OcrSrc src, int n, uint32_t *__restrict__ hist, uint32_t *__restrict__ big)
 {
@@ -749,18 +727,30 @@ void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t 
     hipLaunchKernelGGL(k_ocr_list, dim3(1), dim3(1024), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, list, n_out);
 }
 
+static int ocr_n_cu()
+{
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop{}; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+    return n_cu;
+}
+
+// grids of one round of resident workgroups (k_ocr_hist: 32 KB of LDS -> 5 per compute unit, k_ocr_features: 45 KB -> 3): a second, partly
+// filled round would cost as much as a full one
+void launch_box_thresholds(hipStream_t s, const OcrSrc &src, int n, uint32_t *hist, uint32_t *big, int32_t *thresh)
+{
+    if (n <= 0) return;
+    const int wg = (n + OCR_WAVES - 1) / OCR_WAVES, n_cu = ocr_n_cu();
+    (void)hipMemsetAsync(big, 0, 4, s);
+    hipLaunchKernelGGL(k_ocr_hist, dim3(wg < 5 * n_cu ? wg : 5 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, hist, big);
+    hipLaunchKernelGGL(k_ocr_hist_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, src, hist, (const uint32_t *)big);
+    hipLaunchKernelGGL(k_ocr_otsu, dim3((n + 63) / 64), dim3(64), 0, s, src, n, (const uint32_t *)hist, thresh);
+}
+
 void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m)
 {
     if (n <= 0) return;
-    // grids of one round of resident workgroups (k_ocr_hist: 32 KB of LDS -> 5 per compute unit, k_ocr_features: 45 KB -> 3): a second, partly
-    // filled round would cost as much as a full one
-    static int n_cu = 0;
-    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop{}; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
-    const int wg = (n + OCR_WAVES - 1) / OCR_WAVES;
-    (void)hipMemsetAsync(buf.big, 0, 4, s);
-    hipLaunchKernelGGL(k_ocr_hist, dim3(wg < 5 * n_cu ? wg : 5 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, buf.hist, buf.big);
-    hipLaunchKernelGGL(k_ocr_hist_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, src, buf.hist, (const uint32_t *)buf.big);
-    hipLaunchKernelGGL(k_ocr_otsu, dim3((n + 63) / 64), dim3(64), 0, s, src, n, (const uint32_t *)buf.hist, buf.thresh);
+    const int wg = (n + OCR_WAVES - 1) / OCR_WAVES, n_cu = ocr_n_cu();
+    launch_box_thresholds(s, src, n, buf.hist, buf.big, buf.thresh);
     hipLaunchKernelGGL(k_ocr_features, dim3(wg < 3 * n_cu ? wg : 3 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, (const int32_t *)buf.thresh, buf.q,
                        m ? buf.xf : (float *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dpad : 0);
 }

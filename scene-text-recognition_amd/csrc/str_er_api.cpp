@@ -698,26 +698,16 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
     }
-    // everything after NMS reads the pools: enqueued once, and once more if sibling ties had to be decided by a flood replay
     // everything after NMS reads the pools: enqueued once; if sibling ties had to be decided by a flood order walk, the planes whose
-    // pool that changed are classified again (the others keep their records) and the stages behind classify run once more
-    auto track_stage = [&](bool record, hipStream_t st, const BatchDev &d) {
-        if (stages & STR_ER_STAGE_TRACK) {
-            const int n_img = np / b.planes_per_image;
-            launch_calc_color_batch(st, d, c->d_track);
-            launch_group_ranges(st, d, b.planes_per_image, n_img, c->d_ranges);
-            launch_er_track(st, d.cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
-            if (record) rec(c, "track");
-        }
-    };
+    // pool that changed are classified again (the others keep their records).  calc_color + er_track run when the candidates are final
+    // and the host knows how many of them are strong / weak (below): the colour pass is sized for exactly those boxes.
     if (stages & STR_ER_STAGE_NMS) {
         launch_cand_prefix(s, bd);
         launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
     }
     rec(c, "classify");
-    track_stage(true, s, bd);
-    const int i_cls = (stages & STR_ER_STAGE_TRACK) ? c->n_ev - 2 : c->n_ev - 1;
-    const int i_trk = c->n_ev - 1;
+    const int i_cls = c->n_ev - 1;
+    int       i_trk = -1;
     if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
@@ -806,7 +796,6 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             uint32_t *n_redo = c->d_redo + c->pool_total;
             launch_cand_reprefix(sp, bd, first, c->d_redo, n_redo);
             launch_classify(sp, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, c->d_redo, n_redo);
-            track_stage(false, sp, bd);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
             HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
@@ -873,6 +862,30 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             delete r; return fail(c, STR_ER_EHIP, "candidate copy failed");
         }
     if ((stages & STR_ER_STAGE_TRACK)) {
+        // calc_color + er_track on the final candidates: the strong / weak ones are listed, their boxes' Otsu thresholds and masked colour means
+        // computed a wave per box (big boxes by many workgroups), then er_track per image
+        size_t n_cls = 0;
+        for (int i = 0; i < np; ++i) n_cls += c->h_ctr[i].n_strong + c->h_ctr[i].n_weak;
+        rec(c, "track_host_gap");
+        if (total) {
+            const int    n_img = np / b.planes_per_image;
+            const size_t o_list = 0, o_cs = align_up(4 * (size_t)total + 64 + 256, 256);
+            const int    rcs = ensure_scratch(c, o_cs + calc_color_scratch_bytes(n_cls));
+            if (rcs != STR_ER_OK) { delete r; return rcs; }
+            uint8_t  *sc = static_cast<uint8_t *>(c->d_scratch);
+            uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
+            if (hipMemsetAsync(c->d_track, 0, sizeof(TrackRec) * (size_t)total, s) != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, "track reset failed"); }
+            if (n_cls) {
+                launch_ocr_list(s, bd, d_list + 16, d_list);
+                OcrSrc src{};
+                src.recs = bd.cands; src.list = d_list + 16; src.planes = bd.planes;
+                launch_calc_color(s, src, ColorSrc{}, (int)n_cls, c->d_track, sc + o_cs);
+            }
+            launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
+            launch_er_track(s, bd.cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
+        }
+        rec(c, "track");
+        i_trk = c->n_ev - 1;
         r->tracks.resize(total);
         r->have_tracks = true;
         static_assert(sizeof(str_er_track) == sizeof(TrackRec), "track record layout");
@@ -1023,7 +1036,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     for (int i = 1; i < c->n_ev; ++i)
         if (hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) == hipSuccess) c->profile[i].second = ms;
     r->times[0] = stage_s[0]; r->times[1] = stage_s[1]; r->times[2] = stage_s[2];
-    if ((stages & STR_ER_STAGE_TRACK) && hipEventElapsedTime(&ms, c->ev[i_cls], c->ev[i_trk]) == hipSuccess) r->times[3] = ms * 1e-3;
+    if ((stages & STR_ER_STAGE_TRACK) && i_trk > 0 && hipEventElapsedTime(&ms, c->ev[i_trk - 1], c->ev[i_trk]) == hipSuccess) r->times[3] = ms * 1e-3;
     if (stages & (STR_ER_STAGE_OCR | STR_ER_STAGE_OCR_LINES)) r->times[5] = t_ocr_s;
     r->times[4] = t_group_s;
     r->times[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

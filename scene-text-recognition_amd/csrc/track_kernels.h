@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "er_kernels.h"
+#include "ocr_kernels.h"
 
 namespace str_er {
 
@@ -24,10 +25,11 @@ struct ColorSrc {
     int64_t        stride;
 };
 
-// pipeline: every strong / weak candidate of the batch (cls == 0 gets a zero record)
-void launch_calc_color_batch(hipStream_t s, const BatchDev &b, TrackRec *tr);
-// single-stage API: n boxes on one mask plane
-void launch_calc_color_boxes(hipStream_t s, const uint8_t *mask, int mstride, ColorSrc col, const int32_t *boxes, int n, TrackRec *tr);
+// calc_color for n boxes (src: explicit boxes on one mask plane with the colour image `col`, or records -- then the colour image is the
+// Y, Cr, Cb planes of the record's pyramid level and tr is indexed by the record, not by the box).  scratch: calc_color_scratch_bytes(n).
+// Records that are no box of the call keep what tr holds (the pipeline zeroes tr first).
+size_t calc_color_scratch_bytes(size_t n);
+void launch_calc_color(hipStream_t s, const OcrSrc &src, const ColorSrc &col, int n, TrackRec *tr, uint8_t *scratch);
 // ranges[2g], ranges[2g+1] = candidate range of image g (planes g*ppg .. (g+1)*ppg-1)
 void launch_group_ranges(hipStream_t s, const BatchDev &b, int planes_per_group, int n_groups, uint32_t *ranges);
 // er_track per image; list = scratch of as many words as there are candidates

@@ -12,6 +12,7 @@
 #include "track_kernels.h"
 
 #include "er_device.h"
+#include "ocr_device.h"
 
 namespace str_er {
 
@@ -22,82 +23,155 @@ __device__ __forceinline__ uint32_t wsum32(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_calc_color(const uint8_t *__restrict__ mask, int mstride, int inv, ColorSrc col,
-                                                    const int32_t *__restrict__ boxes, int n_boxes, const CandRec *__restrict__ cands,
-                                                    const uint32_t *__restrict__ total, const PlaneDesc *__restrict__ planes,
-                                                    TrackRec *__restrict__ tr)
+// calc_color (src/ER.cpp:1391-1419) for n boxes whose Otsu thresholds are known (launch_box_thresholds): the mean of the three YCrCb bytes under
+// the mask (255 - roi > threshold).  A wave per box; sums are integers, so the result is the reference's f64 quotient exactly.  The colour image
+// is read from ITS row i / column j, not the box's (:1404-1405, kept).  Boxes above OCR_BIG_PX pixels are queued and summed by many workgroups
+// (k_color_sums_big): a launch lasts as long as its longest wave, and the largest boxes of a batch have 50 times the pixels of the average one.
+struct ColorJob {
+    OcrSrc   src;        // the boxes (mask plane = the box's own channel)
+    ColorSrc col;        // explicit boxes: the colour image; records: taken from the plane descriptor (Y, Cr, Cb planes of the box's level)
+};
+
+__device__ __forceinline__ ColorSrc color_of(const ColorJob &j, int bi)
 {
-    __shared__ uint32_t s_hist[256];
-    __shared__ int      s_th;
-    __shared__ uint32_t s_part[4][4];
-    const int tid = threadIdx.x;
-    const int n = cands ? (int)*total : n_boxes;
-    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-        int bx, by, bw, bh;
-        if (cands) {
-            const CandRec &cd = cands[bi];
-            if (cd.cls == 0) {
-                if (tid == 0) { TrackRec z{}; tr[bi] = z; }
-                continue;
+    if (!j.src.recs) return j.col;
+    const PlaneDesc &pd = j.src.planes[j.src.recs[j.src.list[bi]].plane];
+    ColorSrc c;
+    c.c0 = pd.pix - (size_t)(pd.ch % 3) * pd.color_pitch;          // Y, Cr, Cb planes of this pyramid level
+    c.c1 = c.c0 + pd.color_pitch; c.c2 = c.c1 + pd.color_pitch;
+    c.step = 1; c.stride = pd.stride;
+    return c;
+}
+
+__device__ __forceinline__ void color_store(TrackRec *tr, unsigned long long c, unsigned long long t0, unsigned long long t1, unsigned long long t2)
+{
+    TrackRec r{};
+    r.color1 = (double)t0 / (double)c;      // count == 0: 0.0 / 0 as in the reference
+    r.color2 = (double)t1 / (double)c;
+    r.color3 = (double)t2 / (double)c;
+    *tr = r;
+}
+
+// rows [y_lo, y_hi) step y_step of box b: count and byte sums of the masked pixels, four pixels of a lane requested together
+__device__ __forceinline__ void color_rows(const OcrBox &b, const ColorSrc &col, int th, int y_lo, int y_hi, int y_step, int lane, uint32_t &cnt, uint32_t &a0,
+                                           uint32_t &a1, uint32_t &a2)
+{
+    auto on = [&](int x, int y) -> bool { return (255 - (b.roi[(size_t)y * b.stride + x] ^ b.inv)) > th; };
+    if (b.bw <= 64) {
+        const int rpp = 64 / b.bw, ry = lane / b.bw, x = lane - ry * b.bw;
+        if (ry < rpp)
+            for (int y0 = y_lo; y0 < y_hi; y0 += 4 * rpp * y_step) {
+                bool m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int y = y0 + (u * rpp + ry) * y_step; m[u] = y < y_hi && on(x, y); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (m[u]) {
+                        const int    y = y0 + (u * rpp + ry) * y_step;
+                        const size_t o = (size_t)y * col.stride + (size_t)x * col.step;
+                        ++cnt; a0 += col.c0[o]; a1 += col.c1[o]; a2 += col.c2[o];
+                    }
             }
-            const PlaneDesc &pd = planes[cd.plane];
-            bx = cd.x; by = cd.y; bw = cd.w; bh = cd.h;
-            mask = pd.pix; mstride = pd.stride; inv = pd.invert;
-            col.c0 = pd.pix - (size_t)(pd.ch % 3) * pd.color_pitch;          // Y, Cr, Cb planes of this pyramid level
-            col.c1 = col.c0 + pd.color_pitch; col.c2 = col.c1 + pd.color_pitch;
-            col.step = 1; col.stride = pd.stride;
-        } else {
-            bx = boxes[4 * bi]; by = boxes[4 * bi + 1]; bw = boxes[4 * bi + 2]; bh = boxes[4 * bi + 3];
-        }
-        const uint8_t *roi = mask + (size_t)by * mstride + bx;
-        s_hist[tid] = 0;
-        __syncthreads();
-        const int npx = bw * bh;
-        for (int i = tid; i < npx; i += 256) {
-            const int y = i / bw, x = i - y * bw;
-            atomicAdd(&s_hist[255 - (roi[(size_t)y * mstride + x] ^ inv)], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) s_th = otsu_from_hist(s_hist, (double)bw * bh);          // threshold(255-img, ..., THRESH_OTSU), :1395
-        __syncthreads();
-        const int th = s_th;
-        // masked sums; the colour image is read from ITS row i / column j, not the box's (:1404-1405, kept)
-        uint32_t cnt = 0, a0 = 0, a1 = 0, a2 = 0;
-        for (int i = tid; i < npx; i += 256) {
-            const int y = i / bw, x = i - y * bw;
-            if ((255 - (roi[(size_t)y * mstride + x] ^ inv)) > th) {
-                const size_t o = (size_t)y * col.stride + (size_t)x * col.step;
-                ++cnt; a0 += col.c0[o]; a1 += col.c1[o]; a2 += col.c2[o];
+    } else {
+        for (int y = y_lo; y < y_hi; y += y_step)
+            for (int x0 = 0; x0 < b.bw; x0 += 256) {
+                bool m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int x = x0 + 64 * u + lane; m[u] = x < b.bw && on(x, y); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (m[u]) {
+                        const size_t o = (size_t)y * col.stride + (size_t)(x0 + 64 * u + lane) * col.step;
+                        ++cnt; a0 += col.c0[o]; a1 += col.c1[o]; a2 += col.c2[o];
+                    }
             }
-        }
-        cnt = wsum32(cnt); a0 = wsum32(a0); a1 = wsum32(a1); a2 = wsum32(a2);   // per-wave sums stay below 2^32 (<= 255 * pixels / 4)
-        if ((tid & 63) == 0) { s_part[tid >> 6][0] = cnt; s_part[tid >> 6][1] = a0; s_part[tid >> 6][2] = a1; s_part[tid >> 6][3] = a2; }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long c = 0, t0 = 0, t1 = 0, t2 = 0;
-            for (int w = 0; w < 4; ++w) { c += s_part[w][0]; t0 += s_part[w][1]; t1 += s_part[w][2]; t2 += s_part[w][3]; }
-            TrackRec r{};
-            r.color1 = (double)t0 / (double)c;      // count == 0: 0.0 / 0 as in the reference
-            r.color2 = (double)t1 / (double)c;
-            r.color3 = (double)t2 / (double)c;
-            tr[bi] = r;
-        }
-        __syncthreads();
     }
 }
 
-void launch_calc_color_batch(hipStream_t s, const BatchDev &b, TrackRec *tr)
+// tr index of box bi: the candidate it belongs to (records) or bi itself (explicit boxes)
+__device__ __forceinline__ uint32_t color_slot(const ColorJob &j, int bi) { return j.src.recs ? j.src.list[bi] : (uint32_t)bi; }
+
+__global__ __launch_bounds__(64 * OCR_WAVES) void k_color_sums(ColorJob job, int n, const int32_t *__restrict__ thresh, TrackRec *__restrict__ tr,
+                                                              unsigned long long *__restrict__ sums, uint32_t *__restrict__ big)
 {
-    ColorSrc none{};
-    hipLaunchKernelGGL(k_calc_color, dim3(2048), dim3(256), 0, s, (const uint8_t *)nullptr, 0, 0, none, (const int32_t *)nullptr, 0,
-                       (const CandRec *)b.cands, (const uint32_t *)b.total_cands, (const PlaneDesc *)b.planes, tr);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int bi = blockIdx.x * OCR_WAVES + w; bi < n; bi += gridDim.x * OCR_WAVES) {
+        const OcrBox b = ocr_box(job.src, bi);
+        if (b.bw * b.bh > OCR_BIG_PX) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(big, 1u);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (at < (uint32_t)OCR_BIG_CAP) {
+                if (lane == 0) big[1 + at] = (uint32_t)bi;
+                if (lane < 4) sums[4 * (size_t)bi + lane] = 0;
+                continue;
+            }
+        }
+        const ColorSrc col = color_of(job, bi);
+        uint32_t cnt = 0, a0 = 0, a1 = 0, a2 = 0;           // (a lane's sums stay below 2^32: <= 255 x pixels / 64... a box has < 2^24 pixels)
+        color_rows(b, col, thresh[bi], 0, b.bh, 1, lane, cnt, a0, a1, a2);
+        unsigned long long c = cnt, t0 = a0, t1 = a1, t2 = a2;
+        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+        if (lane == 0) color_store(tr + color_slot(job, bi), c, t0, t1, t2);
+    }
 }
 
-void launch_calc_color_boxes(hipStream_t s, const uint8_t *mask, int mstride, ColorSrc col, const int32_t *boxes, int n, TrackRec *tr)
+__global__ __launch_bounds__(64 * OCR_WAVES) void k_color_sums_big(ColorJob job, const int32_t *__restrict__ thresh, unsigned long long *__restrict__ sums,
+                                                                  const uint32_t *__restrict__ big)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, part = blockIdx.x;
+    const int nq = (int)min(big[0], (uint32_t)OCR_BIG_CAP);
+    for (int qi = blockIdx.y; qi < nq; qi += gridDim.y) {
+        const int    bi = (int)big[1 + qi];
+        const OcrBox b = ocr_box(job.src, bi);
+        const int    y_lo = (int)((long long)part * b.bh / OCR_BIG_PARTS), y_hi = (int)((long long)(part + 1) * b.bh / OCR_BIG_PARTS);
+        if (y_lo + w >= y_hi) continue;
+        const ColorSrc col = color_of(job, bi);
+        uint32_t cnt = 0, a0 = 0, a1 = 0, a2 = 0;
+        color_rows(b, col, thresh[bi], y_lo + w, y_hi, OCR_WAVES, lane, cnt, a0, a1, a2);
+        unsigned long long c = cnt, t0 = a0, t1 = a1, t2 = a2;
+        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+        if (lane == 0) {
+            atomicAdd(&sums[4 * (size_t)bi], c); atomicAdd(&sums[4 * (size_t)bi + 1], t0);
+            atomicAdd(&sums[4 * (size_t)bi + 2], t1); atomicAdd(&sums[4 * (size_t)bi + 3], t2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_color_final_big(ColorJob job, const unsigned long long *__restrict__ sums, const uint32_t *__restrict__ big,
+                                                         TrackRec *__restrict__ tr)
+{
+    const int nq = (int)min(big[0], (uint32_t)OCR_BIG_CAP);
+    for (int qi = blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += gridDim.x * blockDim.x) {
+        const int bi = (int)big[1 + qi];
+        color_store(tr + color_slot(job, bi), sums[4 * (size_t)bi], sums[4 * (size_t)bi + 1], sums[4 * (size_t)bi + 2], sums[4 * (size_t)bi + 3]);
+    }
+}
+
+size_t calc_color_scratch_bytes(size_t n)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(n * 256 * 4) + up(4 * (size_t)(OCR_BIG_CAP + 1)) + up(n * 4) + up(n * 32) + up(4 * (size_t)(OCR_BIG_CAP + 1));
+}
+
+void launch_calc_color(hipStream_t s, const OcrSrc &src, const ColorSrc &col, int n, TrackRec *tr, uint8_t *scratch)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_calc_color, dim3(n < 2048 ? n : 2048), dim3(256), 0, s, mask, mstride, 0, col, boxes, n, (const CandRec *)nullptr,
-                       (const uint32_t *)nullptr, (const PlaneDesc *)nullptr, tr);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    uint32_t *hist = reinterpret_cast<uint32_t *>(scratch);
+    uint32_t *big = reinterpret_cast<uint32_t *>(scratch + up((size_t)n * 256 * 4));
+    int32_t  *thresh = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(big) + up(4 * (size_t)(OCR_BIG_CAP + 1)));
+    unsigned long long *sums = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(thresh) + up((size_t)n * 4));
+    uint32_t *big2 = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(sums) + up((size_t)n * 32));
+    launch_box_thresholds(s, src, n, hist, big, thresh);
+    ColorJob job{src, col};
+    (void)hipMemsetAsync(big2, 0, 4, s);
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop{}; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+    const int wg = (n + OCR_WAVES - 1) / OCR_WAVES;
+    hipLaunchKernelGGL(k_color_sums, dim3(wg < 8 * n_cu ? wg : 8 * n_cu), dim3(64 * OCR_WAVES), 0, s, job, n, (const int32_t *)thresh, tr, sums, big2);
+    hipLaunchKernelGGL(k_color_sums_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, job, (const int32_t *)thresh, sums, (const uint32_t *)big2);
+    hipLaunchKernelGGL(k_color_final_big, dim3(16), dim3(256), 0, s, job, (const unsigned long long *)sums, (const uint32_t *)big2, tr);
 }
 
 __global__ void k_group_ranges(BatchDev b, int ppg, int n_groups, uint32_t *__restrict__ ranges)
