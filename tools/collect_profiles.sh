@@ -2,7 +2,7 @@
 # Run on a GPU box (via gpurun) from the repo root: bench lines + rocprofv3 summaries for profiles/.
 # Usage: tools/collect_profiles.sh r02
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -16,6 +16,14 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BU
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2 -o p -- $B > $OUT/pmc_sq2.log 2>&1
 # bench.py reads roofline.traffic from profiles/pmc_tile_tree.json: write it from the counter passes above before the bench lines are taken
 python $ROOT/tools/make_profile_summary.py $TAG --pmc-json-only > $OUT/pmc_json.log 2>&1
+# (round 5) the legs that have no headline of their own: config 3 (the OCR scorer), the reference's real call pattern (lines, then the scorer), config 5 (4K)
+P1="--steps 6 --warmup 2 --repeats 1 --pipelines 1 --no-cpu-baseline --no-latency --no-host-frames --no-ties-leg"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config3 -o s -- python $ROOT/bench.py --ocr $P1 > $OUT/stats_config3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_group_ocr -o s -- python $ROOT/bench.py --group --ocr $P1 > $OUT/stats_group_ocr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_4k -o s -- python $ROOT/bench.py --size 4k $P1 > $OUT/stats_4k.log 2>&1
+bash $ROOT/tools/dev_ocr_pmc.sh profiles_$TAG/pmc_config3 > /dev/null 2>&1
+bash $ROOT/tools/r05_lat.sh profiles_$TAG/latency > /dev/null 2>&1
+cd /tmp
 python $ROOT/bench.py > $OUT/bench_${TAG}_pyr3x8_text.json 2> $OUT/bench_err.log
 python $ROOT/bench.py --workload native6 > $OUT/bench_${TAG}_native6_text.json 2>> $OUT/bench_err.log
 python $ROOT/bench.py --workload native6 --kind noise --no-cpu-baseline > $OUT/bench_${TAG}_native6_noise.json 2>> $OUT/bench_err.log

@@ -29,6 +29,15 @@ for f in ([] if PMC_JSON_ONLY else sorted(os.listdir(SRC))):
 # 2. kernel stats (rocprofv3 --kernel-trace --stats)
 if not PMC_JSON_ONLY:
     shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_pyr3x8.csv"))
+    for extra, name in (("stats_config3", "kernel_stats_config3"), ("stats_group_ocr", "kernel_stats_group_ocr"), ("stats_4k", "kernel_stats_4k")):
+        f = os.path.join(SRC, extra, "s_kernel_stats.csv")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(DST, f"{tag}_{name}.csv"))
+    for extra, name in ((os.path.join("pmc_config3", "summary.txt"), "pmc_config3.txt"), (os.path.join("latency", "timeline.txt"), "latency_1frame_timeline.txt"),
+                        (os.path.join("latency", "latency.txt"), "latency_1frame_stages.txt")):
+        f = os.path.join(SRC, extra)
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(DST, f"{tag}_{name}"))
 # 3. PMC summaries
 fetch = pmc(os.path.join(SRC, "pmc_fetch", "p_counter_collection.csv"))
 write = pmc(os.path.join(SRC, "pmc_write", "p_counter_collection.csv"))
@@ -99,5 +108,23 @@ if not PMC_JSON_ONLY:
               f"(vector {100 * float(t['SQ_ACTIVE_INST_VALU']) / float(t['SQ_WAVE_CYCLES']):.1f} %), {100 * float(t['SQ_WAIT_ANY']) / float(t['SQ_WAVE_CYCLES']):.0f} % are parked "
               f"(s_waitcnt / barrier) and {100 * float(t['SQ_WAIT_INST_ANY']) / float(t['SQ_WAVE_CYCLES']):.0f} % wait for an issue slot; "
               f"LDS bank conflict cycles / LDS busy cycles = {100 * float(t['SQ_LDS_BANK_CONFLICT']) / float(t['SQ_ACTIVE_INST_LDS']):.0f} %.", ""]
+    # the legs of the default line (round 5)
+    def leg(k, fmt):
+        v = d.get(k)
+        if v:
+            lines.append(fmt(v))
+    leg("config3_ocr_leg", lambda v: f"`config3_ocr_leg` (BASELINE configs[2]: chain-code + SVM scorer on the {v['ers_scored_per_batch']} strong / weak ERs of a batch): **{v['value']:.0f}** frames/s = "
+        f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}; `k_svm_kernel` {v['roofline_svm_kernel']['achieved']} TFLOP/s = "
+        f"{v['roofline_svm_kernel']['frac']:.3f} of the {v['roofline_svm_kernel']['peak']} TFLOP/s f32 MFMA peak; CPU baseline {(v.get('cpu_baseline') or {}).get('value', '-')} frames/s.")
+    leg("group_ocr_leg", lambda v: f"`group_ocr_leg` (calc_color, er_track, er_grouping, then the scorer on the {v['line_members_scored_per_batch']} line members of a batch): **{v['value']:.0f}** frames/s = "
+        f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}.")
+    leg("config5_4k_leg", lambda v: f"`config5_4k_leg` (BASELINE configs[4] on one GPU, 3840x2160 x 12 levels, {v['frames_per_step']} frames per batch): **{v['value']:.0f}** frames/s ({v['mpx_per_s']:.0f} Mpx/s; the 1080p line: "
+        f"{v['mpx_per_s_of_value']:.0f}); `k_tile_tree` {v['roofline']['avg_launch_ms']} ms per launch = {v['roofline']['frac']:.4f} of 8 TB/s; 1-frame latency "
+        f"{(v.get('latency_1frame') or {}).get('ms_per_frame', '-')} ms; exact NMS ties: {v.get('nms_ties')}.")
+    leg("nms_ties_leg", lambda v: f"`nms_ties_leg`: **{v['value']:.0f}** frames/s = {v['frac_of_value']:.3f} of `value` at {v['tie_planes_per_batch']} tie planes per batch ({v['flood_walk_ms_per_batch']} ms of host walks, {v['host_threads']} threads).")
+    leg("pcie_inclusive", lambda v: f"`pcie_inclusive`: **{v['value']:.0f}** frames/s = {v['frac_of_value']:.3f} of `value` ({v['h2d_gbs']} GB/s; the link alone {v['h2d_gbs_link_alone']} GB/s); NV12: "
+        f"{(d.get('pcie_inclusive_nv12') or {}).get('value', '-')} ({(d.get('pcie_inclusive_nv12') or {}).get('frac_of_value', '-')}).")
+    lines.append(f"`value` = median of {d.get('repeats', 1)} timed regions: min {d.get('value_min', '-')}, max {d.get('value_max', '-')}.")
+    lines.append("")
     open(os.path.join(DST, f"{tag}_numbers.md"), "w").write("\n".join(lines))
     print("\n".join(lines))

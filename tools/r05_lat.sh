@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: where one frame's 0.77 ms goes -- per-stage GPU times and the kernel timeline of the 1-frame call
 set -u
-ROOT=$(pwd)
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/${1:-r05lat}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
