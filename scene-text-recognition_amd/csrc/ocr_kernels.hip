@@ -27,6 +27,10 @@ namespace str_er {
 
 typedef float float16v __attribute__((ext_vector_type(16)));
 
+#ifndef SVM_Q_UNROLL
+#define SVM_Q_UNROLL 1        // support vectors per pass of the decision-value loops (2: twice the loads in flight, 144 registers -> 12 waves a CU instead of 16)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // boxes
 // ---------------------------------------------------------------------------------------------------------
@@ -155,17 +159,24 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist_big(OcrSrc src, uin
 // Otsu, part 2: the scan is a chain of 256 dependent f64 steps (two divisions each) whose rounding must be the
 // reference's: it cannot be spread over lanes, so every lane runs the scan of its own box.  The histograms of the
 // wave's 64 boxes are transposed through LDS (row stride 257 words: conflict-free for both access patterns).
-__global__ __launch_bounds__(64) void k_ocr_otsu(OcrSrc src, int n, const uint32_t *__restrict__ hist, int32_t *__restrict__ thresh)
+__global__ __launch_bounds__(256) void k_ocr_otsu(OcrSrc src, int n, const uint32_t *__restrict__ hist, int32_t *__restrict__ thresh)
 {
     __shared__ uint32_t s_h[64 * 257];
-    const int lane = threadIdx.x, b0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, b0 = blockIdx.x * 64;
     const int nb = min(64, n - b0);
-    for (int e = 0; e < nb; ++e)
-        for (int v = lane; v < 256; v += 64) s_h[e * 257 + v] = hist[(size_t)(b0 + e) * 256 + v];
+    // staging by all four waves, 16 loads of a lane in flight (one load per pass made this loop -- 256 memory round trips -- three quarters of the kernel)
+    const uint32_t *hp = hist + (size_t)b0 * 256;
+    for (int i0 = tid; i0 < nb * 256; i0 += 256 * 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = i0 + 256 * u; v[u] = i < nb * 256 ? hp[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = i0 + 256 * u; if (i < nb * 256) s_h[(i >> 8) * 257 + (i & 255)] = v[u]; }
+    }
     __syncthreads();
-    if (lane < nb) {
-        const OcrBox b = ocr_box(src, b0 + lane);
-        thresh[b0 + lane] = otsu_from_hist(s_h + lane * 257, (double)b.bw * b.bh);
+    if (tid < nb) {
+        const OcrBox b = ocr_box(src, b0 + tid);
+        thresh[b0 + tid] = otsu_from_hist(s_h + tid * 257, (double)b.bw * b.bh);
     }
 }
 
@@ -551,11 +562,13 @@ __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv
             qa = max(qa, na[u]); qb = max(qb, nb[u]);
         }
         for (int o = 32; o > 0; o >>= 1) { qa = max(qa, __shfl_xor(qa, o)); qb = max(qb, __shfl_xor(qb, o)); }
+#pragma unroll SVM_Q_UNROLL
         for (int q = 0; q < qa; ++q) {
 #pragma unroll
             for (int u = 0; u < PC; ++u)
                 if (q < na[u]) sum[u] += m.coef_t[(size_t)(sa[u] + q) * kc + cj[u] - 1] * kr[sa[u] + q];
         }
+#pragma unroll SVM_Q_UNROLL
         for (int q = 0; q < qb; ++q) {
 #pragma unroll
             for (int u = 0; u < PC; ++u)
@@ -743,7 +756,7 @@ void launch_box_thresholds(hipStream_t s, const OcrSrc &src, int n, uint32_t *hi
     (void)hipMemsetAsync(big, 0, 4, s);
     hipLaunchKernelGGL(k_ocr_hist, dim3(wg < 5 * n_cu ? wg : 5 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, hist, big);
     hipLaunchKernelGGL(k_ocr_hist_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, src, hist, (const uint32_t *)big);
-    hipLaunchKernelGGL(k_ocr_otsu, dim3((n + 63) / 64), dim3(64), 0, s, src, n, (const uint32_t *)hist, thresh);
+    hipLaunchKernelGGL(k_ocr_otsu, dim3((n + 63) / 64), dim3(256), 0, s, src, n, (const uint32_t *)hist, thresh);
 }
 
 void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m)
