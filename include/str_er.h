@@ -285,7 +285,8 @@ int str_er_cascade_predict(str_er_ctx *ctx, int which, const double *fv, int32_t
 /* ---- OCR scorer, SVM half (config 3) --------------------------------------
  * svm_load_model (src/svm.cpp:2767-2982; OCR::OCR, src/OCR.cpp:19-22): a libsvm C-SVC / RBF text model
  * with probability information (probA/probB).  dim = feature dimension (1800 = 8 x 15 x 15 for the
- * reference's chain-code features, src/OCR.cpp:203-216); must exceed the largest SV index.           */
+ * reference's chain-code features, src/OCR.cpp:203-216); must exceed the largest SV index.  2 <= nr_class <= 125
+ * (the reference's model has 65): STR_ER_EFORMAT otherwise.                                                     */
 int str_er_load_svm_model(str_er_ctx *ctx, const char *path, int32_t dim);
 int str_er_load_svm_model_mem(str_er_ctx *ctx, const char *text, size_t len, int32_t dim);
 int str_er_svm_info(const str_er_ctx *ctx, int32_t *nr_class, int32_t *total_sv, int32_t *dim);
