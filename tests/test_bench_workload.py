@@ -1,5 +1,5 @@
 """Parity of the configurations bench.py TIMES: the exact workloads of the bench line --
-pyr3x8 (BASELINE configs[1]/[2]: 1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels) and native6 (the reference's own six
+pyr3x8 (BASELINE configs[1], and configs[2] with the OCR scorer: 1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels) and native6 (the reference's own six
 planes) -- on the bench's own synthetic frames (S-text and S-noise, seed = 0x5EED0000 + frame index), every plane of every
 frame compared with the oracle: node count, pool, classes, both cascade scores; config 3 adds the chain-code + SVM scorer.
 Plus a bounded soak of the lock-free tree kernels (both sizes of the tile kernel) on random planes."""
