@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/san; mkdir -p $OUT; rm -f $OUT/*
 cd $ROOT
-T="tests/test_stream.py tests/test_gather_native.py tests/test_config5_strips.py tests/test_bench_workload.py::test_bench_workload_ties tests/test_gpu_parity.py::test_errors tests/test_track.py"
+T="tests/test_svm.py tests/test_stream.py tests/test_gather_native.py tests/test_config5_strips.py tests/test_bench_workload.py::test_bench_workload_ties tests/test_gpu_parity.py::test_errors tests/test_track.py"
 for kind in ubsan tsan; do
     echo "== $kind: pytest"
     SAN_LOG=$OUT/$kind timeout 900 bash tools/san_run.sh $kind python -m pytest $T -q -m gpu -x --deselect tests/test_config5_strips.py::test_rccl_device_blobs_world_of_one 2>&1 | tail -5 | tee $OUT/${kind}_pytest.txt
