@@ -448,9 +448,14 @@ def main():
 
         def ocr_leg_run(st, label):
             rig.run(P, d_frames, st)
-            el_o, prof_o, last_o = rig.timed(n_o, d_frames, st)
+            els = []
+            for _ in range(max(1, args.repeats)):
+                el_i, prof_o, last_o = rig.timed(n_o, d_frames, st)
+                els.append(el_i)
+            el_o = float(np.median(els))
             sp, last1 = rig.serial_profile(d_frames, st)
-            out = {"value": round(F * n_o / el_o, 2), "unit": "frames/s", "steps": n_o, "ms_per_step": round(1e3 * el_o / n_o, 3),
+            out = {"value": round(F * n_o / el_o, 2), "unit": "frames/s", "steps": n_o, "repeats": len(els), "value_min": round(F * n_o / max(els), 2),
+                   "value_max": round(F * n_o / min(els), 2), "ms_per_step": round(1e3 * el_o / n_o, 3),
                    "frac_of_value": round(F * n_o / el_o / (F * args.steps / elapsed), 4), "stages": label}
             return out, sp, last1
 

@@ -210,6 +210,7 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
     launch_svm_couple(s, (int)n_m, buf, m);
     rec(c, "svm_couple");
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, wait_stream(c, s));          // (wait, then copy into pageable memory: see run_batch's OCR stage)
     HIP_TRY(c, hipMemcpyAsync(r->line_label.data(), buf.label, 4 * n_m, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(r->line_prob.data(), buf.pbest, 8 * n_m, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, wait_stream(c, s));
@@ -262,13 +263,15 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
         if (img[2 * g + 1] - img[2 * g] > 65535u) return fail(c, STR_ER_ECAPACITY, "more than 65535 candidates in one image");
     hipStream_t s = c->stream;
     const size_t words = 4 * n_c + 4 * (size_t)G + 64;
-    if (words > c->group_words) {
+    if (words > c->group_words) {          // (a quarter more than needed: the candidate count differs from batch to batch, and hipFree / hipMalloc wait for the whole device)
+        const size_t get = words + words / 4;
         if (c->d_group) { (void)hipFree(c->d_group); c->d_group = nullptr; c->group_words = 0; }
-        if (hipMalloc(reinterpret_cast<void **>(&c->d_group), 4 * words) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (grouping workspace)");
-        c->group_words = words;
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_group), 4 * get) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (grouping workspace)");
+        c->group_words = get;
     }
     auto grow_pairs = [&](size_t cap) -> int {
         if (cap <= c->group_pair_cap) return STR_ER_OK;
+        cap += cap / 4;
         if (c->d_group_pairs) { (void)hipFree(c->d_group_pairs); c->d_group_pairs = nullptr; c->group_pair_cap = 0; }
         if (hipMalloc(reinterpret_cast<void **>(&c->d_group_pairs), 4 * cap) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (pair list)");
         c->group_pair_cap = cap;
@@ -287,6 +290,7 @@ int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, 
     launch_group_pairs_fill(s, d_cands, d_track, d_rng, G, gb);
     HIP_TRY(c, hipGetLastError());
     std::vector<uint32_t> n_sorted((size_t)G), pair_off((size_t)G + 1), sorted(n_c);
+    HIP_TRY(c, wait_stream(c, s));          // (wait, then copy into pageable memory: see run_batch's OCR stage)
     HIP_TRY(c, hipMemcpyAsync(n_sorted.data(), gb.n_sorted, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(pair_off.data(), gb.pair_off, 4 * ((size_t)G + 1), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(sorted.data(), gb.sorted, 4 * n_c, hipMemcpyDeviceToHost, s));
@@ -358,9 +362,12 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
     for (int i : amb) { largest = std::max(largest, scratch_need(i)); total += scratch_need(i); }
     const size_t want = std::max(largest, std::min<size_t>(total, (size_t)1 << 30));
     if (want > c->replay_bytes) {
+        // (grown in steps of at least 2 x: hipFree / hipMalloc wait for the whole device -- every other context's kernels included; a rocprofv3 timeline of
+        // six batches in flight showed one such call as a 64 ms hole in the GPU's work)
+        const size_t get = std::max(want, 2 * c->replay_bytes);
         if (c->d_replay) { (void)hipFree(c->d_replay); c->d_replay = nullptr; c->replay_bytes = 0; }
-        if (hipMalloc(reinterpret_cast<void **>(&c->d_replay), want) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (flood replay scratch)");
-        c->replay_bytes = want;
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_replay), get) != hipSuccess) return fail(c, STR_ER_ENOMEM, "hipMalloc (flood replay scratch)");
+        c->replay_bytes = get;
     }
 
     // Planes go in rounds that fit the scratch (one round unless dozens of planes have dense stamps).  A round of the host walk is
@@ -386,10 +393,14 @@ int resolve_sibling_ties(str_er_ctx *c, const Batch &b, const BatchDev &bd, cons
         for (size_t o : hoff) if (o % 256 != 0) return fail(c, STR_ER_ESTATE, "tie plane arena: unaligned plane offset");
         const size_t m = items.size();
         if (hneed > c->h_replay_bytes) {
+            // (the arena's need follows the number of tie planes of a batch, which differs from batch to batch: room for 8 planes of the context's size at once --
+            // at most 64 MB -- then doubling; a page-locked allocation is a 4 ms call that the other contexts' copies queue behind)
+            const size_t plane_bytes = (((size_t)c->prm.max_width * c->prm.max_height + 255) / 256) * 256 + ((3 * 4 * (size_t)NMS_WATCH_CAP + 255) / 256) * 256;
+            const size_t get = std::max(hneed, std::max(2 * c->h_replay_bytes, std::min<size_t>(8 * plane_bytes, (size_t)64 << 20)));
             if (c->h_replay) { (void)hipHostFree(c->h_replay); c->h_replay = nullptr; c->h_replay_bytes = 0; }
-            if (hipHostMalloc(reinterpret_cast<void **>(&c->h_replay), hneed, hipHostMallocMapped) != hipSuccess)
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->h_replay), get, hipHostMallocMapped) != hipSuccess)
                 return fail(c, STR_ER_ENOMEM, "hipHostMalloc (flood order walk staging)");
-            c->h_replay_bytes = hneed;
+            c->h_replay_bytes = get;
         }
         ReplayItem *h_items = reinterpret_cast<ReplayItem *>(c->h_replay);
         // which planes the device has already put into host memory (k_export_tie_planes: the first TIE_SLOTS tie planes of the batch)
@@ -889,7 +900,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         r->tracks.resize(total);
         r->have_tracks = true;
         static_assert(sizeof(str_er_track) == sizeof(TrackRec), "track record layout");
-        if (total && hipMemcpyAsync(r->tracks.data(), c->d_track, sizeof(TrackRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
+        if (total && (wait_stream(c, s) != hipSuccess ||          // (wait, then copy: see the OCR stage below)
+                      hipMemcpyAsync(r->tracks.data(), c->d_track, sizeof(TrackRec) * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess)) {
             delete r; return fail(c, STR_ER_EHIP, "track copy failed");
         }
     }
@@ -946,7 +958,11 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             std::vector<uint32_t> list(n_ocr);
             std::vector<int32_t> lab(n_ocr);
             std::vector<double> pb(n_ocr);
+            // (wait first, copy then: a copy into pageable memory blocks inside the runtime, holding its staging buffers, until the stream's kernels are done --
+            // and the other contexts' copies queue behind it although THEIR streams are idle: six threads inside hipMemcpyAsync and 12 ms without a kernel on the
+            // GPU in a rocprofv3 timeline of six batches in flight)
             hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = wait_stream(c, s);
             if (e == hipSuccess) e = hipMemcpyAsync(list.data(), d_list + 16, 4 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), buf.label, 4 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(pb.data(), buf.pbest, 8 * n_ocr, hipMemcpyDeviceToHost, s);

@@ -240,6 +240,9 @@ int alloc_node_records(str_er_ctx *c, size_t n)
 int ensure_scratch(str_er_ctx *c, size_t bytes)
 {
     if (bytes <= c->scratch_bytes) return STR_ER_OK;
+    // (a quarter more than asked for, and at least 1.5 x what there was: the need follows the batch's content -- how many ERs are scored, how many lines have
+    // members -- and hipFree / hipMalloc wait for the whole device, every other context's kernels included)
+    bytes = std::max(bytes + bytes / 4, c->scratch_bytes + c->scratch_bytes / 2);
     if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
     hipError_t e = hipMalloc(&c->d_scratch, bytes);
     if (e != hipSuccess) return fail(c, STR_ER_ENOMEM, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
