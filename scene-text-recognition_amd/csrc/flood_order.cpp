@@ -28,39 +28,51 @@
 
 namespace str_er {
 
-void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch,
-                      uint32_t n_watch, uint32_t *stamp, const uint32_t *group)
+namespace {
+
+// State per pixel: quantised level (src/ER.cpp:250: 8U -> 8U convertTo with scale 1/step = round-half-even of float(p) * float(1/step)) in the low LBITS bits,
+// "watched" above them, "accessible" on top -- ONE byte where the sentinel level 255 / THRESH_STEP + 1 fits 6 bits (THRESH_STEP >= 5), two otherwise.  The plane is framed by a border of accessible
+// cells, so the four neighbours of a pixel are cur + 1, cur + S, cur - 1, cur - S without any test for the plane's edge.
+// The 256 LIFO buckets of src/ER.cpp:254-255 are contiguous stacks inside one array, level l's from base[l] on with room for every pixel of that level (a
+// pixel is in at most one bucket at a time; the counts come from the pass that quantises the plane): a push and a pop touch the top of a stack, not a link
+// word next to the pixel -- round 5, 5-10 % less per walk than the linked lists through a second per-pixel array (same stamps: tests/test_flood_order.py).
+// (The two arrays are kept per thread: a fresh allocation per walk is thousands of page faults and a memset -- a third of a walk that stops early; both are
+// written before they are read.  Round 4, measured and not adopted: the level looked up from the plane when the walk first touches a pixel -- no pass over the
+// whole plane in front of a walk that stops early -- is 11 % SLOWER on the boxes' EPYC 9575F: two dependent loads per new pixel instead of one, and the walk is
+// a chain of mispredicted branches and dependent loads, ~8 ns per pixel, whatever the bytes.)
+template <typename T, int LBITS>
+void flood_walk(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch, uint32_t n_watch,
+                uint32_t *stamp, const uint32_t *group, std::vector<T> &st_buf, std::vector<uint32_t> &stk_buf)
 {
     const uint32_t n = (uint32_t)w * (uint32_t)h;
-    if (n == 0) return;
     const bool all = n_watch == 0xFFFFFFFFu;
-    // per pixel: quantised level (src/ER.cpp:250: 8U -> 8U convertTo with scale 1/step = round-half-even of float(p) * float(1/step))
-    // in bits 0..8, "watched" in bit 14, "accessible" in bit 15 -- one 16-bit word is all the walk reads per neighbour
-    constexpr uint16_t ACC = 0x8000u, WATCH = 0x4000u, LEVEL = 0x01FFu;
-    uint16_t lut[256];
-    for (int v = 0; v < 256; ++v) lut[v] = (uint16_t)std::lrintf((float)v * qscale);
-    // (the two per-pixel arrays are kept per thread: a fresh 12 MB allocation per walk is ~3000 page faults and a memset -- a third of a
-    // walk that stops early; both are written before they are read.  Round 4, measured and not adopted: one byte of state per pixel and the level
-    // looked up from the plane when the walk first touches a pixel -- no pass over the whole plane in front of a walk that stops early -- is 11 %
-    // SLOWER on the boxes' EPYC 9575F (16.0 -> 17.9 ms for a whole 1920 x 1080 plane, tools/walk_bench.cpp): two dependent loads per new pixel
-    // instead of one, and the walk is a chain of mispredicted branches and dependent loads, ~8 ns per pixel, whatever the bytes)
-    // Kept for the planes a video stream brings again and again, up to one 1920 x 1080 plane (12.4 MB a thread: 0.8 GB for a pool of 64); the scratch
-    // of a larger plane (one 4K plane: 50 MB) is handed back when its walk ends, so that up to 64 pool threads and every caller thread do not hold it
-    // for the life of the process.
-    thread_local std::vector<uint16_t> st_buf;
-    thread_local std::vector<uint32_t> link_buf;
-    struct Shrink {
-        std::vector<uint16_t> &a; std::vector<uint32_t> &b;
-        ~Shrink() { if (a.size() > ((size_t)1 << 21) + ((size_t)1 << 16)) { std::vector<uint16_t>().swap(a); std::vector<uint32_t>().swap(b); } }
-    } shrink{st_buf, link_buf};
-    if (st_buf.size() < n) st_buf.resize(n);
-    if (link_buf.size() < n) link_buf.resize(n);
-    uint16_t *const st = st_buf.data();
+    constexpr T ACC = (T)(1u << (LBITS + 1)), WATCH = (T)(1u << LBITS), LEVEL = (T)((1u << LBITS) - 1u);
+    T lut[256];
+    for (int v = 0; v < 256; ++v) lut[v] = (T)std::lrintf((float)v * qscale);
+    const uint32_t S = (uint32_t)w + 2u;
+    const size_t   NP = (size_t)S * ((size_t)h + 2u);
+    if (st_buf.size() < NP) st_buf.resize(NP);
+    if (stk_buf.size() < (size_t)n + 8) stk_buf.resize((size_t)n + 8);
+    T *const st = st_buf.data();
+    // (four counters per level: neighbouring pixels mostly share a level, and one counter would make the pass a chain of dependent read-modify-writes)
+    uint32_t cnt4[4][257] = {{0}};
+    for (uint32_t x = 0; x < S; ++x) { st[x] = ACC; st[(size_t)(h + 1) * S + x] = ACC; }
     for (int y = 0; y < h; ++y) {
         const uint8_t *row = pix + (size_t)y * stride;
-        uint16_t      *o = st + (size_t)y * w;
-        for (int x = 0; x < w; ++x) o[x] = lut[row[x] ^ invert];
+        T             *o = st + (size_t)(y + 1) * S + 1;
+        o[-1] = ACC; o[w] = ACC;
+        int x = 0;
+        for (; x + 4 <= w; x += 4) {
+            const T l0 = lut[row[x] ^ invert], l1 = lut[row[x + 1] ^ invert], l2 = lut[row[x + 2] ^ invert], l3 = lut[row[x + 3] ^ invert];
+            o[x] = l0; o[x + 1] = l1; o[x + 2] = l2; o[x + 3] = l3;
+            ++cnt4[0][l0]; ++cnt4[1][l1]; ++cnt4[2][l2]; ++cnt4[3][l3];
+        }
+        for (; x < w; ++x) { const T l = lut[row[x] ^ invert]; o[x] = l; ++cnt4[0][l]; }
     }
+    uint32_t cnt[257];
+    for (int l = 0; l < 257; ++l) cnt[l] = cnt4[0][l] + cnt4[1][l] + cnt4[2][l] + cnt4[3][l];
+    auto pad = [&](uint32_t p) -> uint32_t { return (p / (uint32_t)w + 1u) * S + p % (uint32_t)w + 1u; };
+    auto unpad = [&](uint32_t q) -> uint32_t { const uint32_t y = q / S - 1u; return y * (uint32_t)w + (q - (y + 1u) * S - 1u); };
     // `remaining` = watched pixels whose stamps are still needed.  With groups (the children competing for one parent) only the
     // LAST one entered matters: once all but one member of a group are stamped that one is known to come later, so a group of k
     // needs k - 1 stamps; members left unstamped get 0xFFFFFFFF ("later than every stamped one").
@@ -79,28 +91,25 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
             group_left.assign(n_watch, 0);
         }
         for (uint32_t i = 0; i < n_watch; ++i)
-            if (watch[i] < n && !(st[watch[i]] & WATCH)) {
-                st[watch[i]] |= WATCH;
+            if (watch[i] < n && !(st[pad(watch[i])] & WATCH)) {
+                st[pad(watch[i])] |= WATCH;
                 if (group) { if (group_left[open_in_group[i]]++ > 0) ++remaining; }      // k members -> k - 1 needed
                 else ++remaining;
             }
         if (group) for (uint32_t i = 0; i < n_watch; ++i) stamp[i] = 0xFFFFFFFFu;
         if (remaining == 0) return;
     }
-    // the 256 LIFO buckets of src/ER.cpp:254-255 as linked lists through one array (a pixel is in at most one bucket at a time):
-    // link[p] = next entry << 3 | the edge at which p resumes
-    constexpr uint32_t NIL = 0x1FFFFFFFu;
-    uint32_t *const link = link_buf.data();
-    uint32_t head[257];
-    for (uint32_t &v : head) v = NIL;
+    uint32_t *const stk = stk_buf.data();
+    uint32_t top[257], base[257];
+    { uint32_t a = 0; for (int l = 0; l < 257; ++l) { top[l] = base[l] = a; a += cnt[l]; } }
     uint32_t priority = (uint32_t)hi, counter = 0;
-    uint32_t cur = 0, edge = 0, cl = st[0] & LEVEL;
-    const uint32_t W = (uint32_t)w, HI = (uint32_t)hi;
-    auto mark = [&](uint32_t p, uint16_t s) {
+    const uint32_t HI = (uint32_t)hi;
+    auto mark = [&](uint32_t q, T s) {
         ++counter;
-        st[p] = (uint16_t)(s | ACC);
-        if (all) stamp[p] = counter;
+        st[q] = (T)(s | ACC);
+        if (all) stamp[unpad(q)] = counter;
         else if (s & WATCH) {
+            const uint32_t p = unpad(q);
             for (uint32_t j = 0; j < n_watch; ++j)
                 if (watch[j] == p) {          // (a handful per plane)
                     stamp[j] = counter;
@@ -110,43 +119,64 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
                 }
         }
     };
-    mark(0, st[0]);
-    uint32_t x = 0;       // column of `cur`
+    // same start pixel, same edge order (right, bottom, left, top), same LIFO buckets per level, same "priority == highest_level means empty" rule as
+    // src/ER.cpp:254-345: pixels at the sentinel level are marked but never pushed
+    uint32_t cur = S + 1u, edge = 0, cl = st[cur] & LEVEL;
+    mark(cur, st[cur]);
+    const int32_t off[4] = {1, (int32_t)S, -1, -(int32_t)S};
     while (remaining != 0) {
         bool descended = false;
-        for (; edge < 4; ++edge) {
-            uint32_t q;
-            switch (edge) {
-            case 0: if (x + 1 >= W) continue; q = cur + 1; break;
-            case 1: if (cur + W >= n) continue; q = cur + W; break;
-            case 2: if (x == 0) continue; q = cur - 1; break;
-            default: if (cur < W) continue; q = cur - W; break;
-            }
-            const uint16_t s = st[q];
-            if (s & ACC) continue;
+        // the four neighbours' states at once (independent loads), then only the ones not accessible yet, in edge order: marking one does not change another
+        const T  sn[4] = {st[cur + 1u], st[cur + S], st[cur - 1u], st[cur - S]};
+        uint32_t m = ((sn[0] & ACC) ? 0u : 1u) | ((sn[1] & ACC) ? 0u : 2u) | ((sn[2] & ACC) ? 0u : 4u) | ((sn[3] & ACC) ? 0u : 8u);
+        m &= ~((1u << edge) - 1u);
+        while (m) {
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const uint32_t q = cur + (uint32_t)off[k];
+            const T        s = sn[k];
             mark(q, s);
             const uint32_t l = s & LEVEL;
             if (l >= cl) {
-                if (l < HI) { link[q] = head[l] << 3; head[l] = q; }      // (the bucket of the sentinel level is never popped)
+                if (l < HI) stk[top[l]++] = q << 3;
                 if (l < priority) priority = l;
             } else {
-                if (cl < HI) { link[cur] = (head[cl] << 3) | (edge + 1); head[cl] = cur; }
+                if (cl < HI) stk[top[cl]++] = (cur << 3) | (k + 1u);
                 if (cl < priority) priority = cl;
-                cur = q; cl = l;
-                x = edge == 0 ? x + 1 : edge == 2 ? x - 1 : x;
-                edge = 0;
+                cur = q; cl = l; edge = 0;
                 descended = true;
                 break;
             }
         }
         if (descended) continue;
         if (priority == HI) break;
-        cur = head[priority];
-        const uint32_t v = link[cur];
-        head[priority] = v >> 3; edge = v & 7u; cl = priority;
-        x = cur % W;
-        while (priority < HI && head[priority] == NIL) ++priority;
+        const uint32_t v = stk[--top[priority]];
+        cur = v >> 3; edge = v & 7u; cl = priority;
+        while (priority < HI && top[priority] == base[priority]) ++priority;
     }
+}
+
+} // namespace
+
+void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch,
+                      uint32_t n_watch, uint32_t *stamp, const uint32_t *group)
+{
+    if (w <= 0 || h <= 0) return;
+    // Kept for the planes a video stream brings again and again, up to one 1920 x 1080 plane (2 MB of state + 8 MB of stacks a thread); the scratch of a
+    // larger plane (one 4K plane: 42 MB) is handed back when its walk ends, so that up to 64 pool threads and every caller thread do not hold it for the
+    // life of the process.
+    thread_local std::vector<uint8_t>  st8;
+    thread_local std::vector<uint16_t> st16;
+    thread_local std::vector<uint32_t> stk;
+    struct Shrink {
+        std::vector<uint8_t> &a; std::vector<uint16_t> &b; std::vector<uint32_t> &c;
+        ~Shrink()
+        {
+            if (c.size() > ((size_t)1 << 21) + ((size_t)1 << 16)) { std::vector<uint8_t>().swap(a); std::vector<uint16_t>().swap(b); std::vector<uint32_t>().swap(c); }
+        }
+    } shrink{st8, st16, stk};
+    if (hi <= 63) flood_walk<uint8_t, 6>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st8, stk);
+    else flood_walk<uint16_t, 9>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st16, stk);
 }
 
 // ---- the pool ----------------------------------------------------------------------------------------------------------------

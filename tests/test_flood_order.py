@@ -13,6 +13,8 @@ def _planes(S):
     yield 8, S.synth.gray(S.synth.stext_bgr(3, 200, 150))
     yield 8, rng.integers(200, 256, (40, 64), dtype=np.uint8)                 # sentinel walls everywhere
     yield 2, rng.integers(0, 256, (50, 70), dtype=np.uint8)
+    yield 4, rng.integers(0, 256, (50, 70), dtype=np.uint8)                   # sentinel level 64: the last one that needs the two-byte state
+    yield 5, rng.integers(0, 256, (50, 70), dtype=np.uint8)                   # sentinel level 52: one byte of state
     yield 1, rng.integers(0, 256, (33, 47), dtype=np.uint8)                   # 256 levels, no sentinel
     yield 16, np.kron(rng.integers(0, 256, (12, 20), dtype=np.uint8), np.ones((5, 5), np.uint8))
     wall = rng.integers(0, 250, (30, 30), dtype=np.uint8)
