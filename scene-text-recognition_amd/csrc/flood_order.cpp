@@ -124,6 +124,15 @@ void flood_walk(const uint8_t *pix, int w, int h, int64_t stride, int invert, fl
     uint32_t cur = S + 1u, edge = 0, cl = st[cur] & LEVEL;
     mark(cur, st[cur]);
     const int32_t off[4] = {1, (int32_t)S, -1, -(int32_t)S};
+    // The newest push is held back in registers (dv at level dl): in a flat region a step pushes one neighbour and the next step pops that very entry, and
+    // through the stack that is a store and two dependent loads on the walk's critical path.  `priority` describes the stacks in memory only.
+    uint32_t dv = 0, dl = 0;
+    bool     held = false;
+    auto push = [&](uint32_t l, uint32_t v) {
+        if (l >= HI) return;                                   // (the bucket of the sentinel level is never popped)
+        if (held) { stk[top[dl]++] = dv; if (dl < priority) priority = dl; }
+        dv = v; dl = l; held = true;
+    };
     while (remaining != 0) {
         bool descended = false;
         // the four neighbours' states at once (independent loads), then only the ones not accessible yet, in edge order: marking one does not change another
@@ -137,22 +146,25 @@ void flood_walk(const uint8_t *pix, int w, int h, int64_t stride, int invert, fl
             const T        s = sn[k];
             mark(q, s);
             const uint32_t l = s & LEVEL;
-            if (l >= cl) {
-                if (l < HI) stk[top[l]++] = q << 3;
-                if (l < priority) priority = l;
-            } else {
-                if (cl < HI) stk[top[cl]++] = (cur << 3) | (k + 1u);
-                if (cl < priority) priority = cl;
+            if (l >= cl) push(l, q << 3);
+            else {
+                push(cl, (cur << 3) | (k + 1u));
                 cur = q; cl = l; edge = 0;
                 descended = true;
                 break;
             }
         }
         if (descended) continue;
-        if (priority == HI) break;
-        const uint32_t v = stk[--top[priority]];
-        cur = v >> 3; edge = v & 7u; cl = priority;
-        while (priority < HI && top[priority] == base[priority]) ++priority;
+        uint32_t v;
+        if (held && dl <= priority) { v = dv; cl = dl; held = false; }       // the entry held back is the newest of the lowest level
+        else {
+            if (held) { stk[top[dl]++] = dv; held = false; }                   // (dl > priority: it stays where it would have been)
+            if (priority == HI) break;
+            v = stk[--top[priority]];
+            cl = priority;
+            while (priority < HI && top[priority] == base[priority]) ++priority;
+        }
+        cur = v >> 3; edge = v & 7u;
     }
 }
 
