@@ -276,14 +276,36 @@ try {
     const int kc = (int)align_up((size_t)(k - 1), 64);
     std::vector<double> coef_t((size_t)l_pad * kc, 0.0);      // (l_pad rows: the walk reads eight rows at a time)
     for (int j = 0; j < k - 1; ++j) for (int i = 0; i < l; ++i) coef_t[(size_t)i * kc + j] = coef[(size_t)j * l + i];
-    std::vector<uint16_t> pair_ij((size_t)np);
-    for (int i = 0, p = 0; i < k; ++i) for (int j = i + 1; j < k; ++j, ++p) pair_ij[(size_t)p] = (uint16_t)((i << 8) | j);
-    const size_t o_pij = take((size_t)np * 2);
+    // what a lane of k_svm_couple needs about its class pair in one 32-byte record; padded to whole passes of the wave with pairs that have no support vectors
+    const size_t np_pad = align_up((size_t)np, 512);
+    std::vector<SvmPair> pairs(np_pad, SvmPair{0, 0, 0, 0, 0, 1, 0, 0});
+    for (int i = 0, p = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j, ++p)       // (an empty last class starts at l: keep the idle loads inside the tables)
+            pairs[(size_t)p] = SvmPair{std::min(start[i], l - 1), insv[i], std::min(start[j], l - 1), insv[j], i, j, 0, 0};
+    const size_t o_pij = take(np_pad * sizeof(SvmPair));
+    // k <= 65: the coefficients as k_svm_couple's row passes read them (ocr_kernels.h)
+    int msv = 0;
+    for (int i = 0; i < k; ++i) msv = std::max(msv, insv[i]);
+    const int mp = svm_rows_per_class(msv);
+    std::vector<double> rows;
+    if (k <= 65) {
+        if ((size_t)k * 2 * mp * 64 * 8 > ((size_t)1 << 30))
+            return fail(c, STR_ER_EFORMAT, "svm model: a class with so many support vectors that the per-class coefficient rows exceed 1 GB");
+        rows.assign((size_t)k * 2 * mp * 64, 0.0);
+        for (int i = 0; i < k; ++i)
+            for (int b = 0; b + 1 < k; ++b) {                     // b = the row of sv_coef, and the second class b + 1
+                double *r1 = &rows[((size_t)(2 * i) * mp) * 64 + b], *r2 = r1 + (size_t)mp * 64;
+                for (int r = 0; r < insv[i]; ++r) r1[(size_t)r * 64] = coef[(size_t)b * l + start[i] + r];
+                if (i < k - 1) for (int r = 0; r < insv[b + 1]; ++r) r2[(size_t)r * 64] = coef[(size_t)i * l + start[b + 1] + r];
+            }
+    }
+    const size_t o_rows = take(rows.size() * 8);
     const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
                  o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);
     std::vector<uint8_t> blob(off);
     std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
-    std::memcpy(&blob[o_pij], pair_ij.data(), (size_t)np * 2);
+    std::memcpy(&blob[o_pij], pairs.data(), np_pad * sizeof(SvmPair));
+    if (!rows.empty()) std::memcpy(&blob[o_rows], rows.data(), rows.size() * 8);
     std::memcpy(&blob[o_coef], coef.data(), coef.size() * 8); std::memcpy(&blob[o_coeft], coef_t.data(), coef_t.size() * 8); std::memcpy(&blob[o_rho], rho.data(), np * 8);
     std::memcpy(&blob[o_pa], pa.data(), np * 8); std::memcpy(&blob[o_pb], pb.data(), np * 8);
     std::memcpy(&blob[o_lab], ilab.data(), k * 4); std::memcpy(&blob[o_nsv], insv.data(), k * 4); std::memcpy(&blob[o_start], start.data(), k * 4);
@@ -297,7 +319,8 @@ try {
     SvmDev m{};
     m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
     m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
-    m.pair_ij = reinterpret_cast<const uint16_t *>(b + o_pij);
+    m.pairs = reinterpret_cast<const SvmPair *>(b + o_pij);
+    m.coef_rows = rows.empty() ? nullptr : reinterpret_cast<const double *>(b + o_rows); m.msv = msv; m.mp = mp;
     m.kc = kc; m.coef_t = reinterpret_cast<const double *>(b + o_coeft);
     m.coef = reinterpret_cast<const double *>(b + o_coef); m.rho = reinterpret_cast<const double *>(b + o_rho);
     m.probA = reinterpret_cast<const double *>(b + o_pa); m.probB = reinterpret_cast<const double *>(b + o_pb);

@@ -9,6 +9,9 @@
 
 namespace str_er {
 
+// a class pair i < j as k_svm_couple reads it: first support vector and count of both classes
+struct alignas(16) SvmPair { int32_t sa, na, sb, nb, ci, cj, pad0, pad1; };
+
 struct SvmDev {
     int32_t k, l, l_pad, dim, dpad;
     int32_t kc;             // row length of coef_t: k - 1 rounded up to 64 (64 or 128)
@@ -19,7 +22,12 @@ struct SvmDev {
     const double *coef_t;   // [l_pad x kc]              coef_t[q][b] = sv_coef[b][q], zero padded: one coalesced row per support vector
     const double *rho, *probA, *probB;   // [k(k-1)/2]
     const int32_t *label, *nsv, *start;  // [k]
-    const uint16_t *pair_ij;             // [k(k-1)/2]  (i << 8) | j of every class pair i < j, in libsvm's order
+    // k <= 65 only: coef_rows[i][h][r][b], r < mp, b < 64 -- h = 0: sv_coef[b][start[i] + r] (class i's r-th support vector against class b + 1), zero for
+    // r >= nr_sv[i]; h = 1: sv_coef[i][start[b + 1] + r] (class b + 1's r-th support vector against class i), zero for r >= nr_sv[b + 1].  msv = the largest
+    // nr_sv, mp = svm_rows_per_class(msv)
+    const double *coef_rows;
+    int32_t msv, mp;
+    const SvmPair *pairs;                // [k(k-1)/2 rounded up to 512]  every class pair i < j, in libsvm's order
 };
 
 // Where the boxes of a call come from: explicit boxes on one device plane (single-stage API), or records
@@ -68,6 +76,8 @@ void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
 // ... its two halves: the RBF kernel matrix buf.kv; decision values + coupling from buf.kv
 void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
 void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
+// rows per class of SvmDev::coef_rows for a model whose largest class has msv support vectors (the kernel's builds: 5 exactly -- the shape of the reference's training set -- or eights)
+inline int svm_rows_per_class(int msv) { return msv == 5 ? 5 : (msv + 7) / 8 * 8; }
 
 // f64 feature vectors (API entry str_er_svm_predict_probability) -> buf.xf / buf.xnorm
 void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBuf &buf, const SvmDev &m);

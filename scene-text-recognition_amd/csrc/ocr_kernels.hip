@@ -16,6 +16,8 @@
 // checked against the CPU restatement the tests use ("parity unpinned").
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <float.h>
 #include <stdint.h>
 
@@ -489,6 +491,14 @@ __device__ __forceinline__ double bcast(double v, int src)
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// (double)x that stays where it is written: the rows of Q are loop invariants of the sweeps, and hoisted out as doubles they no longer fit the registers
+__device__ __forceinline__ double widen_here(float x)
+{
+    double d;
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -527,158 +537,356 @@ __device__ __forceinline__ double rcp_nr(double x)
 // is evaluated.  The same fixed point, the same sweeps.
 // MODE 0: k <= 64.  MODE 1: k = 65 (the reference's 65 characters): the one class beyond the 64 lanes is carried as a wave-uniform value in
 // every lane -- a second class register per lane would double the vector work of every step for one useful lane.  MODE 2: 66 <= k <= 125.
-template <int MODE>
-__global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv, int l_pad, SvmDev m, double *__restrict__ dec_out,
+// 4 waves per SIMD = the 16 waves per compute unit the LDS allows: 128 registers (the compiler wants 136 and parks 7 values that live across a
+// pass in scratch, outside the loops)
+// LDS of one box: QI[2 k], D[k], V[k (k + 1) / 2] floats, rounded up to 16 bytes
+__host__ __device__ inline size_t svm_couple_lds_doubles(int k) { return ((size_t)3 * k + ((size_t)k * (k + 1) / 2 + 1) / 2 + 1) & ~(size_t)1; }
+#ifndef SVM_COUPLE_WAVES
+#define SVM_COUPLE_WAVES 4
+#endif
+#if SVM_COUPLE_WAVES > 0
+#define SVM_COUPLE_OCC __attribute__((amdgpu_waves_per_eu(SVM_COUPLE_WAVES, SVM_COUPLE_WAVES)))
+#else
+#define SVM_COUPLE_OCC
+#endif
+// SVM_COUPLE_WPB boxes (waves) per workgroup, in step through the row passes (a barrier per pass): the passes stream the whole coefficient table
+// (333 KB for the reference's shape) per box, far more than the 32 KB first-level cache keeps -- waves of one compute unit that read the same rows
+// at the same time share the lines, waves that drift apart fetch them from the second level each on its own (6.4 GB a batch: the kernel's bound)
+#ifndef SVM_COUPLE_WPB
+#define SVM_COUPLE_WPB 1
+#endif
+constexpr int svm_couple_wpb(int mode) { return mode == 2 ? 1 : SVM_COUPLE_WPB; }      // (66+ classes: up to 34 KB a box, one box a workgroup)
+template <int MODE, int MSV>
+__global__ __launch_bounds__(64 * svm_couple_wpb(MODE)) SVM_COUPLE_OCC void k_svm_couple(const double *__restrict__ kv, int l_pad, int n, SvmDev m, double *__restrict__ dec_out,
                                                    double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest)
 {
     constexpr bool TWO = MODE == 2, TAIL = MODE == 1;
-    // LDS: QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps; V[np] pairwise table (f32)
+    // LDS: QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps; V[k (k + 1) / 2] pairwise table (f32)
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
-    const int k = m.k, np = k * (k - 1) / 2, kc = m.kc, l = m.l;
-    double *QI = lds_d, *D = QI + 2 * k;
+    const int k = TAIL ? 65 : m.k, np = k * (k - 1) / 2, nv = k * (k + 1) / 2, kc = m.kc, l = m.l;
+    constexpr int WPB = svm_couple_wpb(MODE);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // (wave-uniform, and the compiler must know it: the box's rows are read with scalar loads)
+    const int v_raw = blockIdx.x * WPB + wv, v = min(v_raw, n - 1);   // (a wave beyond the last box repeats it and stores nothing: it keeps the barriers)
+    const bool live = v_raw < n;
+    double *QI = lds_d + (size_t)wv * svm_couple_lds_doubles(k), *D = QI + 2 * k;
     float  *V = reinterpret_cast<float *>(D + k);
-    const int v = blockIdx.x, lane = threadIdx.x;
     const double *kr = kv + (size_t)v * l_pad;
-    auto rb = [k](int i) -> int { return i * k - i * (i + 1) / 2 - i - 1; };
+    auto rb = [&](int i) -> int { return i * k - i * (i + 1) / 2; };         // row i = columns i .. k - 1 at rb(i) + j
     const int  t0 = lane, t1 = lane + 64;
     const bool on0 = MODE != 0 || t0 < k, on1 = TWO && t1 < k;         // (k >= 64: every lane has a class)
-    const int  rb0 = rb(t0), rb1 = rb(t1);
+    const int  t0c = on0 ? t0 : 0;                                      // (an idle lane walks class 0's row and is masked where it matters)
+    const int  rb0 = rb(t0c), rb1 = rb(t1);
+    if (on0) V[rb0 + t0] = 1.f;                                         // r_tt := 1: its square (1 - r_tt)^2 and its product -(1 - r_tt) r_tt vanish without a mask
+    if (on1) V[rb1 + t1] = 1.f;
+    if (TAIL) V[rb(64) + 64] = 1.f;                                     // (every lane writes the same word)
     // ---- decision values, r_ij = sigmoid_predict(dec, A, B) clamped to [1e-7, 1 - 1e-7] (src/svm.cpp:2603-2611)
-    constexpr int PC = 8;
-    const double  min_prob = 1e-7;
-    for (int c0 = 0; c0 < np; c0 += 64 * PC) {
-        int    ci[PC], cj[PC], sa[PC], na[PC], sb[PC], nb[PC];
-        double sum[PC];
-        int    qa = 0, qb = 0;
+    const double min_prob = 1e-7;
+    // sigmoid_predict (src/svm.cpp:1818-1826): exp(-f) / (1 + exp(-f)) for f >= 0, 1 / (1 + exp(f)) otherwise -- one exp of -|f| and one reciprocal serve
+    // both.  exp on (-inf, 0] without the library's range cases: 2^n e^r, |r| <= ln 2 / 2, degree-11 Taylor (3e-17 relative), below e^-40 the result is
+    // under the 1e-7 clamp whatever it is.  1 ulp here and in the reciprocal; the table entry is an f32.
+    auto pair_prob = [min_prob](double fApB) -> double {
+        const double x = fmax(-fabs(fApB), -40.0), nn = __builtin_rint(x * 1.4426950408889634);
+        double       r = __builtin_fma(nn, -6.93147180369123816490e-01, x);
+        r = __builtin_fma(nn, -1.90821492927058770002e-10, r);
+        double e = 1.0 / 39916800.0;
+        e = __builtin_fma(e, r, 1.0 / 3628800.0); e = __builtin_fma(e, r, 1.0 / 362880.0); e = __builtin_fma(e, r, 1.0 / 40320.0);
+        e = __builtin_fma(e, r, 1.0 / 5040.0); e = __builtin_fma(e, r, 1.0 / 720.0); e = __builtin_fma(e, r, 1.0 / 120.0);
+        e = __builtin_fma(e, r, 1.0 / 24.0); e = __builtin_fma(e, r, 1.0 / 6.0); e = __builtin_fma(e, r, 0.5);
+        e = __builtin_fma(e, r, 1.0); e = __builtin_fma(e, r, 1.0);
+        const double ex = __builtin_amdgcn_ldexp(e, (int)nn);
+        double sg = (fApB >= 0 ? ex : 1.0) * rcp_nr(1.0 + ex);
+        sg = sg > min_prob ? sg : min_prob;
+        return sg < 1 - min_prob ? sg : 1 - min_prob;
+    };
+    if constexpr (!TWO) {
+        // k <= 65: a lane is a second class j = lane + 1, a pass is a first class i (a row of the pair table): class i's kernel values are wave-uniform
+        // (scalar loads), its coefficients one contiguous row per support vector (coef_rows[i][0], zero beyond nr_sv[i]); class j's kernel values are the
+        // same for every row -- MSV registers, loaded once -- and its coefficients for first class i again one row per rank (coef_rows[i][1], zero beyond
+        // nr_sv[j]).  Every load is a full 512-byte line set off a uniform base: the p-indexed walk below issued 640 scattered 8-byte loads per lane (20
+        // cache lines an instruction) and was bound by the address pipeline, not by arithmetic.  The sums run in libsvm's order (adding 0 K is exact).
+        // Rows i and k - 1 - i have 64 pairs between them (k = 65) and share the loads in flight, the sigmoid and the table write.
+        constexpr int CH = MSV > 0 ? MSV : 8;
+        const int     sj = m.start[min(lane + 1, k - 1)];
+        double        K2[CH];
 #pragma unroll
-        for (int u = 0; u < PC; ++u) {
-            const int  p = c0 + 64 * u + lane;
-            const bool ok = p < np;
-            const int  ij = ok ? (int)m.pair_ij[p] : 0;
-            ci[u] = ij >> 8; cj[u] = ij & 255;
-            sa[u] = m.start[ci[u]]; na[u] = ok ? m.nsv[ci[u]] : 0;
-            sb[u] = m.start[cj[u]]; nb[u] = ok ? m.nsv[cj[u]] : 0;
-            sum[u] = 0;
-            qa = max(qa, na[u]); qb = max(qb, nb[u]);
-        }
-        for (int o = 32; o > 0; o >>= 1) { qa = max(qa, __shfl_xor(qa, o)); qb = max(qb, __shfl_xor(qb, o)); }
-#pragma unroll SVM_Q_UNROLL
-        for (int q = 0; q < qa; ++q) {
+        for (int u = 0; u < CH; ++u) K2[u] = kr[min(sj + u, l - 1)];      // (MSV = 0, more than 8 ranks: read again per row instead)
+        const double *tab = m.coef_rows + lane;
+        auto pb = [&](int r) -> int { return r * (k - 1) - r * (r - 1) / 2 - r - 1; };      // pair (r, j) is libsvm's pair number pb(r) + j
+        // pass a: rows a and b = k - 1 - a.  Lanes >= a: pair (a, lane + 1); lanes < a: pair (b, lane + b + 1), summed by lane + b
+        auto pair_of = [&](int a, bool &ra, bool &on, int &row) -> int {
+            const int b = k - 1 - a;
+            ra = lane >= a; on = ra ? lane < k - 1 : b != a; row = ra ? a : b;
+            return on ? (ra ? pb(a) + lane + 1 : pb(b) + lane + b + 1) : 0;
+        };
+        auto finish = [&](int a, double sa, double sb, double rho, double pA, double pB) {
+            bool ra, on; int row;
+            const int    p = pair_of(a, ra, on, row);
+            const double so = __shfl(sb, (lane + k - 1 - a) & 63);
+            if (on) {
+                const double d = (ra ? sa : so) - rho;
+                if (dec_out && live) dec_out[(size_t)v * np + p] = d;
+                V[p + row + 1] = (float)pair_prob(d * pA + pB);           // (rb(row) + j: the rows have a diagonal slot)
+            }
+        };
+        const int n_pass = (k - 1) / 2 + 1;
+        if constexpr (MSV > 0) {
+            // a pass is one memory round trip (46 values a lane at MSV = 5): the next pass's loads are issued as soon as this one's sums are taken,
+            // ahead of its sigmoid and table write
+            struct Loads { double c[4][CH], kq[2][CH], rho, pA, pB; };
+            auto issue = [&](int a, Loads &L) {
+                const int b = k - 1 - a, sa = m.start[a], sb = m.start[b];
+                const double *ta = tab + (size_t)(2 * a) * MSV * 64, *tb = tab + (size_t)(2 * b) * MSV * 64;
 #pragma unroll
-            for (int u = 0; u < PC; ++u)
-                if (q < na[u]) sum[u] += m.coef_t[(size_t)(sa[u] + q) * kc + cj[u] - 1] * kr[sa[u] + q];
-        }
-#pragma unroll SVM_Q_UNROLL
-        for (int q = 0; q < qb; ++q) {
+                for (int u = 0; u < CH; ++u) {
+                    L.c[0][u] = ta[(size_t)u * 64]; L.c[1][u] = ta[(size_t)(MSV + u) * 64];
+                    L.c[2][u] = tb[(size_t)u * 64]; L.c[3][u] = tb[(size_t)(MSV + u) * 64];
+                    L.kq[0][u] = kr[min(sa + u, l - 1)]; L.kq[1][u] = kr[min(sb + u, l - 1)];
+                }
+                bool ra, on; int row;
+                const int p = pair_of(a, ra, on, row);
+                L.rho = m.rho[p]; L.pA = m.probA[p]; L.pB = m.probB[p];
+            };
+            Loads L;
+            issue(0, L);
+            for (int a = 0; a < n_pass; ++a) {
+                double sa = 0, sb = 0;
 #pragma unroll
-            for (int u = 0; u < PC; ++u)
-                if (q < nb[u]) sum[u] += m.coef[(size_t)ci[u] * l + sb[u] + q] * kr[sb[u] + q];
-        }
-        double rho[PC], pA[PC], pB[PC];
+                for (int u = 0; u < CH; ++u) sa = __builtin_fma(L.c[0][u], L.kq[0][u], sa);
 #pragma unroll
-        for (int u = 0; u < PC; ++u) {
-            const int p = min(c0 + 64 * u + lane, np - 1);
-            rho[u] = m.rho[p]; pA[u] = m.probA[p]; pB[u] = m.probB[p];
-        }
+                for (int u = 0; u < CH; ++u) sa = __builtin_fma(L.c[1][u], K2[u], sa);
 #pragma unroll
-        for (int u = 0; u < PC; ++u) {
-            const int p = c0 + 64 * u + lane;
-            if (p < np) {
-                const double d = sum[u] - rho[u];
-                if (dec_out) dec_out[(size_t)v * np + p] = d;
-                const double fApB = d * pA[u] + pB[u];
-                // sigmoid_predict (src/svm.cpp:1818-1826): exp(-f) / (1 + exp(-f)) for f >= 0, 1 / (1 + exp(f)) otherwise -- one exp of -|f| serves both
-                const double ex = exp(-fabs(fApB));
-                double sg = fApB >= 0 ? ex / (1.0 + ex) : 1.0 / (1 + ex);
-                sg = sg > min_prob ? sg : min_prob;
-                sg = sg < 1 - min_prob ? sg : 1 - min_prob;
-                V[p] = (float)sg;
+                for (int u = 0; u < CH; ++u) sb = __builtin_fma(L.c[2][u], L.kq[1][u], sb);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) sb = __builtin_fma(L.c[3][u], K2[u], sb);
+                const double rho = L.rho, pA = L.pA, pB = L.pB;
+                if (WPB > 1) __syncthreads();                             // (the workgroup's waves ask for the same rows together)
+                if (a + 1 < n_pass) issue(a + 1, L);
+                finish(a, sa, sb, rho, pA, pB);
+            }
+        } else {
+            const int MP = m.mp;
+            auto row_sum = [&](int i) -> double {
+                const int     si = m.start[i];
+                const double *t1 = tab + (size_t)(2 * i) * MP * 64, *t2 = t1 + (size_t)MP * 64;
+                double        sum = 0;
+                for (int m0 = 0; m0 < MP; m0 += CH) {
+                    double c[CH], kq[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) { c[u] = t1[(size_t)(m0 + u) * 64]; kq[u] = kr[min(si + m0 + u, l - 1)]; }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) sum = __builtin_fma(c[u], kq[u], sum);
+                }
+                for (int m0 = 0; m0 < MP; m0 += CH) {
+                    double c[CH], kq[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) { c[u] = t2[(size_t)(m0 + u) * 64]; kq[u] = kr[min(sj + m0 + u, l - 1)]; }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) sum = __builtin_fma(c[u], kq[u], sum);
+                }
+                return sum;
+            };
+            for (int a = 0; a < n_pass; ++a) {
+                bool ra, on; int row;
+                if (WPB > 1) __syncthreads();
+                const int    p = pair_of(a, ra, on, row);
+                const double rho = m.rho[p], pA = m.probA[p], pB = m.probB[p];
+                const double sa = row_sum(a), sb = row_sum(k - 1 - a);
+                finish(a, sa, sb, rho, pA, pB);
             }
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- one walk over j for every class t of this lane: Q_tt = sum_{j != t} r_jt^2 and B_t = sum_j Q_tj / k for p = 1 / k, j ascending
-    // (r_jt = V(j, t) for j < t, 1 - V(t, j) for j > t; Q_tj = -r_jt r_tj).  Branch-free: the address is clamped, the term masked.
-    const double ik = 1.0 / k;
-    double qd0 = 0, qd1 = 0, B0 = 0, B1 = 0;
-    for (int j = 0; j < k; ++j) {
-        const int rbj = rb(j);
+    } else {
+        // PCN pairs of a lane at a time (pairs c0 + 64 u + lane).  Branch-free: a rank beyond the class reads the class's first support vector and
+        // leaves the sum alone -- written as `if (q < na[u])` the compiler gives every pair its own block with a full wait on its two loads: 16
+        // dependent memory round trips per rank instead of 16 loads in flight (and 24 more per pass for the class tables).
+        auto pass = [&](int c0, auto pcn) {
+            constexpr int PCN = decltype(pcn)::value;
+            int    ci[PCN], cj[PCN], sa[PCN], na[PCN], sb[PCN], nb[PCN];
+            double sum[PCN];
+            int    qa = 0, qb = 0;
+    #pragma unroll
+            for (int u = 0; u < PCN; ++u) {
+                const SvmPair pr = m.pairs[c0 + 64 * u + lane];               // (the table is padded to whole waves with pairs without support vectors)
+                ci[u] = pr.ci; cj[u] = pr.cj;
+                sa[u] = pr.sa; na[u] = pr.na;
+                sb[u] = pr.sb; nb[u] = pr.nb;
+                sum[u] = 0;
+                qa = max(qa, na[u]); qb = max(qb, nb[u]);
+            }
+            for (int o = 32; o > 0; o >>= 1) { qa = max(qa, __shfl_xor(qa, o)); qb = max(qb, __shfl_xor(qb, o)); }
+    #pragma unroll SVM_Q_UNROLL
+            for (int q = 0; q < qa; ++q) {
+                double c[PCN], kq[PCN];
+    #pragma unroll
+                for (int u = 0; u < PCN; ++u) {
+                    const int r = sa[u] + (q < na[u] ? q : 0);
+                    c[u] = m.coef_t[(size_t)r * kc + cj[u] - 1];
+                    kq[u] = kr[r];
+                }
+    #pragma unroll
+                for (int u = 0; u < PCN; ++u) { const double t = sum[u] + c[u] * kq[u]; sum[u] = q < na[u] ? t : sum[u]; }
+            }
+    #pragma unroll SVM_Q_UNROLL
+            for (int q = 0; q < qb; ++q) {
+                double c[PCN], kq[PCN];
+    #pragma unroll
+                for (int u = 0; u < PCN; ++u) {
+                    const int r = sb[u] + (q < nb[u] ? q : 0);
+                    c[u] = m.coef[(size_t)ci[u] * l + r];
+                    kq[u] = kr[r];
+                }
+    #pragma unroll
+                for (int u = 0; u < PCN; ++u) { const double t = sum[u] + c[u] * kq[u]; sum[u] = q < nb[u] ? t : sum[u]; }
+            }
+            double rho[PCN], pA[PCN], pB[PCN];
+    #pragma unroll
+            for (int u = 0; u < PCN; ++u) {
+                const int p = min(c0 + 64 * u + lane, np - 1);
+                rho[u] = m.rho[p]; pA[u] = m.probA[p]; pB[u] = m.probB[p];
+            }
+    #pragma unroll
+            for (int u = 0; u < PCN; ++u) {
+                const int p = c0 + 64 * u + lane;
+                if (p < np) {
+                    const double d = sum[u] - rho[u];
+                    if (dec_out && live) dec_out[(size_t)v * np + p] = d;
+                    V[p + ci[u] + 1] = (float)pair_prob(d * pA[u] + pB[u]);  // (rb(i) + j: the rows have a diagonal slot)
+                }
+            }
+        };
         {
-            const int    idx = j < t0 ? rbj + t0 : rb0 + j;
-            const double e = (double)V[min(max(idx, 0), np - 1)], r = j < t0 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
-            const bool   on = on0 && j != t0;
-            qd0 += on ? r * r : 0.0;
-            B0 += on ? w * ik : 0.0;
-        }
-        if (TWO) {
-            const int    idx = j < t1 ? rbj + t1 : rb1 + j;
-            const double e = (double)V[min(max(idx, 0), np - 1)], r = j < t1 ? e : 1.0 - e, w = (-(1.0 - e)) * e;
-            const bool   on = on1 && j != t1;
-            qd1 += on ? r * r : 0.0;
-            B1 += on ? w * ik : 0.0;
+            constexpr int PC = 8;
+            int c0 = 0;
+            for (; c0 + 64 * PC <= np; c0 += 64 * PC) pass(c0, std::integral_constant<int, PC>{});
+            for (; c0 < np; c0 += 64) pass(c0, std::integral_constant<int, 1>{});       // (k = 65: 2080 pairs = 4 passes of 512 + 32)
         }
     }
-    B0 += on0 ? qd0 * ik : 0.0;
-    B1 += on1 ? qd1 * ik : 0.0;
-    // the uniform class 64 (MODE 1): lane j holds its pair (j, 64); sums over the wave (the order of the additions differs from the reference's: 1 ulp)
-    double qdT = 0, BT = 0, pT = 0;
-    if (TAIL) {
-        const double e = (double)V[rb0 + 64];
-        qdT = wave_sum(e * e);
-        BT = wave_sum(((-(1.0 - e)) * e) * ik) + qdT * ik;
-        pT = ik;
-    }
-    if (on0) { QI[2 * t0] = qd0; QI[2 * t0 + 1] = 1.0 / qd0; }
-    if (on1) { QI[2 * t1] = qd1; QI[2 * t1 + 1] = 1.0 / qd1; }
-    if (TAIL) { QI[128] = qdT; QI[129] = 1.0 / qdT; }                  // (every lane writes the same words)
     __builtin_amdgcn_wave_barrier();
-    // ---- Q_tj = -r_jt r_tj = -(1 - V) V
-    for (int p = lane; p < np; p += 64) { const double e = (double)V[p]; V[p] = (float)((-(1.0 - e)) * e); }
-    __builtin_amdgcn_wave_barrier();
-    double p0 = on0 ? ik : 0.0, p1 = on1 ? ik : 0.0;
-    double A = wave_sum(p0 * B0 + p1 * B1) + pT * BT;
+    const double ik = 1.0 / k;
     const int    max_iter = k > 100 ? k : 100;
     const double eps = 0.005 / k;
-    for (int iter = 0; iter < max_iter; ++iter) {
-        double err = on0 ? fabs(B0 - A) : 0.0;
-        if (on1) err = fmax(err, fabs(B1 - A));
-        for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
-        if (TAIL) err = fmax(err, fabs(BT - A));
-        if (err < eps) break;
-        double S = 1.0;
-        // one coordinate step (the step of class t on its own B_t -- the diagonal -- is applied after the sweep: nothing reads B_t again before)
-        auto step = [&](int t, double Bt) {
-            const double2 qi = *reinterpret_cast<const double2 *>(QI + 2 * t);
-            const double  d = (rcp_nr(S) * A - Bt) * qi.y;
-            A = A + d * (d * qi.x + 2.0 * Bt);
-            S += d;
-            D[t] = d;                                              // (every lane writes the same word)
-            const int rbt = rb(t);
+    double p0, p1 = 0, pT = 0;
+    if constexpr (!TWO) {
+        // ---- k <= 65: lane t keeps row t of Q in registers (f32; Q_tj = -r_jt r_tj, r_jt = V(j, t) for j < t and 1 - V(t, j) for j > t).  One
+        // unrolled walk over j gives the row, Q_tt = sum_j r_jt^2 and B_t = sum_j Q_tj / k for p = 1 / k; the sweeps then read no table at all.
+        constexpr int NR = TAIL ? 65 : 64;
+        float  Qr[NR];
+        double qd0 = 0, B0 = 0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            Qr[j] = 0.f;
+            if (MODE != 0 || j < k) {
+                const float  ea = V[rb(j) + t0c], eb = V[rb0 + j];
+                const bool   lo = j < t0c;
+                const double e = (double)(lo ? ea : eb), om = 1.0 - e, r = lo ? e : om, w = (-om) * e;
+                qd0 = __builtin_fma(r, r, qd0);
+                B0 = __builtin_fma(w, ik, B0);
+                Qr[j] = (float)w;
+            }
+        }
+        B0 = __builtin_fma(qd0, ik, B0);
+        // the uniform class 64 (MODE 1): lane j holds its pair (j, 64); sums over the wave (the order of the additions differs from the reference's: 1 ulp)
+        double qdT = 0, BT = 0;
+        if (TAIL) {
+            const double e = (double)V[rb0 + 64];
+            qdT = wave_sum(e * e);
+            BT = wave_sum(((-(1.0 - e)) * e) * ik) + qdT * ik;
+            pT = ik;
+        }
+        if (on0) { QI[2 * t0] = qd0; QI[2 * t0 + 1] = 1.0 / qd0; }
+        if (TAIL) { QI[128] = qdT; QI[129] = 1.0 / qdT; }              // (every lane writes the same words)
+        __builtin_amdgcn_wave_barrier();
+        p0 = on0 ? ik : 0.0;
+        double A = wave_sum(p0 * B0) + pT * BT;
+        for (int iter = 0; iter < max_iter; ++iter) {
+            double err = on0 ? fabs(B0 - A) : 0.0;
+            for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+            if (TAIL) err = fmax(err, fabs(BT - A));
+            if (err < eps) break;
+            double S = 1.0;
+            // one coordinate step (the step of class t on its own B_t -- the diagonal -- is applied after the sweep: nothing reads B_t again before).
+            // A, S, B and p follow the d that was applied, whatever it is: the hardware's 1 / S (24 bits) makes the step a coordinate step with a
+            // relaxation factor 1 +- 1e-7 -- the same fixed point, the stopping test is evaluated on exact quantities.
+            auto step = [&](double Bt, const double2 qi) -> double {
+                const double d = __builtin_fma(__builtin_amdgcn_rcp(S), A, -Bt) * qi.y;
+                A = __builtin_fma(d, __builtin_fma(d, qi.x, Bt + Bt), A);
+                S += d;
+                return d;
+            };
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                if (MODE != 0 || t < k) {                              // (no break: the loop must unroll for Qr to stay in registers)
+                    const double d = step(bcast(B0, t), *reinterpret_cast<const double2 *>(QI + 2 * t));
+                    D[t] = d;                                          // (every lane writes the same word)
+                    B0 = __builtin_fma(d, widen_here(Qr[t]), B0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double dt = on0 ? D[t0] : 0.0;                       // this lane's class's step
+            if (TAIL) {
+                // class 64's B is read by its own step only: the 64 updates d_t Q(64, t) are one sum over the lanes
+                BT += wave_sum(dt * widen_here(Qr[NR - 1]));
+                const double d = step(BT, *reinterpret_cast<const double2 *>(QI + 128));
+                B0 = __builtin_fma(d, widen_here(Qr[NR - 1]), B0);
+                pT += d; BT = __builtin_fma(d, qdT, BT);
+            }
+            const double sg = rcp_nr(S);
+            if (on0) { p0 += dt; B0 = __builtin_fma(dt, qd0, B0); }
+            p0 *= sg; B0 *= sg; A *= sg * sg; pT *= sg; BT *= sg;
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // ---- 66 <= k <= 125: two classes per lane, Q's off-diagonal entries replace the r_ij in the table
+        // one walk over j for every class t of this lane: Q_tt = sum_{j != t} r_jt^2 and B_t = sum_j Q_tj / k for p = 1 / k, j ascending
+        double qd0 = 0, qd1 = 0, B0 = 0, B1 = 0;
+        for (int j = 0; j < k; ++j) {
+            const int rbj = rb(j);
             {
-                const int idx = t0 > t ? rbt + t0 : rb0 + t;
-                const float e = V[min(max(idx, 0), np - 1)];
-                B0 = __builtin_fma(d, (double)((on0 && t0 != t) ? e : 0.f), B0);
+                const double e = (double)V[j < t0 ? rbj + t0 : rb0 + j], om = 1.0 - e, r = j < t0 ? e : om;
+                qd0 = __builtin_fma(r, r, qd0);
+                B0 = __builtin_fma((-om) * e, ik, B0);
             }
-            if (TWO) {
-                const int idx = t1 > t ? rbt + t1 : rb1 + t;
-                const float e = V[min(max(idx, 0), np - 1)];
-                B1 = __builtin_fma(d, (double)((on1 && t1 != t) ? e : 0.f), B1);
+            {
+                const double e = (double)V[min(j < t1 ? rbj + t1 : rb1 + j, nv - 1)], om = 1.0 - e, r = j < t1 ? e : om;
+                qd1 = on1 ? __builtin_fma(r, r, qd1) : 0.0;
+                B1 = on1 ? __builtin_fma((-om) * e, ik, B1) : 0.0;
             }
-            if (TAIL && t < 64) BT = __builtin_fma(d, (double)V[rbt + 64], BT);      // (one address for the whole wave)
-        };
-        const int klo = k < 64 ? k : 64;
-        for (int t = 0; t < klo; ++t) step(t, bcast(B0, t));
-        if (TWO) for (int t = 64; t < k; ++t) step(t, bcast(B1, t - 64));
-        if (TAIL) step(64, BT);
+        }
+        B0 = __builtin_fma(qd0, ik, B0);
+        B1 = on1 ? __builtin_fma(qd1, ik, B1) : 0.0;
+        QI[2 * t0] = qd0; QI[2 * t0 + 1] = 1.0 / qd0;
+        if (on1) { QI[2 * t1] = qd1; QI[2 * t1 + 1] = 1.0 / qd1; }
         __builtin_amdgcn_wave_barrier();
-        const double sg = rcp_nr(S);
-        if (on0) { const double d = D[t0]; p0 += d; B0 = __builtin_fma(d, qd0, B0); }
-        if (on1) { const double d = D[t1]; p1 += d; B1 = __builtin_fma(d, qd1, B1); }
-        if (TAIL) { const double d = D[64]; pT += d; BT = __builtin_fma(d, qdT, BT); }
-        p0 *= sg; p1 *= sg; B0 *= sg; B1 *= sg; A *= sg * sg; pT *= sg; BT *= sg;
+        for (int p = lane; p < nv; p += 64) { const double e = (double)V[p]; V[p] = (float)((-(1.0 - e)) * e); }      // (the diagonal slots become -0)
         __builtin_amdgcn_wave_barrier();
+        p0 = ik; p1 = on1 ? ik : 0.0;
+        double A = wave_sum(p0 * B0 + p1 * B1);
+        for (int iter = 0; iter < max_iter; ++iter) {
+            double err = fabs(B0 - A);
+            if (on1) err = fmax(err, fabs(B1 - A));
+            for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+            if (err < eps) break;
+            double S = 1.0;
+            auto step = [&](int t, double Bt) {
+                const double2 qi = *reinterpret_cast<const double2 *>(QI + 2 * t);
+                const double  d = (rcp_nr(S) * A - Bt) * qi.y;
+                A = A + d * (d * qi.x + 2.0 * Bt);
+                S += d;
+                D[t] = d;                                              // (every lane writes the same word)
+                const int rbt = rb(t);
+                B0 = __builtin_fma(d, (double)V[t0 > t ? rbt + t0 : rb0 + t], B0);                    // (t = t0: the diagonal slot, -0)
+                B1 = __builtin_fma(d, (double)V[min(t1 > t ? rbt + t1 : rb1 + t, nv - 1)], B1);       // (an idle second class: any entry, B1 is not read)
+            };
+            for (int t = 0; t < 64; ++t) step(t, bcast(B0, t));
+            for (int t = 64; t < k; ++t) step(t, bcast(B1, t - 64));
+            __builtin_amdgcn_wave_barrier();
+            const double sg = rcp_nr(S);
+            { const double d = D[t0]; p0 += d; B0 = __builtin_fma(d, qd0, B0); }
+            if (on1) { const double d = D[t1]; p1 += d; B1 = __builtin_fma(d, qd1, B1); }
+            p0 *= sg; p1 *= sg; B0 *= sg; B1 *= sg; A *= sg * sg;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    if (prob) {
+    if (prob && live) {
         if (on0) prob[(size_t)v * k + t0] = p0;
         if (on1) prob[(size_t)v * k + t1] = p1;
         if (TAIL && lane == 0) prob[(size_t)v * k + 64] = pT;
@@ -700,7 +908,7 @@ __global__ __launch_bounds__(64) void k_svm_couple(const double *__restrict__ kv
     for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
     if (TAIL && first > 64 && m.label[64] == lab) first = 64;
     const double pf = first < 64 ? bcast(p0, first & 63) : (TAIL ? pT : bcast(p1, (first - 64) & 63));
-    if (lane == 0) { label[v] = lab; pbest[v] = pf; }
+    if (lane == 0 && live) { label[v] = lab; pbest[v] = pf; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -784,13 +992,12 @@ void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
 void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
 {
     if (n <= 0) return;
-    const size_t np = (size_t)m.k * (m.k - 1) / 2, lds = sizeof(double) * 3 * (size_t)m.k + sizeof(float) * np;
-    if (m.k > 65)
-        hipLaunchKernelGGL(k_svm_couple<2>, dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
-    else if (m.k == 65)
-        hipLaunchKernelGGL(k_svm_couple<1>, dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
-    else
-        hipLaunchKernelGGL(k_svm_couple<0>, dim3(n), dim3(64), lds, s, (const double *)buf.kv, m.l_pad, m, buf.dec, buf.prob, buf.label, buf.pbest);
+    const int    wpb = svm_couple_wpb(m.k > 65 ? 2 : 0), wg = (n + wpb - 1) / wpb;
+    const size_t lds = sizeof(double) * svm_couple_lds_doubles(m.k) * wpb;
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wpb), lds, s, (const double *)buf.kv, m.l_pad, n, m, buf.dec, buf.prob, buf.label, buf.pbest); };
+    if (m.k > 65) go(k_svm_couple<2, 0>);
+    else if (m.k == 65) { if (m.mp == 5) go(k_svm_couple<1, 5>); else go(k_svm_couple<1, 0>); }
+    else { if (m.mp == 5) go(k_svm_couple<0, 5>); else go(k_svm_couple<0, 0>); }
 }
 
 void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)

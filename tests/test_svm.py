@@ -398,10 +398,13 @@ def test_direction_marks_are_a_function_of_the_neighbour_mask(oracle):
         assert np.array_equal(oracle.chain_bitmaps(img.copy()), _marks_from_masks(img, lut)), trial
 
 
-# ---- models with other class counts: the coupling kernel has three builds (k <= 64; k = 65; k - 1 > 64 coefficient columns) ----
-def _synthetic_model(path, k, dim, rng, empty_class=None):
-    """A libsvm text model (svm_save_model format) with random support vectors / coefficients; class `empty_class` has no support vector."""
-    nsv = [int(rng.integers(1, 7)) for _ in range(k)]
+# ---- models with other class counts: the coupling kernel has builds for k <= 64, k = 65 and k - 1 > 64 coefficient columns, the first two each for
+# "at most 5 support vectors a class" (registers) and for any count (in eights) ----
+def _synthetic_model(path, k, dim, rng, empty_class=None, nsv_max=6):
+    """A libsvm text model (svm_save_model format) with random support vectors / coefficients (1 .. nsv_max per class, some class has nsv_max);
+    class `empty_class` has no support vector."""
+    nsv = [int(rng.integers(1, nsv_max + 1)) for _ in range(k)]
+    nsv[k // 2] = nsv_max
     if empty_class is not None:
         nsv[empty_class] = 0
     l, npairs = sum(nsv), k * (k - 1) // 2
@@ -421,13 +424,14 @@ def _synthetic_model(path, k, dim, rng, empty_class=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,empty", [(2, None), (7, 3), (64, None), (66, 0), (100, 99)])
-def test_gpu_svm_other_class_counts(S, oracle, tmp_path, k, empty):
+@pytest.mark.parametrize("k,empty,nsv_max", [(2, None, 6), (7, 3, 6), (64, None, 6), (66, 0, 6), (100, 99, 6),
+                                             (2, None, 5), (7, 0, 5), (33, 32, 5), (64, 5, 5), (65, 64, 6), (65, 0, 13), (40, None, 19), (65, 7, 3)])
+def test_gpu_svm_other_class_counts(S, oracle, tmp_path, k, empty, nsv_max):
     from oracle.oracle import OracleSVM
-    rng = np.random.default_rng(1000 + k)
+    rng = np.random.default_rng(1000 + k + 7 * nsv_max)
     dim = 96
     path = str(tmp_path / f"k{k}.model")
-    l = _synthetic_model(path, k, dim, rng, empty)
+    l = _synthetic_model(path, k, dim, rng, empty, nsv_max)
     f = S.ERFilter(8, 120, 900000, 2, 0.7, max_width=64, max_height=64, max_frames=1)
     f.load_svm_model(path, dim)
     assert f.svm_info() == (k, l, dim)

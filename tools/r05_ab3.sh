@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5: svm tests + two runs of the config-3 leg with the default library
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/${1:-r05ab3}
+mkdir -p $OUT
+cd $ROOT
+timeout 900 python -m pytest tests/test_svm.py tests/test_track.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+tail -5 $OUT/pytest.log
+cd /tmp && export TMPDIR=/tmp
+B="python $ROOT/bench.py --ocr --steps 20 --no-latency --no-host-frames --no-cpu-baseline"
+for rep in 1 2; do
+  timeout 200 $B > $OUT/a_$rep.json 2> $OUT/a_$rep.err
+done
+for f in $OUT/a_1 $OUT/a_2; do python -c "
+import json; j=json.load(open('$f.json')); print('$f'.split('/')[-1], j['value'], j['value_min'], j['value_max'], {k:v for k,v in j['gpu_ms_per_step_by_kernel_group_serial'].items() if 'ocr' in k or 'svm' in k})"; done
