@@ -300,9 +300,25 @@ try {
             }
     }
     const size_t o_rows = take(rows.size() * 8);
+    // the support vectors in three bf16 pieces (k_svm_kernel_q): the top 8 significant bits, the next 8, the last 8 -- each cut is a truncation, each remainder exact
+    const int dq = (int)align_up((size_t)dim, 64);
+    std::vector<uint16_t> svq((size_t)3 * l_pad * dq, 0);
+    for (int i = 0; i < l; ++i)
+        for (int j = 0; j < dim; ++j) {
+            float r = sv[(size_t)i * dpad + j];
+            for (int pl = 0; pl < 3; ++pl) {
+                uint32_t u; std::memcpy(&u, &r, 4);
+                u &= 0xFFFF0000u;
+                float piece; std::memcpy(&piece, &u, 4);
+                svq[((size_t)pl * l_pad + i) * dq + j] = (uint16_t)(u >> 16);
+                r -= piece;
+            }
+        }
+    const size_t o_svq = take(svq.size() * 2);
     const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
                  o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);
     std::vector<uint8_t> blob(off);
+    std::memcpy(&blob[o_svq], svq.data(), svq.size() * 2);
     std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
     std::memcpy(&blob[o_pij], pairs.data(), np_pad * sizeof(SvmPair));
     if (!rows.empty()) std::memcpy(&blob[o_rows], rows.data(), rows.size() * 8);
@@ -318,6 +334,7 @@ try {
     const uint8_t *b = static_cast<const uint8_t *>(d);
     SvmDev m{};
     m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
+    m.svq = reinterpret_cast<const uint16_t *>(b + o_svq); m.dq = dq;
     m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
     m.pairs = reinterpret_cast<const SvmPair *>(b + o_pij);
     m.coef_rows = rows.empty() ? nullptr : reinterpret_cast<const double *>(b + o_rows); m.msv = msv; m.mp = mp;
@@ -372,7 +389,7 @@ try {
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemcpyAsync(s + o_x, x, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
     launch_svm_prep(st, reinterpret_cast<const double *>(s + o_x), n, dim, buf, m);
-    launch_svm_score(st, n, buf, m);
+    launch_svm_score(st, n, buf, m, false);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(prob, buf.prob, (size_t)n * m.k * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -430,7 +447,7 @@ try {
     launch_ocr_features(st, src, n, buf, m);
     if (want_svm) {
         // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. assumes model->label[i] == i
-        launch_svm_score(st, n, buf, *m);
+        launch_svm_score(st, n, buf, *m, true);
         HIP_TRY(c, hipMemcpyAsync(prob, buf.pbest, (size_t)n * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     }

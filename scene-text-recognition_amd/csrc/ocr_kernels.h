@@ -17,6 +17,8 @@ struct SvmDev {
     int32_t kc;             // row length of coef_t: k - 1 rounded up to 64 (64 or 128)
     double  gamma;
     const float  *sv;       // [l_pad x dpad] dense, zero padded
+    const uint16_t *svq;    // [3][l_pad x dq] bf16: sv = svq[0] + svq[1] + svq[2] exactly (the f32's 24 significant bits in three pieces)
+    int32_t dq;             // dim rounded up to 64: row length of svq and of OcrBuf::xq
     const double *svnorm;   // [l_pad]
     const double *coef;     // [(k-1) x l]            sv_coef as libsvm stores it (kept for the layout tests)
     const double *coef_t;   // [l_pad x kc]              coef_t[q][b] = sv_coef[b][q], zero padded: one coalesced row per support vector
@@ -48,7 +50,8 @@ struct OcrBuf {
     int32_t  *thresh;    // [n]             Otsu threshold                               (features)
     uint32_t *big;       // [1 + 4095]      count, then the boxes whose histogram is spread over many workgroups (features)
     uint8_t  *q;         // [n x 1800] or null: the features as the reference's 8-bit image (q / 255.0 = the svm input)
-    float    *xf;        // [n_pad x dpad]  svm input, f32, zero padded                  (svm)
+    float    *xf;        // [n_pad x dpad]  svm input, f32, zero padded                  (svm, vectors given as doubles)
+    uint16_t *xq;        // [n_pad x dq]    svm input times 255 -- the features' 8-bit numerators -- as bf16, zero padded (svm, vectors from boxes)
     double   *xnorm;     // [n_pad]         |x|^2                                        (svm)
     double   *kv;        // [n_pad x l_pad] RBF kernel values                            (svm)
     double   *dec;       // [n x k(k-1)/2] or null: decision values
@@ -68,13 +71,13 @@ void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t 
 void launch_box_thresholds(hipStream_t s, const OcrSrc &src, int n, uint32_t *hist, uint32_t *big, int32_t *thresh);
 
 // chain-code features of n boxes: Otsu of 255 - roi, ARAN(30), direction bitmaps, 7x7 Gaussian, min-max, 2x2 decimation
-// -> buf.q (if not null) and buf.xf / buf.xnorm (if m is not null)
+// -> buf.q (if not null) and buf.xq / buf.xnorm (if m is not null)
 void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &buf, const SvmDev *m);
 
-// svm_predict_probability for the n rows of buf.xf / buf.xnorm -> buf.label, buf.pbest (+ buf.prob, buf.dec if not null)
-void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
+// svm_predict_probability for the n rows of buf.xf (numerators = false) or buf.xq (true) and buf.xnorm -> buf.label, buf.pbest (+ buf.prob, buf.dec if not null)
+void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, bool numerators);
 // ... its two halves: the RBF kernel matrix buf.kv; decision values + coupling from buf.kv
-void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
+void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, bool numerators);
 void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
 // rows per class of SvmDev::coef_rows for a model whose largest class has msv support vectors (the kernel's builds: 5 exactly -- the shape of the reference's training set -- or eights)
 inline int svm_rows_per_class(int msv) { return msv == 5 ? 5 : (msv + 7) / 8 * 8; }

@@ -297,7 +297,7 @@ __device__ __forceinline__ void feat_aran(FeatWave &L, const OcrBox &b, int th, 
 }
 
 __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int n, const int32_t *__restrict__ thresh, uint8_t *__restrict__ q_out,
-                                                                float *__restrict__ xf, double *__restrict__ xnorm, int dpad)
+                                                                uint16_t *__restrict__ xq, double *__restrict__ xnorm, int dq)
 {
     __shared__ FeatWave s_w[OCR_WAVES];
     __shared__ uint8_t  s_lut[256];
@@ -386,14 +386,14 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int
             auto nz = [&](uint8_t e) -> int { return min(max(__float2int_rn((float)e * sc + sf), 0), 255); };
             const int v = (nz(m[0]) + nz(m[1]) + nz(m[30]) + nz(m[31]) + 2) >> 2;
             if (q_out) q_out[(size_t)bi * 1800 + i] = (uint8_t)v;
-            if (xf) {
+            if (xq) {
                 const double d = v / 255.0;                         // fv.value = ptr[p] / 255.0 (src/OCR.cpp:211)
-                xf[(size_t)bi * dpad + i] = (float)d;
+                xq[(size_t)bi * dq + i] = (uint16_t)(__float_as_uint((float)v) >> 16);      // the numerator as bf16: 0 .. 255 are exact (k_svm_kernel_q)
                 nrm += d * d;
             }
         }
-        if (xf) {
-            for (int i = 1800 + lane; i < dpad; i += 64) xf[(size_t)bi * dpad + i] = 0.f;
+        if (xq) {
+            for (int i = 1800 + lane; i < dq; i += 64) xq[(size_t)bi * dq + i] = 0;
             for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o);
             if (lane == 0) xnorm[bi] = nrm;
         }
@@ -476,6 +476,81 @@ __global__ __launch_bounds__(256) void k_svm_kernel(const float *__restrict__ xf
             const int row = m0 + wm + 32 * h + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
             if (row < n_rows) {
                 double d2 = xnorm[row] + sn - 2.0 * (double)(h ? acc1[i] : acc0[i]);
+                d2 = d2 > 0 ? d2 : 0;
+                kv[(size_t)row * l_pad + col] = exp(-gamma * d2);
+            }
+        }
+    }
+}
+
+// The same matrix for vectors that are 8-bit numerators over 255 (every vector k_ocr_features makes): x.sv = (q.sv) / 255 with q exact in bf16 and
+// the f32 support vector split exactly into three bf16 pieces -- three v_mfma_f32_32x32x16_bf16 per 16 features (a 16-bit product is exact, the sum
+// runs in f32 as before) instead of eight v_mfma_f32_32x32x2_f32 per accumulator: a fifth of the matrix-pipe time, half the bytes of the vectors.
+// Workgroup tile 128 x 64, four waves of 64 x 32 (two accumulators sharing the B operands), K step 64; operands row-major in LDS, a row = 64 bf16
+// + 8 of padding (144 bytes: the sixteen 16-byte reads of a quarter wave fall in disjoint banks); the next tile travels through registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int QM = 128, QN = 64, QK = 64, QS = QK + 8;
+
+__global__ __launch_bounds__(256) void k_svm_kernel_q(const uint16_t *__restrict__ xq, const double *__restrict__ xnorm, int n_rows,
+                                                      const uint16_t *__restrict__ svq, const double *__restrict__ svnorm, int l_pad, int dq,
+                                                      double gamma, double *__restrict__ kv)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t As[QM][QS];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[3][QN][QS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * QM, n0 = blockIdx.x * QN;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
+    // staging: a thread moves the 16-byte chunk `ch` of rows sr + 32 j: 4 of A, 2 of each B plane
+    const int sr = tid >> 3, ch = (tid & 7) * 8;
+    const uint16_t *pa[4], *pb[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pa[j] = xq + (size_t)min(m0 + sr + 32 * j, n_rows - 1) * dq + ch;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pb[j] = svq + ((size_t)(j >> 1) * l_pad + n0 + sr + 32 * (j & 1)) * dq + ch;
+    // (the staging registers: native vectors in arrays indexed by unrolled loops of this scope -- as HIP's uint4 structs, or through a lambda's reference,
+    // they end up in scratch memory)
+    u32x4 ra[4], rb[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const u32x4 *>(pa[j]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rb[j] = *reinterpret_cast<const u32x4 *>(pb[j]);
+    float16v acc0 = {0}, acc1 = {0};
+    const int nk = dq / QK, fr = lane & 31, fk = 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(&As[sr + 32 * j][ch]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4 *>(&Bs[j >> 1][sr + 32 * (j & 1)][ch]) = rb[j];
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const u32x4 *>(pa[j] + (kt + 1) * QK);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) rb[j] = *reinterpret_cast<const u32x4 *>(pb[j] + (kt + 1) * QK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < QK; ks += 16) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&As[wm + fr][ks + fk]), a1 = *reinterpret_cast<const bf16x8 *>(&As[wm + 32 + fr][ks + fk]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[pl][wn + fr][ks + fk]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // 32x32 accumulator layout: element i of lane L is row 8*(i/4) + 4*(L/32) + i%4, column L%32
+    const int    col = n0 + wn + (lane & 31);
+    const double sn = svnorm[col];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + wm + 32 * h + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+            if (row < n_rows) {
+                double d2 = xnorm[row] + sn - (2.0 / 255.0) * (double)(h ? acc1[i] : acc0[i]);
                 d2 = d2 > 0 ? d2 : 0;
                 kv[(size_t)row * l_pad + col] = exp(-gamma * d2);
             }
@@ -931,6 +1006,7 @@ OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m, bool want_q, bool wa
     if (m) {
         const size_t np = (size_t)m->k * (m->k - 1) / 2;
         b.xf = reinterpret_cast<float *>(take(n_pad * m->dpad * 4));
+        b.xq = reinterpret_cast<uint16_t *>(take(n_pad * m->dq * 2));
         b.xnorm = reinterpret_cast<double *>(take(n_pad * 8));
         b.kv = reinterpret_cast<double *>(take(n_pad * m->l_pad * 8));
         uint8_t *d = take(want_dec ? n * np * 8 : 0), *p = take(want_prob ? n * m->k * 8 : 0);
@@ -973,7 +1049,7 @@ void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &
     const int wg = (n + OCR_WAVES - 1) / OCR_WAVES, n_cu = ocr_n_cu();
     launch_box_thresholds(s, src, n, buf.hist, buf.big, buf.thresh);
     hipLaunchKernelGGL(k_ocr_features, dim3(wg < 3 * n_cu ? wg : 3 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, (const int32_t *)buf.thresh, buf.q,
-                       m ? buf.xf : (float *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dpad : 0);
+                       m ? buf.xq : (uint16_t *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dq : 0);
 }
 
 void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBuf &buf, const SvmDev &m)
@@ -982,9 +1058,14 @@ void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBu
     hipLaunchKernelGGL(k_svm_prep, dim3((n + 3) / 4), dim3(256), 0, s, x, n, dim, buf.xf, m.dpad, buf.xnorm);
 }
 
-void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
+void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, bool numerators)
 {
     if (n <= 0) return;
+    if (numerators) {
+        hipLaunchKernelGGL(k_svm_kernel_q, dim3(m.l_pad / QN, (n + QM - 1) / QM), dim3(256), 0, s, (const uint16_t *)buf.xq, (const double *)buf.xnorm, n, m.svq,
+                           m.svnorm, m.l_pad, m.dq, m.gamma, buf.kv);
+        return;
+    }
     hipLaunchKernelGGL(k_svm_kernel, dim3(m.l_pad / GN, (n + GM - 1) / GM), dim3(256), 0, s, (const float *)buf.xf, (const double *)buf.xnorm, n, m.sv,
                        m.svnorm, m.l_pad, m.dpad, m.gamma, buf.kv);
 }
@@ -1000,9 +1081,9 @@ void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
     else { if (m.mp == 5) go(k_svm_couple<0, 5>); else go(k_svm_couple<0, 0>); }
 }
 
-void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
+void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, bool numerators)
 {
-    launch_svm_kernel(s, n, buf, m);
+    launch_svm_kernel(s, n, buf, m, numerators);
     launch_svm_couple(s, n, buf, m);
 }
 

@@ -205,7 +205,7 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
     rec(c, "ocr_host_gap");
     launch_ocr_features(s, src, (int)n_m, buf, &m);
     rec(c, "ocr_features");
-    launch_svm_kernel(s, (int)n_m, buf, m);
+    launch_svm_kernel(s, (int)n_m, buf, m, true);
     rec(c, "svm_kernel");
     launch_svm_couple(s, (int)n_m, buf, m);
     rec(c, "svm_couple");
@@ -951,7 +951,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             src.recs = bd.cands; src.list = d_list + 16; src.planes = bd.planes;
             launch_ocr_features(s, src, (int)n_ocr, buf, &m);
             rec(c, "ocr_features");
-            launch_svm_kernel(s, (int)n_ocr, buf, m);
+            launch_svm_kernel(s, (int)n_ocr, buf, m, true);
             rec(c, "svm_kernel");
             launch_svm_couple(s, (int)n_ocr, buf, m);
             rec(c, "svm_couple");
