@@ -52,6 +52,7 @@ W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0    # ... and what a float4 copy reaches (same guide)
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense f32 matrix peak (v_mfma_f32_32x32x2_f32: 256 flop/cycle/CU x 256 CUs x 2.4 GHz)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 WORKLOADS = {
     "pyr3x8": dict(n_pyr_levels=8, channel_mask=0x07, label="1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels (BASELINE configs[1])"),
     "native6": dict(n_pyr_levels=1, channel_mask=0x3F, label="1920x1080 BGR, reference-native 6 planes x 1 level"),
@@ -462,20 +463,23 @@ def main():
         ocr_leg, sp_o, last_o = ocr_leg_run(S.STAGE_ALL | S.STAGE_OCR, "STAGE_ALL | STAGE_OCR: chain_run (slope 0) on every strong / weak ER (src/OCR.cpp:67-140)")
         n_sc = int((last_o.ocr_label >= 0).sum()) if last_o.ocr_label is not None else 0
         k_cls, l_sv, _dim = rig.filters[0].svm_info()
-        l_pad, d_pad = -(-l_sv // 64) * 64, -(-1800 // 16) * 16
+        l_pad, d_q = -(-l_sv // 64) * 64, -(-1800 // 64) * 64
         gemm_ms = sp_o.get("svm_kernel", 0.0)
-        flops = 2.0 * n_sc * d_pad * l_pad
+        flops = 3 * 2.0 * n_sc * d_q * l_pad
         tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         ocr_leg.update({
             "ers_scored_per_batch": n_sc, "svm_model": f"ocr_synth.model: {k_cls} classes, {l_sv} support vectors, 1800-d, RBF (stand-in for the missing OCR.model)",
             "gpu_ms_per_batch_isolated": {k: round(sp_o.get(k, 0.0), 4) for k in ("ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")},
-            "gpu_ms_note": "ocr_features = k_ocr_list + k_ocr_hist + k_ocr_otsu + k_ocr_features; svm_kernel = k_svm_kernel (RBF kernel matrix, MFMA); svm_couple = "
+            "gpu_ms_note": "ocr_features = k_ocr_list + k_ocr_hist + k_ocr_otsu + k_ocr_features; svm_kernel = k_svm_kernel_q (RBF kernel matrix, MFMA); svm_couple = "
                            "k_svm_couple (decision values + sigmoid + pairwise coupling); ocr_host_gap = stream idle while the host reads the plane counters "
                            "(the scorer's launch sizes), not GPU work",
-            "roofline_svm_kernel": {"bound": "mfma", "kernel": "k_svm_kernel", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flops_per_launch": int(flops), "avg_launch_ms": round(gemm_ms, 4),
-                                    "note": f"2 x N x {d_pad} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch; f32 in / f32 accumulate; the "
-                                            "launch also evaluates exp() in f64 for every kernel value"}})
+            "roofline_svm_kernel": {"bound": "mfma", "kernel": "k_svm_kernel_q", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 5), "flops_per_launch": int(flops), "avg_launch_ms": round(gemm_ms, 4),
+                                    "f32_equivalent_tflops": round(tf / 3, 2),
+                                    "note": f"3 x 2 x N x {d_q} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch: the f32 product x.sv as three bf16 "
+                                            "MFMAs (the features are 8-bit numerators, exact in bf16; each support vector = three bf16 pieces, exactly), f32 accumulate; "
+                                            "f32_equivalent_tflops = the same launch priced as the one f32 contraction it replaces (f32 matrix peak 157.3); the launch "
+                                            "also evaluates exp() in f64 for every kernel value"}})
         if not args.no_cpu_baseline:
             ocr_leg["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades, budget_s=8.0, ocr_model=svm_path)
         group_ocr_leg, sp_g, last_g = ocr_leg_run(S.STAGE_ALL | st_group | S.STAGE_OCR_LINES,

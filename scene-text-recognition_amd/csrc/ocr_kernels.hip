@@ -36,8 +36,9 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------------
 // boxes
 // ---------------------------------------------------------------------------------------------------------
-// indices of the strong / weak candidates of the batch, in candidate order.  One workgroup; a thread takes four consecutive candidates per
-// pass (the four class bytes are requested together: the scan is a chain of memory round trips otherwise).
+// indices of the strong / weak candidates of the batch, in candidate order.  One workgroup; a thread takes sixteen consecutive candidates per
+// pass (the class bytes are requested together: the scan is a chain of memory round trips otherwise -- three for a batch's 48 k candidates).
+constexpr int LIST_CPT = 16;
 __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ cands, const uint32_t *__restrict__ total_cands,
                                                    uint32_t *__restrict__ list, uint32_t *__restrict__ n_out)
 {
@@ -47,12 +48,12 @@ __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ c
     const uint32_t total = *total_cands;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < total; base += 4096) {
-        const uint32_t i0 = base + 4u * (uint32_t)tid;
-        uint32_t       m4 = 0;
+    for (uint32_t base = 0; base < total; base += 1024u * LIST_CPT) {
+        const uint32_t i0 = base + (uint32_t)LIST_CPT * (uint32_t)tid;
+        uint32_t       mk = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) m4 |= (i0 + u < total && cands[i0 + u].cls != 0) ? 1u << u : 0u;
-        const uint32_t cnt = (uint32_t)__popc(m4);
+        for (int u = 0; u < LIST_CPT; ++u) mk |= (i0 + u < total && cands[min(i0 + u, total - 1)].cls != 0) ? 1u << u : 0u;
+        const uint32_t cnt = (uint32_t)__popc(mk);
         uint32_t       incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
@@ -60,8 +61,7 @@ __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ c
         __syncthreads();
         uint32_t off = s_carry + incl - cnt, tot = 0;
         for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if ((m4 >> u) & 1u) list[off++] = i0 + u;
+        for (uint32_t r = mk; r != 0; r &= r - 1u) list[off++] = i0 + (uint32_t)__builtin_ctz(r);
         __syncthreads();
         if (tid == 0) s_carry += tot;
         __syncthreads();

@@ -229,12 +229,16 @@ def test_gpu_chain_run_end_to_end(erf, oracle, S, model_path):
     boxes = np.stack([c["x"], c["y"], c["w"], c["h"]], axis=1).astype(np.int32)
     assert len(boxes) > 0
     q, label, prob = erf.chain_run(img, boxes)
+    worst = 0.0
     for i, b in enumerate(boxes):
         l, p, _ = m.predict_probability(q[i] / 255.0)
         assert abs(prob[i] - p[np.argmax(p)]) < TOL
+        worst = max(worst, abs(prob[i] - p[np.argmax(p)]))
         top2 = np.sort(p)[-2:]
         if top2[1] - top2[0] > 10 * TOL:
             assert label[i] == l
+    # what the device path actually keeps (the tolerance above is BASELINE's): the kernel matrix through bf16 x 3 / f32 accumulation and the f32 pair table
+    assert worst < 5e-6, worst
 
 
 @pytest.mark.gpu

@@ -114,8 +114,8 @@ if not PMC_JSON_ONLY:
         if v:
             lines.append(fmt(v))
     leg("config3_ocr_leg", lambda v: f"`config3_ocr_leg` (BASELINE configs[2]: chain-code + SVM scorer on the {v['ers_scored_per_batch']} strong / weak ERs of a batch): **{v['value']:.0f}** frames/s = "
-        f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}; `k_svm_kernel` {v['roofline_svm_kernel']['achieved']} TFLOP/s = "
-        f"{v['roofline_svm_kernel']['frac']:.3f} of the {v['roofline_svm_kernel']['peak']} TFLOP/s f32 MFMA peak; CPU baseline {(v.get('cpu_baseline') or {}).get('value', '-')} frames/s.")
+        f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}; `{v['roofline_svm_kernel']['kernel']}` {v['roofline_svm_kernel']['achieved']} TFLOP/s = "
+        f"{v['roofline_svm_kernel']['frac']:.3f} of the {v['roofline_svm_kernel']['peak']} TFLOP/s bf16 MFMA peak; CPU baseline {(v.get('cpu_baseline') or {}).get('value', '-')} frames/s.")
     leg("group_ocr_leg", lambda v: f"`group_ocr_leg` (calc_color, er_track, er_grouping, then the scorer on the {v['line_members_scored_per_batch']} line members of a batch): **{v['value']:.0f}** frames/s = "
         f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}.")
     leg("config5_4k_leg", lambda v: f"`config5_4k_leg` (BASELINE configs[4] on one GPU, 3840x2160 x 12 levels, {v['frames_per_step']} frames per batch): **{v['value']:.0f}** frames/s ({v['mpx_per_s']:.0f} Mpx/s; the 1080p line: "
