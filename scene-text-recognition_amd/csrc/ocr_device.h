@@ -11,7 +11,11 @@ constexpr int OCR_BIG_PX = 4096;       // boxes above this many pixels are sprea
 constexpr int OCR_BIG_CAP = 4095;      // and one wave needs ~7 us per 1000 pixels -- the largest boxes of a batch are 50 times the average one
 constexpr int OCR_BIG_PARTS = 32;      // row ranges a big box is cut into
 
-struct OcrBox { const uint8_t *roi; int stride, inv, bw, bh; };
+// device memory, and said so: a pointer read out of a descriptor is a generic one to the compiler -- flat loads, which count on both wait counters
+// and drag every LDS wait of the loop along
+typedef const __attribute__((address_space(1))) uint8_t *GlobalBytes;
+
+struct OcrBox { GlobalBytes roi; int stride, inv, bw, bh; };
 
 __device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)
 {
@@ -20,11 +24,11 @@ __device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)
         const CandRec   &cd = s.recs[s.list[bi]];
         const PlaneDesc &pd = s.planes[cd.plane];
         b.bw = cd.w; b.bh = cd.h; b.stride = pd.stride; b.inv = pd.invert;
-        b.roi = pd.pix + (size_t)cd.y * pd.stride + cd.x;
+        b.roi = (GlobalBytes)(pd.pix + (size_t)cd.y * pd.stride + cd.x);
     } else {
         const int32_t *q = s.boxes + 4 * (size_t)bi;
         b.bw = q[2]; b.bh = q[3]; b.stride = s.stride; b.inv = s.inv;
-        b.roi = s.plane + (size_t)q[1] * s.stride + q[0];
+        b.roi = (GlobalBytes)(s.plane + (size_t)q[1] * s.stride + q[0]);
     }
     return b;
 }

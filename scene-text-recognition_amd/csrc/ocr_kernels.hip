@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist(OcrSrc src, int n, 
         }
         for (int i = lane; i < 256 * 8 / 4; i += 64) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
         const int sub = lane & 7;
-        // four loads in flight per lane (a load per pass would pay a memory round trip per row of the box)
+        // four loads in flight per lane (a load per pass would pay a memory round trip per row of the box).  The addresses are clamped into the box and
+        // the loads unconditional: as `ok ? load : 0` each load gets a block of its own with a full wait behind it
         auto bin = [&](int y, int x) -> uint32_t { return ((255u - ((uint32_t)b.roi[(size_t)y * b.stride + x] ^ (uint32_t)b.inv)) << 3) | (uint32_t)sub; };
         if (b.bw <= 64) {
             // several rows per pass: lane -> (row in the pass, column)
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist(OcrSrc src, int n, 
                 uint32_t e[4];
                 bool     ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int y = y0 + u * rpp + ry; ok[u] = on && y < b.bh; e[u] = ok[u] ? bin(y, x) : 0u; }
+                for (int u = 0; u < 4; ++u) { const int y = y0 + u * rpp + ry; ok[u] = on && y < b.bh; e[u] = bin(min(y, b.bh - 1), min(x, b.bw - 1)); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (ok[u]) atomicAdd(&h[e[u]], 1u);
             }
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist(OcrSrc src, int n, 
                 for (int x = lane; x < b.bw; x += 64) {
                     uint32_t e[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) e[u] = y0 + u < b.bh ? bin(y0 + u, x) : 0xFFFFFFFFu;
+                    for (int u = 0; u < 4; ++u) e[u] = bin(min(y0 + u, b.bh - 1), x);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (e[u] != 0xFFFFFFFFu) atomicAdd(&h[e[u]], 1u);
+                    for (int u = 0; u < 4; ++u) if (y0 + u < b.bh) atomicAdd(&h[e[u]], 1u);
                 }
         }
         for (int v = lane; v < 256; v += 64) {
@@ -143,12 +144,12 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist_big(OcrSrc src, uin
             for (int x0 = 0; x0 < b.bw; x0 += 256) {
                 uint32_t e[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int x = x0 + 64 * u + lane;
-                    e[u] = x < b.bw ? (((255u - ((uint32_t)b.roi[(size_t)y * b.stride + x] ^ (uint32_t)b.inv)) << 3) | (uint32_t)sub) : 0xFFFFFFFFu;
+                for (int u = 0; u < 4; ++u) {                                  // (clamped, unconditional loads: see k_ocr_hist)
+                    const int x = min(x0 + 64 * u + lane, b.bw - 1);
+                    e[u] = ((255u - ((uint32_t)b.roi[(size_t)y * b.stride + x] ^ (uint32_t)b.inv)) << 3) | (uint32_t)sub;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (e[u] != 0xFFFFFFFFu) atomicAdd(&h[e[u]], 1u);
+                for (int u = 0; u < 4; ++u) if (x0 + 64 * u + lane < b.bw) atomicAdd(&h[e[u]], 1u);
             }
         for (int v = lane; v < 256; v += 64) {
             const uint4 a = *reinterpret_cast<const uint4 *>(h + 8 * v), c = *reinterpret_cast<const uint4 *>(h + 8 * v + 4);
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_ocr_otsu(OcrSrc src, int n, const uint3
 // ---------------------------------------------------------------------------------------------------------
 // Source of ARAN(30): the Otsu-binarised ROI, tap = (255 - (p ^ inv)) > thresh ? 255 : 0 ...
 struct BinSrc {
-    const uint8_t *roi; int stride, inv, th;
+    GlobalBytes roi; int stride, inv, th;
     __device__ __forceinline__ int operator()(int x, int y) const { return (255 - (roi[(size_t)y * stride + x] ^ inv)) > th ? 255 : 0; }
 };
 // ... or that image seen through OCR::rotate_mat (src/OCR.cpp:282-352): canvas pixel (x, y) is rebuilt

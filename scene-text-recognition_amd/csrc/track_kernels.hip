@@ -52,38 +52,44 @@ __device__ __forceinline__ void color_store(TrackRec *tr, unsigned long long c, 
     *tr = r;
 }
 
-// rows [y_lo, y_hi) step y_step of box b: count and byte sums of the masked pixels, four pixels of a lane requested together
+// rows [y_lo, y_hi) step y_step of box b: count and byte sums of the masked pixels, four pixels of a lane requested together -- the mask byte and the
+// three colour bytes of each, at addresses clamped into the box, unconditionally (written as `if (in the box && masked) load` every load is a block
+// of its own with a full wait behind it: sixteen memory round trips per pass instead of one)
 __device__ __forceinline__ void color_rows(const OcrBox &b, const ColorSrc &col, int th, int y_lo, int y_hi, int y_step, int lane, uint32_t &cnt, uint32_t &a0,
                                            uint32_t &a1, uint32_t &a2)
 {
-    auto on = [&](int x, int y) -> bool { return (255 - (b.roi[(size_t)y * b.stride + x] ^ b.inv)) > th; };
+    const GlobalBytes c0 = (GlobalBytes)col.c0, c1 = (GlobalBytes)col.c1, c2 = (GlobalBytes)col.c2;
+    auto take = [&](const bool (&in)[4], const int (&xs)[4], const int (&ys)[4]) {
+        uint32_t mk[4], v0[4], v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = (size_t)ys[u] * col.stride + (size_t)xs[u] * col.step;
+            mk[u] = b.roi[(size_t)ys[u] * b.stride + xs[u]];
+            v0[u] = c0[o]; v1[u] = c1[o]; v2[u] = c2[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool m = in[u] && (255 - (int)(mk[u] ^ (uint32_t)b.inv)) > th;
+            cnt += m ? 1u : 0u; a0 += m ? v0[u] : 0u; a1 += m ? v1[u] : 0u; a2 += m ? v2[u] : 0u;
+        }
+    };
     if (b.bw <= 64) {
-        const int rpp = 64 / b.bw, ry = lane / b.bw, x = lane - ry * b.bw;
-        if (ry < rpp)
-            for (int y0 = y_lo; y0 < y_hi; y0 += 4 * rpp * y_step) {
-                bool m[4];
+        const int rpp = 64 / b.bw, ry = lane / b.bw, x = min(lane - ry * b.bw, b.bw - 1);
+        for (int y0 = y_lo; y0 < y_hi; y0 += 4 * rpp * y_step) {
+            bool in[4];
+            int  xs[4], ys[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int y = y0 + (u * rpp + ry) * y_step; m[u] = y < y_hi && on(x, y); }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (m[u]) {
-                        const int    y = y0 + (u * rpp + ry) * y_step;
-                        const size_t o = (size_t)y * col.stride + (size_t)x * col.step;
-                        ++cnt; a0 += col.c0[o]; a1 += col.c1[o]; a2 += col.c2[o];
-                    }
-            }
+            for (int u = 0; u < 4; ++u) { const int y = y0 + (u * rpp + ry) * y_step; in[u] = ry < rpp && y < y_hi; xs[u] = x; ys[u] = min(y, b.bh - 1); }
+            take(in, xs, ys);
+        }
     } else {
         for (int y = y_lo; y < y_hi; y += y_step)
             for (int x0 = 0; x0 < b.bw; x0 += 256) {
-                bool m[4];
+                bool in[4];
+                int  xs[4], ys[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int x = x0 + 64 * u + lane; m[u] = x < b.bw && on(x, y); }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (m[u]) {
-                        const size_t o = (size_t)y * col.stride + (size_t)(x0 + 64 * u + lane) * col.step;
-                        ++cnt; a0 += col.c0[o]; a1 += col.c1[o]; a2 += col.c2[o];
-                    }
+                for (int u = 0; u < 4; ++u) { const int x = x0 + 64 * u + lane; in[u] = x < b.bw; xs[u] = min(x, b.bw - 1); ys[u] = y; }
+                take(in, xs, ys);
             }
     }
 }
