@@ -1,9 +1,9 @@
 #!/bin/bash
-# Developer aid (GPU box): the longest stretches without a running kernel in the exact-ties bench, and the long HIP API calls around them
+# Developer aid (GPU box): the longest stretches without a running kernel in a bench run (EXTRA="--group --ocr", default: the exact-ties bench), and the long HIP API calls around them
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tg
-rocprofv3 --kernel-trace --hip-trace --output-format csv -d /tmp/tg -o t -- python $ROOT/bench.py --no-cpu-baseline --no-latency --no-host-frames --sibling-order 0 --pipelines ${PIPES:-6} --steps 80 --warmup 6 > /tmp/tg.log 2>/dev/null
+rocprofv3 --kernel-trace --hip-trace --output-format csv -d /tmp/tg -o t -- python $ROOT/bench.py --no-cpu-baseline --no-latency --no-host-frames ${EXTRA:---sibling-order 0} --pipelines ${PIPES:-6} --steps ${STEPS:-80} --warmup 6 > /tmp/tg.log 2>/dev/null
 tail -1 /tmp/tg.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
 python - <<'PY'
 import csv, glob, collections
