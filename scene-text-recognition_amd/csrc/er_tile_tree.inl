@@ -1248,9 +1248,17 @@ extern "C" void str_er_debug_phase_cycles(unsigned long long *out16, int reset)
 }
 #endif
 
+// Developer experiment (STR_ER_TILE_LDS_PAD=bytes, off by default): unused dynamic LDS per workgroup, i.e. fewer tile workgroups resident per compute
+// unit -- wave slots left for the latency-bound passes of the other batches in flight (profiles/r05_cu_partition.md has the result).
+static size_t tile_lds_pad()
+{
+    static const size_t pad = [] { const char *e = getenv("STR_ER_TILE_LDS_PAD"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 65536 ? v : 0); }();
+    return pad;
+}
+
 void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse)
 {
     if (!b.n_tiles) return;
-    if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
-    else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), 0, s, b, p);
+    if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), tile_lds_pad(), s, b, p);
+    else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), tile_lds_pad(), s, b, p);
 }
