@@ -51,8 +51,11 @@ __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ c
     for (uint32_t base = 0; base < total; base += 1024u * LIST_CPT) {
         const uint32_t i0 = base + (uint32_t)LIST_CPT * (uint32_t)tid;
         uint32_t       mk = 0;
+        uint8_t        cl[LIST_CPT];
 #pragma unroll
-        for (int u = 0; u < LIST_CPT; ++u) mk |= (i0 + u < total && cands[min(i0 + u, total - 1)].cls != 0) ? 1u << u : 0u;
+        for (int u = 0; u < LIST_CPT; ++u) cl[u] = cands[min(i0 + u, total - 1)].cls;          // (unconditional: behind `i0 + u < total &&` every load waits for the one before)
+#pragma unroll
+        for (int u = 0; u < LIST_CPT; ++u) mk |= (i0 + u < total && cl[u] != 0) ? 1u << u : 0u;
         const uint32_t cnt = (uint32_t)__popc(mk);
         uint32_t       incl = cnt;
 #pragma unroll
