@@ -2,15 +2,17 @@
 // OCR::chain_run (src/OCR.cpp:67-140) = chain-code features (extract_feature, :144-218) + svm_predict_probability
 // (src/svm.cpp:2592-2629).  Launch chain of one call:
 //
-//   k_ocr_hist      one wave per box: histogram of 255 - roi                              (HBM: the ROI bytes, once)
+//   k_ocr_list      indices of the strong / weak candidates, in candidate order
+//   k_ocr_hist      one wave per box: histogram of 255 - roi (boxes above 4096 px: k_ocr_hist_big)       (HBM: the ROI bytes, once)
 //   k_ocr_otsu      one LANE per box: getThreshVal_Otsu_8u's sequential f64 scan -- 64 boxes per wave instead of one
 //   k_ocr_features  one wave per box: ARAN(30) of the binarised (optionally rotated) ROI, direction bitmaps, 7x7 Gaussian,
-//                   min-max normalisation, 2x2 decimation -> q[1800]; written as the svm's f32 row + |x|^2
-//   k_svm_kernel    K[n][i] = exp(-gamma |x_n - sv_i|^2): the x.sv part is a dense [N x 1808] x [1808 x l] contraction on
-//                   the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate), the exp in f64 in the epilogue
-//   k_svm_couple    one wave per box: the k(k-1)/2 decision values (svm_predict_values, src/svm.cpp:2539-2566) from one
-//                   coalesced coefficient row per support vector, Platt sigmoid (:1818-1826), Wu-Lin-Weng coupling
-//                   (multiclass_probability, :1829-1890), arg max -- all in f64, pairwise values never leave LDS
+//                   min-max normalisation, 2x2 decimation -> q[1800]; written as the svm's row of bf16 numerators + |x|^2
+//   k_svm_kernel_q  K[n][i] = exp(-gamma |x_n - sv_i|^2) for rows of numerators: x.sv = (q.sv) / 255 as three
+//                   v_mfma_f32_32x32x16_bf16 per 16 features (q exact in bf16, sv = three bf16 pieces exactly), exp in f64
+//   k_svm_kernel    the same for f32 rows (vectors handed in as doubles): v_mfma_f32_32x32x2_f32
+//   k_svm_couple    one wave per box: the k(k-1)/2 decision values (svm_predict_values, src/svm.cpp:2539-2566) in row passes
+//                   of coalesced coefficient rows, Platt sigmoid (:1818-1826), Wu-Lin-Weng coupling (multiclass_probability,
+//                   :1829-1890) with Q's rows in registers, arg max -- all in f64, pairwise values never leave LDS
 //
 // The OpenCV primitives involved (Otsu, findContours, GaussianBlur, normalize, resize) are restated from OpenCV 4.x and
 // checked against the CPU restatement the tests use ("parity unpinned").
@@ -30,7 +32,7 @@ namespace str_er {
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 #ifndef SVM_Q_UNROLL
-#define SVM_Q_UNROLL 1        // support vectors per pass of the decision-value loops (2: twice the loads in flight, 144 registers -> 12 waves a CU instead of 16)
+#define SVM_Q_UNROLL 1        // (66+ classes) support vectors per pass of the pair-indexed decision-value loops
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -596,28 +598,27 @@ __device__ __forceinline__ double rcp_nr(double x)
 }
 
 // svm_predict_values + sigmoid_predict + multiclass_probability for one vector per wave.  Class-indexed vectors (p, Qp,
-// Q's diagonal) live in registers: lane L holds classes L and L + 64.  The pairwise table V (k(k-1)/2 entries in LDS, pair
-// (i < j) at rb(i) + j, rb(i) = i k - i (i + 1) / 2 - i - 1) holds the pairwise probabilities r_ij, then Q's off-diagonal
-// entries -r_ji r_ij -- as f32: 8 KB instead of 16, which is what lets 16 waves share a compute unit's LDS (the kernel is a
-// chain of dependent f64 operations per wave: what it needs is waves).  An entry's rounding (6e-8 relative) moves a
-// probability by ~1e-8: Q is strongly diagonally dominant (Q_tt = sum of k - 1 squares, |Q_tj| <= 1/4).
+// Q's diagonal) live in registers: lane L holds class L (and L + 64 in the build for 66+ classes).  The pairwise table V (LDS, f32; row i =
+// columns i .. k - 1 at rb(i) + j, rb(i) = i k - i (i + 1) / 2, the diagonal slot set to 1 so that the walks need no mask) holds the pairwise
+// probabilities r_ij -- as f32: 8 KB instead of 16, which is what lets 16 waves share a compute unit's LDS.  An entry's rounding (6e-8
+// relative) moves a probability by ~1e-8: Q is strongly diagonally dominant (Q_tt = sum of k - 1 squares, |Q_tj| <= 1/4).
 //
-// Decision values: a lane per class pair, eight pairs of a lane at a time, summed exactly as libsvm does (coef[j-1][q] K[q]
-// over class i's support vectors, then coef[i][q] K[q] over class j's, then - rho: src/svm.cpp:2539-2566) -- the first half
-// from the transposed coefficient table (lanes = consecutive j: one row segment per support vector), the second from the
-// table as libsvm stores it (lanes = consecutive j again: neighbouring columns of row i).  The loops run over the support
-// vector's rank inside its class with all eight pairs' loads in flight.
+// Decision values (svm_predict_values, src/svm.cpp:2539-2566: coef[j-1][q] K[q] over class i's support vectors, then coef[i][q] K[q] over class
+// j's, then - rho).  k <= 65: row passes over SvmDev::coef_rows -- first class i per pass, second class j = lane + 1; see the comment in the
+// kernel.  66+ classes: a lane per class pair, eight pairs of a lane at a time, branch-free.
 //
 // Coupling: the reference's Gauss-Seidel sweep divides p and Qp by (1 + diff) after every coordinate step (5 divisions
 // per step, 2 of them on every lane).  Here the sweep runs on the unnormalised iterate -- p~ = p / sigma, B = Q p~,
 // A = p~ Q p~, S = sum p~ = 1 / sigma -- for which a step is d = (A / S - B_t) / Q_tt; p~_t += d; B += d Q_t; A += d (d Q_tt + 2 B_t);
 // S += d: one reciprocal on the critical path and one fused multiply-add per lane; the iterate is renormalised at the end
 // of a sweep, where the reference's stopping test (max_t |Qp_t - pQp| < 0.005 / k, on the same quantities up to rounding)
-// is evaluated.  The same fixed point, the same sweeps.
+// is evaluated.  The same fixed point, the same sweeps.  k <= 65: lane t keeps row t of Q in registers, a step reads no table.
 // MODE 0: k <= 64.  MODE 1: k = 65 (the reference's 65 characters): the one class beyond the 64 lanes is carried as a wave-uniform value in
 // every lane -- a second class register per lane would double the vector work of every step for one useful lane.  MODE 2: 66 <= k <= 125.
-// 4 waves per SIMD = the 16 waves per compute unit the LDS allows: 128 registers (the compiler wants 136 and parks 7 values that live across a
-// pass in scratch, outside the loops)
+// MSV (MODE 0 / 1): 5 = at most five support vectors a class (the reference's training set has five samples a class): class j's kernel values in
+// registers, the next pass's loads issued ahead; 0 = any count, ranks in eights.
+// 4 waves per SIMD = the 16 waves per compute unit the LDS allows: 128 registers (a handful of values that live across a pass are parked in
+// scratch, outside the loops)
 // LDS of one box: QI[2 k], D[k], V[k (k + 1) / 2] floats, rounded up to 16 bytes
 __host__ __device__ inline size_t svm_couple_lds_doubles(int k) { return ((size_t)3 * k + ((size_t)k * (k + 1) / 2 + 1) / 2 + 1) & ~(size_t)1; }
 #ifndef SVM_COUPLE_WAVES
