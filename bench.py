@@ -445,7 +445,7 @@ def main():
     # ---- config 3: the OCR scorer on every strong / weak ER of the same batches; then the reference's own call pattern (lines first)
     ocr_leg = group_ocr_leg = None
     if ocr_legs:
-        n_o = max(P, args.steps // 2)
+        n_o = max(P, args.steps)            # (as many steps as the headline's region: a shorter region would carry a larger share of the drain of the batches in flight)
 
         def ocr_leg_run(st, label):
             rig.run(P, d_frames, st)
@@ -495,7 +495,7 @@ def main():
         d_ties = torch.from_numpy(tf_).to(device)
         torch.cuda.synchronize()
         rig.run(P, d_ties, stages)
-        n_t = max(P, args.steps // 2)
+        n_t = max(P, args.steps)
         a0 = rig.tie_totals()
         cpu1 = time.process_time()
         el, _, _ = rig.timed(n_t, d_ties, stages)
@@ -615,7 +615,7 @@ def main():
         d4 = torch.from_numpy(fr4).to(device)
         rig4 = Rig(S, P, w4, h4, F4, cfg4, dev_index, args.sibling_order, cascades)
         rig4.run(2 * P, d4, S.STAGE_ALL)
-        n4 = max(P, args.steps // 2)
+        n4 = max(P, args.steps)
         el4, prof4, _ = rig4.timed(n4, d4, S.STAGE_ALL)
         sp4, _ = rig4.serial_profile(d4, S.STAGE_ALL)
         px4 = plane_pixels("pyr3x12", w4, h4)
