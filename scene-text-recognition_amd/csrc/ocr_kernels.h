@@ -64,8 +64,10 @@ struct OcrBuf {
 // Offsets are applied to `base` (may be null to size the allocation only: read .bytes).
 OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m /* null: features only */, bool want_q, bool want_dec, bool want_prob);
 
-// indices of the strong / weak candidates of the batch, in candidate order (deterministic): list[0 .. *n_out)
-void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out);
+// indices of the strong / weak candidates of the batch (n_cands = the host's copy of *b.total_cands), in candidate order (deterministic):
+// hdr[0] = their number, hdr[16 .. 272) = scratch, the list itself from hdr + OCR_LIST_HDR (room for n_cands entries)
+constexpr int OCR_LIST_HDR = 272;
+void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t n_cands, uint32_t *hdr);
 
 // Otsu threshold of 255 - roi for n boxes (cv::threshold(..., THRESH_OTSU)): hist [n x 256], big [1 + 4095] (scratch), thresh [n]
 void launch_box_thresholds(hipStream_t s, const OcrSrc &src, int n, uint32_t *hist, uint32_t *big, int32_t *thresh);

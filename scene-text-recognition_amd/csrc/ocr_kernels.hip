@@ -38,26 +38,38 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------------
 // boxes
 // ---------------------------------------------------------------------------------------------------------
-// indices of the strong / weak candidates of the batch, in candidate order.  One workgroup; a thread takes sixteen consecutive candidates per
-// pass (the class bytes are requested together: the scan is a chain of memory round trips otherwise -- three for a batch's 48 k candidates).
-constexpr int LIST_CPT = 16;
-__global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ cands, const uint32_t *__restrict__ total_cands,
-                                                   uint32_t *__restrict__ list, uint32_t *__restrict__ n_out)
+// indices of the strong / weak candidates of the batch, in candidate order: two launches of up to 256 workgroups, each over a contiguous range of the
+// candidates -- count, then (base = the counts before mine) fill.  The class byte sits in a 48-byte record: one workgroup alone pulls 48 k cache lines
+// through one compute unit's address pipeline for a batch (46 us); a thread asks for sixteen records' bytes at once.
+constexpr int LIST_CPT = 16, LIST_THREADS = 256, LIST_CHUNK = LIST_CPT * LIST_THREADS;
+template <bool FILL>
+__global__ __launch_bounds__(LIST_THREADS) void k_ocr_list(const CandRec *__restrict__ cands, const uint32_t *__restrict__ total_cands,
+                                                            uint32_t *__restrict__ hdr, uint32_t *__restrict__ list)
 {
-    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_w[LIST_THREADS / 64];
     __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int      tid = threadIdx.x, lane = tid & 63, G = gridDim.x, g = blockIdx.x;
     const uint32_t total = *total_cands;
-    if (tid == 0) s_carry = 0;
+    // my range: whole chunks, the same split in both launches
+    const uint32_t chunks = (total + LIST_CHUNK - 1) / LIST_CHUNK, per = (chunks + G - 1) / G;
+    const uint32_t lo = min((uint32_t)g * per * LIST_CHUNK, total), hi = min(lo + per * LIST_CHUNK, total);
+    uint32_t *counts = hdr + 16;
+    if (FILL) {
+        uint32_t v = tid < g ? counts[tid] : 0u;           // (G <= 256 = the workgroup)
+        for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+        if (lane == 0) s_w[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) s_carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    } else if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < total; base += 1024u * LIST_CPT) {
+    for (uint32_t base = lo; base < hi; base += LIST_CHUNK) {
         const uint32_t i0 = base + (uint32_t)LIST_CPT * (uint32_t)tid;
         uint32_t       mk = 0;
         uint8_t        cl[LIST_CPT];
 #pragma unroll
-        for (int u = 0; u < LIST_CPT; ++u) cl[u] = cands[min(i0 + u, total - 1)].cls;          // (unconditional: behind `i0 + u < total &&` every load waits for the one before)
+        for (int u = 0; u < LIST_CPT; ++u) cl[u] = cands[min(i0 + u, total - 1)].cls;          // (unconditional: behind `i0 + u < hi &&` every load waits for the one before)
 #pragma unroll
-        for (int u = 0; u < LIST_CPT; ++u) mk |= (i0 + u < total && cl[u] != 0) ? 1u << u : 0u;
+        for (int u = 0; u < LIST_CPT; ++u) mk |= (i0 + u < hi && cl[u] != 0) ? 1u << u : 0u;
         const uint32_t cnt = (uint32_t)__popc(mk);
         uint32_t       incl = cnt;
 #pragma unroll
@@ -65,13 +77,16 @@ __global__ __launch_bounds__(1024) void k_ocr_list(const CandRec *__restrict__ c
         if (lane == 63) s_w[tid >> 6] = incl;
         __syncthreads();
         uint32_t off = s_carry + incl - cnt, tot = 0;
-        for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
-        for (uint32_t r = mk; r != 0; r &= r - 1u) list[off++] = i0 + (uint32_t)__builtin_ctz(r);
+        for (int k = 0; k < LIST_THREADS / 64; ++k) { if (k < (tid >> 6)) off += s_w[k]; tot += s_w[k]; }
+        if (FILL) for (uint32_t r = mk; r != 0; r &= r - 1u) list[off++] = i0 + (uint32_t)__builtin_ctz(r);
         __syncthreads();
         if (tid == 0) s_carry += tot;
         __syncthreads();
     }
-    if (tid == 0) *n_out = s_carry;
+    if (tid == 0) {
+        if (!FILL) counts[g] = s_carry;
+        else if (g == G - 1) hdr[0] = s_carry;            // (the last range's end = the number listed)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1024,9 +1039,12 @@ OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m, bool want_q, bool wa
     return b;
 }
 
-void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t *list, uint32_t *n_out)
+void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t n_cands, uint32_t *hdr)
 {
-    hipLaunchKernelGGL(k_ocr_list, dim3(1), dim3(1024), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, list, n_out);
+    if (!n_cands) { (void)hipMemsetAsync(hdr, 0, 4, s); return; }
+    const uint32_t chunks = (n_cands + LIST_CHUNK - 1) / LIST_CHUNK, G = chunks < 256u ? chunks : 256u;
+    hipLaunchKernelGGL(k_ocr_list<false>, dim3(G), dim3(LIST_THREADS), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, hdr, hdr + OCR_LIST_HDR);
+    hipLaunchKernelGGL(k_ocr_list<true>, dim3(G), dim3(LIST_THREADS), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, hdr, hdr + OCR_LIST_HDR);
 }
 
 static int ocr_n_cu()

@@ -880,16 +880,16 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         rec(c, "track_host_gap");
         if (total) {
             const int    n_img = np / b.planes_per_image;
-            const size_t o_list = 0, o_cs = align_up(4 * (size_t)total + 64 + 256, 256);
+            const size_t o_list = 0, o_cs = align_up(4 * ((size_t)total + OCR_LIST_HDR) + 256, 256);
             const int    rcs = ensure_scratch(c, o_cs + calc_color_scratch_bytes(n_cls));
             if (rcs != STR_ER_OK) { delete r; return rcs; }
             uint8_t  *sc = static_cast<uint8_t *>(c->d_scratch);
             uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
             if (hipMemsetAsync(c->d_track, 0, sizeof(TrackRec) * (size_t)total, s) != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, "track reset failed"); }
             if (n_cls) {
-                launch_ocr_list(s, bd, d_list + 16, d_list);
+                launch_ocr_list(s, bd, (uint32_t)total, d_list);
                 OcrSrc src{};
-                src.recs = bd.cands; src.list = d_list + 16; src.planes = bd.planes;
+                src.recs = bd.cands; src.list = d_list + OCR_LIST_HDR; src.planes = bd.planes;
                 launch_calc_color(s, src, ColorSrc{}, (int)n_cls, c->d_track, sc + o_cs);
             }
             launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
@@ -939,16 +939,16 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             const SvmDev &m = c->svm;
             size_t off = 0;
             auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-            const size_t o_list = take(4 * (size_t)total + 64), o_buf = take(0);
+            const size_t o_list = take(4 * ((size_t)total + OCR_LIST_HDR)), o_buf = take(0);
             int rc2 = ensure_scratch(c, o_buf + ocr_layout(nullptr, n_ocr, &m, false, false, false).bytes);
             if (rc2 != STR_ER_OK) { delete r; return rc2; }
             uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
             const OcrBuf buf = ocr_layout(sc + o_buf, n_ocr, &m, false, false, false);
             uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
             rec(c, "ocr_host_gap");          // (the host read the counters first: this interval is the round trip, not GPU work)
-            launch_ocr_list(s, bd, d_list + 16, d_list);
+            launch_ocr_list(s, bd, (uint32_t)total, d_list);
             OcrSrc src{};
-            src.recs = bd.cands; src.list = d_list + 16; src.planes = bd.planes;
+            src.recs = bd.cands; src.list = d_list + OCR_LIST_HDR; src.planes = bd.planes;
             launch_ocr_features(s, src, (int)n_ocr, buf, &m);
             rec(c, "ocr_features");
             launch_svm_kernel(s, (int)n_ocr, buf, m, true);
@@ -963,7 +963,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             // GPU in a rocprofv3 timeline of six batches in flight)
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = wait_stream(c, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(list.data(), d_list + 16, 4 * n_ocr, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(list.data(), d_list + OCR_LIST_HDR, 4 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), buf.label, 4 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(pb.data(), buf.pbest, 8 * n_ocr, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = wait_stream(c, s);
