@@ -1,5 +1,6 @@
 // api_models.cpp -- the C ABI, part 2: the models -- cascade text (CascadeBoost::load_classifier), libsvm text model, and the entry points that run them on explicit inputs (predict, svm_predict_probability, OCR::chain_run)
 #include "str_er_ctx.h"
+#include "svm_tables.h"
 
 namespace {
 
@@ -291,29 +292,12 @@ try {
     if (k <= 65) {
         if ((size_t)k * 2 * mp * 64 * 8 > ((size_t)1 << 30))
             return fail(c, STR_ER_EFORMAT, "svm model: a class with so many support vectors that the per-class coefficient rows exceed 1 GB");
-        rows.assign((size_t)k * 2 * mp * 64, 0.0);
-        for (int i = 0; i < k; ++i)
-            for (int b = 0; b + 1 < k; ++b) {                     // b = the row of sv_coef, and the second class b + 1
-                double *r1 = &rows[((size_t)(2 * i) * mp) * 64 + b], *r2 = r1 + (size_t)mp * 64;
-                for (int r = 0; r < insv[i]; ++r) r1[(size_t)r * 64] = coef[(size_t)b * l + start[i] + r];
-                if (i < k - 1) for (int r = 0; r < insv[b + 1]; ++r) r2[(size_t)r * 64] = coef[(size_t)i * l + start[b + 1] + r];
-            }
+        rows = svm_coef_rows(coef, start, insv, k, l, mp);
     }
     const size_t o_rows = take(rows.size() * 8);
-    // the support vectors in three bf16 pieces (k_svm_kernel_q): the top 8 significant bits, the next 8, the last 8 -- each cut is a truncation, each remainder exact
+    // the support vectors in three bf16 pieces (k_svm_kernel_q; svm_tables.h)
     const int dq = (int)align_up((size_t)dim, 64);
-    std::vector<uint16_t> svq((size_t)3 * l_pad * dq, 0);
-    for (int i = 0; i < l; ++i)
-        for (int j = 0; j < dim; ++j) {
-            float r = sv[(size_t)i * dpad + j];
-            for (int pl = 0; pl < 3; ++pl) {
-                uint32_t u; std::memcpy(&u, &r, 4);
-                u &= 0xFFFF0000u;
-                float piece; std::memcpy(&piece, &u, 4);
-                svq[((size_t)pl * l_pad + i) * dq + j] = (uint16_t)(u >> 16);
-                r -= piece;
-            }
-        }
+    const std::vector<uint16_t> svq = svm_sv_planes(sv, l, l_pad, dim, dpad, dq);
     const size_t o_svq = take(svq.size() * 2);
     const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
                  o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);

@@ -81,8 +81,7 @@ void launch_svm_score(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, 
 // ... its two halves: the RBF kernel matrix buf.kv; decision values + coupling from buf.kv
 void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, bool numerators);
 void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m);
-// rows per class of SvmDev::coef_rows for a model whose largest class has msv support vectors (the kernel's builds: 5 exactly -- the shape of the reference's training set -- or eights)
-inline int svm_rows_per_class(int msv) { return msv == 5 ? 5 : (msv + 7) / 8 * 8; }
+// (svm_rows_per_class() and the builders of SvmDev::svq / coef_rows: svm_tables.h)
 
 // f64 feature vectors (API entry str_er_svm_predict_probability) -> buf.xf / buf.xnorm
 void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBuf &buf, const SvmDev &m);

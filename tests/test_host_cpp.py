@@ -88,3 +88,13 @@ def test_stream_example_runs(S, cascade_paths, tmp_path):
     assert out[-1] == "stream == direct calls: yes"
     assert len([l for l in out if l.startswith("frame ")]) == 7
     assert sum(int(l.split()[11]) for l in out if l.startswith("frame ")) > 0        # some text lines were found
+
+
+def test_svm_model_tables(tmp_path):
+    """The tables the SVM loader lays out for the device (csrc/svm_tables.h): an f32 as three bf16 pieces is exact, the planes and the per-class
+    coefficient rows hold what their definitions say, and a pair's decision value summed over the zero-padded rows equals libsvm's sum bit for bit."""
+    exe = str(tmp_path / "svm_tables_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "scene-text-recognition_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "cpp", "svm_tables_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().endswith("svm tables ok")
