@@ -40,12 +40,12 @@ namespace {
 // written before they are read.  Round 4, measured and not adopted: the level looked up from the plane when the walk first touches a pixel -- no pass over the
 // whole plane in front of a walk that stops early -- is 11 % SLOWER on the boxes' EPYC 9575F: two dependent loads per new pixel instead of one, and the walk is
 // a chain of mispredicted branches and dependent loads, ~8 ns per pixel, whatever the bytes.)
-template <typename T, int LBITS>
+template <typename T, int LBITS, bool ALL>
 void flood_walk(const uint8_t *pix, int w, int h, int64_t stride, int invert, float qscale, int hi, const uint32_t *watch, uint32_t n_watch,
                 uint32_t *stamp, const uint32_t *group, std::vector<T> &st_buf, std::vector<uint32_t> &stk_buf)
 {
     const uint32_t n = (uint32_t)w * (uint32_t)h;
-    const bool all = n_watch == 0xFFFFFFFFu;
+    constexpr bool all = ALL;          // (n_watch == 0xFFFFFFFF: every pixel is stamped; a build of its own -- the test sits in the walk's innermost step)
     constexpr T ACC = (T)(1u << (LBITS + 1)), WATCH = (T)(1u << LBITS), LEVEL = (T)((1u << LBITS) - 1u);
     T lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (T)std::lrintf((float)v * qscale);
@@ -187,8 +187,14 @@ void flood_order_host(const uint8_t *pix, int w, int h, int64_t stride, int inve
             if (c.size() > ((size_t)1 << 21) + ((size_t)1 << 16)) { std::vector<uint8_t>().swap(a); std::vector<uint16_t>().swap(b); std::vector<uint32_t>().swap(c); }
         }
     } shrink{st8, st16, stk};
-    if (hi <= 63) flood_walk<uint8_t, 6>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st8, stk);
-    else flood_walk<uint16_t, 9>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st16, stk);
+    const bool all = n_watch == 0xFFFFFFFFu;
+    if (hi <= 63) {
+        if (all) flood_walk<uint8_t, 6, true>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st8, stk);
+        else flood_walk<uint8_t, 6, false>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st8, stk);
+    } else {
+        if (all) flood_walk<uint16_t, 9, true>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st16, stk);
+        else flood_walk<uint16_t, 9, false>(pix, w, h, stride, invert, qscale, hi, watch, n_watch, stamp, group, st16, stk);
+    }
 }
 
 // ---- the pool ----------------------------------------------------------------------------------------------------------------
