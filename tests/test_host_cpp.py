@@ -98,3 +98,15 @@ def test_svm_model_tables(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "svm_tables_check.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.strip().endswith("svm tables ok")
+
+
+def test_flood_walk_watch_mode(tmp_path):
+    """flood_order_host with a watch list (the form the NMS tie pass uses): the walk that stops early gives the watched pixels the stamps of the
+    complete walk; with groups it may leave out exactly the member of a set that is reached last.  400 random planes (noise, blocks, ramps, speckles;
+    THRESH_STEP 1 ... 16: both state widths; padded rows; inverted)."""
+    csrc = os.path.join(ROOT, "scene-text-recognition_amd", "csrc")
+    exe = str(tmp_path / "flood_watch_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", csrc, os.path.join(ROOT, "tests", "cpp", "flood_watch_check.cpp"),
+                    os.path.join(csrc, "flood_order.cpp"), "-o", exe, "-lpthread"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().startswith("flood watch ok")
