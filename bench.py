@@ -686,7 +686,6 @@ def main():
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
                        "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P, "host_cpus_busy": round(host_cpu_per_wall, 2),
                        "workspace_bytes_per_batch_in_flight": ws_bytes, "nms_sibling_ties": "exact (reference flood order)" if args.sibling_order == 0 else "key rule",
-                       "cu_partition": os.environ.get("STR_ER_CU_PARTITION", "none"),
                        **({"gather": "RCCL through the C ABI (str_er_gather_last)" if comm is not None else "torch.distributed all_gather"} if world > 1 else {})},
             "nms_ties": nms_ties,
             **({"config3_ocr_leg": ocr_leg} if ocr_leg else {}),

@@ -201,6 +201,10 @@ int  str_er_tie_stats(const str_er_ctx *ctx, uint64_t *planes_walked, double *wa
  * k_group_merge / k_resolve / k_reduce read and write), pixel pairs across tile borders (k_seam: two 16-bit seam entries each) and tiles.
  * Measurement aid (bench.py prices the passes against the HBM roofline with it); the reference has no counterpart.  Any pointer may be NULL. */
 int  str_er_last_tree_stats(const str_er_ctx *ctx, uint64_t *records, uint64_t *seam_pairs, uint64_t *tiles);
+/* The tile trees of the chroma planes (few levels per tile) are built by a second tile kernel, k_tile_tree2 (level by level on bit masks); a tile with
+ * more levels / nodes than it takes is handed back to k_tile_tree.  Since the context was created: tiles given to k_tile_tree2, tiles it handed
+ * back.  Measurement aid; results do not depend on which kernel built a tile's tree.  Any pointer may be NULL. */
+int  str_er_tile2_stats(const str_er_ctx *ctx, uint64_t *tiles, uint64_t *handed_back);
 const char *str_er_runtime_hint(void);
 int  str_er_apply_runtime_hint(void);
 

@@ -203,6 +203,7 @@ def load_library():
     L.str_er_result_cands_to_device.argtypes = [vp, vp, vp, C.c_int32, i32p]
     L.str_er_result_free.argtypes = [vp]
     L.str_er_last_tree_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.str_er_tile2_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.str_er_last_profile.argtypes = [vp, C.POINTER(C.c_char_p), f64p, C.c_int32]
     L.str_er_set_profiling.argtypes = [vp, C.c_int]
     L.str_er_workspace_bytes.argtypes = [vp]
@@ -419,6 +420,12 @@ class ERFilter:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(self.L.str_er_last_tree_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"records": int(a.value), "seam_pairs": int(b.value), "tiles": int(c.value)}
+
+    def tile2_stats(self) -> dict:
+        """Tiles given to the second tile kernel (k_tile_tree2) since the context was created, and how many it handed back (str_er_tile2_stats)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.L.str_er_tile2_stats(self.h, C.byref(a), C.byref(b)))
+        return {"tiles": int(a.value), "handed_back": int(b.value)}
 
     def last_profile(self) -> dict:
         names = (C.c_char_p * 16)()

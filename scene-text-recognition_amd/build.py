@@ -15,10 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libstr_er_hip.so")
 SOURCES = ["er_kernels.hip", "ocr_kernels.hip", "track_kernels.hip", "er_group.cpp", "flood_order.cpp", "gather.cpp", "str_er_api.cpp", "api_models.cpp", "api_strips.cpp", "api_stages.cpp", "stream_api.cpp"]
-DEPS = SOURCES + ["er_planes.inl", "er_tile_tree.inl", "er_tree_passes.inl", "er_nms.inl", "er_classify.inl", "er_kernels.h", "ocr_kernels.h", "ocr_device.h", "svm_tables.h", "str_er_ctx.h", "track_kernels.h", "er_device.h", "er_group.h", "flood_order.h", "er_types.h", os.path.join("..", "..", "include", "str_er.h")]
+DEPS = SOURCES + ["er_planes.inl", "er_tile_tree.inl", "er_tile_tree2.inl", "tile2_body.h", "er_tree_passes.inl", "er_nms.inl", "er_classify.inl", "er_kernels.h", "ocr_kernels.h", "ocr_device.h", "svm_tables.h", "str_er_ctx.h", "track_kernels.h", "er_device.h", "er_group.h", "flood_order.h", "er_types.h", os.path.join("..", "..", "include", "str_er.h")]
 EXTRA = os.environ.get("STR_ER_EXTRA_FLAGS", "").split()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-bitwise-instead-of-logical"]
 
 
 def hipcc() -> str:

@@ -52,7 +52,13 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                    int64_t dframe_pitch, int planes_per_frame, int n_frames);
 
 // sparse: the small-LDS / high-occupancy size of the kernel (text-like frames); dense: the big one (noise-like frames)
-void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse);
+// list: the tiles to work on (batch-wide tile numbers, device), nullptr = all tiles of the batch
+void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse, const uint32_t *list = nullptr, uint32_t n = 0);
+// the tiles k_tile_tree2 handed back (list / count on the device): `grid` workgroups walk the list
+void launch_tile_tree_fb(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse, const uint32_t *list, const uint32_t *count, uint32_t grid);
+// k_tile_tree2 (er_tile_tree2.inl): the level-by-level / bit-mask form for planes with few levels per tile; one wave per pair of horizontally
+// adjacent tiles (entry: first tile | 1 << 31 if the tile to its right takes part); tiles it does not take end up in fb_list
+void launch_tile_tree2(hipStream_t s, const BatchDev &b, const DetectParams &p, const uint32_t *pairs, uint32_t n_pairs, uint32_t *fb_list, uint32_t *fb_count);
 // the tiles of every group of BatchDev::group_x x group_y tiles joined in LDS, in place (variant: LDS capacity / lanes, see er_kernels.hip)
 void launch_group_merge(hipStream_t s, const BatchDev &b, int variant);
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);

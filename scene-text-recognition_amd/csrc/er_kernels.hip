@@ -31,12 +31,14 @@
 
 #include "er_device.h"
 #include "er_kernels.h"
+#include "tile2_body.h"
 
 namespace str_er {
 
-// One translation unit, five parts (device code without relocatable linking: helpers, macros and the developer trace buffers are shared):
+// One translation unit, six parts (device code without relocatable linking: helpers, macros and the developer trace buffers are shared):
 #include "er_planes.inl"        // compute_channels, NV12 ingest, cv::resize
 #include "er_tile_tree.inl"     // k_tile_tree
+#include "er_tile_tree2.inl"    // k_tile_tree2 (chroma / few-level planes)
 #include "er_tree_passes.inl"   // k_group_merge, k_seam, strips, k_resolve, k_reduce, k_root / k_select / k_kept
 #include "er_nms.inl"           // k_nms and everything around NMS ties
 #include "er_classify.inl"      // k_classify, k_lbp_boxes, k_cascade_fv

@@ -442,8 +442,10 @@ constexpr int FOLD_CAP_SPARSE = TILE_H > 32 ? 1024 : 480;   // 16 (32) granules:
 // tile costs is mostly what EVERY tile costs (load phase 22 % of a chroma tile, building the edge list, the reductions of the statistics pass).
 // ------------------------------------------------------------------------------------
 #define LEVK(k) ((((k) < 4 ? lev_lo : lev_hi) >> (8 * ((k) & 3))) & 0xFFu)
+// (the body is a function of the tile: k_tile_tree takes the tile from its workgroup number or from a list of tiles -- the planes k_tile_tree2 does
+// not take --, k_tile_tree_fb walks the list of tiles k_tile_tree2 handed back)
 template <int FOLD_CAP>
-__global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)) void k_tile_tree(BatchDev b, DetectParams prm)
+__device__ __forceinline__ void tile_tree_body(const BatchDev &b, const DetectParams &prm, const uint32_t tile_no)
 {
     constexpr int WORK_WORDS = NODE_WORDS * FOLD_CAP;
     constexpr int STAT_CHUNK = FOLD_CAP < 512 ? FOLD_CAP : 512;   // dense tiles: nodes whose statistics are accumulated per pass
@@ -461,9 +463,6 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
         uint32_t wsum[TILE_THREADS / 64];
         uint32_t walls, start, nbase;
         uint32_t present[8];           // which levels have a node in this tile (big kernel)
-#ifdef STR_ER_PAD_LDS
-        uint32_t pad[STR_ER_PAD_LDS / 4];     // developer aid: extra LDS per workgroup, to see what fewer resident workgroups per CU cost
-#endif
     };
     __shared__ TileLds s_lds;
     uint32_t (&s_par)[TILE_SLOTS] = s_lds.par;
@@ -484,12 +483,9 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     uint32_t *const s_hist = s_work + HIST_AT;
 
     const int       tid = threadIdx.x;
-#ifdef STR_ER_PAD_LDS
-    if (b.n_tiles == 0xFFFFFFFFu) s_lds.pad[tid] = tid;
-#endif
-    const int       pi = b.tile_plane[blockIdx.x];
+    const int       pi = b.tile_plane[tile_no];
     const PlaneDesc pd = b.planes[pi];
-    const uint32_t  tl = blockIdx.x - pd.tile_base;
+    const uint32_t  tl = tile_no - pd.tile_base;
     const int       tx = tl % pd.tiles_x, ty = tl / pd.tiles_x;
     const int       ox = tx * TILE_W, oy = ty * TILE_H;
     const int       ly = tid >> 3, lx = (tid & 7) * TILE_PPT;
@@ -1193,8 +1189,8 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     if (!(W0FOLD && w0fold)) __syncthreads();       // (the small kernel's fold path has read s_nbase behind a barrier already and writes no LDS after it)
     const uint32_t nbase = s_nbase;
     if (tid == 0) {
-        b.tile_nbase[blockIdx.x] = nbase;
-        b.tile_nrec[blockIdx.x] = (uint16_t)total;
+        b.tile_nbase[tile_no] = nbase;
+        b.tile_nrec[tile_no] = (uint16_t)total;
         if (tl == 0) b.ctr[pi].start_node = (s_start == NONE || nbase == NONE) ? NONE : nbase + s_nid[LX(s_start)];
     }
     PHASE_MARK(13);
@@ -1237,6 +1233,23 @@ __global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)
     PHASE_MARK(6);
 }
 
+template <int FOLD_CAP>
+__global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)) void k_tile_tree(BatchDev b, DetectParams prm, const uint32_t *list)
+{
+    tile_tree_body<FOLD_CAP>(b, prm, list ? list[blockIdx.x] : blockIdx.x);
+}
+// the tiles k_tile_tree2 handed back (more levels / nodes / records than it takes): their number is known on the device only, so a fixed number of
+// workgroups walks the list
+template <int FOLD_CAP>
+__global__ __launch_bounds__(TILE_THREADS, (FOLD_CAP == FOLD_CAP_SPARSE ? 8 : 6)) void k_tile_tree_fb(BatchDev b, DetectParams prm, const uint32_t *list, const uint32_t *count)
+{
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        tile_tree_body<FOLD_CAP>(b, prm, list[i]);
+        __syncthreads();
+    }
+}
+
 #ifdef STR_ER_PHASE_PROF
 extern "C" void str_er_debug_phase_cycles(unsigned long long *out16, int reset)
 {
@@ -1248,17 +1261,18 @@ extern "C" void str_er_debug_phase_cycles(unsigned long long *out16, int reset)
 }
 #endif
 
-// Developer experiment (STR_ER_TILE_LDS_PAD=bytes, off by default): unused dynamic LDS per workgroup, i.e. fewer tile workgroups resident per compute
-// unit -- wave slots left for the latency-bound passes of the other batches in flight (profiles/r05_cu_partition.md has the result).
-static size_t tile_lds_pad()
+// list == nullptr: every tile of the batch; else the n listed tiles
+void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse, const uint32_t *list, uint32_t n)
 {
-    static const size_t pad = [] { const char *e = getenv("STR_ER_TILE_LDS_PAD"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 65536 ? v : 0); }();
-    return pad;
+    const uint32_t grid = list ? n : b.n_tiles;
+    if (!grid) return;
+    if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(grid), dim3(TILE_THREADS), 0, s, b, p, list);
+    else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(grid), dim3(TILE_THREADS), 0, s, b, p, list);
 }
 
-void launch_tile_tree(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse)
+void launch_tile_tree_fb(hipStream_t s, const BatchDev &b, const DetectParams &p, bool sparse, const uint32_t *list, const uint32_t *count, uint32_t grid)
 {
-    if (!b.n_tiles) return;
-    if (sparse) hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_SPARSE>, dim3(b.n_tiles), dim3(TILE_THREADS), tile_lds_pad(), s, b, p);
-    else        hipLaunchKernelGGL(k_tile_tree<FOLD_CAP_DENSE>, dim3(b.n_tiles), dim3(TILE_THREADS), tile_lds_pad(), s, b, p);
+    if (!grid) return;
+    if (sparse) hipLaunchKernelGGL(k_tile_tree_fb<FOLD_CAP_SPARSE>, dim3(grid), dim3(TILE_THREADS), 0, s, b, p, list, count);
+    else        hipLaunchKernelGGL(k_tile_tree_fb<FOLD_CAP_DENSE>, dim3(grid), dim3(TILE_THREADS), 0, s, b, p, list, count);
 }

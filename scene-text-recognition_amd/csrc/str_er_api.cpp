@@ -103,18 +103,52 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     return d;
 }
 
-// the wide stream takes over after everything queued on the main stream so far / the main stream continues after the wide one
-static void wide_fork(str_er_ctx *c)
+// The tile trees of a batch: the planes with few levels per tile (the chroma planes of a frame: 2.2 levels and ~15 nodes per tile on text-like
+// content) go to k_tile_tree2, the others to k_tile_tree; tiles k_tile_tree2 does not take (too many levels / nodes / records) come back in a
+// list that k_tile_tree then walks.  Results do not depend on who built a tile's tree (tests: STR_ER_TILE2=0 / 1 / 2 give the same records).
+static bool plane_takes_t2(const str_er_ctx *c, const PlaneDesc &pd, const DetectParams &dp)
 {
-    if (!c->wide) return;
-    (void)hipEventRecord(c->ev_wf, c->stream);
-    (void)hipStreamWaitEvent(c->wide, c->ev_wf, 0);
+    if (c->t2_mode == 0 || !c->tile_sparse) return false;                    // (noise-like batches: hundreds of nodes per tile)
+    if (dp.hi > 32 || dp.hi < 2 || (dp.thresh_step & (dp.thresh_step - 1)) != 0) return false;      // levels as 5 bits; quantisation by shifts
+    if (c->t2_mode == 2) return true;
+    return c->t2_backoff == 0 && pd.ch % 3 != 0;
 }
-static void wide_join(str_er_ctx *c)
+static int launch_tile_trees(str_er_ctx *c, const Batch &b, const BatchDev &bd, const DetectParams &dp)
 {
-    if (!c->wide) return;
-    (void)hipEventRecord(c->ev_wj, c->wide);
-    (void)hipStreamWaitEvent(c->stream, c->ev_wj, 0);
+    hipStream_t s = c->stream;
+    std::vector<uint32_t> key;
+    key.reserve(b.planes.size() * 3 + 1);
+    bool any = false;
+    for (const PlaneDesc &pd : b.planes) {
+        const bool t = plane_takes_t2(c, pd, dp);
+        any |= t;
+        key.push_back((uint32_t)pd.w); key.push_back((uint32_t)pd.h); key.push_back(t ? 1u : 0u);
+    }
+    if (!any) { launch_tile_tree(s, bd, dp, c->tile_sparse); c->n_t2_tiles = 0; return STR_ER_OK; }
+    if (key != c->t2_key) {
+        c->t2_key.clear();
+        c->h_t1_list.clear(); c->h_t2_pairs.clear();
+        uint32_t n2 = 0;
+        for (const PlaneDesc &pd : b.planes) {
+            if (plane_takes_t2(c, pd, dp)) {
+                for (int ty = 0; ty < pd.tiles_y; ++ty)
+                    for (int tx = 0; tx < pd.tiles_x; tx += 2)
+                        c->h_t2_pairs.push_back((pd.tile_base + (uint32_t)(ty * pd.tiles_x + tx)) | (tx + 1 < pd.tiles_x ? 0x80000000u : 0u));
+                n2 += (uint32_t)(pd.tiles_x * pd.tiles_y);
+            } else
+                for (uint32_t k = 0; k < (uint32_t)(pd.tiles_x * pd.tiles_y); ++k) c->h_t1_list.push_back(pd.tile_base + k);
+        }
+        if (!c->h_t1_list.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_t1_list, c->h_t1_list.data(), 4 * c->h_t1_list.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_t2_pairs, c->h_t2_pairs.data(), 4 * c->h_t2_pairs.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, wait_stream(c, s));   // (pageable host vectors)
+        c->n_t2_tiles = n2;
+        c->t2_key = key;
+    }
+    // the small kernel first: its waves are the longer ones (a dependent chain per pair of tiles), the big kernel's workgroups fill in behind
+    launch_tile_tree2(s, bd, dp, c->d_t2_pairs, (uint32_t)c->h_t2_pairs.size(), c->d_fb_list, c->d_total + 1);
+    launch_tile_tree(s, bd, dp, c->tile_sparse, c->d_t1_list, (uint32_t)c->h_t1_list.size());
+    launch_tile_tree_fb(s, bd, dp, c->tile_sparse, c->d_fb_list, c->d_total + 1, std::min<uint32_t>(c->n_t2_tiles, 256u));
+    return STR_ER_OK;
 }
 
 void rec(str_er_ctx *c, const char *name, hipStream_t on)
@@ -565,7 +599,7 @@ int upload_layout(str_er_ctx *c, Batch &b)
     std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
     HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_total, 0, 2 * sizeof(uint32_t), s));      // candidates of the batch, tiles k_tile_tree2 handed back
     {   // tile -> plane and seam-block -> (plane, first pair) tables; re-uploaded only when the layout changes
         std::vector<uint32_t> key;
         key.reserve(np * 2 + 1);
@@ -670,10 +704,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         if (rci != STR_ER_OK) return rci;
         rec(c, "tile_tree");
     } else {
-        wide_fork(c);                   // (the layout upload above is on the main stream)
-        launch_tile_tree(c->wide ? c->wide : s, bd, dp, c->tile_sparse);
-        rec(c, "tile_tree", c->wide);
-        wide_join(c);
+        { const int rct = launch_tile_trees(c, b, bd, dp); if (rct != STR_ER_OK) return rct; }
+        rec(c, "tile_tree");
     }
     if (c->dbg_tile_only) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
@@ -722,7 +754,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     const CandRec *spec_src = nullptr;
     uint32_t       spec_n = 0;
     if ((stages & STR_ER_STAGE_NMS) && np <= SPEC_PLANES && c->pool_total && c->last_total <= SPEC_CANDS) {
@@ -730,6 +762,11 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         HIP_TRY(c, hipMemcpyAsync(c->h_cands_spec, spec_src, sizeof(CandRec) * (size_t)spec_n, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, wait_stream(c, s));
+    if (c->n_t2_tiles && !import_trees) {     // tiles k_tile_tree2 handed back: if they are many, the chroma planes stay with k_tile_tree for a while
+        const uint32_t fbn = c->h_total[1];
+        c->t2_tiles_total += c->n_t2_tiles; c->t2_fb_total += fbn;
+        if (c->t2_mode == 1 && (uint64_t)fbn * 8u > c->n_t2_tiles) c->t2_backoff = 32;
+    } else if (c->t2_backoff > 0) --c->t2_backoff;
     {   // what the tree passes of this batch worked on (str_er_last_tree_stats: bench.py prices them against the HBM roofline)
         uint64_t recs = 0, pairs = 0, tiles = 0;
         for (int i = 0; i < np; ++i) {
@@ -1098,6 +1135,14 @@ try {
     return STR_ER_OK;
 } ABI_GUARD(const_cast<str_er_ctx *>(c))
 
+int str_er_tile2_stats(const str_er_ctx *c, uint64_t *tiles, uint64_t *handed_back)
+try {
+    if (!c) return STR_ER_EINVAL;
+    if (tiles) *tiles = c->t2_tiles_total;
+    if (handed_back) *handed_back = c->t2_fb_total;
+    return STR_ER_OK;
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
+
 const char *str_er_runtime_hint(void) { return "GPU_MAX_HW_QUEUES=16"; }
 int str_er_apply_runtime_hint(void)
 {
@@ -1161,9 +1206,6 @@ void str_er_destroy(str_er_ctx *c)
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->prio) { (void)hipStreamSynchronize(c->prio); (void)hipStreamDestroy(c->prio); }
-    if (c->wide) { (void)hipStreamSynchronize(c->wide); (void)hipStreamDestroy(c->wide); }
-    if (c->ev_wf) (void)hipEventDestroy(c->ev_wf);
-    if (c->ev_wj) (void)hipEventDestroy(c->ev_wj);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1201,6 +1243,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     if (const char *g = std::getenv("STR_ER_GROUP_X")) c->dbg_group[0] = std::atoi(g);
     if (const char *g = std::getenv("STR_ER_GROUP_Y")) c->dbg_group[1] = std::atoi(g);
     if (const char *g = std::getenv("STR_ER_GROUP_KERNEL")) c->dbg_group[2] = std::atoi(g);
+    if (const char *t2 = std::getenv("STR_ER_TILE2")) c->t2_mode = std::max(0, std::min(2, std::atoi(t2)));      // developer switch: 0 k_tile_tree only, 2 k_tile_tree2 on every plane
     c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
     c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
     if (const char *nb = std::getenv("STR_ER_NODE_BLOCKS")) c->node_blocks_cap = (uint32_t)std::max(1, std::atoi(nb));
@@ -1246,36 +1289,6 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
             c->h_tie_count = c->h_tie_plane + TIE_SLOTS;
         }
     }
-    if (const char *e = std::getenv("STR_ER_CU_PARTITION")) {
-        // Mask bits are dealt round-robin over the 8 XCDs (bit i -> XCD i % 8), so a prefix of N bits takes N / 8 compute units of every XCD.
-        const int n = std::atoi(e);
-        hipDeviceProp_t prop{};
-        if (n >= 8 && c->own_stream && hipGetDeviceProperties(&prop, p->device) == hipSuccess && n <= prop.multiProcessorCount - 8) {
-            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-            std::vector<uint32_t> small((size_t)words, 0u), big((size_t)words, 0u);
-            // STR_ER_CU_PARTITION_MODE: "spread" (default) = n / 8 compute units of every XCD; "xcd" = whole XCDs (n / 32 of them);
-            // "full" = both streams on every compute unit (the two-stream structure alone)
-            const char *mode = std::getenv("STR_ER_CU_PARTITION_MODE");
-            const bool by_xcd = mode && std::strcmp(mode, "xcd") == 0, full = mode && std::strcmp(mode, "full") == 0;
-            for (int i = 0; i < ncu; ++i) {
-                const bool in_small = by_xcd ? (i % 8) < n / (ncu / 8) : i < n;
-                if (full || in_small) small[(size_t)(i / 32)] |= 1u << (i % 32);
-                if (full || !in_small) big[(size_t)(i / 32)] |= 1u << (i % 32);
-            }
-            // "prio": no masks -- the passes' stream at the highest priority, the tile kernels' at the lowest, so that a pass's few workgroups are
-            // dispatched ahead of another context's tile kernel backlog as slots free up
-            const bool prio = mode && std::strcmp(mode, "prio") == 0;
-            int plo = 0, phi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-            hipStream_t narrow = nullptr;
-            if ((prio ? hipStreamCreateWithPriority(&narrow, hipStreamNonBlocking, phi) : hipExtStreamCreateWithCUMask(&narrow, (uint32_t)words, small.data())) == hipSuccess &&
-                (prio ? hipStreamCreateWithPriority(&c->wide, hipStreamNonBlocking, plo) : hipExtStreamCreateWithCUMask(&c->wide, (uint32_t)words, big.data())) == hipSuccess &&
-                hipEventCreateWithFlags(&c->ev_wf, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_wj, hipEventDisableTiming) == hipSuccess) {
-                (void)hipStreamDestroy(c->stream);
-                c->stream = narrow;
-            } else A(fail(nullptr, STR_ER_EHIP, "STR_ER_CU_PARTITION: masked stream creation failed"));
-        }
-    }
     c->spin_wait = std::getenv("STR_ER_SPIN_WAIT") != nullptr;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
@@ -1298,6 +1311,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     c->sb_slots = c->seam_slots / (2 * (size_t)std::min(SEAM_BLOCK, 256)) + (size_t)c->max_planes + 16;
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
+    A(dev_alloc(c, c->d_t1_list, c->tile_slots)); A(dev_alloc(c, c->d_t2_pairs, c->tile_slots)); A(dev_alloc(c, c->d_fb_list, c->tile_slots));
     A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * 32));
     A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_done, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
@@ -1414,8 +1428,7 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
     if (frame_bytes * n_frames > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
     auto plane_sz = [&](int l) { return align_up((size_t)geo[l].stride * geo[l].h, 256); };
     c->n_ev = 0; c->profile.clear(); rec(c, "begin");
-    wide_fork(c);
-    const hipStream_t ws = c->wide ? c->wide : c->stream;
+    const hipStream_t ws = c->stream;
     if (nv12)
         launch_nv12_to_ycrcb(ws, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
                              c->d_pix + geo[0].off + 2 * plane_sz(0), geo[0].stride, (int64_t)frame_bytes);

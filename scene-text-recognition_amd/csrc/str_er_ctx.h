@@ -83,10 +83,6 @@ struct str_er_ctx {
     hipStream_t side = nullptr;          // the opposite-rule NMS pass runs here, beside classify
     hipStream_t prio = nullptr;          // high priority: the few small operations that settle an NMS tie (they would queue behind other contexts' big kernels)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // experiment (STR_ER_CU_PARTITION=N): the bandwidth / issue-bound kernels (channels, pyramid, tile trees) on a stream restricted to
-    // 256 - N compute units, everything else on the N others, so that one context's latency-bound passes run BESIDE another context's tile kernel
-    hipStream_t wide = nullptr;
-    hipEvent_t ev_wf = nullptr, ev_wj = nullptr;
     bool own_stream = false;
     int ppf = 0;                     // logical planes per frame
     std::vector<int> chans;          // channel indices selected by the mask
@@ -122,6 +118,14 @@ struct str_er_ctx {
     std::vector<uint16_t> h_tile_plane, h_sb_plane; std::vector<uint32_t> h_sb_first;
     std::vector<uint32_t> layout_key;   // (w,h,...) of the batch whose tables are on the device
     uint32_t *d_tile_nbase = nullptr; size_t tile_slots = 0;
+    // the batch's tiles split between the two tile kernels (launch_tile_trees): the planes k_tile_tree2 takes (chroma: few levels per tile) as
+    // pairs of tiles, the others as a list for k_tile_tree, and the tiles k_tile_tree2 hands back (their count: d_total[1])
+    int       t2_mode = 1;                            // STR_ER_TILE2: 0 off, 1 the chroma planes (ch % 3 != 0), 2 every plane
+    int       t2_backoff = 0;                         // batches for which the chroma planes stay with k_tile_tree (the last batch handed too many tiles back)
+    uint32_t *d_t1_list = nullptr, *d_t2_pairs = nullptr, *d_fb_list = nullptr;
+    std::vector<uint32_t> h_t1_list, h_t2_pairs, t2_key;
+    uint32_t  n_t2_tiles = 0;                         // tiles of the planes k_tile_tree2 takes in the current lists
+    uint64_t  t2_tiles_total = 0, t2_fb_total = 0;    // statistics (str_er_tile2_stats)
     uint32_t *d_pool = nullptr, *d_pool_tmp = nullptr;
     CandRec *d_cands = nullptr, *d_cands2 = nullptr;      // (second set: the layout after an NMS tie pass changed pools, then swapped)
     uint32_t *d_redo = nullptr;                          // candidates to classify again + their count (last word)

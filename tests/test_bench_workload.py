@@ -132,13 +132,16 @@ def test_bench_workload_config3_ocr(S, cascade_paths, oracle, oracle_cascades):
     f.close()
 
 
-@pytest.mark.parametrize("mode", ["sparse", "dense"])
+@pytest.mark.parametrize("mode", ["sparse", "dense", "tile2"])
 def test_soak_random_planes(S, oracle, monkeypatch, mode):
     """Bounded soak of the lock-free tree kernels (was tools/soak.py): random planes -- sizes up to 400x300, six value
-    distributions, thresh steps 1-16, MIN_AREA 1/20/120 -- node for node against the oracle, for 25 s per tile-kernel size."""
-    monkeypatch.setenv("STR_ER_TILE_KERNEL", mode)
+    distributions, thresh steps 1-16, MIN_AREA 1/20/120 -- node for node against the oracle, for 25 s per tile-kernel size; "tile2": every
+    plane through the second tile kernel (k_tile_tree2: level by level on bit masks), which hands the tiles it does not take -- on these
+    planes a good part -- back to the first."""
+    monkeypatch.setenv("STR_ER_TILE_KERNEL", "sparse" if mode == "tile2" else mode)
+    monkeypatch.setenv("STR_ER_TILE2", "2" if mode == "tile2" else "0")
     # (STR_ER_SOAK_SECONDS / STR_ER_SOAK_SEED: a longer or different soak by hand)
-    rng = np.random.default_rng((11 if mode == "sparse" else 12) + int(os.environ.get("STR_ER_SOAK_SEED", "0")))
+    rng = np.random.default_rng({"sparse": 11, "dense": 12, "tile2": 13}[mode] + int(os.environ.get("STR_ER_SOAK_SEED", "0")))
     budget, t0, n = float(os.environ.get("STR_ER_SOAK_SECONDS", "25")), time.time(), 0
     filters, seen_t = {}, set()
     try:

@@ -581,6 +581,42 @@ def test_both_tile_kernel_sizes_give_the_same_answer(S, cascade_paths, monkeypat
     assert len(out[""][0].cands) > 0
 
 
+def test_both_tile_kernels_give_the_same_answer(S, cascade_paths, oracle, oracle_cascades, monkeypatch):
+    """Two tile kernels build the trees of a batch's tiles: k_tile_tree (pieces + union-find in LDS) and k_tile_tree2 (level by level on bit masks;
+    by default on the chroma planes, whose tiles hold two or three levels; a tile it does not take is handed back to the first).  STR_ER_TILE2 = 0
+    (first kernel only) / 1 (default) / 2 (every plane through the second) give the same records, node for node, and they are the oracle's: text-like
+    frames, a walled-in frame, ragged sizes down to 1 x 1, noise (nearly every tile handed back), thresh steps 8 and 16, MIN_AREA 1 and 120."""
+    rng = np.random.default_rng(41)
+    walled = S.synth.stext_bgr(S.synth.frame_seed(34), 448, 320)
+    walled[100:108, :, :] = 255; walled[:, 200:203, :] = 254; walled[0, 0, :] = 255
+    flat = np.full((70, 200, 3), 128, np.uint8); flat[10:20, 30:90, 1] = 140; flat[40:44, 100:180, 2] = 90
+    frames = [S.synth.stext_bgr(S.synth.frame_seed(7), 448, 320), walled, S.synth.stext_bgr(S.synth.frame_seed(8), 200, 70),
+              rng.integers(0, 256, (33, 130, 3), dtype=np.uint8), flat, S.synth.stext_bgr(S.synth.frame_seed(9), 65, 33),
+              rng.integers(100, 140, (1, 1, 3), dtype=np.uint8), rng.integers(100, 140, (3, 2, 3), dtype=np.uint8), S.synth.stext_bgr(S.synth.frame_seed(10), 191, 40)]
+    for step, min_area in ((8, 120), (16, 1), (8, 1)):
+        out = {}
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("STR_ER_TILE2", mode)
+            f = S.ERFilter(params=S.Params(max_width=448, max_height=320, max_frames=1, thresh_step=step, min_area=min_area, kept_cap=160000, pool_cap=160000))
+            f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+            out[mode] = [f.text_detect(x, want_nodes=True) for x in frames]
+            st = f.tile2_stats()
+            assert (st["tiles"] > 0) == (mode != "0")
+            if mode == "1":
+                assert st["handed_back"] < st["tiles"]
+            f.close()
+        for mode in ("1", "2"):
+            for a, b in zip(out["0"], out[mode]):
+                assert a.cands.tobytes() == b.cands.tobytes() and a.info.tobytes() == b.info.tobytes()
+                for pa, pb in zip(a.planes, b.planes):
+                    assert pa.nodes.tobytes() == pb.nodes.tobytes()
+        for x, r in zip(frames, out["2"]):
+            six = oracle.compute_channels(x)
+            for p in r.planes:
+                check_plane_against_oracle(oracle, p, six[p.ch], oracle_cascades, step=step, min_area=min_area)
+    assert len(out["2"][0].cands) > 0
+
+
 # ---- SURVEY 8(f)-4: one plane in strips over several GPUs ------------------------------------------------------------------
 @pytest.mark.parametrize("n_strips", [2, 3, 5])
 def test_strips_of_a_plane_merge_into_the_unsplit_result(S, cascade_paths, oracle, oracle_cascades, n_strips):

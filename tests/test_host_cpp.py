@@ -110,3 +110,20 @@ def test_flood_walk_watch_mode(tmp_path):
                     os.path.join(csrc, "flood_order.cpp"), "-o", exe, "-lpthread"], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.strip().startswith("flood watch ok")
+
+
+@pytest.mark.parametrize("caps", ["kernel", "unbounded"])
+def test_tile2_algorithm_on_the_host(tmp_path, caps):
+    """k_tile_tree2's algorithm (csrc/tile2_body.h: the component tree of a tile level by level on bit masks -- the very source the device kernel compiles,
+    here with 64-element arrays for its per-lane values, executed in lock step) against a brute-force component tree of every tile: exported
+    records (totals of the closed descendants folded in, boxes, flags, parents, start node), seam map, wall count.  Speckles, blocks, noise, ramps,
+    walls, wall lattices (tile roots), stripes; sizes 1 x 1 ... 300 x 45 with ragged tiles and unpadded rows; thresh steps 8 / 16 / 32; MIN_AREA
+    1 / 20 / 120; inverted planes.  "kernel": with the kernel's limits (tiles beyond them are handed back, and must be listed); "unbounded": the
+    limits raised so that the algorithm itself runs on every tile, noise included."""
+    csrc = os.path.join(ROOT, "scene-text-recognition_amd", "csrc")
+    exe = str(tmp_path / "tile2_model_check")
+    extra = ["-DSTR_ER_T2_REC_CAP=2048", "-DSTR_ER_T2_MAX_LEVELS=32", "-DSTR_ER_T2_MAX_STEPS=100000"] if caps == "unbounded" else []
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", csrc, "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", *extra,
+                    os.path.join(ROOT, "tests", "cpp", "tile2_model_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe, "8" if caps == "unbounded" else "16"], check=True, capture_output=True, text=True).stdout
+    assert " 0 errors" in out.strip().splitlines()[-1], out

@@ -64,27 +64,3 @@ def test_stream_matches_direct_calls(S, cascade_paths):
     st.submit_copy(batches[0], S.STAGE_ALL)
     assert st.next()[1].cands.tobytes() == ref.text_detect(batches[0]).cands.tobytes()
     st.close(); ref.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["spread", "prio", "full"])
-def test_two_stream_experiment_gives_the_same_results(S, cascade_paths, monkeypatch, mode):
-    """STR_ER_CU_PARTITION (profiles/r05_cu_partition.md: measured, off by default): channels / pyramid / tile trees on a second,
-    CU-masked or low-priority stream, forked and joined with events.  The results must not depend on it."""
-    W, H, F = 320, 240, 2
-    prm = S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=3, channel_mask=0x07)
-    frames = np.stack([S.synth.stext_bgr(S.synth.frame_seed(300 + i), W, H) for i in range(F)])
-    stages = S.STAGE_ALL | S.STAGE_TRACK | S.STAGE_GROUP
-    ref = S.ERFilter(params=prm)
-    ref.load_cascade(0, cascade_paths[0]); ref.load_cascade(1, cascade_paths[1])
-    want = ref.text_detect(frames, stages)
-    ref.close()
-    monkeypatch.setenv("STR_ER_CU_PARTITION", "64")
-    monkeypatch.setenv("STR_ER_CU_PARTITION_MODE", mode)
-    f = S.ERFilter(params=prm)                                  # (the variable is read when the context is created)
-    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
-    for _ in range(3):
-        got = f.text_detect(frames, stages)
-        assert got.cands.tobytes() == want.cands.tobytes() and got.info.tobytes() == want.info.tobytes()
-        assert got.tracks.tobytes() == want.tracks.tobytes() and got.texts.tobytes() == want.texts.tobytes()
-    f.close()

@@ -30,6 +30,7 @@ def main():
         tot = sum(r.profile.values())
         print(f'iter {it}: wall {dt*1e3:.2f} ms  -> {F/dt:.1f} fps ; gpu groups {tot:.2f} ms; cands {len(r.cands)}; '
               + ' '.join(f'{k}={v:.3f}' for k, v in r.profile.items()), flush=True)
+    print('tile2', f.tile2_stats(), flush=True)
     p = r.planes
     print('planes', len(p), 'kept', sum(x.n_kept for x in p), 'created', sum(x.n_created for x in p), 'pool', sum(x.n_pool for x in p),
           'strong', sum(x.n_strong for x in p), 'weak', sum(x.n_weak for x in p), 'amb', sum(x.ambiguous for x in p))
