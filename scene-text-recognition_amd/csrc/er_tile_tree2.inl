@@ -16,6 +16,7 @@ struct DevWave {
     uint8_t  *lds_idmap;    // [2][2048]: key pixel of an exported node -> its record
 
     static __device__ __forceinline__ void mark(int) {}
+    static __device__ __forceinline__ void stat(int, int) {}
     __device__ __forceinline__ u32 lane() const { return threadIdx.x & 63u; }
     static __device__ __forceinline__ u32 bc(uint32_t s) { return s; }
     static __device__ __forceinline__ u64 bc64(uint64_t s) { return s; }
@@ -69,6 +70,28 @@ struct DevWave {
         const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)a, 0x130, 0xF, 0xF, false);
         const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(a >> 32), 0x130, 0xF, 0xF, false);
         return (uint64_t)l | ((uint64_t)h << 32);
+    }
+    // the value of the row k above / below inside the 16-lane DPP row, 0 where that leaves the row (row_shr / row_shl, bound_ctrl: 0)
+    template <int CTRL> static __device__ __forceinline__ u64 dpp64(u64 a)
+    {
+        const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)a, CTRL, 0xF, 0xF, true);
+        const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(a >> 32), CTRL, 0xF, 0xF, true);
+        return (uint64_t)l | ((uint64_t)h << 32);
+    }
+    static __device__ __forceinline__ u64 rows_down(u64 a, int k) { return k == 1 ? dpp64<0x111>(a) : k == 2 ? dpp64<0x112>(a) : k == 4 ? dpp64<0x114>(a) : dpp64<0x118>(a); }
+    static __device__ __forceinline__ u64 rows_up(u64 a, int k) { return k == 1 ? dpp64<0x101>(a) : k == 2 ? dpp64<0x102>(a) : k == 4 ? dpp64<0x104>(a) : dpp64<0x108>(a); }
+    // the tile's row 15 as seen from its rows 16 .. 31 (row_bcast:15 writes lane 15 of every DPP row to the next row; other lanes: 0) / its row 16 as seen
+    // from rows 0 .. 15 (no DPP form: two lane reads)
+    static __device__ __forceinline__ u64 row15_of_upper(u64 a)
+    {
+        const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)a, 0x142, 0xA, 0xF, false);
+        const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(a >> 32), 0x142, 0xA, 0xF, false);
+        return (uint64_t)l | ((uint64_t)h << 32);
+    }
+    static __device__ __forceinline__ u64 row16_of_lower(u64 a)
+    {
+        const uint64_t a16 = read_lane64(a, 16), b16 = read_lane64(a, 48);
+        return (threadIdx.x & 32u) ? b16 : a16;
     }
     // all-reduce over the 32 lanes of a tile: lane ^ 1, lane ^ 2, mirror in 8, mirror in 16 (fused DPP), lane ^ 16 (swizzle)
 #define T2_HALF_RED(v, OPNAME, COMBINE)                                        \

@@ -94,6 +94,23 @@ struct Body {
         return up | dn;
     }
 
+    // every column of f continued up and down through m, over the tile's 32 rows: Kogge-Stone over the lanes inside the 16-row blocks a DPP row shift
+    // reaches (4 steps each way; afterwards p is the AND of m from the block's first / last row up to the lane's row), then across the blocks' border
+    // with what row 15 (going down) / row 16 (going up) ended with
+    T2_FN u64 vfill(W &w, u64 f, u64 m, mask lower_block)
+    {
+        u64 g = f, p = m;
+#pragma unroll
+        for (int k = 1; k < 16; k *= 2) { g = W::and_or64(w.rows_down(g, k), p, g); p = p & w.rows_down(p, k); }
+        g = W::and_or64(W::sel64(lower_block, w.row15_of_upper(g), W::bc64(0ull)), p, g);
+        u64 g2 = f;
+        p = m;
+#pragma unroll
+        for (int k = 1; k < 16; k *= 2) { g2 = W::and_or64(w.rows_up(g2, k), p, g2); p = p & w.rows_up(p, k); }
+        g2 = W::and_or64(W::sel64(lower_block, W::bc64(0ull), w.row16_of_lower(g2)), p, g2);
+        return g | g2;
+    }
+
     T2_FN void run(W &w, const BatchDev &b, const DetectParams &prm, const Args &a, uint32_t pair)
     {
         const uint32_t  entry = a.pairs[pair];
@@ -170,6 +187,9 @@ struct Body {
         // the sides that have a neighbouring tile (top 1, bottom 2, left 4, right 8)
         const u32 sidemask = W::bc((ty > 0 ? 1u : 0u) | (ty + 1 < pd.tiles_y ? 2u : 0u)) | W::sel((W::bc((uint32_t)tx0) + half) > 0u, W::bc(4u), W::bc(0u)) |
                              W::sel((W::bc((uint32_t)tx0) + half + 1u) < (uint32_t)pd.tiles_x, W::bc(8u), W::bc(0u));
+        // the pixels of the lane's row that lie on such a side
+        const u64 SP = W::sel64(((sidemask & 1u) != 0u) & (row == 0u), W::bc64(~0ull), W::bc64(0ull)) | W::sel64(((sidemask & 2u) != 0u) & (row == 31u), W::bc64(~0ull), W::bc64(0ull)) |
+                       W::mk64((sidemask >> 2) & 1u, (sidemask >> 3) << 31);
         const u32 npix = w.half_sum(W::popc64(inimg & ~Wm));          // flooded pixels of the tile
         const u32 nwall = w.half_sum(W::popc64(inimg & Wm));           // in-image pixels at the sentinel level
         const mask haswalls = w.half_sum(W::popc64(Wm)) != 0u;       // (outside-the-image pixels count: a ragged tile takes the general root test)
@@ -185,6 +205,9 @@ struct Body {
             if (sr >= 0) spm = W::sel64(lane == (uint32_t)sr, W::bc64(1ull << sc), W::bc64(0ull));
         }
         if (!supported || __builtin_popcount(present) > MAX_LEVELS) { fb = live; dead = W::all(); present = 0; }
+        // Isolated runs (below) may be marked in bulk where a small closed node can be neither a tile root nor the start pixel's node: no walls in
+        // the tile (then anything smaller than the tile borders on a flooded pixel) and at least two rows of it inside the image
+        const mask bulk_ok = !haswalls & W::sel_half(isB, 1u, has_start ? 0u : 1u) != 0u & (W::bc((uint32_t)(pd.h - oy)) >= 2u);
 
         uint32_t steps = 0;
         while (present) {
@@ -198,20 +221,41 @@ struct Body {
             if (!W::any(U != 0ull)) continue;
             const u64 Mr = W::brev64(M);
             const u64 Mup = W::sel64(row != 0u, M, W::bc64(0ull)), Mdn = W::sel64(row != 31u, M, W::bc64(0ull));
+            {
+                // ---- speckles in bulk.  A run of M with no pixel of M above or below it is a whole component; if it holds an own-level pixel it is a
+                // node, closed unless it lies on an open side, and with 2 * length <= MIN_AREA too small to be kept (area = pixels + nodes <= 2 * pixels):
+                // such a node leaves nothing behind but its mark in N.  Three quarters of the nodes of a text-like chroma tile are of this kind.
+                const u64  V = W::sel64(row != 0u, w.row_above(M), W::bc64(0ull)) | W::sel64(row != 31u, w.row_below(M), W::bc64(0ull));
+                const u64  touched = hfill(M, Mr, M & (V | SP));
+                const mask rowok = bulk_ok & !W::gt_i64(W::popc64(M) * 2u, prm.min_area);
+                const u64  iso = W::sel64(rowok, M & ~touched, W::bc64(0ull));
+                // (the runs of `iso` are whole runs of M.  The mark goes to the run's first OWN-level pixel -- where the carry of M + s starts --: the run's
+                // first pixel may be a lower node's mark)
+                const u64  sd = U & iso;
+                const u64  upf = W::bfi64(M + sd, sd, M);
+                const u64  sdr = W::brev64(sd);
+                const u64  Rn = upf | W::brev64(W::bfi64(Mr + sdr, sdr, Mr));
+                N = N | (upf & ~(upf << 1));
+                U = U & ~Rn;
+            }
             while (W::any(U != 0ull)) {
                 if (++steps > (uint32_t)MAX_STEPS) { fb = fb | (live & !dead); dead = W::all(); present = 0; break; }
                 W::mark(3);
                 // ---- the seed: first unclaimed own-level pixel in raster order = the node's key pixel
-                const u32  pos = W::sel(U != 0ull, (row << 6) | W::ffs64(U), W::bc(0xFFFFu));
-                const u32  sp = w.half_min(pos);
-                const mask act = sp != 0xFFFFu;
-                const u64  seed = W::sel64(row == (sp >> 6), W::shl64(W::bc64(1ull), sp & 63u), W::bc64(0ull));
+                const uint64_t ub = W::ballot(U != 0ull);
+                const uint32_t ubA = (uint32_t)ub, ubB = (uint32_t)(ub >> 32);
+                const uint32_t rA = ubA ? (uint32_t)__builtin_ctz(ubA) : 63u, rB = ubB ? (uint32_t)__builtin_ctz(ubB) : 63u;     // (63: no row of the half)
+                const mask     act = W::sel_half(isB, ubB, ubA) != 0u;
+                const u64      seed = W::sel64(row == W::sel_half(isB, rB, rA), U & (W::bc64(0ull) - U), W::bc64(0ull));
                 W::mark(4);
                 // ---- the component of M that holds it
                 u64  F = hfill(M, Mr, seed);
                 mask merged;
+                int  rounds = 0;
                 {
                     bool force = false;
+                    // (a seed in a long run is a seed in something big: no point in creeping row by row first)
+                    const bool wide = W::any(W::popc64(F) >= 24u);
                     merged = W::none();
                     bool bg_on = W::any((BG != 0ull) & act);
                     for (;;) {
@@ -230,19 +274,28 @@ struct Body {
                         const u64 nb = W::bfi64(F, W::bc64(0ull), W::and_or64(w.row_above(F), Mup, w.row_below(F) & Mdn));     // vertical neighbours inside M, not in F yet
                         if (!force && !W::any(nb != 0ull)) break;
                         F = hfill(M, Mr, F | nb);
+                        W::stat(0, 1);
                         force = false;
+                        if (++rounds >= 4 || (wide && rounds <= 2)) {
+                            // still growing after four rounds of one row each (or big from the start; measured on text-like chroma planes with the
+                            // host model: without this step 58 rounds per pair of tiles instead of 19, the thresholds hardly matter): every column of F up and down through M as far
+                            // as it goes (log steps over the lanes), then the runs again -- a component that spans the tile takes 2 or 3 such rounds, not 30
+                            W::stat(1, 1);
+                            const u64 Fv = vfill(w, F, M, (row & 16u) != 0u);
+                            if (W::any((Fv & ~F) != 0ull)) F = hfill(M, Mr, F | Fv);
+                        }
                     }
                 }
                 W::mark(5);
+                W::stat(2, rounds);
                 U = U & ~F;
                 // ---- the node (t, F)
                 const u64 X = F & ~O;
                 u32       w1 = W::popc64(X) | (W::popc64(X & N) << 16);
-                u32       sf = W::sel(F != 0ull, rowflag, W::bc(0u)) | ((W::lo(F) & 1u) << 2) | ((W::hi(F) >> 31) << 3);
                 w1 = w.half_sum(w1);
-                sf = w.half_or(sf) & sidemask;
-                const u32  cnt = w1 & 0xFFFFu, nodc = (w1 >> 16) + 1u;
-                const mask open = act & (sf != 0u);
+                const u32      cnt = w1 & 0xFFFFu, nodc = (w1 >> 16) + 1u;
+                const uint64_t ob = W::ballot((F & SP) != 0ull);
+                const mask     open = act & (W::sel_half(isB, (uint32_t)(ob >> 32), (uint32_t)ob) != 0u);
                 const u32  area = cnt + nodc;
                 const mask small = !(W::gt_i64(area, prm.min_area));
                 // a closed small node leaves the tile only as a tile root (nothing flooded borders on it) or as the start pixel's node
@@ -263,16 +316,22 @@ struct Body {
                     W::mark(6);
                     const u32 id = nrec;
                     nrec = nrec + W::sel(exported, W::bc(1u), W::bc(0u));
+                    // the sides of the tile the component lies on
+                    const u32 sf = w.half_or(W::sel(F != 0ull, rowflag, W::bc(0u)) | ((W::lo(F) & 1u) << 2) | ((W::hi(F) >> 31) << 3)) & sidemask;
                     const mask over = exported & (id >= (uint32_t)REC_CAP);
                     if (W::any(over)) { fb = fb | over; dead = dead | over; }
                     const mask ex = exported & !over;
+                    // the key pixel: row << 6 | column
+                    const uint64_t sdA = w.read_lane64(seed, (int)(rA & 31u)), sdB = w.read_lane64(seed, (int)(32u + (rB & 31u)));
+                    const u32      sp = W::sel_half(isB, (rB << 6) | (sdB ? (uint32_t)__builtin_ctzll(sdB) : 0u), (rA << 6) | (sdA ? (uint32_t)__builtin_ctzll(sdA) : 0u));
                     // box of F \ O
                     const u32      cl = w.half_or(W::lo(X)), ch = w.half_or(W::hi(X));
                     const u64      cols = W::mk64(cl, ch);
                     const uint64_t rb = W::ballot(X != 0ull);
                     const u32      rows = W::sel_half(isB, (uint32_t)(rb >> 32), (uint32_t)rb);
-                    const u32      x0 = ox + W::ffs64(cols | W::sel64(ex, W::bc64(0ull), W::bc64(1ull))), x1 = ox + W::fls64(cols | W::sel64(ex, W::bc64(0ull), W::bc64(1ull)));
-                    const u32      y0 = W::ffs32(rows | W::sel(ex, W::bc(0u), W::bc(1u))) + (uint32_t)oy, y1 = W::fls32(rows | W::sel(ex, W::bc(0u), W::bc(1u))) + (uint32_t)oy;
+                    // (a half that exports nothing computes on zeros here; nothing of it is used)
+                    const u32      x0 = ox + W::ffs64(cols), x1 = ox + W::fls64(cols);
+                    const u32      y0 = W::ffs32(rows) + (uint32_t)oy, y1 = W::fls32(rows) + (uint32_t)oy;
                     const u32      key = ((W::bc((uint32_t)oy) + (sp >> 6)) * (uint32_t)pd.w + ox + (sp & 63u)) | (t << 24);
                     const u32      flags = W::sel(open, sf << 26, W::bc(NODE_CLOSED));
                     {

@@ -22,6 +22,7 @@ using namespace str_er;
 static unsigned long long g_ops = 0;      // vector operations (32-bit units)
 static unsigned long long g_phase_ops[8], g_phase_n[8], g_mark_at = 0;
 static int g_phase = 0;
+static unsigned long long g_stat[32];
 
 template <class T> struct V {
     T v[64];
@@ -61,6 +62,7 @@ struct HostWave {
     uint16_t lds_idmap[2][2048];     // (bytes on the device, where REC_CAP <= 256)
     bool     junk_neighbours = true;      // rows beyond a half's first / last row read the other half's rows, like the hardware's wave shift
 
+    static void stat(int i, int add) { if (i == 2) { ++g_stat[8 + std::min(add, 15)]; } else g_stat[i] += add; }
     static void mark(int ph) { g_phase_ops[g_phase] += g_ops - g_mark_at; g_mark_at = g_ops; g_phase = ph; ++g_phase_n[ph]; }
     u32 lane() const { u32 r; for (int i = 0; i < 64; ++i) r.v[i] = (uint32_t)i; return r; }
     static u32 bc(uint32_t s) { return u32(s); }
@@ -95,6 +97,12 @@ struct HostWave {
     // cross-lane
     u64 row_above(const u64 &a) const { u64 r; for (int i = 0; i < 64; ++i) r.v[i] = i == 0 ? (junk_neighbours ? 0x5555AAAA5555AAAAull : 0ull) : a.v[i - 1]; g_ops += 2; return r; }
     u64 row_below(const u64 &a) const { u64 r; for (int i = 0; i < 64; ++i) r.v[i] = i == 63 ? (junk_neighbours ? 0xAAAA5555AAAA5555ull : 0ull) : a.v[i + 1]; g_ops += 2; return r; }
+    // the value of the row k above / below inside the 16-lane DPP row; 0 where that leaves the row
+    u64 rows_down(const u64 &a, int k) const { u64 r; for (int i = 0; i < 64; ++i) r.v[i] = (i % 16) >= k ? a.v[i - k] : 0ull; g_ops += 2; return r; }
+    u64 rows_up(const u64 &a, int k) const { u64 r; for (int i = 0; i < 64; ++i) r.v[i] = (i % 16) + k < 16 ? a.v[i + k] : 0ull; g_ops += 2; return r; }
+    // the tile's row 15 as seen from rows 16 .. 31 / row 16 as seen from rows 0 .. 15 (other lanes: anything)
+    u64 row15_of_upper(const u64 &a) const { u64 r; for (int i = 0; i < 64; ++i) r.v[i] = a.v[(i & 32) + 15]; g_ops += 2; return r; }
+    u64 row16_of_lower(const u64 &a) const { u64 r; for (int i = 0; i < 64; ++i) r.v[i] = a.v[(i & 32) + 16]; g_ops += 6; return r; }
     template <class F> static u32 half_red(const u32 &a, F f) { u32 r; for (int h = 0; h < 2; ++h) { uint32_t x = a.v[32 * h]; for (int i = 1; i < 32; ++i) x = f(x, a.v[32 * h + i]); for (int i = 0; i < 32; ++i) r.v[32 * h + i] = x; } g_ops += 6; return r; }
     u32 half_sum(const u32 &a) const { return half_red(a, [](uint32_t x, uint32_t y) { return x + y; }); }
     u32 half_or(const u32 &a) const { return half_red(a, [](uint32_t x, uint32_t y) { return x | y; }); }
@@ -411,6 +419,9 @@ int main(int argc, char **argv)
         printf("%s: %d errors, %.0f tiles, %u to the fall-back, %.0f vector ops per tile = %.0f per 512 pixels\n", argv[2], e, tiles, fbn, ops / tiles, ops / tiles / 4.0);
         HostWave::mark(0);
         const char *names[8] = {"load+quantise", "walls+presence+setup", "level masks", "seed", "flood", "node stats", "export node", "tile export"};
+        printf("   growth rounds %.1f, vfills %.1f per pair; floods by rounds:", g_stat[0] / (tiles / 2), g_stat[1] / (tiles / 2));
+        for (int i = 0; i < 16; ++i) printf(" %d:%.2f", i, g_stat[8 + i] / (tiles / 2));
+        printf("\n");
         for (int i = 0; i < 8; ++i) printf("   %-22s %8.0f ops per tile, entered %.1f times per pair\n", names[i], g_phase_ops[i] / tiles, g_phase_n[i] / (tiles / 2));
         return e != 0;
     }
