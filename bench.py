@@ -240,7 +240,10 @@ def make_frames(S, kind, w, h, F, first=0, ties_every=8):
         return np.stack(list(ex.map(lambda i: make(S.synth.frame_seed(first + i), w, h), range(F))))
 
 
-def tile_roofline(px, F, tile_ms, tile_ms_overlapped, workload):
+def tile_roofline(px, F, tile_ms, tile_ms_overlapped, workload, t2_ms=0.0, t2_share=0.0):
+    """The tile trees of a batch are built by two kernels since round 6 -- k_tile_tree2 (level by level on bit masks: the chroma planes) and
+    k_tile_tree (pieces + union-find in LDS: the luma planes, and the tiles the first one hands back) -- which between them read every plane
+    pixel exactly once: tile_ms is the time of both launches (t2_ms of it k_tile_tree2's, which read t2_share of the pixels)."""
     tile_bytes = px * F
     achieved = tile_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
     traffic, traffic_source = None, "not measured in this run (no rocprofv3 counter pass)"
@@ -256,7 +259,16 @@ def tile_roofline(px, F, tile_ms, tile_ms_overlapped, workload):
                                   f"{F} frames per launch")
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": "k_tile_tree", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    per_kernel = None
+    if t2_ms > 0 and tile_ms > t2_ms:
+        b2, b1, t1_ms = tile_bytes * t2_share, tile_bytes * (1.0 - t2_share), tile_ms - t2_ms
+        per_kernel = {"k_tile_tree2": {"avg_launch_ms": round(t2_ms, 4), "bytes_per_launch": int(b2), "achieved": round(b2 / (t2_ms * 1e-3) / 1e9, 2),
+                                       "frac": round(b2 / (t2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "planes": "chroma (ch % 3 != 0)"},
+                      "k_tile_tree": {"avg_launch_ms": round(t1_ms, 4), "bytes_per_launch": int(b1), "achieved": round(b1 / (t1_ms * 1e-3) / 1e9, 2),
+                                      "frac": round(b1 / (t1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "planes": "luma + the tiles k_tile_tree2 hands back (k_tile_tree_fb)"}}
+    return {"bound": "hbm", "kernel": "k_tile_tree2 + k_tile_tree (the tile trees: every plane pixel read once, by one of the two)" if per_kernel else "k_tile_tree",
+            **({"per_kernel": per_kernel} if per_kernel else {}),
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_peak": round(achieved / HBM_MEASURED_GBS, 5),
             "measured_peak": HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "bytes_per_launch": tile_bytes, "avg_launch_ms": round(tile_ms, 4),
@@ -269,6 +281,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="timed batches per region (one step = one batch of --frames-per-gpu frames per GPU; 40 steps = about a fifth of a second)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--min-region-s", type=float, default=0.5,
+                    help="a timed region lasts at least this long whatever --steps says: a step then runs its batch several times over (config.batches_per_step; "
+                         "frames_per_gpu_per_step counts all of them).  A region of 20 single-batch steps is 0.1 s, which one box-to-box hiccup moves by 10 %%")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region of --steps steps is run this many times; `value` is the median region")
     ap.add_argument("--frames-per-gpu", type=int, default=None,
                     help="frames per batch (= per step) and GPU; 48-64 amortise the per-batch launch latencies best (32 or 96: about 7 %% slower); default 48 (12 for --size 4k)")
@@ -292,7 +307,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-frame-per-call latency leg (`latency_1frame`)")
     ap.add_argument("--ocr", action="store_true",
                     help="BASELINE configs[2] as the MAIN timed region: also run the chain-code + SVM character scorer on every strong/weak ER "
-                         "(synthetic stand-in for the missing classifier/OCR.model: scene-text-recognition_amd/data/ocr_synth.model.gz)")
+                         "(synthetic stand-in for the missing classifier/OCR.model: scene-text-recognition_amd/data/ocr_synth120.model.gz)")
     ap.add_argument("--no-ocr-legs", action="store_true", help="skip `config3_ocr_leg` / `group_ocr_leg` of the default run")
     ap.add_argument("--no-4k-leg", action="store_true", help="skip `config5_4k_leg` of the default run")
     ap.add_argument("--pipelines", type=int, default=6,
@@ -383,7 +398,10 @@ def main():
     P = max(1, args.pipelines)
     tmp = tempfile.mkdtemp()
     cascades = S.cascade_io.write_golden(tmp)
-    svm_text = gzip.open(S.cascade_io.ocr_model_path()).read()
+    # config 3's SVM: the stand-in at the reference's training-set size (120 samples per class, src/utils.cpp:1478-1541: 4299 support vectors); the small one of
+    # rounds 1-5 (5 per class, 319 support vectors) is timed beside it
+    svm_text_small = gzip.open(S.cascade_io.ocr_model_path(5)).read()
+    svm_text = gzip.open(S.cascade_io.ocr_model_path(120)).read()
     svm_path = os.path.join(tmp, "ocr_synth.model")
     with open(svm_path, "wb") as fh:
         fh.write(svm_text)
@@ -406,6 +424,22 @@ def main():
     # W untimed warm-up steps -- on EVERY context: a context's first batch sizes its node records for the frames' content (and on
     # noise-like frames picks the large tile kernel), which must not happen inside the timed region of whichever contexts W did not reach
     rig.run(args.warmup * P, d_frames, stages, comm, rank, world, gather_device)
+    # batches per step: enough of them that the K steps of a region last --min-region-s (measured here on 2 P batches; the same on every rank)
+    inner = 1
+    if args.min_region_s > 0:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rig.run(2 * P, d_frames, stages, comm, rank, world, gather_device)
+        torch.cuda.synchronize()
+        t_batch = (time.perf_counter() - t0) / (2 * P)
+        inner = max(1, int(np.ceil(args.min_region_s / max(args.steps * t_batch, 1e-9))))
+        if world > 1:
+            t = torch.tensor([inner], dtype=torch.int64, device=gather_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            inner = int(t.item())
+    NB = args.steps * inner          # batches per timed region
     regions = []
     prof_sum, r = {}, None
     ties0 = rig.tie_totals()
@@ -416,7 +450,7 @@ def main():
         torch.cuda.synchronize()
         cpu0 = time.process_time()
         t0 = time.perf_counter()
-        prof_sum, r = rig.run(args.steps, d_frames, stages, comm, rank, world, gather_device)
+        prof_sum, r = rig.run(NB, d_frames, stages, comm, rank, world, gather_device)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -431,21 +465,22 @@ def main():
     n_reg = len(regions)
     elapsed = float(np.median(regions))
     host_cpu_per_wall = float(np.median(host_cpu))
-    nms_ties = {"tie_planes_per_batch": round((ties1[0] - ties0[0]) / (args.steps * n_reg), 2),
-                "flood_walk_ms_per_batch": round((ties1[1] - ties0[1]) / (args.steps * n_reg), 2), "host_threads": ties1[2],
+    nms_ties = {"tie_planes_per_batch": round((ties1[0] - ties0[0]) / (NB * n_reg), 2),
+                "flood_walk_ms_per_batch": round((ties1[1] - ties0[1]) / (NB * n_reg), 2), "host_threads": ties1[2],
                 "note": "planes of a batch whose NMS sibling tie changes the pool: the reference's flood order is walked on a host core for each "
                         "(host ms summed over planes), on the library's process-wide pool of at most host_threads threads"}
 
     if P > 1:
         serial_prof, _ = rig.serial_profile(d_frames, stages)
     else:
-        serial_prof = {k: v / max(args.steps, 1) for k, v in prof_sum.items()}
+        serial_prof = {k: v / max(NB, 1) for k, v in prof_sum.items()}
     r_tree_stats = rig.filters[0].last_tree_stats()
+    r_tile2 = {**rig.filters[0].tile2_stats(), "note": "tiles of the chroma planes given to k_tile_tree2 by this context so far, and how many it handed back to k_tile_tree"}
 
     # ---- config 3: the OCR scorer on every strong / weak ER of the same batches; then the reference's own call pattern (lines first)
     ocr_leg = group_ocr_leg = None
     if ocr_legs:
-        n_o = max(P, args.steps)            # (as many steps as the headline's region: a shorter region would carry a larger share of the drain of the batches in flight)
+        n_o = max(P, NB)            # (as many steps as the headline's region: a shorter region would carry a larger share of the drain of the batches in flight)
 
         def ocr_leg_run(st, label):
             rig.run(P, d_frames, st)
@@ -457,7 +492,7 @@ def main():
             sp, last1 = rig.serial_profile(d_frames, st)
             out = {"value": round(F * n_o / el_o, 2), "unit": "frames/s", "steps": n_o, "repeats": len(els), "value_min": round(F * n_o / max(els), 2),
                    "value_max": round(F * n_o / min(els), 2), "ms_per_step": round(1e3 * el_o / n_o, 3),
-                   "frac_of_value": round(F * n_o / el_o / (F * args.steps / elapsed), 4), "stages": label}
+                   "frac_of_value": round(F * n_o / el_o / (F * NB / elapsed), 4), "stages": label}
             return out, sp, last1
 
         ocr_leg, sp_o, last_o = ocr_leg_run(S.STAGE_ALL | S.STAGE_OCR, "STAGE_ALL | STAGE_OCR: chain_run (slope 0) on every strong / weak ER (src/OCR.cpp:67-140)")
@@ -467,8 +502,10 @@ def main():
         gemm_ms = sp_o.get("svm_kernel", 0.0)
         flops = 3 * 2.0 * n_sc * d_q * l_pad
         tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        alg_flops = 2.0 * n_sc * 1800 * l_sv
         ocr_leg.update({
-            "ers_scored_per_batch": n_sc, "svm_model": f"ocr_synth.model: {k_cls} classes, {l_sv} support vectors, 1800-d, RBF (stand-in for the missing OCR.model)",
+            "ers_scored_per_batch": n_sc, "svm_model": f"ocr_synth120.model: {k_cls} classes, {l_sv} support vectors, 1800-d, RBF (stand-in for the missing OCR.model, trained on 120 "
+                                                       "samples per class like the reference's get_ocr_data, src/utils.cpp:1478-1541)",
             "gpu_ms_per_batch_isolated": {k: round(sp_o.get(k, 0.0), 4) for k in ("ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")},
             "gpu_ms_note": "ocr_features = k_ocr_list + k_ocr_hist + k_ocr_otsu + k_ocr_features; svm_kernel = k_svm_kernel_q (RBF kernel matrix, MFMA); svm_couple = "
                            "k_svm_couple (decision values + sigmoid + pairwise coupling); ocr_host_gap = stream idle while the host reads the plane counters "
@@ -476,17 +513,27 @@ def main():
             "roofline_svm_kernel": {"bound": "mfma", "kernel": "k_svm_kernel_q", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 5), "flops_per_launch": int(flops), "avg_launch_ms": round(gemm_ms, 4),
                                     "f32_equivalent_tflops": round(tf / 3, 2),
+                                    "algorithmic_flops_per_launch": int(alg_flops), "algorithmic_tflops": round(alg_flops / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else 0.0,
+                                    "frac_algorithmic": round(alg_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5) if gemm_ms > 0 else 0.0,
                                     "note": f"3 x 2 x N x {d_q} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch: the f32 product x.sv as three bf16 "
                                             "MFMAs (the features are 8-bit numerators, exact in bf16; each support vector = three bf16 pieces, exactly), f32 accumulate; "
                                             "f32_equivalent_tflops = the same launch priced as the one f32 contraction it replaces (f32 matrix peak 157.3); the launch "
                                             "also evaluates exp() in f64 for every kernel value"}})
         if not args.no_cpu_baseline:
             ocr_leg["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades, budget_s=8.0, ocr_model=svm_path)
+        # the same leg on the small model of rounds 1-5 (319 support vectors, at most 5 a class: k_svm_couple's register build)
+        for f in rig.filters:
+            f.load_svm_model_text(svm_text_small, 1800)
+        small_leg, sp_s, _ = ocr_leg_run(S.STAGE_ALL | S.STAGE_OCR, "the same with the 5-samples-per-class model")
+        ocr_leg["small_model_5_per_class"] = {"value": small_leg["value"], "frac_of_value": small_leg["frac_of_value"], "support_vectors": rig.filters[0].svm_info()[1],
+                                              "gpu_ms_per_batch_isolated": {k: round(sp_s.get(k, 0.0), 4) for k in ("ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")}}
+        for f in rig.filters:
+            f.load_svm_model_text(svm_text, 1800)
         group_ocr_leg, sp_g, last_g = ocr_leg_run(S.STAGE_ALL | st_group | S.STAGE_OCR_LINES,
                                                   "STAGE_ALL | TRACK | GROUP(inner_sup) | OCR_LINES: calc_color, er_track, er_grouping, then chain_run on the members "
                                                   "of the text lines with the line's slope (er_ocr, src/ER.cpp:695-747)")
         group_ocr_leg["line_members_scored_per_batch"] = int(len(last_g.line_label)) if getattr(last_g, "line_label", None) is not None else None
-        group_ocr_leg["gpu_ms_per_batch_isolated"] = {k: round(sp_g.get(k, 0.0), 4) for k in ("track", "ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")}
+        group_ocr_leg["gpu_ms_per_batch_isolated"] = {k: round(sp_g.get(k, 0.0), 4) for k in ("track", "line_ocr_host_gap", "line_ocr_features", "line_svm_kernel", "line_svm_couple")}
 
     # ties leg: the same measurement on tie-rich frames (S-ties), so that the cost of exactness is on the line
     ties_leg = None
@@ -495,14 +542,14 @@ def main():
         d_ties = torch.from_numpy(tf_).to(device)
         torch.cuda.synchronize()
         rig.run(P, d_ties, stages)
-        n_t = max(P, args.steps)
+        n_t = max(P, NB)
         a0 = rig.tie_totals()
         cpu1 = time.process_time()
         el, _, _ = rig.timed(n_t, d_ties, stages)
         ties_cpu = (time.process_time() - cpu1) / max(el, 1e-9)
         a1 = rig.tie_totals()
         ties_leg = {"value": round(F * n_t / el, 2), "unit": "frames/s", "steps": n_t, "ms_per_step": round(1e3 * el / n_t, 3),
-                    "frac_of_value": round(F * n_t / el / (F * args.steps / elapsed), 4),
+                    "frac_of_value": round(F * n_t / el / (F * NB / elapsed), 4),
                     "tie_planes_per_batch": round((a1[0] - a0[0]) / n_t, 2), "tie_plane_share": round((a1[0] - a0[0]) / n_t / (F * bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels']), 4),
                     "flood_walk_ms_per_batch": round((a1[1] - a0[1]) / n_t, 2), "host_threads": a1[2], "host_cores": os.cpu_count(), "host_cpu_quota": effective_cpus(), "host_cpus_busy": round(ties_cpu, 2),
                     "note": f"S-ties frames (S-text + one double-L glyph in every {args.ties_every}th frame: an NMS sibling tie with two different outcomes); same "
@@ -579,14 +626,14 @@ def main():
         filled = [False] * P
         stream_steps(max(P, args.warmup), frames, st.submit)
         t1 = time.perf_counter()
-        stream_steps(args.steps, frames, st.submit)
+        stream_steps(NB, frames, st.submit)
         el = time.perf_counter() - t1
-        pcie = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
-                "frac_of_value": round(F * args.steps / el / (F * args.steps / elapsed), 4),
-                "h2d_bytes_per_step": int(frames.size), "h2d_gbs": round(frames.size * args.steps / el / 1e9, 2),
+        pcie = {"value": round(F * NB / el, 2), "unit": "frames/s (this rank)", "ms_per_batch": round(1e3 * el / NB, 3),
+                "frac_of_value": round(F * NB / el / (F * NB / elapsed), 4),
+                "h2d_bytes_per_step": int(frames.size), "h2d_gbs": round(frames.size * NB / el / 1e9, 2),
                 # (a torch copy of the same bytes from a torch-pinned tensor, nothing else running: 57 GB/s on most of the round's boxes, 26 on one where the
                 # stream itself -- hipHostMalloc'ed staging, several copies queued -- moved 43: the larger of the two is what the link is known to deliver)
-                "h2d_gbs_link_alone": round(h2d_gbs, 2), "frames_per_s_at_link_rate": round(max(h2d_gbs, frames.size * args.steps / el / 1e9) * 1e9 / (frames.size / F), 1),
+                "h2d_gbs_link_alone": round(h2d_gbs, 2), "frames_per_s_at_link_rate": round(max(h2d_gbs, frames.size * NB / el / 1e9) * 1e9 / (frames.size / F), 1),
                 "note": "host BGR frames in page-locked memory -> str_er_stream (upload of one batch overlaps the kernels of the others)"}
         # ... and the same frames as a video decoder would deliver them: NV12, half the bytes (build-defined ingest, include/str_er.h)
         with ThreadPoolExecutor(min(F, max(1, (os.cpu_count() or 1) // 2), 16)) as ex:
@@ -594,11 +641,11 @@ def main():
         filled = [False] * P
         stream_steps(max(P, args.warmup), nv, st.submit_nv12)
         t1 = time.perf_counter()
-        stream_steps(args.steps, nv, st.submit_nv12)
+        stream_steps(NB, nv, st.submit_nv12)
         el = time.perf_counter() - t1
-        pcie_nv12 = {"value": round(F * args.steps / el, 2), "unit": "frames/s (this rank)", "ms_per_step": round(1e3 * el / args.steps, 3),
-                     "frac_of_value": round(F * args.steps / el / (F * args.steps / elapsed), 4),
-                     "h2d_bytes_per_step": int(nv.size), "h2d_gbs": round(nv.size * args.steps / el / 1e9, 2),
+        pcie_nv12 = {"value": round(F * NB / el, 2), "unit": "frames/s (this rank)", "ms_per_batch": round(1e3 * el / NB, 3),
+                     "frac_of_value": round(F * NB / el / (F * NB / elapsed), 4),
+                     "h2d_bytes_per_step": int(nv.size), "h2d_gbs": round(nv.size * NB / el / 1e9, 2),
                      "note": "the same frames as NV12 (luma + interleaved Cb/Cr at half resolution: what a decoder delivers) through the same stream; "
                              "the NV12 -> Y/Cr/Cb step is build-defined (chroma replicated 2x2), so the planes -- and the candidates -- are not "
                              "those of the BGR frames"}
@@ -615,15 +662,16 @@ def main():
         d4 = torch.from_numpy(fr4).to(device)
         rig4 = Rig(S, P, w4, h4, F4, cfg4, dev_index, args.sibling_order, cascades)
         rig4.run(2 * P, d4, S.STAGE_ALL)
-        n4 = max(P, args.steps)
+        n4 = max(P, NB)
         el4, prof4, _ = rig4.timed(n4, d4, S.STAGE_ALL)
         sp4, _ = rig4.serial_profile(d4, S.STAGE_ALL)
         px4 = plane_pixels("pyr3x12", w4, h4)
         k4_leg = {"value": round(F4 * n4 / el4, 2), "unit": "frames/s", "steps": n4, "frames_per_step": F4, "ms_per_step": round(1e3 * el4 / n4, 3),
                   "plane_pixels_per_frame": px4, "mpx_per_s": round(px4 * F4 * n4 / el4 / 1e6, 1),
-                  "mpx_per_s_of_value": round(plane_pixels(args.workload) * F * args.steps / elapsed / 1e6, 1),
+                  "mpx_per_s_of_value": round(plane_pixels(args.workload) * F * NB / elapsed / 1e6, 1),
                   "workload": WORKLOADS["pyr3x12"]["label"] + "; S-text frames; one GPU",
-                  "roofline": tile_roofline(px4, F4, sp4.get("tile_tree", 0.0), prof4.get("tile_tree", 0.0) / n4, "pyr3x12"),
+                  "roofline": tile_roofline(px4, F4, sp4.get("tile_tree", 0.0) + sp4.get("tile_tree2", 0.0), (prof4.get("tile_tree", 0.0) + prof4.get("tile_tree2", 0.0)) / n4, "pyr3x12",
+                                            sp4.get("tile_tree2", 0.0), 2.0 / 3.0),
                   "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in sp4.items()}}
         # the cost of exact NMS ties at this size: the host walk of one 8.3 Mpx plane
         if args.sibling_order == 0 and not args.no_ties_leg:
@@ -644,7 +692,7 @@ def main():
         del d4
 
     if rank == 0:
-        total_frames = F * world * args.steps
+        total_frames = F * world * NB
         fps = total_frames / elapsed
         px = plane_pixels(args.workload)
         n_pool = len(r.cands)
@@ -654,9 +702,11 @@ def main():
         # dominant kernel: k_tile_tree reads every plane pixel once -> px bytes per frame.  Its duration is the ISOLATED one
         # (one batch in flight, HIP events on the library's stream around the launch): with P batches sharing the GPU an
         # event-to-event time also contains the other batches' kernels and is not a per-launch cost.
-        tile_ms_overlapped = prof_sum.get("tile_tree", 0.0) / max(args.steps, 1)
-        tile_ms = serial_prof.get("tile_tree", 0.0) or tile_ms_overlapped
-        roof = tile_roofline(px, F, tile_ms, tile_ms_overlapped, args.workload)
+        tile_ms_overlapped = (prof_sum.get("tile_tree", 0.0) + prof_sum.get("tile_tree2", 0.0)) / max(NB, 1)
+        tile_ms = (serial_prof.get("tile_tree", 0.0) + serial_prof.get("tile_tree2", 0.0)) or tile_ms_overlapped
+        chans = [i for i in range(6) if cfg["channel_mask"] >> i & 1]
+        roof = tile_roofline(px, F, tile_ms, tile_ms_overlapped, args.workload, serial_prof.get("tile_tree2", 0.0), sum(1 for ch in chans if ch % 3) / max(len(chans), 1))
+        roof["tile2"] = r_tile2
         roof["path_bytes_per_frame"] = int(b_alg)
         roof["path_frac"] = round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)
         # the other passes of the component tree, priced the same way: algorithmic bytes = what the pass has to read and write once
@@ -681,7 +731,7 @@ def main():
                                    ("; + chain-code/SVM OCR scorer on strong+weak ERs (configs[2])" if args.ocr and not args.group else "") +
                                    ("; + calc_color, er_track, er_grouping (text lines)" if args.group else "") +
                                    ("; + chain-code/SVM OCR scorer on the line members with the line slope (er_ocr, configs[2])" if args.ocr and args.group else ""),
-                       "frames_per_gpu_per_step": F,
+                       "frames_per_gpu_per_step": F * inner, "batches_per_step": inner, "frames_per_batch": F,
                        "planes_per_frame": bin(cfg['channel_mask']).count('1') * cfg['n_pyr_levels'],
                        "plane_pixels_per_frame": px, "thresh_step": 8, "min_area": 120, "parallelism": f"frames sharded over {world} GPU(s)",
                        "pooled_per_frame": round(n_pool / F, 1), "batches_in_flight": P, "host_cpus_busy": round(host_cpu_per_wall, 2),
@@ -697,7 +747,7 @@ def main():
             **({"latency_1frame": latency} if latency else {}),
             "roofline": roof,
             "tree_passes_roofline": tree_roof,
-            "gpu_ms_per_step_by_kernel_group": {k: round(v / args.steps, 4) for k, v in prof_sum.items()},
+            "gpu_ms_per_step_by_kernel_group": {k: round(v / NB, 4) for k, v in prof_sum.items()},
             "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in serial_prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:

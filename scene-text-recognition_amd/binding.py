@@ -428,10 +428,10 @@ class ERFilter:
         return {"tiles": int(a.value), "handed_back": int(b.value)}
 
     def last_profile(self) -> dict:
-        names = (C.c_char_p * 16)()
-        ms = (C.c_double * 16)()
-        k = self.L.str_er_last_profile(self.h, names, ms, 16)
-        return {names[i].decode(): ms[i] for i in range(min(k, 16))}
+        names = (C.c_char_p * 32)()
+        ms = (C.c_double * 32)()
+        k = self.L.str_er_last_profile(self.h, names, ms, 32)
+        return {names[i].decode(): ms[i] for i in range(min(k, 32))}
 
     # ---- the hot path ---------------------------------------------------------------------------
     def text_detect(self, src: np.ndarray, stages: int = STAGE_ALL, want_nodes: bool = False) -> Result:

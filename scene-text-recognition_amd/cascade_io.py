@@ -16,10 +16,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "casca
 OCR_MODEL_GZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ocr_synth.model.gz")
 
 
-def ocr_model_path() -> str:
+OCR_MODEL120_GZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ocr_synth120.model.gz")
+
+
+def ocr_model_path(per_class: int = 5) -> str:
     """The gzip-ed libsvm text model that stands in for the reference's missing classifier/OCR.model: 65 classes, 1800 features,
-    trained on synthetic vectors by the reference's own svm-train with the reference's flags (tests/golden/make_svm_fixture.py)."""
-    return OCR_MODEL_GZ
+    trained on synthetic vectors by the reference's own svm-train with the reference's flags (tests/golden/make_svm_fixture.py).
+    per_class = 120: the reference's training-set size (30 fonts x 4 styles, src/utils.cpp:1478-1541), 4299 support vectors; per_class = 5: the
+    small model of rounds 1-5 (319 support vectors) that the parity tests were written on."""
+    if per_class not in (5, 120):
+        raise ValueError("the stand-in OCR models have 5 or 120 samples per class")
+    return OCR_MODEL120_GZ if per_class == 120 else OCR_MODEL_GZ
 
 
 def _num(v: float) -> str:

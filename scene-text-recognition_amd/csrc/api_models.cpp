@@ -260,7 +260,7 @@ try {
             p = end;
             if (idx < 0 || idx >= dim) return fail(c, STR_ER_EFORMAT, "svm model: SV feature index outside [0, dim)");
             sv[(size_t)i * dpad + idx] = (float)v;
-            nrm += v * v;
+            nrm += (double)(float)v * (double)(float)v;       // (of the f32 value the kernels multiply with: |x - sv|^2 = |x|^2 + |sv|^2 - 2 x.sv stays consistent)
         }
         svnorm[i] = nrm;
     }
@@ -430,7 +430,7 @@ try {
     src.rot = slope ? reinterpret_cast<const RotGeom *>(s + o_rot) : nullptr;
     launch_ocr_features(st, src, n, buf, m);
     if (want_svm) {
-        // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. assumes model->label[i] == i
+        // prob = pv[label]; the reference indexes pv with the label itself (src/OCR.cpp:92-93), which k_svm_couple does too (the arg max's entry only for labels 0 .. k - 1 in order)
         launch_svm_score(st, n, buf, *m, true);
         HIP_TRY(c, hipMemcpyAsync(prob, buf.pbest, (size_t)n * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(label, buf.label, (size_t)n * 4, hipMemcpyDeviceToHost, st));

@@ -54,12 +54,21 @@ struct OcrBuf {
     uint16_t *xq;        // [n_pad x dq]    svm input times 255 -- the features' 8-bit numerators -- as bf16, zero padded (svm, vectors from boxes)
     double   *xnorm;     // [n_pad]         |x|^2                                        (svm)
     double   *kv;        // [n_pad x l_pad] RBF kernel values                            (svm)
+    double   *av;        // [n_pad x k x 64] or null: per class c and slot j the sum of sv_coef[j][q] K[q] over class c's support vectors (svm, svm_uses_class_sums())
     double   *dec;       // [n x k(k-1)/2] or null: decision values
     double   *prob;      // [n x k] or null: class probabilities
     int32_t  *label;     // [n]
     double   *pbest;     // [n]             probability of the predicted label (pv[label], src/OCR.cpp:92-93)
     size_t    bytes;     // total size of the carve-up
 };
+
+// compute units of the device (read once per process, thread-safe)
+int ocr_n_cu();
+
+// Models with many support vectors a class (the reference's shape: 120 training samples a class) take the decision values in two steps -- k_svm_decide sums
+// coefficient x kernel value per (class, other class) as one dense product per class (f64 MFMA, 64 vectors a wave), k_svm_couple adds the two halves of a
+// pair -- instead of k_svm_couple walking the coefficient table per vector
+inline bool svm_uses_class_sums(const SvmDev &m) { return m.k <= 65 && m.kc == 64 && m.mp > 8; }
 
 // Offsets are applied to `base` (may be null to size the allocation only: read .bytes).
 OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m /* null: features only */, bool want_q, bool want_dec, bool want_prob);

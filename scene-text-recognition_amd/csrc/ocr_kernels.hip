@@ -612,6 +612,63 @@ __device__ __forceinline__ double rcp_nr(double x)
     return __builtin_fma(r, e, r);
 }
 
+// Decision values, first half, for models with many support vectors a class (svm_uses_class_sums): per vector n, class c and slot j < k - 1
+//   av[n][c][j] = sum over class c's support vectors q of sv_coef[j][q] K[n][q]
+// (libsvm's sums of svm_predict_values, src/svm.cpp:2539-2566, split where it switches from class i's support vectors to class j's: the decision value of
+// the pair i < j is av[i][j - 1] + av[j][i] - rho; slot j of class c is the other class j < c, or j + 1).  Per class that is a dense product -- kernel values
+// [vectors x support vectors of c] times coefficients [support vectors of c x 64] -- and the one place of this path besides the kernel matrix where the matrix
+// unit fits: v_mfma_f64_16x16x4_f64, a wave = 64 vectors x one class (16 accumulator tiles), operands straight from memory (a tile of kernel values is 16
+// row pieces of 32 bytes, a tile of coefficients 4 x 128 bytes; every operand feeds four instructions).  2 l 64 flops a vector in all.
+// (k_svm_couple walking the coefficient rows per vector did the same sums in 27 ms a batch of 16 k vectors on the 4299-vector model -- a dependent round
+// trip per eight ranks, 2 MB of rows per vector; a first form with a lane per slot, eight vectors per wave and the kernel values by scalar loads took 1.1 ms:
+// 8 bytes from memory per multiply-add, none of them reused.)
+typedef double double4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_svm_decide(const double *__restrict__ kv, int l_pad, int n, SvmDev m, double *__restrict__ av)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int v0 = blockIdx.x * 64, c = blockIdx.y * 4 + wv;
+    if (c >= m.k) return;
+    const int q0 = m.start[c], nq = m.nsv[c];
+    const int r16 = lane & 15, kq = lane >> 4;
+    double4v  acc[4][4];
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) acc[bt][st] = double4v{0.0, 0.0, 0.0, 0.0};
+    // operand A: kernel value of vector v0 + 16 bt + (lane & 15), support vector q0 + step + (lane >> 4); B: coefficient of that support vector for slot
+    // 16 st + (lane & 15), zero beyond the class (the fourth-rounded last step reads the next class's kernel values)
+    const double *ka[4];
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) ka[bt] = kv + (size_t)min(v0 + 16 * bt + r16, n - 1) * l_pad + q0 + kq;
+    const double *cb = m.coef_t + (size_t)(q0 + kq) * 64 + r16;
+    for (int q = 0; q < nq; q += 4) {
+        double a[4], b[4];
+        const bool on = q + kq < nq;
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) a[bt] = ka[bt][q];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[st] = cb[(size_t)q * 64 + 16 * st];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[st] = on ? b[st] : 0.0;
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc[bt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt], b[st], acc[bt][st], 0, 0, 0);
+    }
+    // result tile: element r of lane L is row (L >> 4) + 4 r, column L & 15
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + 16 * bt + kq + 4 * r;
+            if (v < n) {
+                double *dst = av + ((size_t)v * m.k + c) * 64 + r16;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) dst[16 * st] = acc[bt][st][r];
+            }
+        }
+}
+
 // svm_predict_values + sigmoid_predict + multiclass_probability for one vector per wave.  Class-indexed vectors (p, Qp,
 // Q's diagonal) live in registers: lane L holds class L (and L + 64 in the build for 66+ classes).  The pairwise table V (LDS, f32; row i =
 // columns i .. k - 1 at rb(i) + j, rb(i) = i k - i (i + 1) / 2, the diagonal slot set to 1 so that the walks need no mask) holds the pairwise
@@ -653,7 +710,7 @@ __host__ __device__ inline size_t svm_couple_lds_doubles(int k) { return ((size_
 constexpr int svm_couple_wpb(int mode) { return mode == 2 ? 1 : SVM_COUPLE_WPB; }      // (66+ classes: up to 34 KB a box, one box a workgroup)
 template <int MODE, int MSV>
 __global__ __launch_bounds__(64 * svm_couple_wpb(MODE)) SVM_COUPLE_OCC void k_svm_couple(const double *__restrict__ kv, int l_pad, int n, SvmDev m, double *__restrict__ dec_out,
-                                                   double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest)
+                                                   double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest, const double *__restrict__ av)
 {
     constexpr bool TWO = MODE == 2, TAIL = MODE == 1;
     // LDS: QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps; V[k (k + 1) / 2] pairwise table (f32)
@@ -703,8 +760,10 @@ __global__ __launch_bounds__(64 * svm_couple_wpb(MODE)) SVM_COUPLE_OCC void k_sv
         constexpr int CH = MSV > 0 ? MSV : 8;
         const int     sj = m.start[min(lane + 1, k - 1)];
         double        K2[CH];
+        if constexpr (MSV >= 0) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) K2[u] = kr[min(sj + u, l - 1)];      // (MSV = 0, more than 8 ranks: read again per row instead)
+            for (int u = 0; u < CH; ++u) K2[u] = kr[min(sj + u, l - 1)];      // (MSV = 0, more than 8 ranks: read again per row instead)
+        }
         const double *tab = m.coef_rows + lane;
         auto pb = [&](int r) -> int { return r * (k - 1) - r * (r - 1) / 2 - r - 1; };      // pair (r, j) is libsvm's pair number pb(r) + j
         // pass a: rows a and b = k - 1 - a.  Lanes >= a: pair (a, lane + 1); lanes < a: pair (b, lane + b + 1), summed by lane + b
@@ -724,7 +783,23 @@ __global__ __launch_bounds__(64 * svm_couple_wpb(MODE)) SVM_COUPLE_OCC void k_sv
             }
         };
         const int n_pass = (k - 1) / 2 + 1;
-        if constexpr (MSV > 0) {
+        if constexpr (MSV < 0) {
+            // the sums per (class, other class) are there already (k_svm_decide): a pair i < j is av[i][j - 1] + av[j][i] - rho -- the first a lane's word of
+            // a 512-byte row, the second one word of 64 different rows (66 such loads a lane for the whole table: the first-level cache holds the vector's 33 KB)
+            const double *A = av + (size_t)v * k * 64;
+            for (int a = 0; a < n_pass; ++a) {
+                bool ra, on; int row;
+                const int p = pair_of(a, ra, on, row);
+                const int j = on ? (ra ? lane + 1 : lane + (k - 1 - a) + 1) : 1, i = on ? row : 0;       // (an idle lane reads pair (0, 1) and drops it)
+                const double s1 = A[(size_t)i * 64 + (j - 1)], s2 = A[(size_t)j * 64 + i];
+                const double rho = m.rho[p], pA = m.probA[p], pB = m.probB[p];
+                if (on) {
+                    const double d = (s1 + s2) - rho;
+                    if (dec_out && live) dec_out[(size_t)v * np + p] = d;
+                    V[p + row + 1] = (float)pair_prob(d * pA + pB);
+                }
+            }
+        } else if constexpr (MSV > 0) {
             // a pass is one memory round trip (46 values a lane at MSV = 5): the next pass's loads are issued as soon as this one's sums are taken,
             // ahead of its sigmoid and table write
             struct Loads { double c[4][CH], kq[2][CH], rho, pA, pB; };
@@ -996,13 +1071,11 @@ __global__ __launch_bounds__(64 * svm_couple_wpb(MODE)) SVM_COUPLE_OCC void k_sv
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (TAIL && pT > best) { best = pT; bi = 64; }
-    // prob of the result = pv[label]: the reference indexes pv with the label itself (src/OCR.cpp:92-93), i.e. takes the entry
-    // of the first class carrying that label
+    // prob of the result = pv[label]: the reference indexes pv with the label VALUE (src/OCR.cpp:92-93), which is the arg max's entry only for a model whose
+    // labels are 0 .. k - 1 in order; a label outside [0, k) makes the reference read outside pv -- the arg max's probability is returned then
     const int lab = m.label[bi];
-    int first = (on0 && m.label[t0] == lab) ? t0 : ((on1 && m.label[t1] == lab) ? t1 : 1 << 20);
-    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-    if (TAIL && first > 64 && m.label[64] == lab) first = 64;
-    const double pf = first < 64 ? bcast(p0, first & 63) : (TAIL ? pT : bcast(p1, (first - 64) & 63));
+    double    pf = best;
+    if (lab >= 0 && lab < k) pf = lab < 64 ? bcast(p0, lab) : (TAIL ? pT : bcast(p1, (lab - 64) & 63));
     if (lane == 0 && live) { label[v] = lab; pbest[v] = pf; }
 }
 
@@ -1029,6 +1102,8 @@ OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m, bool want_q, bool wa
         b.xq = reinterpret_cast<uint16_t *>(take(n_pad * m->dq * 2));
         b.xnorm = reinterpret_cast<double *>(take(n_pad * 8));
         b.kv = reinterpret_cast<double *>(take(n_pad * m->l_pad * 8));
+        uint8_t *av = take(svm_uses_class_sums(*m) ? n_pad * (size_t)m->k * 64 * 8 : 0);
+        b.av = reinterpret_cast<double *>(base ? skip(av, svm_uses_class_sums(*m)) : nullptr);
         uint8_t *d = take(want_dec ? n * np * 8 : 0), *p = take(want_prob ? n * m->k * 8 : 0);
         b.dec = reinterpret_cast<double *>(base ? skip(d, want_dec) : nullptr);
         b.prob = reinterpret_cast<double *>(base ? skip(p, want_prob) : nullptr);
@@ -1047,10 +1122,10 @@ void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t n_cands, uint32_
     hipLaunchKernelGGL(k_ocr_list<true>, dim3(G), dim3(LIST_THREADS), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, hdr, hdr + OCR_LIST_HDR);
 }
 
-static int ocr_n_cu()
+int ocr_n_cu()
 {
-    static int n_cu = 0;
-    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop{}; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+    // (initialised once, thread-safe; the compute-unit count of the first device used -- the library is built for one kind of GPU)
+    static const int n_cu = [] { int dev = 0; hipDeviceProp_t prop{}; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }();
     return n_cu;
 }
 
@@ -1098,7 +1173,12 @@ void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
     if (n <= 0) return;
     const int    wpb = svm_couple_wpb(m.k > 65 ? 2 : 0), wg = (n + wpb - 1) / wpb;
     const size_t lds = sizeof(double) * svm_couple_lds_doubles(m.k) * wpb;
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wpb), lds, s, (const double *)buf.kv, m.l_pad, n, m, buf.dec, buf.prob, buf.label, buf.pbest); };
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wpb), lds, s, (const double *)buf.kv, m.l_pad, n, m, buf.dec, buf.prob, buf.label, buf.pbest, (const double *)buf.av); };
+    if (svm_uses_class_sums(m) && buf.av) {
+        hipLaunchKernelGGL(k_svm_decide, dim3((n + 63) / 64, (m.k + 3) / 4), dim3(256), 0, s, (const double *)buf.kv, m.l_pad, n, m, buf.av);
+        if (m.k == 65) go(k_svm_couple<1, -1>); else go(k_svm_couple<0, -1>);
+        return;
+    }
     if (m.k > 65) go(k_svm_couple<2, 0>);
     else if (m.k == 65) { if (m.mp == 5) go(k_svm_couple<1, 5>); else go(k_svm_couple<1, 0>); }
     else { if (m.mp == 5) go(k_svm_couple<0, 5>); else go(k_svm_couple<0, 0>); }

@@ -146,6 +146,7 @@ static int launch_tile_trees(str_er_ctx *c, const Batch &b, const BatchDev &bd, 
     }
     // the small kernel first: its waves are the longer ones (a dependent chain per pair of tiles), the big kernel's workgroups fill in behind
     launch_tile_tree2(s, bd, dp, c->d_t2_pairs, (uint32_t)c->h_t2_pairs.size(), c->d_fb_list, c->d_total + 1);
+    rec(c, "tile_tree2");
     launch_tile_tree(s, bd, dp, c->tile_sparse, c->d_t1_list, (uint32_t)c->h_t1_list.size());
     launch_tile_tree_fb(s, bd, dp, c->tile_sparse, c->d_fb_list, c->d_total + 1, std::min<uint32_t>(c->n_t2_tiles, 256u));
     return STR_ER_OK;
@@ -153,7 +154,8 @@ static int launch_tile_trees(str_er_ctx *c, const Batch &b, const BatchDev &bd, 
 
 void rec(str_er_ctx *c, const char *name, hipStream_t on)
 {
-    if (c->n_ev < 24) {
+    static_assert(str_er_ctx::MAX_EV >= 32, "the fullest call (BGR prologue, both tile kernels, track, group, both scorer stages) records 27 events");
+    if (c->n_ev < str_er_ctx::MAX_EV) {
         (void)hipEventRecord(c->ev[c->n_ev], on ? on : c->stream);
         c->profile.emplace_back(name, 0.0);
         ++c->n_ev;
@@ -236,13 +238,13 @@ int line_ocr_phase(str_er_ctx *c, const PlaneDesc *d_planes, str_er_result *r)
     OcrSrc src{};
     src.recs = reinterpret_cast<const CandRec *>(sc + o_rec); src.list = reinterpret_cast<const uint32_t *>(sc + o_list); src.planes = d_planes;
     src.rot = reinterpret_cast<const RotGeom *>(sc + o_rot);
-    rec(c, "ocr_host_gap");
+    rec(c, "line_ocr_host_gap");
     launch_ocr_features(s, src, (int)n_m, buf, &m);
-    rec(c, "ocr_features");
+    rec(c, "line_ocr_features");
     launch_svm_kernel(s, (int)n_m, buf, m, true);
-    rec(c, "svm_kernel");
+    rec(c, "line_svm_kernel");
     launch_svm_couple(s, (int)n_m, buf, m);
-    rec(c, "svm_couple");
+    rec(c, "line_svm_couple");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, wait_stream(c, s));          // (wait, then copy into pageable memory: see run_batch's OCR stage)
     HIP_TRY(c, hipMemcpyAsync(r->line_label.data(), buf.label, 4 * n_m, hipMemcpyDeviceToHost, s));

@@ -169,7 +169,8 @@ struct str_er_ctx {
     bool svm_loaded = false;
     SvmDev svm{};
     void *d_svm_blob = nullptr;
-    hipEvent_t ev[24]{};
+    static constexpr int MAX_EV = 32;
+    hipEvent_t ev[MAX_EV]{};
     int n_ev = 0;
     bool profiling = false;
     std::vector<std::pair<const char *, double>> profile;

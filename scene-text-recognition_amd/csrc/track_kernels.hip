@@ -172,8 +172,7 @@ void launch_calc_color(hipStream_t s, const OcrSrc &src, const ColorSrc &col, in
     launch_box_thresholds(s, src, n, hist, big, thresh);
     ColorJob job{src, col};
     (void)hipMemsetAsync(big2, 0, 4, s);
-    static int n_cu = 0;
-    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop{}; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+    const int n_cu = ocr_n_cu();
     const int wg = (n + OCR_WAVES - 1) / OCR_WAVES;
     hipLaunchKernelGGL(k_color_sums, dim3(wg < 8 * n_cu ? wg : 8 * n_cu), dim3(64 * OCR_WAVES), 0, s, job, n, (const int32_t *)thresh, tr, sums, big2);
     hipLaunchKernelGGL(k_color_sums_big, dim3(OCR_BIG_PARTS, 64), dim3(64 * OCR_WAVES), 0, s, job, (const int32_t *)thresh, sums, (const uint32_t *)big2);

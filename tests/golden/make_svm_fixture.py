@@ -11,6 +11,13 @@ Outputs:
                                       -- (svm_save_model format, src/svm.cpp:2641-2736)
   tests/golden/svm_vectors.npz      48 test vectors (8-bit numerators q, x = q/255.0 as in src/OCR.cpp:211) + what the reference's svm_predict_probability /
                                     svm_predict_values (oracle/_ref/libref_svm.so) return for them
+
+`make_svm_fixture.py 120` mints the model AT THE REFERENCE'S TRAINING-SET SIZE: get_ocr_data (src/utils.cpp:1478-1541) writes one sample per class for
+30 fonts x 4 styles = 120 samples per class, 7800 in all (the first stand-in has 5 per class: 319 support vectors, a kernel matrix of 320 columns and the
+"at most 5 support vectors a class" build of k_svm_couple -- numbers measured on it flatter the scorer).  Same flags; samples noisier than the small set's
+(sigma 0.3, 40 % of a prototype's features dropped, 60 stray features) so that, as with real glyph data, more than half of the training set ends up as
+support vectors: 4299 of them, up to 90 per class.
+  scene-text-recognition_amd/data/ocr_synth120.model.gz, tests/golden/svm_vectors120.npz
 """
 import ctypes as C
 import gzip
@@ -23,19 +30,23 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 HERE = os.path.dirname(os.path.abspath(__file__))
-MODEL_GZ = os.path.join(ROOT, "scene-text-recognition_amd", "data", "ocr_synth.model.gz")
 REF = os.path.join(ROOT, "oracle", "_ref")
-K, D, PER_CLASS = 65, 1800, 5
+K, D = 65, 1800
+BIG = len(sys.argv) > 1 and sys.argv[1] == "120"
+PER_CLASS = 120 if BIG else 5
+NOISE, KEEP, EXTRA = (0.3, 0.6, 60) if BIG else (0.08, 0.85, 12)
+MODEL_GZ = os.path.join(ROOT, "scene-text-recognition_amd", "data", "ocr_synth120.model.gz" if BIG else "ocr_synth.model.gz")
+VECTORS = os.path.join(HERE, "svm_vectors120.npz" if BIG else "svm_vectors.npz")
 
 
 def sample(rng, proto_idx, proto_val):
-    keep = rng.random(len(proto_idx)) < 0.85
+    keep = rng.random(len(proto_idx)) < KEEP
     idx = proto_idx[keep]
-    val = np.clip(proto_val[keep] + rng.normal(0, 0.08, keep.sum()), 1 / 255.0, 1.0)
-    extra = rng.choice(D, size=12, replace=False)
+    val = np.clip(proto_val[keep] + rng.normal(0, NOISE, keep.sum()), 1 / 255.0, 1.0)
+    extra = rng.choice(D, size=EXTRA, replace=False)
     x = np.zeros(D)
     x[idx] = np.round(val * 255) / 255.0          # features are v/255 (src/OCR.cpp:211)
-    x[extra] = np.round(rng.uniform(0.05, 0.5, 12) * 255) / 255.0
+    x[extra] = np.round(rng.uniform(0.05, 0.5, EXTRA) * 255) / 255.0
     return x
 
 
@@ -97,9 +108,9 @@ def main():
         dec[i] = list(dv)
     q = np.round(X * 255).astype(np.uint8)
     assert np.array_equal(q / 255.0, X), "features must be exact multiples of 1/255"
-    np.savez_compressed(os.path.join(HERE, "svm_vectors.npz"), q=q, label=lab, prob=prob, dec=dec[:8])
+    np.savez_compressed(VECTORS, q=q, label=lab, prob=prob, dec=dec[:8])
     print("model", len(raw), "bytes ->", os.path.getsize(MODEL_GZ), "gz; vectors",
-          os.path.getsize(os.path.join(HERE, "svm_vectors.npz")), "bytes; labels", np.bincount(lab, minlength=K).tolist()[:10], "...")
+          os.path.getsize(VECTORS), "bytes; labels", np.bincount(lab, minlength=K).tolist()[:10], "...")
 
 
 if __name__ == "__main__":

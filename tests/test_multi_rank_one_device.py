@@ -28,10 +28,12 @@ def test_bench_two_ranks_on_one_device():
     assert len(lines) == 1, r.stdout                                   # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["frames_per_gpu_per_step"] == 4 and d["value"] > 0
+    # (a step runs its 4-frame batch as often as it takes for the timed region to last --min-region-s)
+    per_step = d["config"]["frames_per_gpu_per_step"]
+    assert d["config"]["frames_per_batch"] == 4 and per_step == 4 * d["config"]["batches_per_step"] and d["value"] > 0
     assert "gather" in d["config"]                                     # the exchange ran (torch.distributed over gloo here)
     # whole-job value = frames of BOTH ranks per second of the slowest rank
-    assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02
+    assert abs(d["value"] - 2 * per_step * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02
 
 
 def test_config4_dataflow_eight_ranks_in_one_process(S, cascade_paths):

@@ -67,6 +67,72 @@ def test_gpu_svm_matches_reference_vectors(erf, model_path, vectors):
     assert np.abs(gp.sum(axis=1) - 1).max() < 1e-9
 
 
+# ---- the model at the reference's training-set size (120 samples per class, src/utils.cpp:1478-1541): 4299 support vectors, up to 90 a class --------------
+@pytest.fixture(scope="module")
+def model120_path(tmp_path_factory, S):
+    p = tmp_path_factory.mktemp("svm120") / "ocr_synth120.model"
+    p.write_bytes(gzip.open(S.cascade_io.ocr_model_path(120)).read())
+    return str(p)
+
+
+@pytest.fixture(scope="module")
+def vectors120():
+    z = np.load(os.path.join(GOLDEN, "svm_vectors120.npz"))
+    return z["q"] / 255.0, z["label"], z["prob"], z["dec"]
+
+
+def test_oracle_matches_reference_vectors_120(oracle, model120_path, vectors120):
+    """oracle/svm_oracle.c against what the reference's own libsvm returned for the 48 golden vectors on the big model: bit for bit."""
+    from oracle.oracle import OracleSVM
+    m = OracleSVM(oracle, model120_path)
+    assert (m.k, m.l) == (65, 4299)
+    x, lab, prob, dec = vectors120
+    for i in range(len(x)):
+        l, p, d = m.predict_probability(x[i])
+        assert l == lab[i] and np.array_equal(p, prob[i])
+        if i < len(dec):
+            assert np.array_equal(d, dec[i])
+
+
+@pytest.mark.gpu
+def test_gpu_svm_matches_reference_vectors_120(S, model120_path, vectors120):
+    """svm_predict_probability on the model of the reference's shape -- thousands of support vectors, the general (any count per class) build of
+    k_svm_couple -- against the reference's libsvm: labels equal, probabilities and decision values within 1e-4."""
+    f = S.ERFilter(params=S.Params(max_width=64, max_height=64, max_frames=1))
+    f.load_svm_model(model120_path, 1800)
+    assert f.svm_info() == (65, 4299, 1800)
+    x, lab, prob, dec = vectors120
+    gl, gp, gd = f.svm_predict_probability(x, want_dec=True)
+    assert (gl == lab).all()
+    assert np.abs(gp - prob).max() < TOL
+    assert np.abs(gd[:len(dec)] - dec).max() < TOL
+    assert np.abs(gp.sum(axis=1) - 1).max() < 1e-9
+    f.close()
+
+
+@pytest.mark.gpu
+def test_gpu_chain_run_end_to_end_120(S, oracle, model120_path):
+    """chain_run on real candidates with the big model (the box path: features as bf16 numerators, kernel matrix as three bf16 MFMAs) against the oracle."""
+    from oracle.oracle import OracleSVM
+    f = S.ERFilter(params=S.Params(max_width=640, max_height=480, max_frames=1))
+    f.load_svm_model(model120_path, 1800)
+    m = OracleSVM(oracle, model120_path)
+    img = S.synth.gray(S.synth.stext_bgr(S.synth.frame_seed(6), 640, 480))
+    res = f.detect_planes(img, S.STAGE_EXTRACT | S.STAGE_NMS)
+    rng = np.random.default_rng(120)
+    rnd = [(int(x), int(y), int(rng.integers(4, 640 - x + 1)), int(rng.integers(4, 480 - y + 1))) for x, y in zip(rng.integers(0, 600, 70), rng.integers(0, 440, 70))]
+    boxes = np.concatenate([np.stack([res.cands["x"], res.cands["y"], res.cands["w"], res.cands["h"]], axis=1).astype(np.int32), np.array(rnd, np.int32)])
+    assert len(boxes) > 70          # (more than 64: two groups of eight vectors per wave of k_svm_decide, and a ragged last one)
+    q, label, prob = f.chain_run(img, boxes)
+    for i, b in enumerate(boxes):
+        l, p, _ = m.predict_probability(q[i] / 255.0)
+        assert abs(prob[i] - p[np.argmax(p)]) < TOL
+        top2 = np.sort(p)[-2:]
+        if top2[1] - top2[0] > 10 * TOL:
+            assert label[i] == l
+    f.close()
+
+
 @pytest.mark.gpu
 def test_gpu_svm_matches_oracle_on_many(erf, oracle, model_path):
     from oracle.oracle import OracleSVM

@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config3 -o s 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_group_ocr -o s -- python $ROOT/bench.py --group --ocr $P1 > $OUT/stats_group_ocr.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_4k -o s -- python $ROOT/bench.py --size 4k $P1 > $OUT/stats_4k.log 2>&1
 bash $ROOT/tools/dev_ocr_pmc.sh profiles_$TAG/pmc_config3 > /dev/null 2>&1
-bash $ROOT/tools/r05_lat.sh profiles_$TAG/latency > /dev/null 2>&1
+bash $ROOT/tools/dev_lat.sh profiles_$TAG/latency > /dev/null 2>&1
 cd /tmp
 python $ROOT/bench.py > $OUT/bench_${TAG}_pyr3x8_text.json 2> $OUT/bench_err.log
 python $ROOT/bench.py --workload native6 > $OUT/bench_${TAG}_native6_text.json 2>> $OUT/bench_err.log
