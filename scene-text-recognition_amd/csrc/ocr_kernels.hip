@@ -425,6 +425,21 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int
 // ---------------------------------------------------------------------------------------------------------
 // libsvm inference
 // ---------------------------------------------------------------------------------------------------------
+// exp(x) for x <= 0 without the library's range cases: 2^n e^r, |r| <= ln 2 / 2, degree-11 Taylor (3e-17 relative); below e^-700 the result is 0
+__device__ __forceinline__ double exp_neg(double x)
+{
+    x = fmax(x, -700.0);
+    const double nn = __builtin_rint(x * 1.4426950408889634);
+    double       r = __builtin_fma(nn, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(nn, -1.90821492927058770002e-10, r);
+    double e = 1.0 / 39916800.0;
+    e = __builtin_fma(e, r, 1.0 / 3628800.0); e = __builtin_fma(e, r, 1.0 / 362880.0); e = __builtin_fma(e, r, 1.0 / 40320.0);
+    e = __builtin_fma(e, r, 1.0 / 5040.0); e = __builtin_fma(e, r, 1.0 / 720.0); e = __builtin_fma(e, r, 1.0 / 120.0);
+    e = __builtin_fma(e, r, 1.0 / 24.0); e = __builtin_fma(e, r, 1.0 / 6.0); e = __builtin_fma(e, r, 0.5);
+    e = __builtin_fma(e, r, 1.0); e = __builtin_fma(e, r, 1.0);
+    return __builtin_amdgcn_ldexp(e, (int)nn);
+}
+
 __global__ __launch_bounds__(256) void k_svm_prep(const double *__restrict__ x, int n, int dim, float *__restrict__ xf, int dpad,
                                                   double *__restrict__ xnorm)
 {
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(256) void k_svm_kernel(const float *__restrict__ xf
             if (row < n_rows) {
                 double d2 = xnorm[row] + sn - 2.0 * (double)(h ? acc1[i] : acc0[i]);
                 d2 = d2 > 0 ? d2 : 0;
-                kv[(size_t)row * l_pad + col] = exp(-gamma * d2);
+                kv[(size_t)row * l_pad + col] = exp_neg(-gamma * d2);
             }
         }
     }
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(256) void k_svm_kernel_q(const uint16_t *__restrict
             if (row < n_rows) {
                 double d2 = xnorm[row] + sn - (2.0 / 255.0) * (double)(h ? acc1[i] : acc0[i]);
                 d2 = d2 > 0 ? d2 : 0;
-                kv[(size_t)row * l_pad + col] = exp(-gamma * d2);
+                kv[(size_t)row * l_pad + col] = exp_neg(-gamma * d2);
             }
         }
     }
@@ -641,19 +656,31 @@ __global__ __launch_bounds__(256) void k_svm_decide(const double *__restrict__ k
 #pragma unroll
     for (int bt = 0; bt < 4; ++bt) ka[bt] = kv + (size_t)min(v0 + 16 * bt + r16, n - 1) * l_pad + q0 + kq;
     const double *cb = m.coef_t + (size_t)(q0 + kq) * 64 + r16;
+    // (the next step's eight operands are requested before this step's sixteen matrix instructions: with the accumulators in 128 registers there are only three
+    // waves a SIMD to cover a trip to memory)
+    double a[4], b[4];
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) a[bt] = ka[bt][0];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) b[st] = cb[16 * st];
     for (int q = 0; q < nq; q += 4) {
-        double a[4], b[4];
+        double     an[4], bn[4];
         const bool on = q + kq < nq;
+        const int  qn = q + 4 < nq ? q + 4 : q;          // (the last step asks for its own operands again)
 #pragma unroll
-        for (int bt = 0; bt < 4; ++bt) a[bt] = ka[bt][q];
+        for (int bt = 0; bt < 4; ++bt) an[bt] = ka[bt][qn];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) b[st] = cb[(size_t)q * 64 + 16 * st];
+        for (int st = 0; st < 4; ++st) bn[st] = cb[(size_t)qn * 64 + 16 * st];
 #pragma unroll
         for (int st = 0; st < 4; ++st) b[st] = on ? b[st] : 0.0;
 #pragma unroll
         for (int bt = 0; bt < 4; ++bt)
 #pragma unroll
             for (int st = 0; st < 4; ++st) acc[bt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt], b[st], acc[bt][st], 0, 0, 0);
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) a[bt] = an[bt];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[st] = bn[st];
     }
     // result tile: element r of lane L is row (L >> 4) + 4 r, column L & 15
 #pragma unroll

@@ -144,6 +144,18 @@ static int launch_tile_trees(str_er_ctx *c, const Batch &b, const BatchDev &bd, 
         c->n_t2_tiles = n2;
         c->t2_key = key;
     }
+    if ((int)b.planes.size() <= SPEC_PLANES && c->side && c->ev_fork && c->ev_join) {
+        // a call of a frame or two: the two kernels side by side (a wave of k_tile_tree2 is one long dependent chain -- 70 us for a pair of tiles whatever
+        // else the GPU does --, and a frame's tiles do not fill the GPU: one after the other they took 130 us, k_tile_tree alone on all tiles 100)
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        launch_tile_tree2(c->side, bd, dp, c->d_t2_pairs, (uint32_t)c->h_t2_pairs.size(), c->d_fb_list, c->d_total + 1);
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+        launch_tile_tree(s, bd, dp, c->tile_sparse, c->d_t1_list, (uint32_t)c->h_t1_list.size());
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        launch_tile_tree_fb(s, bd, dp, c->tile_sparse, c->d_fb_list, c->d_total + 1, std::min<uint32_t>(c->n_t2_tiles, 256u));
+        return STR_ER_OK;
+    }
     // the small kernel first: its waves are the longer ones (a dependent chain per pair of tiles), the big kernel's workgroups fill in behind
     launch_tile_tree2(s, bd, dp, c->d_t2_pairs, (uint32_t)c->h_t2_pairs.size(), c->d_fb_list, c->d_total + 1);
     rec(c, "tile_tree2");
@@ -598,10 +610,15 @@ int upload_layout(str_er_ctx *c, Batch &b)
         }
         c->n_node_blocks = at;
     }
-    std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
-    HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(PlaneCtr) * np, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_total, 0, 2 * sizeof(uint32_t), s));      // candidates of the batch, tiles k_tile_tree2 handed back
+    // (the descriptors of a video's frames are the same call after call -- planes in the context's own pool, same shares of the tables: uploaded when they change)
+    if (c->planes_on_device != np || std::memcmp(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np) != 0) {
+        c->planes_on_device = 0;
+        std::memcpy(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np);
+        HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc) * np, hipMemcpyHostToDevice, s));
+        c->planes_on_device = np;
+    }
+    // counters of the batch (candidates, tiles k_tile_tree2 handed back), plane counters, the groups' done flags
+    HIP_TRY(c, hipMemsetAsync(c->d_zero, 0, align_up(c->zero_gd_off + b.n_groups, 256), s));      // (a whole number of 256-byte pieces: one fill kernel, not two)
     {   // tile -> plane and seam-block -> (plane, first pair) tables; re-uploaded only when the layout changes
         std::vector<uint32_t> key;
         key.reserve(np * 2 + 1);
@@ -717,7 +734,6 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
     if (grouped && b.n_groups) {
-        HIP_TRY(c, hipMemsetAsync(c->d_group_done, 0, b.n_groups, s));
         launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 2 : 6));       // (measured, tools/dev_groups.sh)
     }
     rec(c, "group");
@@ -755,8 +771,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     int       i_trk = -1;
     if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_zero, c->d_zero, 256 + sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));        // (counters of the batch + plane counters: one block)
     const CandRec *spec_src = nullptr;
     uint32_t       spec_n = 0;
     if ((stages & STR_ER_STAGE_NMS) && np <= SPEC_PLANES && c->pool_total && c->last_total <= SPEC_CANDS) {
@@ -847,8 +862,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             launch_cand_reprefix(sp, bd, first, c->d_redo, n_redo);
             launch_classify(sp, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, c->d_redo, n_redo);
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
-            HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
+            HIP_TRY(c, hipMemcpyAsync(c->h_zero, c->d_zero, 256 + sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
             HIP_TRY(c, wait_stream(c, sp));
             if (c->dbg_stats) std::fprintf(stderr, "[str_er] classify again after the tie pass: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count());
             bool again = false;             // (a pool of the tie pass did not fit: same remedy as above)
@@ -1202,8 +1216,7 @@ void str_er_destroy(str_er_ctx *c)
     for (auto &hc : c->casc) if (hc.d_blob) (void)hipFree(hc.d_blob);
     if (c->d_svm_blob) (void)hipFree(c->d_svm_blob);
     if (c->h_planes) (void)hipHostFree(c->h_planes);
-    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
-    if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_zero) (void)hipHostFree(c->h_zero);
     if (c->h_cands_spec) (void)hipHostFree(c->h_cands_spec);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -1305,7 +1318,6 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_in, c->in_bytes));
     A(dev_alloc(c, c->d_pix, c->pix_bytes));
     A(dev_alloc(c, c->d_planes, (size_t)c->max_planes));
-    A(dev_alloc(c, c->d_ctr, (size_t)c->max_planes));
     A(alloc_node_records(c, (size_t)std::ceil((double)S * c->node_share) + 256 * (size_t)c->max_planes));
     A(alloc_tables(c, KP, PP));
     A(dev_alloc(c, c->d_seam, c->seam_slots));
@@ -1315,9 +1327,17 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
     A(dev_alloc(c, c->d_t1_list, c->tile_slots)); A(dev_alloc(c, c->d_t2_pairs, c->tile_slots)); A(dev_alloc(c, c->d_fb_list, c->tile_slots));
     A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * 32));
-    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_done, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots));
+    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
-    A(dev_alloc(c, c->d_total, 4));
+    {   // what a batch starts from zero -- the candidate / handed-back-tile counters, the plane counters, the groups' done flags -- is ONE block: one
+        // memset per batch, and the counters come back with one copy (a call of one frame is a chain of ~30 operations: each costs 5 - 10 us)
+        c->zero_gd_off = 256 + align_up(sizeof(PlaneCtr) * (size_t)c->max_planes, 256);
+        A(dev_alloc(c, c->d_zero, align_up(c->zero_gd_off + c->tile_slots, 256)));
+        if (c->d_zero) {
+            c->d_total = reinterpret_cast<uint32_t *>(c->d_zero); c->d_ctr = reinterpret_cast<PlaneCtr *>(c->d_zero + 256);
+            c->d_group_done = c->d_zero + c->zero_gd_off;
+        }
+    }
     A(dev_alloc(c, c->d_watch, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wstamp, (size_t)c->max_planes * NMS_WATCH_CAP)); A(dev_alloc(c, c->d_wparent, (size_t)c->max_planes * NMS_WATCH_CAP));
     A(dev_alloc(c, c->d_replay_items, (size_t)c->max_planes));
     A(dev_alloc(c, c->d_tie_slot_plane, (size_t)TIE_SLOTS));
@@ -1325,11 +1345,11 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_strip_flag, (size_t)1));
     if (rc == STR_ER_OK) {
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_planes), sizeof(PlaneDesc) * c->max_planes) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void **>(&c->h_ctr), sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void **>(&c->h_total), 64) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&c->h_zero), 256 + sizeof(PlaneCtr) * c->max_planes) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_cands_spec), sizeof(CandRec) * SPEC_CANDS) != hipSuccess)
             rc = fail(nullptr, STR_ER_ENOMEM, "hipHostMalloc failed");
     }
+    if (rc == STR_ER_OK) { c->h_total = reinterpret_cast<uint32_t *>(c->h_zero); c->h_ctr = reinterpret_cast<PlaneCtr *>(c->h_zero + 256); }
     if (rc != STR_ER_OK) { std::string keep = g_create_error.empty() ? c->err : g_create_error; str_er_destroy(c); g_create_error = keep; return rc; }
     *out = c;
     return STR_ER_OK;

@@ -107,6 +107,8 @@ struct str_er_ctx {
     uint8_t *d_pix = nullptr; size_t pix_bytes = 0;   // physical planes (Y,Cr,Cb per level)
     PlaneDesc *d_planes = nullptr;
     PlaneCtr *d_ctr = nullptr;
+    uint8_t *d_zero = nullptr, *h_zero = nullptr; size_t zero_gd_off = 0;      // the block a batch zeroes: d_total | d_ctr | d_group_done (and its page-locked mirror: h_total | h_ctr)
+    int planes_on_device = 0;         // plane descriptors in d_planes = the first so many of h_planes (0: none)
     NodeArrays na{};
     KeptArrays ka{};
     uint16_t *d_seam = nullptr; size_t seam_slots = 0;
