@@ -52,6 +52,7 @@ W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0    # ... and what a float4 copy reaches (same guide)
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense f32 matrix peak (v_mfma_f32_32x32x2_f32: 256 flop/cycle/CU x 256 CUs x 2.4 GHz)
+MFMA_I8_PEAK_TOPS = 5000.0     # same guide: 8-bit matrix instructions run at twice the bf16 rate (microbenchmark ceiling there: 3944 TOPS)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 WORKLOADS = {
     "pyr3x8": dict(n_pyr_levels=8, channel_mask=0x07, label="1920x1080 BGR, {Y,Cr,Cb} x 8 pyramid levels (BASELINE configs[1])"),
@@ -500,25 +501,33 @@ def main():
         k_cls, l_sv, _dim = rig.filters[0].svm_info()
         l_pad, d_q = -(-l_sv // 64) * 64, -(-1800 // 64) * 64
         gemm_ms = sp_o.get("svm_kernel", 0.0)
-        flops = 3 * 2.0 * n_sc * d_q * l_pad
+        forms = rig.filters[0].svm_forms()
+        d_q8 = -(-1800 // 128) * 128
+        # executed operations of the kernel-matrix launch: one 8-bit multiply-add per (vector, support vector, padded feature) when the model's support vectors are
+        # bytes, else three bf16 ones (the f32 value in three pieces)
+        flops = 2.0 * n_sc * d_q8 * l_pad if forms["bytes"] else 3 * 2.0 * n_sc * d_q * l_pad
+        peak = MFMA_I8_PEAK_TOPS if forms["bytes"] else MFMA_BF16_PEAK_TFLOPS
         tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         alg_flops = 2.0 * n_sc * 1800 * l_sv
         ocr_leg.update({
             "ers_scored_per_batch": n_sc, "svm_model": f"ocr_synth120.model: {k_cls} classes, {l_sv} support vectors, 1800-d, RBF (stand-in for the missing OCR.model, trained on 120 "
                                                        "samples per class like the reference's get_ocr_data, src/utils.cpp:1478-1541)",
+            "svm_forms": forms,
             "gpu_ms_per_batch_isolated": {k: round(sp_o.get(k, 0.0), 4) for k in ("ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple")},
-            "gpu_ms_note": "ocr_features = k_ocr_list + k_ocr_hist + k_ocr_otsu + k_ocr_features; svm_kernel = k_svm_kernel_q (RBF kernel matrix, MFMA); svm_couple = "
-                           "k_svm_couple (decision values + sigmoid + pairwise coupling); ocr_host_gap = stream idle while the host reads the plane counters "
-                           "(the scorer's launch sizes), not GPU work",
-            "roofline_svm_kernel": {"bound": "mfma", "kernel": "k_svm_kernel_q", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 5), "flops_per_launch": int(flops), "avg_launch_ms": round(gemm_ms, 4),
-                                    "f32_equivalent_tflops": round(tf / 3, 2),
+            "gpu_ms_note": "ocr_features = k_ocr_list + k_ocr_hist + k_ocr_otsu + k_ocr_features; svm_kernel = the RBF kernel matrix (k_svm_kernel_i8: 8-bit MFMA, exact "
+                           "integer distances -- the model's support vectors are 8-bit numerators like the reference's; k_svm_kernel_q, three bf16 MFMAs per product, for any "
+                           "other model); svm_couple = k_svm_decide (per-class sums of coefficient x kernel value: f64 MFMA) + k_svm_couple (sigmoid + pairwise coupling); "
+                           "ocr_host_gap = stream idle while the host reads the plane counters (the scorer's launch sizes), not GPU work",
+            "roofline_svm_kernel": {"bound": "mfma", "kernel": "k_svm_kernel_i8" if forms["bytes"] else "k_svm_kernel_q", "achieved": round(tf, 2), "peak": peak,
+                                    "unit": "TOP/s (8-bit)" if forms["bytes"] else "TFLOP/s", "frac": round(tf / peak, 5), "flops_per_launch": int(flops), "avg_launch_ms": round(gemm_ms, 4),
                                     "algorithmic_flops_per_launch": int(alg_flops), "algorithmic_tflops": round(alg_flops / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else 0.0,
-                                    "frac_algorithmic": round(alg_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5) if gemm_ms > 0 else 0.0,
-                                    "note": f"3 x 2 x N x {d_q} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch: the f32 product x.sv as three bf16 "
-                                            "MFMAs (the features are 8-bit numerators, exact in bf16; each support vector = three bf16 pieces, exactly), f32 accumulate; "
-                                            "f32_equivalent_tflops = the same launch priced as the one f32 contraction it replaces (f32 matrix peak 157.3); the launch "
-                                            "also evaluates exp() in f64 for every kernel value"}})
+                                    "frac_algorithmic": round(alg_flops / (gemm_ms * 1e-3) / 1e12 / peak, 5) if gemm_ms > 0 else 0.0,
+                                    "frac_algorithmic_of_bf16_peak": round(alg_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5) if gemm_ms > 0 else 0.0,
+                                    "note": (f"2 x N x {d_q8} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch: features and support vectors are 8-bit numerators over 255, "
+                                             "so x.sv is one v_mfma_i32_32x32x32_i8 per 32 features and |x - sv|^2 an exact integer; " if forms["bytes"] else
+                                             f"3 x 2 x N x {d_q} x l_pad (N = {n_sc} ERs, l_pad = {l_pad}) over the isolated launch: the f32 product x.sv as three bf16 MFMAs, f32 accumulate; ") +
+                                            "algorithmic = SURVEY 8(d)'s 2 N 1800 l; the launch also evaluates exp() in f64 and writes 8 bytes for every kernel value "
+                                            f"({n_sc * l_pad * 8 / 1e6:.0f} MB), which is what bounds it"}})
         if not args.no_cpu_baseline:
             ocr_leg["cpu_baseline"] = cpu_baseline(args.kind, args.workload, cascades, budget_s=8.0, ocr_model=svm_path)
         # the same leg on the small model of rounds 1-5 (319 support vectors, at most 5 a class: k_svm_couple's register build)

@@ -294,6 +294,11 @@ int str_er_cascade_predict(str_er_ctx *ctx, int which, const double *fv, int32_t
 int str_er_load_svm_model(str_er_ctx *ctx, const char *path, int32_t dim);
 int str_er_load_svm_model_mem(str_er_ctx *ctx, const char *text, size_t len, int32_t dim);
 int str_er_svm_info(const str_er_ctx *ctx, int32_t *nr_class, int32_t *total_sv, int32_t *dim);
+/* How the loaded model's kernel matrix is computed for vectors that come from boxes (chain_run, STR_ER_STAGE_OCR / _OCR_LINES; measurement aid, any pointer
+ * may be NULL): *bytes = 1 if the support vectors are 8-bit numerators over 255 -- as the reference's are, being feature vectors of its training set
+ * (src/OCR.cpp:211) -- and |x - sv|^2 is an exact integer from 8-bit matrix instructions, 0 if each f32 value goes as three bf16 pieces; *class_sums = 1 if
+ * the decision values are summed per class as dense f64 products (models with more than 8 support vectors a class), 0 if per vector. */
+int str_er_svm_forms(const str_er_ctx *ctx, int32_t *bytes, int32_t *class_sums);
 /* svm_predict_probability (inc/svm.h:88, src/svm.cpp:2592-2629) for n dense feature vectors x[n][dim]
  * (zeros = absent svm_nodes): label[i] = model->label[argmax], prob[i][nr_class]; dec (optional, may
  * be NULL) receives the nr_class*(nr_class-1)/2 decision values of svm_predict_values.              */

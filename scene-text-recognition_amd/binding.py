@@ -136,6 +136,7 @@ def load_library():
     L.str_er_load_svm_model.argtypes = [vp, C.c_char_p, C.c_int32]
     L.str_er_load_svm_model_mem.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int32]
     L.str_er_svm_info.argtypes = [vp, i32p, i32p, i32p]
+    L.str_er_svm_forms.argtypes = [vp, i32p, i32p]
     L.str_er_svm_predict_probability.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.str_er_ocr_chain_run.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp]
     L.str_er_ocr_chain_run_slope.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int32, vp, vp, vp]
@@ -618,6 +619,13 @@ class ERFilter:
         a, b, d = C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self.L.str_er_svm_info(self.h, C.byref(a), C.byref(b), C.byref(d)))
         return a.value, b.value, d.value
+
+    def svm_forms(self) -> dict:
+        """How the loaded model is evaluated (str_er_svm_forms): support vectors as bytes (exact 8-bit kernel matrix) or as three bf16 pieces; decision values
+        summed per class (f64 matrix products) or per vector."""
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self.L.str_er_svm_forms(self.h, C.byref(a), C.byref(b)))
+        return {"bytes": bool(a.value), "class_sums": bool(b.value)}
 
     def svm_predict_probability(self, x: np.ndarray, want_dec: bool = False):
         """svm_predict_probability (src/svm.cpp:2592-2629) for dense (n, dim) features -> (label, prob[, dec])."""

@@ -245,6 +245,7 @@ try {
         return fail(c, STR_ER_EFORMAT, "svm model: incomplete header (need nr_class<=125, rho, label, probA, probB, nr_sv)");
     const int dpad = (int)align_up((size_t)dim, 16), l_pad = (int)align_up((size_t)l, 64);
     std::vector<float> sv((size_t)l_pad * dpad, 0.f);
+    std::vector<double> sv_exact((size_t)l * dim, 0.0);      // as parsed (the byte form of the vectors is decided on these)
     std::vector<double> svnorm(l_pad, 0.0), coef((size_t)(k - 1) * l, 0.0);
     for (int i = 0; i < l; ++i) {
         if (!next_line(line)) return fail(c, STR_ER_EFORMAT, "svm model: fewer SV lines than total_sv");
@@ -260,6 +261,7 @@ try {
             p = end;
             if (idx < 0 || idx >= dim) return fail(c, STR_ER_EFORMAT, "svm model: SV feature index outside [0, dim)");
             sv[(size_t)i * dpad + idx] = (float)v;
+            sv_exact[(size_t)i * dim + idx] = v;
             nrm += (double)(float)v * (double)(float)v;       // (of the f32 value the kernels multiply with: |x - sv|^2 = |x|^2 + |sv|^2 - 2 x.sv stays consistent)
         }
         svnorm[i] = nrm;
@@ -299,10 +301,16 @@ try {
     const int dq = (int)align_up((size_t)dim, 64);
     const std::vector<uint16_t> svq = svm_sv_planes(sv, l, l_pad, dim, dpad, dq);
     const size_t o_svq = take(svq.size() * 2);
+    // ... and as bytes, if they are 8-bit numerators over 255 (the reference's models: k_svm_kernel_i8)
+    const int dq8 = (int)align_up((size_t)dim, 128);
+    std::vector<uint8_t> sv8; std::vector<int32_t> sv8s;
+    const bool bytes_ok = svm_sv_bytes(sv_exact, l, l_pad, dim, dq8, sv8, sv8s);
+    const size_t o_sv8 = take(sv8.size()), o_sv8s = take(sv8s.size() * 4);
     const size_t o_sv = take(sv.size() * 4), o_nrm = take(svnorm.size() * 8), o_coef = take(coef.size() * 8), o_coeft = take(coef_t.size() * 8), o_rho = take(np * 8),
                  o_pa = take(np * 8), o_pb = take(np * 8), o_lab = take(k * 4), o_nsv = take(k * 4), o_start = take(k * 4);
     std::vector<uint8_t> blob(off);
     std::memcpy(&blob[o_svq], svq.data(), svq.size() * 2);
+    if (bytes_ok) { std::memcpy(&blob[o_sv8], sv8.data(), sv8.size()); std::memcpy(&blob[o_sv8s], sv8s.data(), sv8s.size() * 4); }
     std::memcpy(&blob[o_sv], sv.data(), sv.size() * 4); std::memcpy(&blob[o_nrm], svnorm.data(), svnorm.size() * 8);
     std::memcpy(&blob[o_pij], pairs.data(), np_pad * sizeof(SvmPair));
     if (!rows.empty()) std::memcpy(&blob[o_rows], rows.data(), rows.size() * 8);
@@ -319,6 +327,7 @@ try {
     SvmDev m{};
     m.k = k; m.l = l; m.l_pad = l_pad; m.dim = dim; m.dpad = dpad; m.gamma = gamma;
     m.svq = reinterpret_cast<const uint16_t *>(b + o_svq); m.dq = dq;
+    m.sv8 = bytes_ok ? b + o_sv8 : nullptr; m.sv8s = bytes_ok ? reinterpret_cast<const int32_t *>(b + o_sv8s) : nullptr; m.dq8 = dq8;
     m.sv = reinterpret_cast<const float *>(b + o_sv); m.svnorm = reinterpret_cast<const double *>(b + o_nrm);
     m.pairs = reinterpret_cast<const SvmPair *>(b + o_pij);
     m.coef_rows = rows.empty() ? nullptr : reinterpret_cast<const double *>(b + o_rows); m.msv = msv; m.mp = mp;
@@ -352,6 +361,14 @@ try {
     if (nr_class) *nr_class = c->svm_loaded ? c->svm.k : 0;
     if (total_sv) *total_sv = c->svm_loaded ? c->svm.l : 0;
     if (dim) *dim = c->svm_loaded ? c->svm.dim : 0;
+    return STR_ER_OK;
+} ABI_GUARD(const_cast<str_er_ctx *>(c))
+
+int str_er_svm_forms(const str_er_ctx *c, int32_t *bytes, int32_t *class_sums)
+try {
+    if (!c) return STR_ER_EINVAL;
+    if (bytes) *bytes = c->svm_loaded && c->svm.sv8 ? 1 : 0;
+    if (class_sums) *class_sums = c->svm_loaded && svm_uses_class_sums(c->svm) ? 1 : 0;
     return STR_ER_OK;
 } ABI_GUARD(const_cast<str_er_ctx *>(c))
 

@@ -19,6 +19,10 @@ struct SvmDev {
     const float  *sv;       // [l_pad x dpad] dense, zero padded
     const uint16_t *svq;    // [3][l_pad x dq] bf16: sv = svq[0] + svq[1] + svq[2] exactly (the f32's 24 significant bits in three pieces)
     int32_t dq;             // dim rounded up to 64: row length of svq and of OcrBuf::xq
+    // models whose support vectors are 8-bit numerators over 255 (the reference's are: svm_tables.h svm_sv_bytes), else null
+    const uint8_t *sv8;     // [l_pad x dq8] numerator ^ 0x80, padding 0x80
+    const int32_t *sv8s;    // [l_pad x 2] sum of the numerators, sum of their squares
+    int32_t dq8;            // dim rounded up to 128: row length of sv8 and of OcrBuf::x8
     const double *svnorm;   // [l_pad]
     const double *coef;     // [(k-1) x l]            sv_coef as libsvm stores it (kept for the layout tests)
     const double *coef_t;   // [l_pad x kc]              coef_t[q][b] = sv_coef[b][q], zero padded: one coalesced row per support vector
@@ -53,6 +57,8 @@ struct OcrBuf {
     float    *xf;        // [n_pad x dpad]  svm input, f32, zero padded                  (svm, vectors given as doubles)
     uint16_t *xq;        // [n_pad x dq]    svm input times 255 -- the features' 8-bit numerators -- as bf16, zero padded (svm, vectors from boxes)
     double   *xnorm;     // [n_pad]         |x|^2                                        (svm)
+    uint8_t  *x8;        // [n_pad x dq8] or null: the numerators ^ 0x80, padding 0x80 (svm, models with SvmDev::sv8)
+    int32_t  *x8s;       // [n_pad x 2] or null: sum of the numerators, sum of their squares
     double   *kv;        // [n_pad x l_pad] RBF kernel values                            (svm)
     double   *av;        // [n_pad x k x 64] or null: per class c and slot j the sum of sv_coef[j][q] K[q] over class c's support vectors (svm, svm_uses_class_sums())
     double   *dec;       // [n x k(k-1)/2] or null: decision values

@@ -318,7 +318,8 @@ __device__ __forceinline__ void feat_aran(FeatWave &L, const OcrBox &b, int th, 
 }
 
 __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int n, const int32_t *__restrict__ thresh, uint8_t *__restrict__ q_out,
-                                                                uint16_t *__restrict__ xq, double *__restrict__ xnorm, int dq)
+                                                                uint16_t *__restrict__ xq, double *__restrict__ xnorm, int dq,
+                                                                uint8_t *__restrict__ x8, int32_t *__restrict__ x8s, int dq8)
 {
     __shared__ FeatWave s_w[OCR_WAVES];
     __shared__ uint8_t  s_lut[256];
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int
         }
         __builtin_amdgcn_wave_barrier();
         double nrm = 0;
+        int    s1 = 0, s2 = 0;
         for (int i = lane; i < 1800; i += 64) {
             const int c = i / 225, r = i - c * 225, y = r / 15, x = r - y * 15;
             const uint8_t *m = L.v + c * 900 + (2 * y) * 30 + 2 * x;
@@ -412,6 +414,12 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int
                 xq[(size_t)bi * dq + i] = (uint16_t)(__float_as_uint((float)v) >> 16);      // the numerator as bf16: 0 .. 255 are exact (k_svm_kernel_q)
                 nrm += d * d;
             }
+            if (x8) { x8[(size_t)bi * dq8 + i] = (uint8_t)(v ^ 0x80); s1 += v; s2 += v * v; }      // (the numerator itself, as a signed byte minus 128: k_svm_kernel_i8)
+        }
+        if (x8) {
+            for (int i = 1800 + lane; i < dq8; i += 64) x8[(size_t)bi * dq8 + i] = 0x80;
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if (lane == 0) { x8s[2 * (size_t)bi] = s1; x8s[2 * (size_t)bi + 1] = s2; }
         }
         if (xq) {
             for (int i = 1800 + lane; i < dq; i += 64) xq[(size_t)bi * dq + i] = 0;
@@ -589,6 +597,74 @@ __global__ __launch_bounds__(256) void k_svm_kernel_q(const uint16_t *__restrict
                 double d2 = xnorm[row] + sn - (2.0 / 255.0) * (double)(h ? acc1[i] : acc0[i]);
                 d2 = d2 > 0 ? d2 : 0;
                 kv[(size_t)row * l_pad + col] = exp_neg(-gamma * d2);
+            }
+        }
+    }
+}
+
+// The same matrix when BOTH sides are 8-bit numerators over 255 -- every vector k_ocr_features makes, and the support vectors of a model trained on such
+// vectors (the reference's: SvmDev::sv8): |x - sv|^2 = (sum a^2 + sum b^2 - 2 sum a b) / 255^2 with all three sums EXACT integers, sum a b from
+// v_mfma_i32_32x32x32_i8 on a - 128, b - 128 (signed bytes; sum a b = sum (a - 128)(b - 128) + 128 (sum a + sum b) - 128^2 D, D = the padded row length).
+// One matrix instruction per 32 features where the bf16 form takes six per 32: the kernel is then as long as its epilogue (exp, 8 bytes written per value).
+// Same tiling as k_svm_kernel_q: workgroup 128 x 64, four waves of 64 x 32, K step 128 bytes, rows of 128 + 16 bytes in LDS, the next tile through registers.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int IK = 128, IS = IK + 16;
+__global__ __launch_bounds__(256) void k_svm_kernel_i8(const uint8_t *__restrict__ x8, const int32_t *__restrict__ x8s, int n_rows, const uint8_t *__restrict__ sv8,
+                                                       const int32_t *__restrict__ sv8s, int l_pad, int dq8, double gamma, double *__restrict__ kv)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t As[QM][IS];
+    __shared__ __attribute__((aligned(16))) uint8_t Bs[QN][IS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * QM, n0 = blockIdx.x * QN;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
+    const int sr = tid >> 3, ch = (tid & 7) * 16;            // a thread moves the 16-byte chunk `ch` of rows sr + 32 j: 4 of A, 2 of B
+    const uint8_t *pa[4], *pb[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pa[j] = x8 + (size_t)min(m0 + sr + 32 * j, n_rows - 1) * dq8 + ch;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pb[j] = sv8 + (size_t)(n0 + sr + 32 * j) * dq8 + ch;
+    u32x4 ra[4], rb[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const u32x4 *>(pa[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rb[j] = *reinterpret_cast<const u32x4 *>(pb[j]);
+    i32x16 acc0 = {0}, acc1 = {0};
+    const int nk = dq8 / IK, fr = lane & 31, fk = 16 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(&As[sr + 32 * j][ch]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4 *>(&Bs[sr + 32 * j][ch]) = rb[j];
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const u32x4 *>(pa[j] + (kt + 1) * IK);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rb[j] = *reinterpret_cast<const u32x4 *>(pb[j] + (kt + 1) * IK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < IK; ks += 32) {
+            const i32x4 a0 = *reinterpret_cast<const i32x4 *>(&As[wm + fr][ks + fk]), a1 = *reinterpret_cast<const i32x4 *>(&As[wm + 32 + fr][ks + fk]);
+            const i32x4 b = *reinterpret_cast<const i32x4 *>(&Bs[wn + fr][ks + fk]);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // 32x32 accumulator layout: element i of lane L is row 8*(i/4) + 4*(L/32) + i%4, column L%32
+    const int       col = n0 + wn + (lane & 31);
+    const long long sb = sv8s[2 * (size_t)col], sb2 = sv8s[2 * (size_t)col + 1], base = 16384ll * dq8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + wm + 32 * h + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+            if (row < n_rows) {
+                const long long sa = x8s[2 * (size_t)row], sa2 = x8s[2 * (size_t)row + 1];
+                const long long ab = (long long)(h ? acc1[i] : acc0[i]) + 128ll * (sa + sb) - base;
+                const long long d2i = sa2 + sb2 - 2ll * ab;                      // sum (a - b)^2 >= 0, exact
+                kv[(size_t)row * l_pad + col] = exp_neg(-gamma * ((double)d2i * (1.0 / 65025.0)));
             }
         }
     }
@@ -1128,6 +1204,8 @@ OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m, bool want_q, bool wa
         b.xf = reinterpret_cast<float *>(take(n_pad * m->dpad * 4));
         b.xq = reinterpret_cast<uint16_t *>(take(n_pad * m->dq * 2));
         b.xnorm = reinterpret_cast<double *>(take(n_pad * 8));
+        uint8_t *x8 = take(m->sv8 ? n_pad * (size_t)m->dq8 : 0), *x8s = take(m->sv8 ? n_pad * 8 : 0);
+        b.x8 = base && m->sv8 ? x8 : nullptr; b.x8s = reinterpret_cast<int32_t *>(base && m->sv8 ? x8s : nullptr);
         b.kv = reinterpret_cast<double *>(take(n_pad * m->l_pad * 8));
         uint8_t *av = take(svm_uses_class_sums(*m) ? n_pad * (size_t)m->k * 64 * 8 : 0);
         b.av = reinterpret_cast<double *>(base ? skip(av, svm_uses_class_sums(*m)) : nullptr);
@@ -1174,7 +1252,8 @@ void launch_ocr_features(hipStream_t s, const OcrSrc &src, int n, const OcrBuf &
     const int wg = (n + OCR_WAVES - 1) / OCR_WAVES, n_cu = ocr_n_cu();
     launch_box_thresholds(s, src, n, buf.hist, buf.big, buf.thresh);
     hipLaunchKernelGGL(k_ocr_features, dim3(wg < 3 * n_cu ? wg : 3 * n_cu), dim3(64 * OCR_WAVES), 0, s, src, n, (const int32_t *)buf.thresh, buf.q,
-                       m ? buf.xq : (uint16_t *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dq : 0);
+                       m && !buf.x8 ? buf.xq : (uint16_t *)nullptr, m ? buf.xnorm : (double *)nullptr, m ? m->dq : 0, m ? buf.x8 : (uint8_t *)nullptr, m ? buf.x8s : (int32_t *)nullptr,
+                       m ? m->dq8 : 0);
 }
 
 void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBuf &buf, const SvmDev &m)
@@ -1186,6 +1265,11 @@ void launch_svm_prep(hipStream_t s, const double *x, int n, int dim, const OcrBu
 void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m, bool numerators)
 {
     if (n <= 0) return;
+    if (numerators && m.sv8 && buf.x8) {
+        hipLaunchKernelGGL(k_svm_kernel_i8, dim3(m.l_pad / QN, (n + QM - 1) / QM), dim3(256), 0, s, (const uint8_t *)buf.x8, (const int32_t *)buf.x8s, n, m.sv8, m.sv8s, m.l_pad,
+                           m.dq8, m.gamma, buf.kv);
+        return;
+    }
     if (numerators) {
         hipLaunchKernelGGL(k_svm_kernel_q, dim3(m.l_pad / QN, (n + QM - 1) / QM), dim3(256), 0, s, (const uint16_t *)buf.xq, (const double *)buf.xnorm, n, m.svq,
                            m.svnorm, m.l_pad, m.dq, m.gamma, buf.kv);

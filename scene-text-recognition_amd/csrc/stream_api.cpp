@@ -35,8 +35,8 @@ struct str_er_stream {
         str_er_ctx *ctx = nullptr;
         uint8_t    *pinned = nullptr;
         uint8_t    *d_in = nullptr;        // the batch's frames on the device (upload target)
-        hipStream_t copy = nullptr;        // the upload's stream
-        hipEvent_t  landed = nullptr;
+        hipStream_t copy = nullptr, copy2 = nullptr;        // the upload's streams: the two halves of a batch travel side by side (one DMA engine each)
+        hipEvent_t  landed = nullptr, landed2 = nullptr;
         // job
         bool     busy = false, has_job = false, done = false;
         int32_t  w = 0, h = 0, n_frames = 0;
@@ -56,8 +56,10 @@ struct str_er_stream {
     std::condition_variable cv;
     std::deque<int> order;       // slots in submission order, oldest first
     uint64_t next_ticket = 1;
-    uint64_t upload_turn = 1;    // ticket of the batch whose upload may use the link now
+    uint64_t upload_turn = 1;    // ticket of the batch whose upload is enqueued next
+    hipEvent_t last_landed = nullptr, last_landed2 = nullptr;      // events of the upload enqueued last (touched by the worker whose turn it is)
     size_t   upload_piece = (size_t)1 << 40;       // (developer knob STR_ER_UPLOAD_PIECE_MB: the upload in pieces; 4 / 16 MB made no difference that stands out of the run-to-run scatter)
+    int      upload_streams = 2;                   // (developer knob STR_ER_UPLOAD_STREAMS = 1: the whole batch through one copy stream, as in rounds 4 and 5)
     bool     stop = false;
     std::string err;
 };
@@ -87,22 +89,36 @@ void worker_main(str_er_stream *s, int idx)
                 s->cv.wait(lk, [&] { return s->upload_turn == sl.ticket; });
             }
             hipError_t e = hipSuccess;
+            size_t     half = bytes;
             {
+                // (the turn passes on as soon as this upload is ENQUEUED: the next one is ordered behind it on the device -- its streams wait for this one's
+                // events -- so the link never idles while a worker thread wakes up; round 5 passed the turn when the bytes had landed: ~0.2 ms of an idle
+                // link per 6 ms upload)
                 struct TurnGuard {
                     str_er_stream *s; uint64_t next;
                     ~TurnGuard() { { std::lock_guard<std::mutex> lk(s->mu); s->upload_turn = next; } s->cv.notify_all(); }
                 } pass_on{s, sl.ticket + 1};
                 const size_t piece = s->upload_piece;
-                for (size_t at = 0; at < bytes && e == hipSuccess; at += piece)
-                    e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, bytes - at), hipMemcpyHostToDevice, sl.copy);
+                // two halves on two streams: a copy stream is served by one DMA engine, which alone does not fill the link
+                half = s->upload_streams > 1 && bytes >= ((size_t)8 << 20) ? ((bytes / 2 + 4095) & ~(size_t)4095) : bytes;
+                for (hipEvent_t prev : {s->last_landed, s->last_landed2})
+                    if (prev && e == hipSuccess) { e = hipStreamWaitEvent(sl.copy, prev, 0); if (e == hipSuccess && half < bytes) e = hipStreamWaitEvent(sl.copy2, prev, 0); }
+                for (size_t at = 0; at < half && e == hipSuccess; at += piece)
+                    e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, half - at), hipMemcpyHostToDevice, sl.copy);
+                for (size_t at = half; at < bytes && e == hipSuccess; at += piece)
+                    e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, bytes - at), hipMemcpyHostToDevice, sl.copy2);
                 if (e == hipSuccess) e = hipEventRecord(sl.landed, sl.copy);
-                // (poll, then sleep between polls: a spinning wait per slot would keep `depth` host cores busy)
-                for (int spins = 0; e == hipSuccess;) {
-                    const hipError_t q = hipEventQuery(sl.landed);
-                    if (q == hipSuccess) break;
-                    if (q != hipErrorNotReady) { e = q; break; }
-                    if (++spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(50));
-                }
+                if (e == hipSuccess && half < bytes) e = hipEventRecord(sl.landed2, sl.copy2);
+                s->last_landed = e == hipSuccess ? sl.landed : nullptr;
+                s->last_landed2 = e == hipSuccess && half < bytes ? sl.landed2 : nullptr;
+            }
+            // (poll, then sleep between polls: a spinning wait per slot would keep `depth` host cores busy)
+            for (int spins = 0; e == hipSuccess;) {
+                hipError_t q = hipEventQuery(sl.landed);
+                if (q == hipSuccess && half < bytes) q = hipEventQuery(sl.landed2);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { e = q; break; }
+                if (++spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
             if (e != hipSuccess) { rc = STR_ER_EHIP; upload_failed = true; sl.err = std::string("upload: ") + hipGetErrorString(e); }
             if (rc == STR_ER_OK)
@@ -140,6 +156,7 @@ try {
     str_er_stream *s = new (std::nothrow) str_er_stream();
     if (!s) return STR_ER_ENOMEM;
     s->device = p->device;
+    if (const char *e = std::getenv("STR_ER_UPLOAD_STREAMS")) s->upload_streams = std::atoi(e) > 1 ? 2 : 1;
     if (const char *e = std::getenv("STR_ER_UPLOAD_PIECE_MB")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) s->upload_piece = (size_t)v << 20; }
     s->slot_bytes = (size_t)p->max_frames * (size_t)p->max_width * (size_t)p->max_height * 3;
     s->slots.resize((size_t)depth);
@@ -153,6 +170,8 @@ try {
         if (rc == STR_ER_OK && (hipSetDevice(p->device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&s->slots[(size_t)i].d_in), s->slot_bytes) != hipSuccess))
             rc = STR_ER_ENOMEM;
         if (rc == STR_ER_OK && (hipStreamCreateWithFlags(&s->slots[(size_t)i].copy, hipStreamNonBlocking) != hipSuccess ||
+                                hipStreamCreateWithFlags(&s->slots[(size_t)i].copy2, hipStreamNonBlocking) != hipSuccess ||
+                                hipEventCreateWithFlags(&s->slots[(size_t)i].landed2, hipEventDisableTiming) != hipSuccess ||
                                 hipEventCreateWithFlags(&s->slots[(size_t)i].landed, hipEventDisableTiming) != hipSuccess))
             rc = STR_ER_EHIP;
     }
@@ -161,7 +180,9 @@ try {
             if (sl.pinned) (void)hipHostFree(sl.pinned);
             if (sl.d_in) (void)hipFree(sl.d_in);
             if (sl.landed) (void)hipEventDestroy(sl.landed);
+            if (sl.landed2) (void)hipEventDestroy(sl.landed2);
             if (sl.copy) (void)hipStreamDestroy(sl.copy);
+            if (sl.copy2) (void)hipStreamDestroy(sl.copy2);
             if (sl.ctx) str_er_destroy(sl.ctx);
         }
         delete s;
@@ -186,7 +207,9 @@ void str_er_stream_destroy(str_er_stream *s)
         if (sl.pinned) (void)hipHostFree(sl.pinned);
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.landed) (void)hipEventDestroy(sl.landed);
+        if (sl.landed2) (void)hipEventDestroy(sl.landed2);
         if (sl.copy) (void)hipStreamDestroy(sl.copy);
+        if (sl.copy2) (void)hipStreamDestroy(sl.copy2);
         if (sl.ctx) str_er_destroy(sl.ctx);
     }
     delete s;

@@ -44,6 +44,26 @@ inline std::vector<uint16_t> svm_sv_planes(const std::vector<float> &sv, int l, 
     return svq;
 }
 
+// The reference's support vectors ARE feature vectors of its training set: 8-bit numerators over 255 (src/OCR.cpp:211, src/utils.cpp:1478-1541), written to the model
+// with 8 significant digits.  A model all of whose values are such multiples of 1 / 255 gets its support vectors as bytes: |x - sv|^2 is then an EXACT integer
+// over 255^2, from one 8-bit matrix instruction per 32 features (k_svm_kernel_i8).  sv8[i][j], i < l_pad, j < dq8: numerator ^ 0x80 (= numerator - 128 as a signed
+// byte; padding: numerator 0); svs[2 i] = sum of the numerators, svs[2 i + 1] = sum of their squares.  Returns false (and leaves the outputs alone) for any other model.
+inline bool svm_sv_bytes(const std::vector<double> &sv_exact, int l, int l_pad, int dim, int dq8, std::vector<uint8_t> &sv8, std::vector<int32_t> &svs)
+{
+    std::vector<uint8_t> out((size_t)l_pad * dq8, 0x80);
+    std::vector<int32_t> sums((size_t)2 * l_pad, 0);
+    for (int i = 0; i < l; ++i)
+        for (int j = 0; j < dim; ++j) {
+            const double v = sv_exact[(size_t)i * dim + j] * 255.0;
+            const double q = v < 0 ? -1.0 : (double)(long)(v + 0.5);
+            if (q < 0 || q > 255 || v - q > 1e-3 || q - v > 1e-3) return false;
+            out[(size_t)i * dq8 + j] = (uint8_t)((int)q ^ 0x80);
+            sums[2 * (size_t)i] += (int32_t)q; sums[2 * (size_t)i + 1] += (int32_t)q * (int32_t)q;
+        }
+    sv8.swap(out); svs.swap(sums);
+    return true;
+}
+
 // coef_rows[i][h][r][b], r < mp, b < 64 (k <= 65 classes): h = 0: sv_coef[b][start[i] + r], zero for r >= nsv[i]; h = 1: sv_coef[i][start[b + 1] + r],
 // zero for r >= nsv[b + 1] -- coef is libsvm's [(k - 1) x l]
 inline std::vector<double> svm_coef_rows(const std::vector<double> &coef, const std::vector<int32_t> &start, const std::vector<int32_t> &nsv, int k, int l, int mp)

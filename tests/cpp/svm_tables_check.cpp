@@ -90,6 +90,33 @@ int main()
                 if (a != bsum) { printf("pair (%d, %d) of %d: %.17g vs %.17g\n", i, j, k, a, bsum); return 1; }
             }
     }
+    // 4. svm_sv_bytes: numerators over 255 written with 8 significant digits (svm_save_model: "%.8g") and read back come out as the bytes, their sums and
+    // sums of squares; a model with one value that is no such multiple is refused
+    for (int trial = 0; trial < 20; ++trial) {
+        const int l = 1 + (int)(rng() % 9), dim = 40 + (int)(rng() % 60), l_pad = (l + 63) / 64 * 64, dq8 = (dim + 127) / 128 * 128;
+        std::vector<int> q((size_t)l * dim);
+        std::vector<double> sv((size_t)l * dim);
+        for (size_t i = 0; i < q.size(); ++i) {
+            q[i] = (int)(rng() % 4 == 0 ? rng() % 256 : 0);
+            char txt[32];
+            snprintf(txt, sizeof txt, "%.8g", q[i] / 255.0);
+            sv[i] = strtod(txt, nullptr);
+        }
+        std::vector<uint8_t> b8; std::vector<int32_t> sums;
+        if (!svm_sv_bytes(sv, l, l_pad, dim, dq8, b8, sums)) { printf("svm_sv_bytes refused a model of numerators\n"); return 1; }
+        for (int i = 0; i < l_pad; ++i) {
+            int s1 = 0, s2 = 0;
+            for (int j = 0; j < dq8; ++j) {
+                const int want = i < l && j < dim ? q[(size_t)i * dim + j] : 0;
+                if ((b8[(size_t)i * dq8 + j] ^ 0x80) != want) { printf("svm_sv_bytes: byte (%d, %d)\n", i, j); return 1; }
+                s1 += want; s2 += want * want;
+            }
+            if (sums[2 * (size_t)i] != s1 || sums[2 * (size_t)i + 1] != s2) { printf("svm_sv_bytes: sums of row %d\n", i); return 1; }
+        }
+        sv[rng() % sv.size()] = 0.5003;
+        std::vector<uint8_t> keep = b8;
+        if (svm_sv_bytes(sv, l, l_pad, dim, dq8, b8, sums) || b8 != keep) { printf("svm_sv_bytes took a value that is no multiple of 1 / 255\n"); return 1; }
+    }
     printf("svm tables ok\n");
     return 0;
 }
