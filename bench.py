@@ -600,6 +600,10 @@ def main():
     rig.close()
     if not args.no_latency and rank == 0:
         latency = latency_leg(W, H, cfg, frames, d_frames, stages, args.ocr)
+        if ocr_legs and not args.ocr:
+            # ... and with the config-3 scorer behind classify (the host reads the plane counters in between: one more round trip than the plain call)
+            lo = latency_leg(W, H, cfg, frames, d_frames, S.STAGE_ALL | S.STAGE_OCR, True)
+            latency["with_stage_ocr"] = {k: lo[k] for k in ("ms_per_frame", "frames_per_s", "ms_per_frame_p90")}
 
     pcie = pcie_nv12 = None
     if not args.no_host_frames and not args.ocr and rank == 0:

@@ -2,13 +2,13 @@
 # Run on a GPU box (via gpurun) from the repo root: bench lines + rocprofv3 summaries for profiles/.
 # Usage: tools/collect_profiles.sh r02
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (the profiled runs keep ONE batch in flight: a kernel's average duration is then its isolated launch duration, the quantity roofline.avg_launch_ms reports)
-B="python $ROOT/bench.py --steps 6 --warmup 2 --pipelines 1 --no-cpu-baseline --no-latency --no-host-frames --no-ties-leg"
+B="python $ROOT/bench.py --steps 6 --warmup 2 --pipelines 1 --min-region-s 0 --no-ocr-legs --no-4k-leg --no-cpu-baseline --no-latency --no-host-frames --no-ties-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $B > $OUT/pmc_write.log 2>&1
@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 # bench.py reads roofline.traffic from profiles/pmc_tile_tree.json: write it from the counter passes above before the bench lines are taken
 python $ROOT/tools/make_profile_summary.py $TAG --pmc-json-only > $OUT/pmc_json.log 2>&1
 # (round 5) the legs that have no headline of their own: config 3 (the OCR scorer), the reference's real call pattern (lines, then the scorer), config 5 (4K)
-P1="--steps 6 --warmup 2 --repeats 1 --pipelines 1 --no-cpu-baseline --no-latency --no-host-frames --no-ties-leg"
+P1="--steps 6 --warmup 2 --repeats 1 --pipelines 1 --min-region-s 0 --no-cpu-baseline --no-latency --no-host-frames --no-ties-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config3 -o s -- python $ROOT/bench.py --ocr $P1 > $OUT/stats_config3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_group_ocr -o s -- python $ROOT/bench.py --group --ocr $P1 > $OUT/stats_group_ocr.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_4k -o s -- python $ROOT/bench.py --size 4k $P1 > $OUT/stats_4k.log 2>&1

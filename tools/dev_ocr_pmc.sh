@@ -4,7 +4,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/${1:-ocr_pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --ocr --steps 4 --warmup 1 --repeats 1 --pipelines 1 --no-latency --no-host-frames --no-cpu-baseline"
+B="python $ROOT/bench.py --ocr --steps 4 --warmup 1 --repeats 1 --pipelines 1 --min-region-s 0 --no-latency --no-host-frames --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --output-format csv -d /tmp/pmc_a -o p -- $B > $OUT/pmc_a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH --output-format csv -d /tmp/pmc_b -o p -- $B > $OUT/pmc_b.log 2>&1
 python - > $OUT/summary.txt <<PY

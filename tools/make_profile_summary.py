@@ -60,12 +60,19 @@ with open(os.path.join(DST, f"{tag}_pmc_per_launch_pyr3x8.csv") if not PMC_JSON_
     for d in rows:
         w.writerow([d.get(c, "") if not isinstance(d.get(c), float) else f"{d[c]:.6g}" for c in cols])
 # 4. the number bench.py reads for roofline.traffic
-F = 48 if PMC_JSON_ONLY else json.load(open(os.path.join(DST, f"bench_{tag}_pyr3x8_text.json")))["config"]["frames_per_gpu_per_step"]
-tt = {"workload": "pyr3x8", "frames_per_launch": F, "kernel": "k_tile_tree",
-      "FETCH_SIZE_KB": fetch["k_tile_tree"]["FETCH_SIZE"], "WRITE_SIZE_KB": write["k_tile_tree"]["WRITE_SIZE"],
-      "hbm_bytes_per_launch_raw": (fetch["k_tile_tree"]["FETCH_SIZE"] + write["k_tile_tree"]["WRITE_SIZE"]) * 1024,
+_cfg = {} if PMC_JSON_ONLY else json.load(open(os.path.join(DST, f"bench_{tag}_pyr3x8_text.json")))["config"]
+F = 48 if PMC_JSON_ONLY else _cfg.get("frames_per_batch", _cfg["frames_per_gpu_per_step"])
+# (round 6: the tile trees of a batch are built by two kernels -- k_tile_tree2 on the chroma planes, k_tile_tree on the luma planes, k_tile_tree_fb on the
+# tiles the first hands back: their traffic is added up, like their times in bench.py's roofline)
+TILE_KERNELS = [k for k in ("k_tile_tree2", "k_tile_tree", "k_tile_tree_fb") if k in fetch]
+t_fetch = sum(fetch[k]["FETCH_SIZE"] for k in TILE_KERNELS)
+t_write = sum(write.get(k, {}).get("WRITE_SIZE", 0.0) for k in TILE_KERNELS)
+tt = {"workload": "pyr3x8", "frames_per_launch": F, "kernel": " + ".join(TILE_KERNELS),
+      "per_kernel_KB": {k: {"FETCH_SIZE": fetch[k]["FETCH_SIZE"], "WRITE_SIZE": write.get(k, {}).get("WRITE_SIZE")} for k in TILE_KERNELS},
+      "FETCH_SIZE_KB": t_fetch, "WRITE_SIZE_KB": t_write,
+      "hbm_bytes_per_launch_raw": (t_fetch + t_write) * 1024,
       # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> double the read side
-      "hbm_bytes_per_launch": (2 * fetch["k_tile_tree"]["FETCH_SIZE"] + write["k_tile_tree"]["WRITE_SIZE"]) * 1024,
+      "hbm_bytes_per_launch": (2 * t_fetch + t_write) * 1024,
       "calibration": {"kernel": "k_bgr_to_ycrcb", "known_read_bytes": 3 * 1920 * 1080 * F, "FETCH_SIZE_bytes": fetch["k_bgr_to_ycrcb"]["FETCH_SIZE"] * 1024,
                       "known_write_bytes": 3 * 1920 * 1080 * F, "WRITE_SIZE_bytes": write["k_bgr_to_ycrcb"]["WRITE_SIZE"] * 1024},
       "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE); values are means over the launches of the run; "
@@ -78,7 +85,7 @@ print(json.dumps(tt, indent=1))
 # 5. the numbers of the round as one table (profiles/<tag>_numbers.md), so that README.md can stay prose
 if not PMC_JSON_ONLY:
     lines = [f"# Round {tag[1:].lstrip('0')} numbers (generated by tools/make_profile_summary.py from the files beside it)", "",
-             "| bench line | frames/s | ms per step | `k_tile_tree` ms per launch (isolated) | GB/s (algorithmic plane bytes) | frac of 8 TB/s | 1-frame latency ms | PCIe-inclusive frames/s | CPU baseline frames/s |",
+             "| bench line | frames/s | ms per step (a step = `config.batches_per_step` batches) | tile trees (`k_tile_tree2` + `k_tile_tree`) ms per batch (isolated) | GB/s (algorithmic plane bytes) | frac of 8 TB/s | 1-frame latency ms | PCIe-inclusive frames/s | CPU baseline frames/s |",
              "|---|---|---|---|---|---|---|---|---|"]
     for n in ("pyr3x8_text", "native6_text", "native6_noise"):
         fn = os.path.join(DST, f"bench_{tag}_{n}.json")
@@ -91,14 +98,21 @@ if not PMC_JSON_ONLY:
     d = json.load(open(os.path.join(DST, f"bench_{tag}_pyr3x8_text.json")))
     lines += ["", "Per-kernel GPU time per 48-frame batch of pyr3x8, one batch in flight (HIP events, ms): " +
               ", ".join(f"{k} {v:.2f}" for k, v in d["gpu_ms_per_step_by_kernel_group_serial"].items()) +
-              f" (sum {sum(d['gpu_ms_per_step_by_kernel_group_serial'].values()):.2f}; the timed region, six batches overlapping, needs {d['ms_per_step']:.2f} ms per batch).", ""]
+              f" (sum {sum(d['gpu_ms_per_step_by_kernel_group_serial'].values()):.2f}; the timed region, six batches overlapping, needs {d['ms_per_step'] / d['config'].get('batches_per_step', 1):.2f} ms per batch).", ""]
     st = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(DST, f"{tag}_kernel_stats_pyr3x8.csv")))}
-    tt_ms = float(st["k_tile_tree"]["AverageNs"]) / 1e6
+    tks = [k for k in ("k_tile_tree2", "k_tile_tree", "k_tile_tree_fb") if k in st]
+    tt_ms = sum(float(st[k]["AverageNs"]) for k in tks) / 1e6
     alg = 12395367 * F
-    lines += [f"`{tag}_kernel_stats_pyr3x8.csv` (rocprofv3, one batch in flight): `k_tile_tree` {st['k_tile_tree']['Calls']} calls, average {tt_ms:.3f} ms -> "
-              f"{alg} B / {tt_ms:.3f} ms = {alg / tt_ms / 1e6:.1f} GB/s = {alg / tt_ms / 1e6 / 8000:.4f} of 8 TB/s (the bench line's HIP-event figure: "
-              f"{d['roofline']['avg_launch_ms']:.3f} ms, frac {d['roofline']['frac']:.4f}).", ""]
+    lines += [f"`{tag}_kernel_stats_pyr3x8.csv` (rocprofv3, one batch in flight): " + ", ".join(f"`{k}` {st[k]['Calls']} calls, average {float(st[k]['AverageNs']) / 1e6:.3f} ms" for k in tks) +
+              f" -> the tile trees of a batch {tt_ms:.3f} ms -> {alg} B / {tt_ms:.3f} ms = {alg / tt_ms / 1e6:.1f} GB/s = {alg / tt_ms / 1e6 / 8000:.4f} of 8 TB/s (the bench line's "
+              f"HIP-event figure: {d['roofline']['avg_launch_ms']:.3f} ms, frac {d['roofline']['frac']:.4f}; per kernel: {d['roofline'].get('per_kernel')}).", ""]
     pm = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(DST, f"{tag}_pmc_per_launch_pyr3x8.csv")))}
+    for tk in [k for k in ("k_tile_tree2",) if k in pm]:
+        t2 = pm[tk]
+        w2 = float(t2["SQ_WAVES"])
+        lines += [f"`{tk}` counters per launch of {F} frames ({w2:.0f} waves = pairs of tiles): FETCH_SIZE {float(t2['FETCH_SIZE_KB']) / 1e6:.3f} GB raw, WRITE_SIZE {float(t2['WRITE_SIZE_KB']) / 1e6:.3f} GB; "
+                  f"per wave {float(t2['SQ_INSTS_VALU']) / w2:.0f} vector + {float(t2['SQ_INSTS_SALU']) / w2:.0f} scalar + {float(t2['SQ_INSTS_LDS']) / w2:.0f} LDS instructions "
+                  f"(= {float(t2['SQ_INSTS_VALU']) / w2 / 8:.0f} vector instructions per 512 pixels; `k_tile_tree`: its per-wave figure below).", ""]
     t = pm["k_tile_tree"]
     w = float(t["SQ_WAVES"])
     lines += [f"`k_tile_tree` counters per launch of {F} frames: FETCH_SIZE {float(t['FETCH_SIZE_KB']) / 1e6:.3f} GB raw (algorithmic plane bytes {alg / 1e9:.3f} GB), WRITE_SIZE {float(t['WRITE_SIZE_KB']) / 1e6:.3f} GB; "
@@ -114,12 +128,13 @@ if not PMC_JSON_ONLY:
         if v:
             lines.append(fmt(v))
     leg("config3_ocr_leg", lambda v: f"`config3_ocr_leg` (BASELINE configs[2]: chain-code + SVM scorer on the {v['ers_scored_per_batch']} strong / weak ERs of a batch): **{v['value']:.0f}** frames/s = "
-        f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}; `{v['roofline_svm_kernel']['kernel']}` {v['roofline_svm_kernel']['achieved']} TFLOP/s = "
-        f"{v['roofline_svm_kernel']['frac']:.3f} of the {v['roofline_svm_kernel']['peak']} TFLOP/s bf16 MFMA peak; CPU baseline {(v.get('cpu_baseline') or {}).get('value', '-')} frames/s.")
+        f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}; `{v['roofline_svm_kernel']['kernel']}` {v['roofline_svm_kernel']['achieved']} {v['roofline_svm_kernel']['unit']} = "
+        f"{v['roofline_svm_kernel']['frac']:.3f} of the {v['roofline_svm_kernel']['peak']} peak (algorithmic 2 N 1800 l: {v['roofline_svm_kernel'].get('algorithmic_tflops')} = {v['roofline_svm_kernel'].get('frac_algorithmic')}); "
+        f"the 5-per-class model: {v.get('small_model_5_per_class')}; CPU baseline {(v.get('cpu_baseline') or {}).get('value', '-')} frames/s.")
     leg("group_ocr_leg", lambda v: f"`group_ocr_leg` (calc_color, er_track, er_grouping, then the scorer on the {v['line_members_scored_per_batch']} line members of a batch): **{v['value']:.0f}** frames/s = "
         f"{v['frac_of_value']:.3f} of `value`; isolated GPU ms per batch {v['gpu_ms_per_batch_isolated']}.")
     leg("config5_4k_leg", lambda v: f"`config5_4k_leg` (BASELINE configs[4] on one GPU, 3840x2160 x 12 levels, {v['frames_per_step']} frames per batch): **{v['value']:.0f}** frames/s ({v['mpx_per_s']:.0f} Mpx/s; the 1080p line: "
-        f"{v['mpx_per_s_of_value']:.0f}); `k_tile_tree` {v['roofline']['avg_launch_ms']} ms per launch = {v['roofline']['frac']:.4f} of 8 TB/s; 1-frame latency "
+        f"{v['mpx_per_s_of_value']:.0f}); tile trees {v['roofline']['avg_launch_ms']} ms per batch = {v['roofline']['frac']:.4f} of 8 TB/s; 1-frame latency "
         f"{(v.get('latency_1frame') or {}).get('ms_per_frame', '-')} ms; exact NMS ties: {v.get('nms_ties')}.")
     leg("nms_ties_leg", lambda v: f"`nms_ties_leg`: **{v['value']:.0f}** frames/s = {v['frac_of_value']:.3f} of `value` at {v['tie_planes_per_batch']} tie planes per batch ({v['flood_walk_ms_per_batch']} ms of host walks, {v['host_threads']} threads).")
     leg("pcie_inclusive", lambda v: f"`pcie_inclusive`: **{v['value']:.0f}** frames/s = {v['frac_of_value']:.3f} of `value` ({v['h2d_gbs']} GB/s; the link alone {v['h2d_gbs_link_alone']} GB/s); NV12: "
