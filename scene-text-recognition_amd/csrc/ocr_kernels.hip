@@ -790,8 +790,10 @@ __global__ __launch_bounds__(256) void k_svm_decide(const double *__restrict__ k
 // is evaluated.  The same fixed point, the same sweeps.  k <= 65: lane t keeps row t of Q in registers, a step reads no table.
 // MODE 0: k <= 64.  MODE 1: k = 65 (the reference's 65 characters): the one class beyond the 64 lanes is carried as a wave-uniform value in
 // every lane -- a second class register per lane would double the vector work of every step for one useful lane.  MODE 2: 66 <= k <= 125.
-// MSV (MODE 0 / 1): 5 = at most five support vectors a class (the reference's training set has five samples a class): class j's kernel values in
-// registers, the next pass's loads issued ahead; 0 = any count, ranks in eights.
+// MSV (MODE 0 / 1): 5 = at most five support vectors a class (the small stand-in model of rounds 1-5, tests/golden/make_svm_fixture.py: five samples a class;
+// the reference's training set has 120, src/utils.cpp:1478-1541): class j's kernel values in registers, the next pass's loads issued ahead; 0 = any count up
+// to eight ranks a class, in eights; -1 = the sums per (class, other class) come from k_svm_decide (models with more support vectors a class: the reference's
+// shape -- svm_uses_class_sums).
 // 4 waves per SIMD = the 16 waves per compute unit the LDS allows: 128 registers (a handful of values that live across a pass are parked in
 // scratch, outside the loops)
 // LDS of one box: QI[2 k], D[k], V[k (k + 1) / 2] floats, rounded up to 16 bytes
