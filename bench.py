@@ -227,11 +227,22 @@ class Rig:
         """un-overlapped kernel durations: single-context steps (with P > 1 the events of a timed region include the time a
         kernel spends sharing the GPU with the other batches)"""
         sp, last = {}, None
+        self.filters[0].set_profiling(True)
         for _ in range(n_cal):
             last = self.filters[0].detect_bgr_device(d_in.data_ptr(), self.w, self.h, self.F, stages)
             for k, v in last.profile.items():
                 sp[k] = sp.get(k, 0.0) + v / n_cal
+        self.filters[0].set_profiling(False)
         return sp, last
+
+    def overlapped_profile(self, d_in, stages, n_batches):
+        """the same events with every context busy (a short region of its own: the timed regions run without the per-group events, which cost stream time)"""
+        for f in self.filters:
+            f.set_profiling(True)
+        prof, _ = self.run(n_batches, d_in, stages)
+        for f in self.filters:
+            f.set_profiling(False)
+        return {k: v / n_batches for k, v in prof.items()}
 
 
 def make_frames(S, kind, w, h, F, first=0, ties_every=8):
@@ -471,10 +482,10 @@ def main():
                 "note": "planes of a batch whose NMS sibling tie changes the pool: the reference's flood order is walked on a host core for each "
                         "(host ms summed over planes), on the library's process-wide pool of at most host_threads threads"}
 
-    if P > 1:
-        serial_prof, _ = rig.serial_profile(d_frames, stages)
-    else:
-        serial_prof = {k: v / max(NB, 1) for k, v in prof_sum.items()}
+    # per-kernel-group GPU times come from runs of their own with the library's per-group events on (str_er_set_profiling): one context alone, and --
+    # a short region -- all of them busy; the timed regions run without those events
+    serial_prof, _ = rig.serial_profile(d_frames, stages)
+    prof_ov = rig.overlapped_profile(d_frames, stages, 2 * P) if world == 1 else {}
     r_tree_stats = rig.filters[0].last_tree_stats()
     r_tile2 = {**rig.filters[0].tile2_stats(), "note": "tiles of the chroma planes given to k_tile_tree2 by this context so far, and how many it handed back to k_tile_tree"}
 
@@ -678,12 +689,13 @@ def main():
         n4 = max(P, NB)
         el4, prof4, _ = rig4.timed(n4, d4, S.STAGE_ALL)
         sp4, _ = rig4.serial_profile(d4, S.STAGE_ALL)
+        ov4 = rig4.overlapped_profile(d4, S.STAGE_ALL, 2 * P)
         px4 = plane_pixels("pyr3x12", w4, h4)
         k4_leg = {"value": round(F4 * n4 / el4, 2), "unit": "frames/s", "steps": n4, "frames_per_step": F4, "ms_per_step": round(1e3 * el4 / n4, 3),
                   "plane_pixels_per_frame": px4, "mpx_per_s": round(px4 * F4 * n4 / el4 / 1e6, 1),
                   "mpx_per_s_of_value": round(plane_pixels(args.workload) * F * NB / elapsed / 1e6, 1),
                   "workload": WORKLOADS["pyr3x12"]["label"] + "; S-text frames; one GPU",
-                  "roofline": tile_roofline(px4, F4, sp4.get("tile_tree", 0.0) + sp4.get("tile_tree2", 0.0), (prof4.get("tile_tree", 0.0) + prof4.get("tile_tree2", 0.0)) / n4, "pyr3x12",
+                  "roofline": tile_roofline(px4, F4, sp4.get("tile_tree", 0.0) + sp4.get("tile_tree2", 0.0), ov4.get("tile_tree", 0.0) + ov4.get("tile_tree2", 0.0), "pyr3x12",
                                             sp4.get("tile_tree2", 0.0), 2.0 / 3.0),
                   "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in sp4.items()}}
         # the cost of exact NMS ties at this size: the host walk of one 8.3 Mpx plane
@@ -715,7 +727,7 @@ def main():
         # dominant kernel: k_tile_tree reads every plane pixel once -> px bytes per frame.  Its duration is the ISOLATED one
         # (one batch in flight, HIP events on the library's stream around the launch): with P batches sharing the GPU an
         # event-to-event time also contains the other batches' kernels and is not a per-launch cost.
-        tile_ms_overlapped = (prof_sum.get("tile_tree", 0.0) + prof_sum.get("tile_tree2", 0.0)) / max(NB, 1)
+        tile_ms_overlapped = prof_ov.get("tile_tree", 0.0) + prof_ov.get("tile_tree2", 0.0)
         tile_ms = (serial_prof.get("tile_tree", 0.0) + serial_prof.get("tile_tree2", 0.0)) or tile_ms_overlapped
         chans = [i for i in range(6) if cfg["channel_mask"] >> i & 1]
         roof = tile_roofline(px, F, tile_ms, tile_ms_overlapped, args.workload, serial_prof.get("tile_tree2", 0.0), sum(1 for ch in chans if ch % 3) / max(len(chans), 1))
@@ -760,7 +772,7 @@ def main():
             **({"latency_1frame": latency} if latency else {}),
             "roofline": roof,
             "tree_passes_roofline": tree_roof,
-            "gpu_ms_per_step_by_kernel_group": {k: round(v / NB, 4) for k, v in prof_sum.items()},
+            "gpu_ms_per_step_by_kernel_group": {k: round(v, 4) for k, v in prof_ov.items()},
             "gpu_ms_per_step_by_kernel_group_serial": {k: round(v, 4) for k, v in serial_prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:

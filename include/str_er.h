@@ -205,6 +205,11 @@ int  str_er_last_tree_stats(const str_er_ctx *ctx, uint64_t *records, uint64_t *
  * more levels / nodes than it takes is handed back to k_tile_tree.  Since the context was created: tiles given to k_tile_tree2, tiles it handed
  * back.  Measurement aid; results do not depend on which kernel built a tile's tree.  Any pointer may be NULL. */
 int  str_er_tile2_stats(const str_er_ctx *ctx, uint64_t *tiles, uint64_t *handed_back);
+/* STR_ER_STAGE_OCR is enqueued right behind classify, sized from the previous batch of the context and working on the device's own count of strong / weak
+ * ERs (the reference's call site, src/ER.cpp:728-735, has no barrier between the two either); a batch with more ERs than guessed, or whose candidates an NMS
+ * tie pass re-made, is scored again after the counters were read.  Since the context was created: batches whose early scores were used, batches scored again.
+ * Measurement aid; results do not depend on it.  Any pointer may be NULL. */
+int  str_er_ocr_stage_stats(const str_er_ctx *ctx, uint64_t *scored_early, uint64_t *scored_again);
 const char *str_er_runtime_hint(void);
 int  str_er_apply_runtime_hint(void);
 

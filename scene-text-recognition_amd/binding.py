@@ -205,6 +205,7 @@ def load_library():
     L.str_er_result_free.argtypes = [vp]
     L.str_er_last_tree_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.str_er_tile2_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.str_er_ocr_stage_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.str_er_last_profile.argtypes = [vp, C.POINTER(C.c_char_p), f64p, C.c_int32]
     L.str_er_set_profiling.argtypes = [vp, C.c_int]
     L.str_er_workspace_bytes.argtypes = [vp]
@@ -427,6 +428,18 @@ class ERFilter:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.L.str_er_tile2_stats(self.h, C.byref(a), C.byref(b)))
         return {"tiles": int(a.value), "handed_back": int(b.value)}
+
+    def set_profiling(self, on: bool = True) -> None:
+        """Per-kernel-group HIP events for the calls that follow (Result.profile / last_profile()); off by default: an event between two kernels costs
+        stream time (str_er_set_profiling)."""
+        self._check(self.L.str_er_set_profiling(self.h, 1 if on else 0))
+
+    def ocr_stage_stats(self) -> dict:
+        """Batches whose STAGE_OCR scores were computed right behind classify (sized from the previous batch), and batches scored again after the
+        counters were read (str_er_ocr_stage_stats)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.L.str_er_ocr_stage_stats(self.h, C.byref(a), C.byref(b)))
+        return {"scored_early": int(a.value), "scored_again": int(b.value)}
 
     def last_profile(self) -> dict:
         names = (C.c_char_p * 32)()

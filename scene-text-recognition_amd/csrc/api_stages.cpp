@@ -119,6 +119,8 @@ static int nms_tree_impl(str_er_ctx *c, const str_er_node *nodes, int32_t n_node
     PlaneCtr pc{};
     pc.n_kept = (uint32_t)n_nodes; pc.root_slot = (uint32_t)root; pc.max_level = (uint32_t)maxl;
     c->h_ctr[0] = pc;
+    c->zero_clean_bytes = 0;          // (the counter block is written here, not through upload_layout)
+    c->planes_on_device = 0;
     HIP_TRY(c, hipMemcpyAsync(c->d_planes, c->h_planes, sizeof(PlaneDesc), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_ctr, c->h_ctr, sizeof(PlaneCtr), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->ka.key, key.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, s));

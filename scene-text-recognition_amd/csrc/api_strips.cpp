@@ -272,7 +272,7 @@ try {
         if ((size_t)blob_bytes[i] != v.L.total) return fail(c, STR_ER_EFORMAT, "strip blob: size does not match its headers (strip " + std::to_string(i) + ")");
     }
     int pstride = 0; size_t psize = 0;
-    c->n_ev = 0; c->profile.clear(); rec(c, "begin");
+    c->n_ev = 0; c->profile.clear(); rec(c, "begin", nullptr, true);
     int rc = frame_to_planes(c, bgr, w, h, stride, mem_kind, pstride, psize);
     if (rc != STR_ER_OK) return rc;
     rec(c, "channels");

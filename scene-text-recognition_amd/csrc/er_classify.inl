@@ -314,6 +314,9 @@ __device__ __forceinline__ double cascade_from_stage_sums(const CascadeDev &c, c
 }
 
 // (list / n_list: only these candidates -- the planes whose pool the NMS tie pass changed)
+// PER = candidates a workgroup takes at a time: 64 (a lane per candidate in the cascades), or 16 -- one per wave in the histogram phase instead of four
+// in a row -- for calls with so few candidates (a frame or two: ~1000) that 64 a workgroup would leave most of the chip idle
+template <int PER>
 __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectParams prm, CascadeDev strong,
                                                           CascadeDev weak, int run_cascades, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list)
 {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
 #else
 #define CLS_MARK(i) do { } while (0)
 #endif
-    for (uint32_t c0 = blockIdx.x * CLS_PER_BLOCK; c0 < total; c0 += gridDim.x * CLS_PER_BLOCK) {
+    for (uint32_t c0 = blockIdx.x * PER; c0 < total; c0 += gridDim.x * PER) {
         CLS_MARK(0);
 #ifdef STR_ER_PHASE_PROF
         const unsigned long long tp0 = wall_clock64();
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
         // ITSELF -- a wave's LDS operations are carried out in the order it issues them -- so the steps are separated by a wave-level fence, not
         // by a workgroup barrier: the 16 waves' ERs differ in size, and a barrier per step had every wave wait for the largest four times per ER.
         if (run_cascades) {
-            for (int it = 0; it < CLS_PER_BLOCK / CLS64_WAVES; ++it) {
+            for (int it = 0; it < PER / CLS64_WAVES; ++it) {
                 const uint32_t cpos = c0 + it * CLS64_WAVES + wv;
                 const bool     ok = cpos < total;
                 const uint32_t cidx = ok && list ? list[cpos] : cpos;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
         CLS_MARK(3);
         if (wv == 0) {
             const uint32_t cpos = c0 + lane;
-            const bool     ok = cpos < total;
+            const bool     ok = cpos < total && lane < PER;
             const uint32_t cidx = ok && list ? list[cpos] : cpos;
             int    cls = 0;
             double ss = -DBL_MAX, sw = 0;
@@ -531,9 +534,11 @@ __global__ __launch_bounds__(CLS64_THREADS) void k_classify(BatchDev b, DetectPa
 }
 
 void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong, CascadeDev weak,
-                     int run_cascades, const uint32_t *list, const uint32_t *n_list)
+                     int run_cascades, const uint32_t *list, const uint32_t *n_list, bool few)
 {
-    hipLaunchKernelGGL(k_classify, dim3(list ? 64 : 1024), dim3(CLS64_THREADS), 0, s, b, p, strong, weak, run_cascades, list, n_list);
+    static_assert(CLS_PER_BLOCK == 64 && CLS64_WAVES == 16, "the two builds: four candidates a wave, or one");
+    if (few) hipLaunchKernelGGL(k_classify<16>, dim3(list ? 64 : 512), dim3(CLS64_THREADS), 0, s, b, p, strong, weak, run_cascades, list, n_list);
+    else hipLaunchKernelGGL(k_classify<64>, dim3(list ? 64 : 1024), dim3(CLS64_THREADS), 0, s, b, p, strong, weak, run_cascades, list, n_list);
 }
 
 // Single-stage entry points (str_er_classify_boxes / str_er_lbp_hist): explicit boxes.

@@ -92,9 +92,12 @@ void launch_nms_resolve(hipStream_t s, const BatchDev &b, const DetectParams &p,
 void launch_cand_prefix(hipStream_t s, const BatchDev &b);
 // classify (src/ER.cpp:507-528) over the packed pool of the batch.
 void launch_classify(hipStream_t s, const BatchDev &b, const DetectParams &p, CascadeDev strong,
-                     CascadeDev weak, int run_cascades, const uint32_t *list = nullptr, const uint32_t *n_list = nullptr);
+                     CascadeDev weak, int run_cascades, const uint32_t *list = nullptr, const uint32_t *n_list = nullptr, bool few = false);      // (few: a call of a frame or two -- 16 candidates a workgroup instead of 64)
 // after the NMS tie pass: new candidate offsets (b.cands / b.cand_plane = the second set of buffers), the records of unchanged planes
 // moved over from `from`, the candidates of the changed planes listed in redo[0 .. *n_redo) for launch_classify
+// (calls of a frame or two) the counter block and the first candidate records to device-addressable host memory, one launch
+void launch_results_to_host(hipStream_t s, const void *ctr_block, void *to_ctr, size_t ctr_bytes, const CandRec *cands, CandRec *to_cands, uint32_t cap_cands,
+                            const uint32_t *total_cands);
 void launch_cand_reprefix(hipStream_t s, const BatchDev &b, const CandRec *from, uint32_t *redo, uint32_t *n_redo);
 
 // Stand-alone classify chain on explicit boxes of one device plane (single-stage API).

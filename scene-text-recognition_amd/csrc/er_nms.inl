@@ -706,6 +706,30 @@ __global__ __launch_bounds__(256) void k_cand_move(BatchDev b, const CandRec *__
     }
 }
 
+// The end of a call of a frame or two: the batch's counter block and its first candidate records written to page-locked host memory by ONE launch (the
+// two copies they replace were two launches of the runtime's copy kernel with ~10 us of queue switching around each: a twentieth of such a call).
+// to_ctr / to_cands are device-addressable host memory; n_words = the counter block in 16-byte words; at most cap_cands records.
+__global__ __launch_bounds__(256) void k_results_to_host(const uint4 *__restrict__ ctr_block, uint4 *__restrict__ to_ctr, uint32_t n_words, const CandRec *__restrict__ cands,
+                                                        CandRec *__restrict__ to_cands, uint32_t cap_cands, const uint32_t *__restrict__ total_cands)
+{
+    static_assert(sizeof(CandRec) % 16 == 0, "candidate records are moved as 16-byte words");
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (uint32_t i = t; i < n_words; i += nt) to_ctr[i] = ctr_block[i];
+    if (to_cands) {
+        const uint32_t n = min(*total_cands, cap_cands) * (uint32_t)(sizeof(CandRec) / 16);
+        const uint4   *src = reinterpret_cast<const uint4 *>(cands);
+        uint4         *dst = reinterpret_cast<uint4 *>(to_cands);
+        for (uint32_t i = t; i < n; i += nt) dst[i] = src[i];
+    }
+}
+
+void launch_results_to_host(hipStream_t s, const void *ctr_block, void *to_ctr, size_t ctr_bytes, const CandRec *cands, CandRec *to_cands, uint32_t cap_cands,
+                            const uint32_t *total_cands)
+{
+    hipLaunchKernelGGL(k_results_to_host, dim3(32), dim3(256), 0, s, static_cast<const uint4 *>(ctr_block), static_cast<uint4 *>(to_ctr), (uint32_t)((ctr_bytes + 15) / 16), cands,
+                       to_cands, cap_cands, total_cands);
+}
+
 void launch_cand_reprefix(hipStream_t s, const BatchDev &b, const CandRec *from, uint32_t *redo, uint32_t *n_redo)
 {
     hipLaunchKernelGGL(k_cand_reprefix, dim3(1), dim3(1024), 0, s, b, redo, n_redo);

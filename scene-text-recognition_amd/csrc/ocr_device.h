@@ -15,6 +15,9 @@ constexpr int OCR_BIG_PARTS = 32;      // row ranges a big box is cut into
 // and drag every LDS wait of the loop along
 typedef const __attribute__((address_space(1))) uint8_t *GlobalBytes;
 
+// boxes of a launch: the host's number, or -- a launch sized before the host knew it (OcrSrc::n_dev) -- the device's count, at most the number sized for
+__device__ __forceinline__ int ocr_count(const OcrSrc &s, int n) { return s.n_dev ? (int)min((uint32_t)n, *s.n_dev) : n; }
+
 struct OcrBox { GlobalBytes roi; int stride, inv, bw, bh; };
 
 __device__ __forceinline__ OcrBox ocr_box(const OcrSrc &s, int bi)

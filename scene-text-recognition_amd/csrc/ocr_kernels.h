@@ -46,6 +46,9 @@ struct OcrSrc {
     const uint32_t  *list;
     const PlaneDesc *planes;
     const RotGeom   *rot;
+    // null, or the number of boxes as the DEVICE knows it (k_ocr_list's count): the launches are then sized for the `n` handed to the launcher, an upper
+    // bound the host guessed, and the kernels work on min(n, *n_dev) boxes -- no read of the counters between classify and the scorer (str_er_api.cpp)
+    const uint32_t  *n_dev;
 };
 
 // Scratch of one scoring call (all device pointers; carve them out of one allocation with ocr_layout()).
@@ -65,6 +68,7 @@ struct OcrBuf {
     double   *prob;      // [n x k] or null: class probabilities
     int32_t  *label;     // [n]
     double   *pbest;     // [n]             probability of the predicted label (pv[label], src/OCR.cpp:92-93)
+    const uint32_t *n_dev; // null, or the device's count of vectors (see OcrSrc::n_dev); set by the caller after ocr_layout()
     size_t    bytes;     // total size of the carve-up
 };
 
@@ -83,6 +87,8 @@ OcrBuf ocr_layout(uint8_t *base, size_t n, const SvmDev *m /* null: features onl
 // hdr[0] = their number, hdr[16 .. 272) = scratch, the list itself from hdr + OCR_LIST_HDR (room for n_cands entries)
 constexpr int OCR_LIST_HDR = 272;
 void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t n_cands, uint32_t *hdr);
+// the same for the candidates named in from[0 .. *from_n) (device memory; in the order of that list): the planes an NMS tie pass re-made
+void launch_ocr_list_from(hipStream_t s, const BatchDev &b, const uint32_t *from, const uint32_t *from_n, uint32_t *hdr);
 
 // Otsu threshold of 255 - roi for n boxes (cv::threshold(..., THRESH_OTSU)): hist [n x 256], big [1 + 4095] (scratch), thresh [n]
 void launch_box_thresholds(hipStream_t s, const OcrSrc &src, int n, uint32_t *hist, uint32_t *big, int32_t *thresh);

@@ -89,6 +89,31 @@ __global__ __launch_bounds__(LIST_THREADS) void k_ocr_list(const CandRec *__rest
     }
 }
 
+// The same for the candidates NAMED in a list (from[0 .. *from_n): the candidates of the planes whose pools an NMS tie pass re-made, a few hundred at most):
+// one workgroup, order of the list.
+__global__ __launch_bounds__(256) void k_ocr_list_from(const CandRec *__restrict__ cands, const uint32_t *__restrict__ from, const uint32_t *__restrict__ from_n,
+                                                      uint32_t *__restrict__ hdr, uint32_t *__restrict__ list)
+{
+    __shared__ uint32_t s_w[4];
+    const int      tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t n = *from_n;
+    uint32_t       carry = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + (uint32_t)tid;
+        const uint32_t ci = i < n ? from[i] : 0u;
+        const bool     on = i < n && cands[ci].cls != 0;
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(on);
+        if (lane == 0) s_w[wv] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t off = carry, tot = 0;
+        for (int k = 0; k < 4; ++k) { if (k < wv) off += s_w[k]; tot += s_w[k]; }
+        if (on) list[off + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = ci;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) hdr[0] = carry;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Otsu, part 1: the histogram of 255 - roi.  One wave per box; eight interleaved sub-histograms (a binarisable
 // ROI has two dominant grey values: with one copy most lanes of a wave would queue on the same LDS word).
@@ -99,6 +124,7 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_hist(OcrSrc src, int n, 
     __shared__ uint32_t s_h[OCR_WAVES][256 * 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *h = s_h[w];
+    n = ocr_count(src, n);
     for (int bi = blockIdx.x * OCR_WAVES + w; bi < n; bi += gridDim.x * OCR_WAVES) {
         const OcrBox b = ocr_box(src, bi);
         if (b.bw * b.bh > OCR_BIG_PX) {
@@ -186,7 +212,9 @@ __global__ __launch_bounds__(256) void k_ocr_otsu(OcrSrc src, int n, const uint3
 {
     __shared__ uint32_t s_h[64 * 257];
     const int tid = threadIdx.x, b0 = blockIdx.x * 64;
+    n = ocr_count(src, n);
     const int nb = min(64, n - b0);
+    if (nb <= 0) return;
     // staging by all four waves, 16 loads of a lane in flight (one load per pass made this loop -- 256 memory round trips -- three quarters of the kernel)
     const uint32_t *hp = hist + (size_t)b0 * 256;
     for (int i0 = tid; i0 < nb * 256; i0 += 256 * 16) {
@@ -333,6 +361,7 @@ __global__ __launch_bounds__(64 * OCR_WAVES) void k_ocr_features(OcrSrc src, int
         s_g7[t] = (uint16_t)(255 * (8 * ((t & 1) + ((t >> 6) & 1)) + 28 * (((t >> 1) & 1) + ((t >> 5) & 1)) + 56 * (((t >> 2) & 1) + ((t >> 4) & 1)) + 72 * ((t >> 3) & 1)));
     }
     __syncthreads();
+    n = ocr_count(src, n);
     // (from here on the waves of the workgroup are independent: every wave owns its part of LDS; the wave is the synchronisation unit)
     for (int bi = blockIdx.x * OCR_WAVES + w; bi < n; bi += gridDim.x * OCR_WAVES) {
         const OcrBox b = ocr_box(src, bi);
@@ -448,6 +477,9 @@ __device__ __forceinline__ double exp_neg(double x)
     return __builtin_amdgcn_ldexp(e, (int)nn);
 }
 
+// rows of a launch: the host's number, or -- a launch sized before the host knew it (OcrBuf::n_dev) -- the device's count, at most the number sized for
+__device__ __forceinline__ int svm_count(const uint32_t *n_dev, int n) { return n_dev ? (int)min((uint32_t)n, *n_dev) : n; }
+
 __global__ __launch_bounds__(256) void k_svm_prep(const double *__restrict__ x, int n, int dim, float *__restrict__ xf, int dpad,
                                                   double *__restrict__ xnorm)
 {
@@ -472,12 +504,14 @@ constexpr int GM = 128, GN = 64, GK = 16;
 
 __global__ __launch_bounds__(256) void k_svm_kernel(const float *__restrict__ xf, const double *__restrict__ xnorm, int n_rows,
                                                     const float *__restrict__ sv, const double *__restrict__ svnorm, int l_pad,
-                                                    int dpad, double gamma, double *__restrict__ kv)
+                                                    int dpad, double gamma, double *__restrict__ kv, const uint32_t *__restrict__ n_dev)
 {
     __shared__ float As[2][GK][GM + 4];
     __shared__ float Bs[2][GK][GN + 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    n_rows = svm_count(n_dev, n_rows);
+    if (m0 >= n_rows) return;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
     // staging: A = 128 rows x 16 k = 512 float4 (2 per thread), B = 64 rows x 16 k = 256 float4 (1 per thread)
     const int arow0 = tid >> 2, arow1 = arow0 + 64, ak = (tid & 3) * 4;
@@ -538,12 +572,14 @@ constexpr int QM = 128, QN = 64, QK = 64, QS = QK + 8;
 
 __global__ __launch_bounds__(256) void k_svm_kernel_q(const uint16_t *__restrict__ xq, const double *__restrict__ xnorm, int n_rows,
                                                       const uint16_t *__restrict__ svq, const double *__restrict__ svnorm, int l_pad, int dq,
-                                                      double gamma, double *__restrict__ kv)
+                                                      double gamma, double *__restrict__ kv, const uint32_t *__restrict__ n_dev)
 {
     __shared__ __attribute__((aligned(16))) uint16_t As[QM][QS];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[3][QN][QS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * QM, n0 = blockIdx.x * QN;
+    n_rows = svm_count(n_dev, n_rows);
+    if (m0 >= n_rows) return;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
     // staging: a thread moves the 16-byte chunk `ch` of rows sr + 32 j: 4 of A, 2 of each B plane
     const int sr = tid >> 3, ch = (tid & 7) * 8;
@@ -611,12 +647,15 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 constexpr int IK = 128, IS = IK + 16;
 __global__ __launch_bounds__(256) void k_svm_kernel_i8(const uint8_t *__restrict__ x8, const int32_t *__restrict__ x8s, int n_rows, const uint8_t *__restrict__ sv8,
-                                                       const int32_t *__restrict__ sv8s, int l_pad, int dq8, double gamma, double *__restrict__ kv)
+                                                       const int32_t *__restrict__ sv8s, int l_pad, int dq8, double gamma, double *__restrict__ kv,
+                                                       const uint32_t *__restrict__ n_dev)
 {
     __shared__ __attribute__((aligned(16))) uint8_t As[QM][IS];
     __shared__ __attribute__((aligned(16))) uint8_t Bs[QN][IS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * QM, n0 = blockIdx.x * QN;
+    n_rows = svm_count(n_dev, n_rows);
+    if (m0 >= n_rows) return;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
     const int sr = tid >> 3, ch = (tid & 7) * 16;            // a thread moves the 16-byte chunk `ch` of rows sr + 32 j: 4 of A, 2 of B
     const uint8_t *pa[4], *pb[2];
@@ -714,11 +753,12 @@ __device__ __forceinline__ double rcp_nr(double x)
 // trip per eight ranks, 2 MB of rows per vector; a first form with a lane per slot, eight vectors per wave and the kernel values by scalar loads took 1.1 ms:
 // 8 bytes from memory per multiply-add, none of them reused.)
 typedef double double4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_svm_decide(const double *__restrict__ kv, int l_pad, int n, SvmDev m, double *__restrict__ av)
+__global__ __launch_bounds__(256) void k_svm_decide(const double *__restrict__ kv, int l_pad, int n, SvmDev m, double *__restrict__ av, const uint32_t *__restrict__ n_dev)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int v0 = blockIdx.x * 64, c = blockIdx.y * 4 + wv;
-    if (c >= m.k) return;
+    n = svm_count(n_dev, n);
+    if (c >= m.k || v0 >= n) return;
     const int q0 = m.start[c], nq = m.nsv[c];
     const int r16 = lane & 15, kq = lane >> 4;
     double4v  acc[4][4];
@@ -815,9 +855,12 @@ __host__ __device__ inline size_t svm_couple_lds_doubles(int k) { return ((size_
 constexpr int svm_couple_wpb(int mode) { return mode == 2 ? 1 : SVM_COUPLE_WPB; }      // (66+ classes: up to 34 KB a box, one box a workgroup)
 template <int MODE, int MSV>
 __global__ __launch_bounds__(64 * svm_couple_wpb(MODE)) SVM_COUPLE_OCC void k_svm_couple(const double *__restrict__ kv, int l_pad, int n, SvmDev m, double *__restrict__ dec_out,
-                                                   double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest, const double *__restrict__ av)
+                                                   double *__restrict__ prob, int32_t *__restrict__ label, double *__restrict__ pbest, const double *__restrict__ av,
+                                                   const uint32_t *__restrict__ n_dev)
 {
     constexpr bool TWO = MODE == 2, TAIL = MODE == 1;
+    n = svm_count(n_dev, n);
+    if ((int)blockIdx.x * svm_couple_wpb(MODE) >= n) return;          // (a launch sized for more boxes than the device counted)
     // LDS: QI[2 k] = {Q_tt, 1 / Q_tt} per class; D[k] = the sweep's steps; V[k (k + 1) / 2] pairwise table (f32)
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int k = TAIL ? 65 : m.k, np = k * (k - 1) / 2, nv = k * (k + 1) / 2, kc = m.kc, l = m.l;
@@ -1229,6 +1272,11 @@ void launch_ocr_list(hipStream_t s, const BatchDev &b, uint32_t n_cands, uint32_
     hipLaunchKernelGGL(k_ocr_list<true>, dim3(G), dim3(LIST_THREADS), 0, s, (const CandRec *)b.cands, (const uint32_t *)b.total_cands, hdr, hdr + OCR_LIST_HDR);
 }
 
+void launch_ocr_list_from(hipStream_t s, const BatchDev &b, const uint32_t *from, const uint32_t *from_n, uint32_t *hdr)
+{
+    hipLaunchKernelGGL(k_ocr_list_from, dim3(1), dim3(256), 0, s, (const CandRec *)b.cands, from, from_n, hdr, hdr + OCR_LIST_HDR);
+}
+
 int ocr_n_cu()
 {
     // (initialised once, thread-safe; the compute-unit count of the first device used -- the library is built for one kind of GPU)
@@ -1269,16 +1317,16 @@ void launch_svm_kernel(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m,
     if (n <= 0) return;
     if (numerators && m.sv8 && buf.x8) {
         hipLaunchKernelGGL(k_svm_kernel_i8, dim3(m.l_pad / QN, (n + QM - 1) / QM), dim3(256), 0, s, (const uint8_t *)buf.x8, (const int32_t *)buf.x8s, n, m.sv8, m.sv8s, m.l_pad,
-                           m.dq8, m.gamma, buf.kv);
+                           m.dq8, m.gamma, buf.kv, buf.n_dev);
         return;
     }
     if (numerators) {
         hipLaunchKernelGGL(k_svm_kernel_q, dim3(m.l_pad / QN, (n + QM - 1) / QM), dim3(256), 0, s, (const uint16_t *)buf.xq, (const double *)buf.xnorm, n, m.svq,
-                           m.svnorm, m.l_pad, m.dq, m.gamma, buf.kv);
+                           m.svnorm, m.l_pad, m.dq, m.gamma, buf.kv, buf.n_dev);
         return;
     }
     hipLaunchKernelGGL(k_svm_kernel, dim3(m.l_pad / GN, (n + GM - 1) / GM), dim3(256), 0, s, (const float *)buf.xf, (const double *)buf.xnorm, n, m.sv,
-                       m.svnorm, m.l_pad, m.dpad, m.gamma, buf.kv);
+                       m.svnorm, m.l_pad, m.dpad, m.gamma, buf.kv, buf.n_dev);
 }
 
 void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
@@ -1286,9 +1334,9 @@ void launch_svm_couple(hipStream_t s, int n, const OcrBuf &buf, const SvmDev &m)
     if (n <= 0) return;
     const int    wpb = svm_couple_wpb(m.k > 65 ? 2 : 0), wg = (n + wpb - 1) / wpb;
     const size_t lds = sizeof(double) * svm_couple_lds_doubles(m.k) * wpb;
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wpb), lds, s, (const double *)buf.kv, m.l_pad, n, m, buf.dec, buf.prob, buf.label, buf.pbest, (const double *)buf.av); };
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wpb), lds, s, (const double *)buf.kv, m.l_pad, n, m, buf.dec, buf.prob, buf.label, buf.pbest, (const double *)buf.av, buf.n_dev); };
     if (svm_uses_class_sums(m) && buf.av) {
-        hipLaunchKernelGGL(k_svm_decide, dim3((n + 63) / 64, (m.k + 3) / 4), dim3(256), 0, s, (const double *)buf.kv, m.l_pad, n, m, buf.av);
+        hipLaunchKernelGGL(k_svm_decide, dim3((n + 63) / 64, (m.k + 3) / 4), dim3(256), 0, s, (const double *)buf.kv, m.l_pad, n, m, buf.av, buf.n_dev);
         if (m.k == 65) go(k_svm_couple<1, -1>); else go(k_svm_couple<0, -1>);
         return;
     }

@@ -164,8 +164,9 @@ static int launch_tile_trees(str_er_ctx *c, const Batch &b, const BatchDev &bd, 
     return STR_ER_OK;
 }
 
-void rec(str_er_ctx *c, const char *name, hipStream_t on)
+void rec(str_er_ctx *c, const char *name, hipStream_t on, bool always)
 {
+    if (!always && !c->profiling) return;
     static_assert(str_er_ctx::MAX_EV >= 32, "the fullest call (BGR prologue, both tile kernels, track, group, both scorer stages) records 27 events");
     if (c->n_ev < str_er_ctx::MAX_EV) {
         (void)hipEventRecord(c->ev[c->n_ev], on ? on : c->stream);
@@ -618,7 +619,13 @@ int upload_layout(str_er_ctx *c, Batch &b)
         c->planes_on_device = np;
     }
     // counters of the batch (candidates, tiles k_tile_tree2 handed back), plane counters, the groups' done flags
-    HIP_TRY(c, hipMemsetAsync(c->d_zero, 0, align_up(c->zero_gd_off + b.n_groups, 256), s));      // (a whole number of 256-byte pieces: one fill kernel, not two)
+    // (a whole number of 256-byte pieces: one fill kernel, not two.  The last call of the context usually left the block zeroed -- a fill in front of the tile
+    // kernels is ~20 us of a 1-frame call, with the queue switches around it)
+    {
+        const size_t need = align_up(c->zero_gd_off + b.n_groups, 256);
+        if (c->zero_clean_bytes < need) HIP_TRY(c, hipMemsetAsync(c->d_zero, 0, need, s));
+        c->zero_clean_bytes = 0;
+    }
     {   // tile -> plane and seam-block -> (plane, first pair) tables; re-uploaded only when the layout changes
         std::vector<uint32_t> key;
         key.reserve(np * 2 + 1);
@@ -659,6 +666,60 @@ int upload_layout(str_er_ctx *c, Batch &b)
 // Enqueue extract -> NMS -> classify for a laid-out batch and build the result.
 // import_trees (optional): the tile trees were built elsewhere (strips of a plane extracted by other GPUs) -- instead of running
 // k_tile_tree / k_seam the hook puts node records and counters in place on the context's stream.
+// STR_ER_STAGE_OCR: chain_run on the strong / weak ERs of the batch (src/ER.cpp:728-735 calls it per ER).  `cap` = the number of ERs the launches and the
+// scratch are sized for; the kernels work on min(cap, the device's own count) -- so the stage can be enqueued right behind classify with a guessed cap, or
+// after the host has read the counters with the exact number.  The results travel to the context's page-locked block: count | list | labels | probabilities.
+// (two regions: the scores of the batch, and -- while those wait to be read -- the scores of the planes an NMS tie pass re-made)
+struct OcrPinned { uint32_t *count; uint32_t *list; int32_t *label; double *prob; };
+static OcrPinned ocr_pinned(const str_er_ctx *c, size_t cap, int region = 0)
+{
+    OcrPinned p;
+    uint8_t  *base = c->h_ocr + (size_t)region * (64 + 16 * c->h_ocr_cap);
+    p.count = reinterpret_cast<uint32_t *>(base);
+    p.prob = reinterpret_cast<double *>(base + 64);
+    p.list = reinterpret_cast<uint32_t *>(base + 64 + 8 * cap);
+    p.label = reinterpret_cast<int32_t *>(base + 64 + 12 * cap);
+    return p;
+}
+static int ocr_stage(str_er_ctx *c, const BatchDev &bd, size_t cap, hipStream_t s, bool again, const uint32_t *from = nullptr, const uint32_t *from_n = nullptr, int region = 0)
+{
+    static const char *const names[2][4] = {{"ocr_host_gap", "ocr_features", "svm_kernel", "svm_couple"}, {"ocr_again_host_gap", "ocr_again_features", "ocr_again_svm_kernel", "ocr_again_svm_couple"}};
+    const char *const *nm = names[again ? 1 : 0];
+    if (cap > c->h_ocr_cap) {
+        const size_t want = cap + cap / 4;
+        if (c->h_ocr) { (void)hipHostFree(c->h_ocr); c->h_ocr = nullptr; c->h_ocr_cap = 0; }
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ocr), 2 * (64 + 16 * want)));
+        c->h_ocr_cap = want;
+    }
+    const SvmDev &m = c->svm;
+    const size_t  n_cands = c->pool_total;        // (the list has room for every candidate the tables hold)
+    const size_t  o_list = 0, o_buf = align_up(4 * (n_cands + OCR_LIST_HDR), 256);
+    const int     rc = ensure_scratch(c, o_buf + ocr_layout(nullptr, cap, &m, false, false, false).bytes);
+    if (rc != STR_ER_OK) return rc;
+    uint8_t  *sc = static_cast<uint8_t *>(c->d_scratch);
+    OcrBuf    buf = ocr_layout(sc + o_buf, cap, &m, false, false, false);
+    uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
+    buf.n_dev = d_list;                          // (hdr[0]: k_ocr_list's count)
+    rec(c, nm[0]);          // (what lies between classify and the scorer: a round trip to the host when the counters were read first)
+    if (from) launch_ocr_list_from(s, bd, from, from_n, d_list);       // (the candidates of the planes a tie pass re-made)
+    else launch_ocr_list(s, bd, (uint32_t)n_cands, d_list);
+    OcrSrc src{};
+    src.recs = bd.cands; src.list = d_list + OCR_LIST_HDR; src.planes = bd.planes; src.n_dev = d_list;
+    launch_ocr_features(s, src, (int)cap, buf, &m);
+    rec(c, nm[1]);
+    launch_svm_kernel(s, (int)cap, buf, m, true);
+    rec(c, nm[2]);
+    launch_svm_couple(s, (int)cap, buf, m);
+    rec(c, nm[3]);
+    HIP_TRY(c, hipGetLastError());
+    const OcrPinned hp = ocr_pinned(c, cap, region);
+    HIP_TRY(c, hipMemcpyAsync(hp.count, d_list, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hp.list, d_list + OCR_LIST_HDR, 4 * cap, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hp.label, buf.label, 4 * cap, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hp.prob, buf.pbest, 8 * cap, hipMemcpyDeviceToHost, s));
+    return STR_ER_OK;
+}
+
 int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result **out,
               std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees, int attempt)
 {
@@ -716,7 +777,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     hipStream_t s = c->stream;
     { const int rcu = upload_layout(c, b); if (rcu != STR_ER_OK) return rcu; }
     BatchDev bd = make_batchdev(c, b);
-    if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin"); }
+    if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin", nullptr, true); }
 
     if (import_trees) {
         const int rci = (*import_trees)(b, bd);
@@ -743,10 +804,10 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     launch_reduce(s, bd);                             rec(c, "accumulate");
     launch_root(s, bd, dp);
     launch_select(s, bd, dp);
-    launch_kept(s, bd, dp);                           rec(c, "select");
+    launch_kept(s, bd, dp);                           rec(c, "select", nullptr, true);
     const int i_extract = c->n_ev - 1;
     if (stages & STR_ER_STAGE_NMS) launch_nms(s, bd, dp);
-    rec(c, "nms");
+    rec(c, "nms", nullptr, true);
     const int i_nms = c->n_ev - 1;
     const bool alt_pass = (stages & STR_ER_STAGE_NMS) && c->prm.sibling_order == 0;
     if (alt_pass) {       // beside classify: it only decides whether a tie needs the flood order walk
@@ -764,19 +825,33 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     // and the host knows how many of them are strong / weak (below): the colour pass is sized for exactly those boxes.
     if (stages & STR_ER_STAGE_NMS) {
         launch_cand_prefix(s, bd);
-        launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0);
+        launch_classify(s, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, nullptr, nullptr, np <= SPEC_PLANES);
     }
-    rec(c, "classify");
+    rec(c, "classify", nullptr, true);
     const int i_cls = c->n_ev - 1;
     int       i_trk = -1;
+    // the scorer of STR_ER_STAGE_OCR behind classify, sized from the last batch (ocr_stage): no trip to the host between the two, like the reference's
+    // call site (src/ER.cpp:728-735)
+    size_t ocr_cap = 0, ocr_cap2 = 0;
+    bool   cands_remade = false;
+    if ((stages & STR_ER_STAGE_OCR) && c->ocr_spec && c->ocr_last_n > 0 && c->pool_total) {
+        ocr_cap = align_up(c->ocr_last_n + c->ocr_last_n / 8 + 256, 128);
+        const int rco = ocr_stage(c, bd, ocr_cap, s, false);
+        if (rco != STR_ER_OK) return rco;
+    }
     if (alt_pass) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_zero, c->d_zero, 256 + sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));        // (counters of the batch + plane counters: one block)
     const CandRec *spec_src = nullptr;
     uint32_t       spec_n = 0;
     if ((stages & STR_ER_STAGE_NMS) && np <= SPEC_PLANES && c->pool_total && c->last_total <= SPEC_CANDS) {
         spec_src = c->d_cands; spec_n = (uint32_t)std::min<size_t>(SPEC_CANDS, c->pool_total);
-        HIP_TRY(c, hipMemcpyAsync(c->h_cands_spec, spec_src, sizeof(CandRec) * (size_t)spec_n, hipMemcpyDeviceToHost, s));
+    }
+    if (np <= SPEC_PLANES) {
+        // a call of a frame or two: counters and (if they are likely to fit) the candidate records go to the page-locked block in one launch
+        launch_results_to_host(s, c->d_zero, c->h_zero, 256 + sizeof(PlaneCtr) * np, spec_src, spec_src ? c->h_cands_spec : nullptr, spec_n, c->d_total);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(c->h_zero, c->d_zero, 256 + sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));        // (counters of the batch + plane counters: one block)
     }
     HIP_TRY(c, wait_stream(c, s));
     if (c->n_t2_tiles && !import_trees) {     // tiles k_tile_tree2 handed back: if they are many, the chroma planes stay with k_tile_tree for a while
@@ -853,6 +928,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         const auto tr1 = std::chrono::steady_clock::now();
         if (replayed && c->dbg_stats) std::fprintf(stderr, "[str_er] tie resolution (copies + walk + NMS pass): %.1f ms\n", std::chrono::duration<double, std::milli>(tr1 - tr0).count());
         if (replayed) {
+            cands_remade = true;
             hipStream_t sp = c->prio ? c->prio : s;         // same stream as the tie pass: ordered behind it
             const CandRec *first = c->d_cands;
             std::swap(c->d_cands, c->d_cands2);
@@ -860,7 +936,14 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             bd = make_batchdev(c, b);
             uint32_t *n_redo = c->d_redo + c->pool_total;
             launch_cand_reprefix(sp, bd, first, c->d_redo, n_redo);
-            launch_classify(sp, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, c->d_redo, n_redo);
+            launch_classify(sp, bd, dp, c->casc[0].dev, c->casc[1].dev, (stages & STR_ER_STAGE_CLASSIFY) ? 1 : 0, c->d_redo, n_redo, true);
+            if (ocr_cap && *ocr_pinned(c, ocr_cap).count <= ocr_cap) {
+                // the batch was scored behind classify: the candidates of the re-made planes are scored behind THEIR classify, again without a trip to the
+                // host -- as many as the device lists (the scratch is sized for the whole batch)
+                ocr_cap2 = ocr_cap;
+                const int rco = ocr_stage(c, bd, ocr_cap2, sp, true, c->d_redo, n_redo, 1);
+                if (rco != STR_ER_OK) return rco;
+            }
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(c->h_zero, c->d_zero, 256 + sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, sp));
             HIP_TRY(c, wait_stream(c, sp));
@@ -930,7 +1013,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         // computed a wave per box (big boxes by many workgroups), then er_track per image
         size_t n_cls = 0;
         for (int i = 0; i < np; ++i) n_cls += c->h_ctr[i].n_strong + c->h_ctr[i].n_weak;
-        rec(c, "track_host_gap");
+        rec(c, "track_host_gap", nullptr, true);
         if (total) {
             const int    n_img = np / b.planes_per_image;
             const size_t o_list = 0, o_cs = align_up(4 * ((size_t)total + OCR_LIST_HDR) + 256, 256);
@@ -948,7 +1031,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
             launch_group_ranges(s, bd, b.planes_per_image, n_img, c->d_ranges);
             launch_er_track(s, bd.cands, c->d_track, c->d_track_list, c->d_ranges, n_img);
         }
-        rec(c, "track");
+        rec(c, "track", nullptr, true);
         i_trk = c->n_ev - 1;
         r->tracks.resize(total);
         r->have_tracks = true;
@@ -982,51 +1065,65 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     }
     if (stages & STR_ER_STAGE_OCR) r->have_ocr = true;      // (an empty table, not a missing one, when there are no candidates)
     if ((stages & STR_ER_STAGE_OCR) && total) {
-        // second phase: the host now knows how many strong/weak ERs there are
         size_t n_ocr = 0;
         for (int i = 0; i < np; ++i) n_ocr += c->h_ctr[i].n_strong + c->h_ctr[i].n_weak;
         r->ocr_label.assign(total, -1);
         r->ocr_prob.assign(total, 0.0);
         r->have_ocr = true;
-        if (n_ocr) {
-            const SvmDev &m = c->svm;
-            size_t off = 0;
-            auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-            const size_t o_list = take(4 * ((size_t)total + OCR_LIST_HDR)), o_buf = take(0);
-            int rc2 = ensure_scratch(c, o_buf + ocr_layout(nullptr, n_ocr, &m, false, false, false).bytes);
-            if (rc2 != STR_ER_OK) { delete r; return rc2; }
-            uint8_t *sc = static_cast<uint8_t *>(c->d_scratch);
-            const OcrBuf buf = ocr_layout(sc + o_buf, n_ocr, &m, false, false, false);
-            uint32_t *d_list = reinterpret_cast<uint32_t *>(sc + o_list);
-            rec(c, "ocr_host_gap");          // (the host read the counters first: this interval is the round trip, not GPU work)
-            launch_ocr_list(s, bd, (uint32_t)total, d_list);
-            OcrSrc src{};
-            src.recs = bd.cands; src.list = d_list + OCR_LIST_HDR; src.planes = bd.planes;
-            launch_ocr_features(s, src, (int)n_ocr, buf, &m);
-            rec(c, "ocr_features");
-            launch_svm_kernel(s, (int)n_ocr, buf, m, true);
-            rec(c, "svm_kernel");
-            launch_svm_couple(s, (int)n_ocr, buf, m);
-            rec(c, "svm_couple");
-            std::vector<uint32_t> list(n_ocr);
-            std::vector<int32_t> lab(n_ocr);
-            std::vector<double> pb(n_ocr);
-            // (wait first, copy then: a copy into pageable memory blocks inside the runtime, holding its staging buffers, until the stream's kernels are done --
-            // and the other contexts' copies queue behind it although THEIR streams are idle: six threads inside hipMemcpyAsync and 12 ms without a kernel on the
-            // GPU in a rocprofv3 timeline of six batches in flight)
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = wait_stream(c, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(list.data(), d_list + OCR_LIST_HDR, 4 * n_ocr, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), buf.label, 4 * n_ocr, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(pb.data(), buf.pbest, 8 * n_ocr, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = wait_stream(c, s);
-            if (e != hipSuccess) { delete r; return fail(c, STR_ER_EHIP, std::string("OCR stage: ") + hipGetErrorString(e)); }
-            for (size_t i = 0; i < n_ocr; ++i) {
-                if (list[i] >= total) continue;
-                r->ocr_label[list[i]] = lab[i];
-                r->ocr_prob[list[i]] = pb[i];
+        // scored behind classify already?  Only if the guess covered the batch.  If an NMS tie pass re-made the candidates of a few planes since, the scores of
+        // the other planes are still good (their records were moved, PlaneCtr::cand_base_old -> cand_base) and only the re-made planes are scored again
+        const uint32_t early_n = ocr_cap ? *ocr_pinned(c, ocr_cap).count : 0u;
+        const bool     early = ocr_cap != 0 && early_n <= ocr_cap && (cands_remade || early_n == n_ocr);
+        auto scatter = [&](size_t cap, size_t n, int region = 0) {
+            const OcrPinned hp = ocr_pinned(c, cap, region);
+            for (size_t i = 0; i < n; ++i) {
+                if (hp.list[i] >= total) continue;
+                r->ocr_label[hp.list[i]] = hp.label[i];
+                r->ocr_prob[hp.list[i]] = hp.prob[i];
             }
+        };
+        auto run_stage = [&](size_t cap, size_t expect, const uint32_t *from, const uint32_t *from_n) -> int {
+            bd = make_batchdev(c, b);
+            hipStream_t so = (cands_remade && c->prio) ? c->prio : s;        // (behind the tie pass and its classify)
+            const int rc2 = ocr_stage(c, bd, cap, so, ocr_cap != 0, from, from_n);
+            if (rc2 != STR_ER_OK) return rc2;
+            if (wait_stream(c, so) != hipSuccess) return fail(c, STR_ER_EHIP, "OCR stage failed");
+            if (*ocr_pinned(c, cap).count != expect)
+                return fail(c, STR_ER_EHIP, "OCR stage: the device listed a different number of strong / weak ERs than the plane counters say (internal error)");
+            return STR_ER_OK;
+        };
+        if (ocr_cap) { if (early && !cands_remade) ++c->n_ocr_spec; else ++c->n_ocr_redo; }
+        if (early && !cands_remade) {
+            scatter(ocr_cap, n_ocr);
+        } else if (early) {
+            const OcrPinned hp = ocr_pinned(c, ocr_cap);
+            size_t n2 = 0;
+            int    pl = 0;
+            for (int i = 0; i < np; ++i) if (c->h_ctr[i].pool_changed) n2 += c->h_ctr[i].n_strong + c->h_ctr[i].n_weak;
+            for (size_t i = 0; i < early_n; ++i) {                // (the list is in candidate order: the planes come by)
+                const uint32_t old = hp.list[i];
+                while (pl + 1 < np && c->h_ctr[pl + 1].cand_base_old <= old) ++pl;
+                const PlaneCtr &pc = c->h_ctr[pl];
+                if (pc.pool_changed || old < pc.cand_base_old) continue;
+                const uint32_t now = old - pc.cand_base_old + pc.cand_base;
+                if (now >= total) continue;
+                r->ocr_label[now] = hp.label[i];
+                r->ocr_prob[now] = hp.prob[i];
+            }
+            if (n2 && ocr_cap2 && n2 <= ocr_cap2 && *ocr_pinned(c, ocr_cap2, 1).count == n2) {
+                scatter(ocr_cap2, n2, 1);
+            } else if (n2) {
+                const int rc2 = run_stage(n2, n2, c->d_redo, c->d_redo + c->pool_total);
+                if (rc2 != STR_ER_OK) { delete r; return rc2; }
+                scatter(n2, n2);
+            }
+        } else if (n_ocr) {
+            // the slow way: the host knows the number now
+            const int rc2 = run_stage(n_ocr, n_ocr, nullptr, nullptr);
+            if (rc2 != STR_ER_OK) { delete r; return rc2; }
+            scatter(n_ocr, n_ocr);
         }
+        c->ocr_last_n = n_ocr;
     }
     const double t_ocr_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ocr0).count();
     const bool want_nodes = (stages & STR_ER_WANT_NODES) != 0;
@@ -1110,6 +1207,10 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     r->times[4] = t_group_s;
     r->times[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     *out = r;
+    {   // everything of this batch has been read: the counter block is zeroed for the context's next batch now, behind the caller's back (upload_layout)
+        const size_t need = align_up(c->zero_gd_off + b.n_groups, 256);
+        if (hipMemsetAsync(c->d_zero, 0, need, s) == hipSuccess) c->zero_clean_bytes = need;
+    }
     return STR_ER_OK;
 }
 
@@ -1160,6 +1261,14 @@ try {
 } ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 const char *str_er_runtime_hint(void) { return "GPU_MAX_HW_QUEUES=16"; }
+int str_er_ocr_stage_stats(const str_er_ctx *c, uint64_t *scored_early, uint64_t *scored_again)
+{
+    if (!c) return STR_ER_EINVAL;
+    if (scored_early) *scored_early = c->n_ocr_spec;
+    if (scored_again) *scored_again = c->n_ocr_redo;
+    return STR_ER_OK;
+}
+
 int str_er_apply_runtime_hint(void)
 {
     if (getenv("GPU_MAX_HW_QUEUES")) return 0;
@@ -1218,6 +1327,7 @@ void str_er_destroy(str_er_ctx *c)
     if (c->h_planes) (void)hipHostFree(c->h_planes);
     if (c->h_zero) (void)hipHostFree(c->h_zero);
     if (c->h_cands_spec) (void)hipHostFree(c->h_cands_spec);
+    if (c->h_ocr) (void)hipHostFree(c->h_ocr);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->prio) { (void)hipStreamSynchronize(c->prio); (void)hipStreamDestroy(c->prio); }
@@ -1260,7 +1370,9 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     if (const char *g = std::getenv("STR_ER_GROUP_KERNEL")) c->dbg_group[2] = std::atoi(g);
     if (const char *t2 = std::getenv("STR_ER_TILE2")) c->t2_mode = std::max(0, std::min(2, std::atoi(t2)));      // developer switch: 0 k_tile_tree only, 2 k_tile_tree2 on every plane
     c->dbg_tile_only = std::getenv("STR_ER_DEBUG_TILE_ONLY") != nullptr;
+    if (c->dbg_tile_only) c->profiling = true;
     c->dbg_stats = std::getenv("STR_ER_DEBUG_STATS") != nullptr;
+    if (const char *os = std::getenv("STR_ER_OCR_SPEC")) c->ocr_spec = std::atoi(os) != 0;      // developer switch: 0 = the scorer is sized after the counters were read
     if (const char *nb = std::getenv("STR_ER_NODE_BLOCKS")) c->node_blocks_cap = (uint32_t)std::max(1, std::atoi(nb));
     if (const char *rp = std::getenv("STR_ER_REPLAY")) c->replay_on_gpu = !std::strcmp(rp, "gpu");
     for (int i = 0; i < 6; ++i) if (p->channel_mask & (1u << i)) c->chans.push_back(i);
@@ -1449,7 +1561,7 @@ static int detect_bgr_impl(str_er_ctx *c, const uint8_t *bgr, int32_t w, int32_t
     }
     if (frame_bytes * n_frames > c->pix_bytes) return fail(c, STR_ER_ECAPACITY, "plane pool too small");
     auto plane_sz = [&](int l) { return align_up((size_t)geo[l].stride * geo[l].h, 256); };
-    c->n_ev = 0; c->profile.clear(); rec(c, "begin");
+    c->n_ev = 0; c->profile.clear(); rec(c, "begin", nullptr, true);
     const hipStream_t ws = c->stream;
     if (nv12)
         launch_nv12_to_ycrcb(ws, dbgr, w, h, dstride, dpitch, n_frames, c->d_pix + geo[0].off, c->d_pix + geo[0].off + plane_sz(0),
@@ -1658,7 +1770,7 @@ void str_er_result_free(str_er_result *r) { delete r; }
 
 int str_er_last_profile(const str_er_ctx *c, const char **names, double *ms, int32_t cap)
 try {
-    if (!c) return 0;
+    if (!c || !c->profiling) return 0;          // (without profiling the few events of a call are not one per kernel group)
     int k = 0;
     for (size_t i = 1; i < c->profile.size(); ++i, ++k)
         if (k < cap) { if (names) names[k] = c->profile[i].first; if (ms) ms[k] = c->profile[i].second; }

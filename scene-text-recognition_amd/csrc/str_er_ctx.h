@@ -108,6 +108,7 @@ struct str_er_ctx {
     PlaneDesc *d_planes = nullptr;
     PlaneCtr *d_ctr = nullptr;
     uint8_t *d_zero = nullptr, *h_zero = nullptr; size_t zero_gd_off = 0;      // the block a batch zeroes: d_total | d_ctr | d_group_done (and its page-locked mirror: h_total | h_ctr)
+    size_t zero_clean_bytes = 0;      // so many bytes of d_zero are zero already: filled behind the last call's results (run_batch), off the next call's critical path
     int planes_on_device = 0;         // plane descriptors in d_planes = the first so many of h_planes (0: none)
     NodeArrays na{};
     KeptArrays ka{};
@@ -166,6 +167,13 @@ struct str_er_ctx {
     PlaneCtr *h_ctr = nullptr;
     uint32_t *h_total = nullptr;
     CandRec  *h_cands_spec = nullptr;                 // small calls: the first SPEC_CANDS candidate records come back WITH the counters (run_batch)
+    // STR_ER_STAGE_OCR behind classify, before the host has read a counter (run_batch): the launches are sized for a little more than the last batch's number of
+    // strong / weak ERs and work on the device's own count; the results come back with the counters in one page-locked block
+    // (count | list | labels | probabilities).  A batch with more ERs than guessed, or whose candidates an NMS tie pass re-made, is scored again the slow way.
+    bool      ocr_spec = true;                        // STR_ER_OCR_SPEC=0 turns it off (developer switch)
+    size_t    ocr_last_n = 0;                         // strong + weak ERs of the last batch scored
+    uint8_t  *h_ocr = nullptr; size_t h_ocr_cap = 0;  // page-locked results for up to so many ERs
+    uint64_t  n_ocr_spec = 0, n_ocr_redo = 0;         // statistics: batches scored behind classify / scored again
 
     HostCascade casc[2];
     bool svm_loaded = false;
@@ -312,7 +320,10 @@ void assign_node_records(Batch &b, double share);
 void assign_tables(Batch &b, const str_er_ctx *c);
 int alloc_tables(str_er_ctx *c, size_t KP, size_t PP);
 BatchDev make_batchdev(str_er_ctx *c, const Batch &b);
-void rec(str_er_ctx *c, const char *name, hipStream_t on = nullptr);
+// an event behind what was enqueued so far.  `always`: one of the few a call needs for str_er_result_times (begin, end of extraction, NMS, classify, track);
+// the others -- one per kernel group -- are recorded only while str_er_set_profiling is on: an event between two kernels costs ~7 us of stream time
+// (1-frame calls: a dozen of them were a tenth of the call)
+void rec(str_er_ctx *c, const char *name, hipStream_t on = nullptr, bool always = false);
 RotGeom make_rot_geom(int w, int h, double slope);
 int group_phase(str_er_ctx *c, const CandRec *d_cands, const TrackRec *d_track, const std::vector<uint32_t> &img, bool inner_sup, str_er_result *r,
                 bool presorted = false);

@@ -342,6 +342,44 @@ def test_gpu_config3_full_pipeline(S, cascade_paths, oracle, oracle_cascades, mo
 
 
 @pytest.mark.gpu
+def test_gpu_ocr_stage_sized_on_the_device(S, cascade_paths, model_path, monkeypatch):
+    """STAGE_OCR is enqueued behind classify, sized from the context's previous batch and working on the device's own count of strong / weak ERs
+    (no read of the counters between classify and the scorer, like src/ER.cpp:728-735).  A sequence of batches -- few ERs, many more than guessed (scored
+    again), the same again (early scores used), fewer, none, a batch in which an NMS tie pass re-makes the
+    candidates of a plane after they were scored (only that plane is scored again) -- gives exactly what a context that sizes the scorer after reading the counters gives."""
+    W, H = 1920, 1080
+    def make():
+        f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=2, n_pyr_levels=8, channel_mask=0x07))
+        f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+        f.load_svm_model(model_path, 1800)
+        return f
+    full = [S.synth.stext_bgr(S.synth.frame_seed(40 + i), W, H) for i in range(2)]
+    few = np.full((H, W, 3), 128, np.uint8)
+    few[300:460, 500:900] = full[0][300:460, 500:900]
+    blank = np.full((H, W, 3), 90, np.uint8)
+    ties = np.stack([S.synth.sties_bgr(S.synth.frame_seed(40), W, H), full[1]])       # (an NMS sibling tie that changes a pool: that plane's candidates are re-made)
+    seq = [few[None], np.stack(full), np.stack(full), full[1][None], blank[None], full[0][None], ties, ties]
+    stages = S.STAGE_ALL | S.STAGE_OCR
+    f = make()
+    got = [f.text_detect(a, stages) for a in seq]
+    st = f.ocr_stage_stats()
+    assert f.tie_stats()["planes_walked"] >= 2
+    f.close()
+    monkeypatch.setenv("STR_ER_OCR_SPEC", "0")
+    g = make()
+    want = [g.text_detect(a, stages) for a in seq]
+    assert g.ocr_stage_stats() == {"scored_early": 0, "scored_again": 0}
+    g.close()
+    n = [int((r.cands["cls"] > 0).sum()) for r in want]
+    assert n[0] >= 1 and n[1] > n[0] + n[0] // 8 + 256 + 128 and n[3] >= 1 and n[5] >= 1, n      # (the sequence exercises what it says)
+    assert st["scored_again"] >= 3 and st["scored_early"] >= 3, st
+    for a, b in zip(got, want):
+        assert np.array_equal(a.cands, b.cands)
+        assert np.array_equal(a.ocr_label, b.ocr_label) and np.array_equal(a.ocr_prob, b.ocr_prob)
+        assert ((a.ocr_label >= 0) == (a.cands["cls"] > 0)).all()
+
+
+@pytest.mark.gpu
 def test_gpu_line_ocr_stage(S, cascade_paths, oracle, model_path):
     """er_ocr's first half (src/ER.cpp:695-747) on the lines of er_grouping: chain_run with the line's slope on every member's
     (merged) bound, the 0.95-overlap deletion, MIN_OCR_PROB, min_pass_ocr -- restated here over the oracle's pieces."""

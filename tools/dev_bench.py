@@ -16,6 +16,7 @@ def main():
     tmp = tempfile.mkdtemp()
     sp, wp = S.cascade_io.write_golden(tmp)
     f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=levels, channel_mask=mask))
+    f.set_profiling(True)
     f.load_cascade(0, sp); f.load_cascade(1, wp)
     print('workspace GB', f.workspace_bytes() / 1e9, flush=True)
     nsrc = min(F, 4)

@@ -48,6 +48,7 @@ def check(f, img, tag, step=8, min_area=120):
 
 def main():
     f = S.ERFilter(params=S.Params(max_width=1920, max_height=1080, max_frames=2))
+    f.set_profiling(True)
     f.load_cascade(0, sp); f.load_cascade(1, wp)
     print('workspace MB', f.workspace_bytes() / 1e6, flush=True)
     rng = np.random.default_rng(1)

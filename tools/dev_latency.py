@@ -13,15 +13,17 @@ f.load_cascade(0, sp); f.load_cascade(1, wp)
 frames = S.synth.frames_bgr("text", 0, 8, W, H)
 d = torch.from_numpy(frames).cuda()
 fb = frames[0].nbytes
-for i in range(5):
-    f.detect_bgr_device(d.data_ptr() + (i % 8) * fb, W, H, 1)
-ms, prof = [], {}
 n = int(os.environ.get("DEV_LAT_N", "40"))
-for i in range(n):
-    t0 = time.perf_counter()
-    r = f.detect_bgr_device(d.data_ptr() + (i % 8) * fb, W, H, 1)
-    ms.append(1e3 * (time.perf_counter() - t0))
-    for k, v in r.profile.items():
-        prof[k] = prof.get(k, 0.0) + v / n
-print(f"1 frame per call: median {np.median(ms):.3f} ms, p10 {np.percentile(ms, 10):.3f}, p90 {np.percentile(ms, 90):.3f}")
+for prof_on in (False, True):          # (the per-group events cost stream time: the call is timed without them first)
+    f.set_profiling(prof_on)
+    for i in range(5):
+        f.detect_bgr_device(d.data_ptr() + (i % 8) * fb, W, H, 1)
+    ms, prof = [], {}
+    for i in range(n):
+        t0 = time.perf_counter()
+        r = f.detect_bgr_device(d.data_ptr() + (i % 8) * fb, W, H, 1)
+        ms.append(1e3 * (time.perf_counter() - t0))
+        for k, v in r.profile.items():
+            prof[k] = prof.get(k, 0.0) + v / n
+    print(f"1 frame per call ({'with' if prof_on else 'without'} per-group events): median {np.median(ms):.3f} ms, p10 {np.percentile(ms, 10):.3f}, p90 {np.percentile(ms, 90):.3f}")
 print("GPU ms per stage (events):", {k: round(v, 4) for k, v in prof.items()}, "sum", round(sum(prof.values()), 4))

@@ -9,6 +9,7 @@ import str_er_amd as S
 W, H = 1920, 1080
 sp, wp = S.cascade_io.write_golden(tempfile.mkdtemp())
 f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=1, n_pyr_levels=8, channel_mask=7))
+f.set_profiling(True)
 f.load_cascade(0, sp); f.load_cascade(1, wp)
 d = torch.from_numpy(S.synth.frames_bgr("text", 0, 1, W, H)).cuda()
 L = S.load_library()

@@ -10,6 +10,7 @@ F = 8; W, H = 1920, 1080
 kind = sys.argv[1] if len(sys.argv) > 1 else 'text'
 tmp = tempfile.mkdtemp(); sp, wp = S.cascade_io.write_golden(tmp)
 f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=8, channel_mask=0x7))
+f.set_profiling(True)
 f.load_cascade(0, sp); f.load_cascade(1, wp)
 src = S.synth.frames_bgr(kind, 0, 4, W, H)
 d = torch.from_numpy(np.stack([src[i % 4] for i in range(F)])).cuda()
