@@ -106,15 +106,20 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
     __shared__ uint32_t s_lcur[256];
     __shared__ uint16_t s_perm[NMS_LDS_CAP];
     uint32_t node_r[NPT];
-    if (in_lds && tid < 256) s_lcur[tid] = 0;
-    if (in_lds) __syncthreads();
+    // (planes too big for LDS -- a 3840 x 2160 level-0 plane keeps 10-20 k nodes -- are handed out in level order too, from a list in memory: every pass
+    // below then touches a node once, where each level of the level loop used to test the level byte of ALL nodes: 1.03 ms for the largest plane of a
+    // 4K batch, a quarter of that batch's GPU time)
+    uint32_t *kperm = b.ka.perm + kb;
+    if (tid < 256) s_lcur[tid] = 0;
+    __syncthreads();
     for (uint32_t i = tid; i < K; i += NMS_THREADS) {
         kstart[i] = i; kncand[i] = 0; kbest[i] = ~0ull;
-        if (in_lds) { s_npar[i] = b.ka.parent[kb + i]; s_nsa[i] = s_narea[i] = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]; atomicAdd(&s_lcur[klev[i]], 1u); }
+        if (in_lds) { s_npar[i] = b.ka.parent[kb + i]; s_nsa[i] = s_narea[i] = (int)kbox[4 * i + 2] * (int)kbox[4 * i + 3]; }
+        atomicAdd(&s_lcur[klev[i]], 1u);
         atomicOr(&s_levels[klev[i] >> 5], 1u << (klev[i] & 31));
     }
     __syncthreads();
-    if (in_lds) {
+    {
         if (tid < 64) {              // counts -> first positions: four levels a lane, a scan over the wave
             const uint32_t c0 = s_lcur[4 * tid], c1 = s_lcur[4 * tid + 1], c2 = s_lcur[4 * tid + 2], c3 = s_lcur[4 * tid + 3], tot = c0 + c1 + c2 + c3;
             uint32_t incl = tot;
@@ -123,8 +128,11 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
             s_lcur[4 * tid] = e; s_lcur[4 * tid + 1] = e + c0; s_lcur[4 * tid + 2] = e + c0 + c1; s_lcur[4 * tid + 3] = e + c0 + c1 + c2;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < K; i += NMS_THREADS) s_perm[atomicAdd(&s_lcur[klev[i]], 1u)] = (uint16_t)i;
-        __syncthreads();
+        if (in_lds) for (uint32_t i = tid; i < K; i += NMS_THREADS) s_perm[atomicAdd(&s_lcur[klev[i]], 1u)] = (uint16_t)i;
+        else for (uint32_t i = tid; i < K; i += NMS_THREADS) kperm[atomicAdd(&s_lcur[klev[i]], 1u)] = i;
+        __syncthreads();          // (s_lcur[l] is now the END of level l's stretch of the list = the start of level l + 1's)
+    }
+    if (in_lds) {
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             const uint32_t pos = (uint32_t)tid + (uint32_t)k * NMS_THREADS;
@@ -187,8 +195,8 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
                 }
             }
         } else
-        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
-            if (klev[i] != t) continue;
+        for (uint32_t pos = (t ? s_lcur[t - 1] : 0u) + (uint32_t)tid, pend = s_lcur[t]; pos < pend; pos += NMS_THREADS) {
+            const uint32_t i = kperm[pos];
             uint32_t s = i;
             const uint32_t nc = LD_AGENT(&kncand[i]);
             if (nc) {
@@ -296,33 +304,45 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(BatchDev b, DetectParams pr
                 if (slot < pd.pool_cap) b.pool_tmp[pb + slot] = best;
             }
         }
-    } else
-    for (uint32_t X = tid; X < K; X += NMS_THREADS) {
-        if (kstart[X] != X) continue;
-        int      len = 1;
-        uint32_t p = X;
-        while (p != root && kstart[kpar[p]] == X) { p = (uint32_t)kpar[p]; ++len; }
-        if (len < 1 + T) continue;
-        uint32_t trail = X, lead = X;
-        for (int i = 0; i < T; ++i) lead = (uint32_t)kpar[lead];
-        uint32_t best = X;
-        double   best_st = 0;
-        int      best_a = 0;
-        for (int i = 0; i < len - T; ++i) {
-            const int a = barea(trail);
-            const int bb = barea(lead);
+    } else {
+        // the same three rounds on the tables in memory (kbest: the chain's largest stability, in the slot of its start; kncand: the level of the lowest
+        // member that has it -- levels grow along a chain, so the level names the member).  A member's stability is worked out again in each round: T
+        // dependent loads, against a table of 8 bytes per kept node
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) { kbest[i] = 0ull; kncand[i] = 0xFFFFFFFFu; }
+        __syncthreads();
+        auto stab = [&](uint32_t i, uint32_t &X) -> unsigned long long {
+            X = kstart[i];
+            uint32_t anc = i;
+            for (int j = 0; j < T; ++j) { if (anc == root) return 0ull; anc = (uint32_t)kpar[anc]; }
+            if (kstart[anc] != X) return 0ull;
+            const int    a = barea(i), bb = barea(anc);
             const double st = (double)a / (double)(bb - a);   // 0 denominator -> +inf, as in the reference
-            if (i == 0 || st > best_st) { best = trail; best_st = st; best_a = a; }
-            else if (st == best_st && a < best_a) { best = trail; best_a = a; }
-            trail = (uint32_t)kpar[trail];
-            lead = (uint32_t)kpar[lead];
+            return (unsigned long long)__double_as_longlong(st);
+        };
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            uint32_t X;
+            const unsigned long long st = stab(i, X);
+            if (st != 0ull) atomicMax(&kbest[X], st);
         }
-        const int    bw = kbox[4 * best + 2], bh = kbox[4 * best + 3];
-        const double ar = (double)bw / (double)bh;
-        const int    area = (int)b.ka.area[kb + best];
-        if (ar < 2.0 && ar > 0.10 && area < prm.max_area && area > prm.min_area && bh < pd.h * 0.8 && bw < pd.w * 0.8) {
-            const uint32_t slot = atomicAdd(&s_npool, 1u);
-            if (slot < pd.pool_cap) b.pool_tmp[pb + slot] = best;
+        __syncthreads();
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            uint32_t X;
+            const unsigned long long st = stab(i, X);
+            if (st != 0ull && st == LD_AGENT(&kbest[X])) atomicMin(&kncand[X], (uint32_t)klev[i]);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < K; i += NMS_THREADS) {
+            uint32_t X;
+            const unsigned long long st = stab(i, X);
+            if (st == 0ull || st != LD_AGENT(&kbest[X]) || LD_AGENT(&kncand[X]) != (uint32_t)klev[i]) continue;
+            const uint32_t best = i;
+            const int    bw = kbox[4 * best + 2], bh = kbox[4 * best + 3];
+            const double ar = (double)bw / (double)bh;
+            const int    area = (int)b.ka.area[kb + best];
+            if (ar < 2.0 && ar > 0.10 && area < prm.max_area && area > prm.min_area && bh < pd.h * 0.8 && bw < pd.w * 0.8) {
+                const uint32_t slot = atomicAdd(&s_npool, 1u);
+                if (slot < pd.pool_cap) b.pool_tmp[pb + slot] = best;
+            }
         }
     }
     __syncthreads();

@@ -121,6 +121,7 @@ struct KeptArrays {
     uint32_t *start;        // NMS: chain start of the chain that owns this node
     uint32_t *ncand;        // NMS: number of child chains that want this node
     unsigned long long *best; // NMS: (order key << 32 | child slot), minimum wins
+    uint32_t *perm;         // NMS, planes whose scratch does not fit LDS: the plane's kept slots in level order
 };
 
 // Cascade tables on the device (CascadeBoost, inc/adaboost.h:158-185).

@@ -80,7 +80,7 @@ int alloc_tables(str_er_ctx *c, size_t KP, size_t PP)
     int rc = STR_ER_OK;
 #define T_(p, n) if (rc == STR_ER_OK) rc = re(p, n)
     T_(c->ka.node, KP); T_(c->ka.key, KP); T_(c->ka.area, KP); T_(c->ka.parent, KP); T_(c->ka.box, 4 * KP); T_(c->ka.level, KP);
-    T_(c->ka.start, KP); T_(c->ka.ncand, KP); T_(c->ka.best, KP);
+    T_(c->ka.start, KP); T_(c->ka.ncand, KP); T_(c->ka.best, KP); T_(c->ka.perm, KP);
     T_(c->d_pool, PP); T_(c->d_pool_tmp, PP); T_(c->d_cands, PP); T_(c->d_cand_plane, PP); T_(c->d_cands2, PP); T_(c->d_cand_plane2, PP);
     T_(c->d_redo, PP + 1); T_(c->d_track, PP); T_(c->d_track_list, PP);
 #undef T_
@@ -1317,7 +1317,7 @@ void str_er_destroy(str_er_ctx *c)
     if (c->na.rec) (void)hipFree(c->na.rec);
     if (c->na.aux) (void)hipFree(c->na.aux);
     for (void *p : {(void *)c->ka.node, (void *)c->ka.key, (void *)c->ka.area, (void *)c->ka.parent, (void *)c->ka.box, (void *)c->ka.level, (void *)c->ka.start,
-                    (void *)c->ka.ncand, (void *)c->ka.best, (void *)c->d_pool, (void *)c->d_pool_tmp, (void *)c->d_cands, (void *)c->d_cand_plane, (void *)c->d_cands2,
+                    (void *)c->ka.ncand, (void *)c->ka.best, (void *)c->ka.perm, (void *)c->d_pool, (void *)c->d_pool_tmp, (void *)c->d_cands, (void *)c->d_cand_plane, (void *)c->d_cands2,
                     (void *)c->d_cand_plane2, (void *)c->d_redo, (void *)c->d_track, (void *)c->d_track_list})
         if (p) (void)hipFree(p);
     if (c->d_group) (void)hipFree(c->d_group);
