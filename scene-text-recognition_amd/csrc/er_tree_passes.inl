@@ -499,11 +499,33 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// What the lanes of a wave send to the same record is combined before it goes out -- the pieces a seam cut a big node into all hand over to ONE
+// survivor, the children of a big node all count into (k_resolve) and push into (k_reduce) ONE parent, and without combining these few hot records
+// serialise the kernels.  Until round 6 the combining was a loop over the wave's distinct targets, a leader lane and seven butterfly reductions per
+// target: 64 passes for a wave of 64 different targets, in k_reduce each with two dependent trips to the coherence point inside (timing-only builds:
+// the loops were 52 of k_resolve's 90 us and 45 of k_reduce's 165 us on one 1080p frame, 0.25 and 0.2 ms of a 4K batch).  Now every wave has a
+// small table in LDS (128 slots keyed by the target): all lanes claim their target's slot with ONE compare-and-swap instruction (the first lane of a
+// target becomes its owner, lanes whose slot belongs to another target keep their contribution to themselves), add into it with LDS atomics, the
+// owners read the sums back, clear the slot and issue the global atomics -- owners and loners side by side in ONE set of instructions.  No barriers:
+// a wave's LDS operations are carried out in program order.
+constexpr int WTAB = 128;
+struct WaveTab {
+    uint32_t key[WTAB];                       // target record (plane-local id), NONE: free
+    uint32_t c[WTAB], nd[WTAB], x0[WTAB], y0[WTAB], x1[WTAB], y1[WTAB], ky[WTAB], k[WTAB];
+};
+__device__ __forceinline__ void wtab_clear(WaveTab &t, int i)
+{
+    t.key[i] = NONE; t.c[i] = 0; t.nd[i] = 0; t.x0[i] = 0xFFFFFFFFu; t.y0[i] = 0xFFFFFFFFu; t.x1[i] = 0; t.y1[i] = 0; t.ky[i] = 0xFFFFFFFFu; t.k[i] = 0;
+}
+__device__ __forceinline__ uint32_t wtab_hash(uint32_t target) { return (target * 2654435761u) >> 25; }
+static_assert(WTAB == 128, "wtab_hash takes the top 7 bits");
+
 // Nodes that were unified into another node of the same level hand their own statistics to the surviving level root;
 // surviving nodes get a canonical parent (the parent node's level root).  Every node that will push its totals to a parent
 // -- open, alive, not a tree root -- is counted in the parent's dependency counter (aux).
 __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
 {
+    __shared__ WaveTab s_tab[4];
     const int       pi = b.nb_plane[blockIdx.x];
     const uint32_t  bi = blockIdx.x - b.planes[pi].nb_base, nbp = b.planes[pi].nb_count;     // this plane's workgroups: bi of nbp
     const uint32_t  n = plane_nodes(b, pi);
@@ -511,6 +533,8 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
     uint32_t       *aux = b.na.aux + b.planes[pi].node_base;
     uint32_t       *arr = b.na.arr + b.planes[pi].node_base;
     const int       lane = threadIdx.x & 63;
+    WaveTab        &tab = s_tab[threadIdx.x >> 6];
+    wtab_clear(tab, lane); wtab_clear(tab, lane + 64);
     for (uint32_t x0 = bi * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += nbp * blockDim.x) {
         const uint32_t  x = x0 + (uint32_t)lane;
         uint32_t        push_to = NONE;         // the parent this node will push its totals to
@@ -546,42 +570,31 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
                 if (!(me.nod & NODE_CLOSED)) push_to = q;                 // closed nodes never push (their totals are final)
             }
         }
-        // The pieces a seam cut a big node into all hand over to ONE survivor, and the children of a big node all count into ONE
-        // parent: the lanes of a wave that share a target combine first (ballot + butterfly) -- one set of atomics per distinct
-        // target and wave; without it these few hot words serialise the whole kernel.
-        unsigned long long todo = __ballot(hand_to != NONE);
-        while (todo) {
-            const int      leader = __ffsll((long long)todo) - 1;
-            const uint32_t lr = __shfl(hand_to, leader);
-            const bool     mine = hand_to == lr;
-            const unsigned long long m = __ballot(mine);
-            if (__popcll(m) == 1) {
-                if (mine) {
-                    atomicAdd(&nr[lr].cnt, c);
-                    if (nd) atomicAdd(&nr[lr].nod, nd);
-                    atomicMin(&nr[lr].x0, bx0); atomicMin(&nr[lr].y0, by0); atomicMax(&nr[lr].x1, bx1); atomicMax(&nr[lr].y1, by1);
-                    atomicMin(&nr[lr].key, ky);          // same level: the top byte is equal, the minimum is over the pixel index
-                }
-            } else {
-                const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
-                const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
-                const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u), mk = wave_min(mine ? ky : 0xFFFFFFFFu);
-                if (lane == leader) {
-                    atomicAdd(&nr[lr].cnt, sc);
-                    if (sn) atomicAdd(&nr[lr].nod, sn);
-                    atomicMin(&nr[lr].x0, mx0); atomicMin(&nr[lr].y0, my0); atomicMax(&nr[lr].x1, mx1); atomicMax(&nr[lr].y1, my1);
-                    atomicMin(&nr[lr].key, mk);
-                }
+        // (a record hands over or counts, never both; a target may be handed to by some lanes and counted into by others: one slot)
+        const bool     hands = hand_to != NONE;
+        const uint32_t tgt = hands ? hand_to : push_to;
+        uint32_t       kk = push_to != NONE ? 1u : 0u;
+        if (tgt != NONE) {
+            const uint32_t h = wtab_hash(tgt);
+            const uint32_t old = atomicCAS(&tab.key[h], NONE, tgt);
+            if (old == NONE || old == tgt) {
+                if (hands) {
+                    atomicAdd(&tab.c[h], c); atomicAdd(&tab.nd[h], nd);
+                    atomicMin(&tab.x0[h], bx0); atomicMin(&tab.y0[h], by0); atomicMax(&tab.x1[h], bx1); atomicMax(&tab.y1[h], by1);
+                    atomicMin(&tab.ky[h], ky);
+                } else atomicAdd(&tab.k[h], 1u);
+                if (old == NONE) {               // the owner: the sums of everybody who shares the target (their LDS operations precede these reads)
+                    c = tab.c[h]; nd = tab.nd[h]; bx0 = tab.x0[h]; by0 = tab.y0[h]; bx1 = tab.x1[h]; by1 = tab.y1[h]; ky = tab.ky[h]; kk = tab.k[h];
+                    wtab_clear(tab, (int)h);
+                } else { ky = 0xFFFFFFFFu; kk = 0; }      // a member: the owner sends its share
             }
-            todo &= ~m;
-        }
-        todo = __ballot(push_to != NONE);
-        while (todo) {
-            const int      leader = __ffsll((long long)todo) - 1;
-            const uint32_t lq = __shfl(push_to, leader);
-            const unsigned long long m = __ballot(push_to == lq);
-            if (lane == leader) atomicAdd(&aux[lq], (uint32_t)__popcll(m));
-            todo &= ~m;
+            if (ky != 0xFFFFFFFFu) {             // something is handed over (a piece always brings its key)
+                atomicAdd(&nr[tgt].cnt, c);
+                if (nd) atomicAdd(&nr[tgt].nod, nd);
+                atomicMin(&nr[tgt].x0, bx0); atomicMin(&nr[tgt].y0, by0); atomicMax(&nr[tgt].x1, bx1); atomicMax(&nr[tgt].y1, by1);
+                atomicMin(&nr[tgt].key, ky);          // same level: the top byte is equal, the minimum is over the pixel index
+            }
+            if (kk) atomicAdd(&aux[tgt], kk);
         }
     }
 }
@@ -639,6 +652,7 @@ __device__ __forceinline__ bool node_arrive(uint32_t *arrived, uint32_t expect, 
 
 __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
 {
+    __shared__ WaveTab s_tab[4];
     const int       pi = b.nb_plane[blockIdx.x];
     const uint32_t  bi = blockIdx.x - b.planes[pi].nb_base, nbp = b.planes[pi].nb_count;
     const uint32_t  n = plane_nodes(b, pi);
@@ -646,6 +660,8 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
     const uint32_t *aux = b.na.aux + b.planes[pi].node_base;       // (constant here: plain loads)
     uint32_t       *arr = b.na.arr + b.planes[pi].node_base;
     const int       lane = threadIdx.x & 63;
+    WaveTab        &tab = s_tab[threadIdx.x >> 6];
+    wtab_clear(tab, lane); wtab_clear(tab, lane + 64);
     for (uint32_t x0 = bi * blockDim.x + (threadIdx.x & ~63u); x0 < n; x0 += nbp * blockDim.x) {
         const uint32_t x = x0 + lane;
         bool     act = false;
@@ -660,25 +676,23 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
                 nd &= NODE_CNT;
             }
         }
-        // first step: lanes of the wave that share a parent combine (ballot + butterfly): one set of atomics and one
-        // decrement per distinct parent and wave -- the background node of a tile has hundreds of such children
+        // first step: the lanes of the wave that share a parent combine in the wave's table (above): one set of atomics and one arrival per
+        // distinct parent and wave -- the background node of a plane has thousands of such children --, all parents of the wave side by side
         bool cont = false;
-        unsigned long long todo = __ballot(act);
-        while (todo) {
-            const int      leader = __ffsll((long long)todo) - 1;
-            const uint32_t lq = __shfl(q, leader);
-            const bool     mine = act && q == lq;
-            const unsigned long long m = __ballot(mine);
-            const uint32_t k = (uint32_t)__popcll(m);
-            if (k == 1) {
-                if (mine) { const uint32_t ex = aux[lq]; cont = node_arrive(&arr[lq], ex, 1u, node_push(nr + lq, c, nd, bx0, by0, bx1, by1)); }
-            } else {
-                const uint32_t sc = wave_sum(mine ? c : 0u), sn = wave_sum(mine ? nd : 0u);
-                const uint32_t mx0 = wave_min(mine ? bx0 : 0xFFFFFFFFu), my0 = wave_min(mine ? by0 : 0xFFFFFFFFu);
-                const uint32_t mx1 = wave_max(mine ? bx1 : 0u), my1 = wave_max(mine ? by1 : 0u);
-                if (lane == leader) { const uint32_t ex = aux[lq]; cont = node_arrive(&arr[lq], ex, k, node_push(nr + lq, sc, sn, mx0, my0, mx1, my1)); }
+        if (act) {
+            uint32_t       k = 1;
+            const uint32_t h = wtab_hash(q);
+            const uint32_t old = atomicCAS(&tab.key[h], NONE, q);
+            if (old == NONE || old == q) {
+                atomicAdd(&tab.c[h], c); atomicAdd(&tab.nd[h], nd);
+                atomicMin(&tab.x0[h], bx0); atomicMin(&tab.y0[h], by0); atomicMax(&tab.x1[h], bx1); atomicMax(&tab.y1[h], by1);
+                atomicAdd(&tab.k[h], 1u);
+                if (old == NONE) {
+                    c = tab.c[h]; nd = tab.nd[h]; bx0 = tab.x0[h]; by0 = tab.y0[h]; bx1 = tab.x1[h]; by1 = tab.y1[h]; k = tab.k[h];
+                    wtab_clear(tab, (int)h);
+                } else k = 0;                    // (the owner pushes this lane's share)
             }
-            todo &= ~m;
+            if (k) { const uint32_t ex = aux[q]; cont = node_arrive(&arr[q], ex, k, node_push(nr + q, c, nd, bx0, by0, bx1, by1)); }
         }
         // the lanes that now own a parent carry it upward
         uint32_t g = q;

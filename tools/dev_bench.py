@@ -12,7 +12,7 @@ def main():
     kind = sys.argv[2] if len(sys.argv) > 2 else 'text'
     levels = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     mask = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0x3F
-    W, H = 1920, 1080
+    W, H = int(os.environ.get('DEV_W', 1920)), int(os.environ.get('DEV_H', 1080))
     tmp = tempfile.mkdtemp()
     sp, wp = S.cascade_io.write_golden(tmp)
     f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=F, n_pyr_levels=levels, channel_mask=mask))
