@@ -678,9 +678,9 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
         }
         // first step: the lanes of the wave that share a parent combine in the wave's table (above): one set of atomics and one arrival per
         // distinct parent and wave -- the background node of a plane has thousands of such children --, all parents of the wave side by side
-        bool cont = false;
+        uint32_t k = 0;
         if (act) {
-            uint32_t       k = 1;
+            k = 1;
             const uint32_t h = wtab_hash(q);
             const uint32_t old = atomicCAS(&tab.key[h], NONE, q);
             if (old == NONE || old == q) {
@@ -692,19 +692,37 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
                     wtab_clear(tab, (int)h);
                 } else k = 0;                    // (the owner pushes this lane's share)
             }
-            if (k) { const uint32_t ex = aux[q]; cont = node_arrive(&arr[q], ex, k, node_push(nr + q, c, nd, bx0, by0, bx1, by1)); }
         }
-        // the lanes that now own a parent carry it upward
-        uint32_t g = q;
-        while (cont) {
-            const uint32_t w = nr[g].par;                                  // (final since k_resolve, like the flags)
-            uint32_t gc, gf, gx0, gy0, gx1, gy1;
-            node_totals(nr + g, gc, gf, gx0, gy0, gx1, gy1);
-            if (w == NONE || (gf & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
-            const uint32_t p = PAR_ID(w);
-            const uint32_t ex = aux[p];
-            cont = node_arrive(&arr[p], ex, 1u, node_push(nr + p, gc, gf & NODE_CNT, gx0, gy0, gx1, gy1));
-            g = p;
+        // The lane carries (c, nd, box) -- the totals of k children -- into node g and, whenever that completes g, on towards the root.
+        // A node that waits for exactly the children the lane brings (k of k: every node with ONE pushing child, most of a text-like tree) is
+        // completed without any atomic: nobody else writes its record, so its totals are its own statistics (a plain load, requested a step ahead
+        // together with its child count) plus what the lane carries, stored back as they are -- one trip to memory per level of such a chain
+        // instead of three (push, arrival, totals).  Timing-only builds: the upward walks were 107 of the kernel's 165 us on one 1080p frame.
+        if (k) {
+            uint32_t g = q;
+            uint32_t ex = aux[g];
+            NodeRec  rec = nr[g];                // (par and flags are final since k_resolve; cnt / nod / box only used where nobody else pushes into g)
+            for (;;) {
+                const uint32_t w = rec.par;
+                const uint32_t gn = w != NONE ? PAR_ID(w) : g;
+                const uint32_t ex_n = aux[gn];   // the next node's, requested before this one's atomics are waited for
+                const NodeRec  rec_n = nr[gn];
+                if (ex == k) {
+                    c += rec.cnt; nd += rec.nod & NODE_CNT;
+                    bx0 = min(bx0, rec.x0); by0 = min(by0, rec.y0); bx1 = max(bx1, rec.x1); by1 = max(by1, rec.y1);
+                    unsigned long long *d = reinterpret_cast<unsigned long long *>(__builtin_assume_aligned(&nr[g].cnt, 8));
+                    d[0] = (unsigned long long)c | ((unsigned long long)((rec.nod & ~NODE_CNT) | nd) << 32);
+                    d[1] = (unsigned long long)bx0 | ((unsigned long long)by0 << 32);
+                    d[2] = (unsigned long long)bx1 | ((unsigned long long)by1 << 32);
+                } else {
+                    if (!node_arrive(&arr[g], ex, k, node_push(nr + g, c, nd, bx0, by0, bx1, by1))) break;
+                    if (w == NONE) break;
+                    node_totals(nr + g, c, nd, bx0, by0, bx1, by1);
+                    nd &= NODE_CNT;
+                }
+                if (w == NONE || (rec.nod & (NODE_DEAD | NODE_CLOSED))) break;       // a tree root (or a node that never pushes)
+                g = gn; ex = ex_n; rec = rec_n; k = 1;
+            }
         }
     }
 }

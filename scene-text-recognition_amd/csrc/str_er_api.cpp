@@ -601,15 +601,19 @@ int upload_layout(str_er_ctx *c, Batch &b)
     {   // workgroups of the per-record kernels: by plane size, the largest plane node_blocks of them
         size_t most_tiles = 1;
         for (const PlaneDesc &pd : b.planes) most_tiles = std::max(most_tiles, (size_t)pd.tiles_x * pd.tiles_y);
-        const uint32_t nb = std::min<uint32_t>(std::max<uint32_t>(c->node_blocks, 1u), 32u);
-        uint32_t at = 0;
-        for (PlaneDesc &pd : b.planes) {
-            const size_t t = (size_t)pd.tiles_x * pd.tiles_y;
-            pd.nb_count = (uint8_t)std::max<size_t>(1, (t * nb + most_tiles - 1) / most_tiles);
-            pd.nb_base = at;
-            at += pd.nb_count;
+        uint32_t nb = std::min<uint32_t>(std::max<uint32_t>(c->node_blocks, 1u), 255u);
+        for (;;) {
+            uint32_t at = 0;
+            for (PlaneDesc &pd : b.planes) {
+                const size_t t = (size_t)pd.tiles_x * pd.tiles_y;
+                pd.nb_count = (uint8_t)std::max<size_t>(1, (t * nb + most_tiles - 1) / most_tiles);
+                pd.nb_base = at;
+                at += pd.nb_count;
+            }
+            c->n_node_blocks = at;
+            if (at <= (size_t)c->max_planes * str_er_ctx::NB_PLANE_SHARE || nb == 1) break;        // (the workgroup -> plane table holds NB_PLANE_SHARE entries a plane)
+            nb = std::max<uint32_t>(1, nb / 2);
         }
-        c->n_node_blocks = at;
     }
     // (the descriptors of a video's frames are the same call after call -- planes in the context's own pool, same shares of the tables: uploaded when they change)
     if (c->planes_on_device != np || std::memcmp(c->h_planes, b.planes.data(), sizeof(PlaneDesc) * np) != 0) {
@@ -983,10 +987,16 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         uint32_t most = 0;
         for (int i = 0; i < np; ++i) most = std::max(most, c->h_ctr[i].n_nodes);
         // (more lanes than this in flight only queue up behind the same hot parent words: measured on noise, 256 workgroups per
-        // plane made k_resolve 4x slower than 12, 32 10 % slower; text-like batches -- the ones the small tile kernel runs on -- are
-        // fastest with 24: resolve + accumulate 1.42 -> 1.26 ms per 48 frames against 12, and slower again with 48)
-        const uint32_t cap = c->node_blocks_cap ? c->node_blocks_cap : (c->tile_sparse ? 24u : 12u);
-        c->node_blocks = std::min<uint32_t>(cap, std::max<uint32_t>(4, (most + 255) / 256));
+        // plane made k_resolve 4x slower than 12, 32 10 % slower; text-like batches -- the ones the small tile kernel runs on -- were
+        // fastest with 24 while the kernels combined a wave's targets in a loop.  Round 6, with the per-wave tables: a batch of a thousand planes does not care
+        // (24 / 48 / 96: resolve + accumulate 0.43 / 0.41 / 0.43 ms), but a wave of k_reduce walks its chains towards the root one sweep step after the other, so
+        // a call of a frame or two wants its few big planes spread over many waves (one 1080p frame: accumulate 117 / 72 / 73 us, resolve 36 / 28 / 22) and a 4K
+        // batch a little (accumulate 0.45 / 0.39 / 0.33, resolve 0.26 / 0.29 / 0.32 -- more waves, less combining))
+        const uint32_t cap = c->node_blocks_cap ? c->node_blocks_cap : (c->tile_sparse ? (np <= 96 ? 96u : 48u) : 12u);
+        // (in powers of two: the number is part of the layout key, and a video whose frames ask for 79, 98, 85 ... would upload its tables again call after call)
+        uint32_t want = 4;
+        while (want < (most + 255) / 256 && want < 256u) want *= 2;
+        c->node_blocks = std::min<uint32_t>(cap, want);
     }
     if (c->tile_mode == 0 && b.n_tiles) {      // text-like frames make a few dozen nodes per tile, noise several hundred
         unsigned long long created = 0;
@@ -1438,7 +1448,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_plane, c->tile_slots)); A(dev_alloc(c, c->d_sb_plane, c->sb_slots)); A(dev_alloc(c, c->d_sb_first, c->sb_slots));
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
     A(dev_alloc(c, c->d_t1_list, c->tile_slots)); A(dev_alloc(c, c->d_t2_pairs, c->tile_slots)); A(dev_alloc(c, c->d_fb_list, c->tile_slots));
-    A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * 32));
+    A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * str_er_ctx::NB_PLANE_SHARE));
     A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     {   // what a batch starts from zero -- the candidate / handed-back-tile counters, the plane counters, the groups' done flags -- is ONE block: one

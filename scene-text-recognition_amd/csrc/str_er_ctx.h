@@ -88,6 +88,8 @@ struct str_er_ctx {
     std::vector<int> chans;          // channel indices selected by the mask
     size_t slots = 0;                // node slots (== plane pixels) the workspace can hold
     int max_planes = 0;
+    static constexpr size_t NB_PLANE_SHARE = 64;     // entries of the workgroup -> plane table (d_nb_plane) per plane of the capacity
+
     int kept_cap = 0, pool_cap = 0;   // per plane: the most a plane may get
     bool auto_caps = true;            // (neither was given: every plane gets a share of the tables by its pixel count)
     double kept_share = 1.0 / 64, pool_share = 1.0 / 256;   // ... kept nodes / pooled ERs per padded pixel; grown -- and the batch repeated -- on overflow
