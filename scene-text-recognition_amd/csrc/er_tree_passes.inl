@@ -363,6 +363,9 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
     if (mine) { const uint32_t at = atomicAdd(&s_n, 1u); s_pa[at] = na; s_pb[at] = nbn; }
     __syncthreads();
     if (threadIdx.x >= s_n) return;
+#ifdef STR_ER_ABL_SEAM
+    return;
+#endif
     node_connect(b.na.rec + pd.node_base, s_pa[threadIdx.x], s_pb[threadIdx.x]);
 }
 

@@ -31,12 +31,13 @@
 #include <vector>
 
 struct str_er_stream {
+    static constexpr int MAX_UPLOAD_STREAMS = 4;
     struct Slot {
         str_er_ctx *ctx = nullptr;
         uint8_t    *pinned = nullptr;
         uint8_t    *d_in = nullptr;        // the batch's frames on the device (upload target)
-        hipStream_t copy = nullptr, copy2 = nullptr;        // the upload's streams: the two halves of a batch travel side by side (one DMA engine each)
-        hipEvent_t  landed = nullptr, landed2 = nullptr;
+        hipStream_t copy[MAX_UPLOAD_STREAMS] = {};          // the upload's streams: the parts of a batch travel side by side (one DMA engine each)
+        hipEvent_t  landed[MAX_UPLOAD_STREAMS] = {};
         // job
         bool     busy = false, has_job = false, done = false;
         int32_t  w = 0, h = 0, n_frames = 0;
@@ -57,9 +58,9 @@ struct str_er_stream {
     std::deque<int> order;       // slots in submission order, oldest first
     uint64_t next_ticket = 1;
     uint64_t upload_turn = 1;    // ticket of the batch whose upload is enqueued next
-    hipEvent_t last_landed = nullptr, last_landed2 = nullptr;      // events of the upload enqueued last (touched by the worker whose turn it is)
+    hipEvent_t last_landed[MAX_UPLOAD_STREAMS] = {};               // events of the upload enqueued last (touched by the worker whose turn it is)
     size_t   upload_piece = (size_t)1 << 40;       // (developer knob STR_ER_UPLOAD_PIECE_MB: the upload in pieces; 4 / 16 MB made no difference that stands out of the run-to-run scatter)
-    int      upload_streams = 2;                   // (developer knob STR_ER_UPLOAD_STREAMS = 1: the whole batch through one copy stream, as in rounds 4 and 5)
+    int      upload_streams = 2;                   // (developer knob STR_ER_UPLOAD_STREAMS = 1 .. 4; 1: the whole batch through one copy stream, as in rounds 4 and 5)
     bool     stop = false;
     std::string err;
 };
@@ -89,7 +90,7 @@ void worker_main(str_er_stream *s, int idx)
                 s->cv.wait(lk, [&] { return s->upload_turn == sl.ticket; });
             }
             hipError_t e = hipSuccess;
-            size_t     half = bytes;
+            int        parts = 1;
             {
                 // (the turn passes on as soon as this upload is ENQUEUED: the next one is ordered behind it on the device -- its streams wait for this one's
                 // events -- so the link never idles while a worker thread wakes up; round 5 passed the turn when the bytes had landed: ~0.2 ms of an idle
@@ -99,23 +100,24 @@ void worker_main(str_er_stream *s, int idx)
                     ~TurnGuard() { { std::lock_guard<std::mutex> lk(s->mu); s->upload_turn = next; } s->cv.notify_all(); }
                 } pass_on{s, sl.ticket + 1};
                 const size_t piece = s->upload_piece;
-                // two halves on two streams: a copy stream is served by one DMA engine, which alone does not fill the link
-                half = s->upload_streams > 1 && bytes >= ((size_t)8 << 20) ? ((bytes / 2 + 4095) & ~(size_t)4095) : bytes;
-                for (hipEvent_t prev : {s->last_landed, s->last_landed2})
-                    if (prev && e == hipSuccess) { e = hipStreamWaitEvent(sl.copy, prev, 0); if (e == hipSuccess && half < bytes) e = hipStreamWaitEvent(sl.copy2, prev, 0); }
-                for (size_t at = 0; at < half && e == hipSuccess; at += piece)
-                    e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, half - at), hipMemcpyHostToDevice, sl.copy);
-                for (size_t at = half; at < bytes && e == hipSuccess; at += piece)
-                    e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, bytes - at), hipMemcpyHostToDevice, sl.copy2);
-                if (e == hipSuccess) e = hipEventRecord(sl.landed, sl.copy);
-                if (e == hipSuccess && half < bytes) e = hipEventRecord(sl.landed2, sl.copy2);
-                s->last_landed = e == hipSuccess ? sl.landed : nullptr;
-                s->last_landed2 = e == hipSuccess && half < bytes ? sl.landed2 : nullptr;
+                // the batch in parts on as many streams: a copy stream is served by one DMA engine, which alone does not fill the link
+                parts = bytes >= ((size_t)8 << 20) ? std::max(1, std::min(s->upload_streams, (int)str_er_stream::MAX_UPLOAD_STREAMS)) : 1;
+                const size_t part = ((bytes / (size_t)parts + 4095) & ~(size_t)4095);
+                for (int k = 0; k < str_er_stream::MAX_UPLOAD_STREAMS; ++k)
+                    if (s->last_landed[k])
+                        for (int j = 0; j < parts && e == hipSuccess; ++j) e = hipStreamWaitEvent(sl.copy[j], s->last_landed[k], 0);
+                for (int j = 0; j < parts; ++j) {
+                    const size_t lo = std::min(bytes, (size_t)j * part), hi = j + 1 == parts ? bytes : std::min(bytes, (size_t)(j + 1) * part);
+                    for (size_t at = lo; at < hi && e == hipSuccess; at += piece)
+                        e = hipMemcpyAsync(sl.d_in + at, sl.pinned + at, std::min(piece, hi - at), hipMemcpyHostToDevice, sl.copy[j]);
+                    if (e == hipSuccess) e = hipEventRecord(sl.landed[j], sl.copy[j]);
+                }
+                for (int k = 0; k < str_er_stream::MAX_UPLOAD_STREAMS; ++k) s->last_landed[k] = e == hipSuccess && k < parts ? sl.landed[k] : nullptr;
             }
             // (poll, then sleep between polls: a spinning wait per slot would keep `depth` host cores busy)
             for (int spins = 0; e == hipSuccess;) {
-                hipError_t q = hipEventQuery(sl.landed);
-                if (q == hipSuccess && half < bytes) q = hipEventQuery(sl.landed2);
+                hipError_t q = hipSuccess;
+                for (int j = 0; j < parts && q == hipSuccess; ++j) q = hipEventQuery(sl.landed[j]);
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) { e = q; break; }
                 if (++spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -156,7 +158,7 @@ try {
     str_er_stream *s = new (std::nothrow) str_er_stream();
     if (!s) return STR_ER_ENOMEM;
     s->device = p->device;
-    if (const char *e = std::getenv("STR_ER_UPLOAD_STREAMS")) s->upload_streams = std::atoi(e) > 1 ? 2 : 1;
+    if (const char *e = std::getenv("STR_ER_UPLOAD_STREAMS")) s->upload_streams = std::max(1, std::min(std::atoi(e), (int)str_er_stream::MAX_UPLOAD_STREAMS));
     if (const char *e = std::getenv("STR_ER_UPLOAD_PIECE_MB")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) s->upload_piece = (size_t)v << 20; }
     s->slot_bytes = (size_t)p->max_frames * (size_t)p->max_width * (size_t)p->max_height * 3;
     s->slots.resize((size_t)depth);
@@ -169,20 +171,17 @@ try {
             rc = STR_ER_ENOMEM;
         if (rc == STR_ER_OK && (hipSetDevice(p->device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&s->slots[(size_t)i].d_in), s->slot_bytes) != hipSuccess))
             rc = STR_ER_ENOMEM;
-        if (rc == STR_ER_OK && (hipStreamCreateWithFlags(&s->slots[(size_t)i].copy, hipStreamNonBlocking) != hipSuccess ||
-                                hipStreamCreateWithFlags(&s->slots[(size_t)i].copy2, hipStreamNonBlocking) != hipSuccess ||
-                                hipEventCreateWithFlags(&s->slots[(size_t)i].landed2, hipEventDisableTiming) != hipSuccess ||
-                                hipEventCreateWithFlags(&s->slots[(size_t)i].landed, hipEventDisableTiming) != hipSuccess))
-            rc = STR_ER_EHIP;
+        for (int k = 0; k < str_er_stream::MAX_UPLOAD_STREAMS && rc == STR_ER_OK; ++k)
+            if (k < s->upload_streams && (hipStreamCreateWithFlags(&s->slots[(size_t)i].copy[k], hipStreamNonBlocking) != hipSuccess ||
+                                          hipEventCreateWithFlags(&s->slots[(size_t)i].landed[k], hipEventDisableTiming) != hipSuccess))
+                rc = STR_ER_EHIP;
     }
     if (rc != STR_ER_OK) {
         for (auto &sl : s->slots) {
             if (sl.pinned) (void)hipHostFree(sl.pinned);
             if (sl.d_in) (void)hipFree(sl.d_in);
-            if (sl.landed) (void)hipEventDestroy(sl.landed);
-            if (sl.landed2) (void)hipEventDestroy(sl.landed2);
-            if (sl.copy) (void)hipStreamDestroy(sl.copy);
-            if (sl.copy2) (void)hipStreamDestroy(sl.copy2);
+            for (hipEvent_t ev : sl.landed) if (ev) (void)hipEventDestroy(ev);
+            for (hipStream_t cs : sl.copy) if (cs) (void)hipStreamDestroy(cs);
             if (sl.ctx) str_er_destroy(sl.ctx);
         }
         delete s;
@@ -206,10 +205,8 @@ void str_er_stream_destroy(str_er_stream *s)
         if (sl.result) str_er_result_free(sl.result);
         if (sl.pinned) (void)hipHostFree(sl.pinned);
         if (sl.d_in) (void)hipFree(sl.d_in);
-        if (sl.landed) (void)hipEventDestroy(sl.landed);
-        if (sl.landed2) (void)hipEventDestroy(sl.landed2);
-        if (sl.copy) (void)hipStreamDestroy(sl.copy);
-        if (sl.copy2) (void)hipStreamDestroy(sl.copy2);
+        for (hipEvent_t ev : sl.landed) if (ev) (void)hipEventDestroy(ev);
+        for (hipStream_t cs : sl.copy) if (cs) (void)hipStreamDestroy(cs);
         if (sl.ctx) str_er_destroy(sl.ctx);
     }
     delete s;
