@@ -511,6 +511,11 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // target becomes its owner, lanes whose slot belongs to another target keep their contribution to themselves), add into it with LDS atomics, the
 // owners read the sums back, clear the slot and issue the global atomics -- owners and loners side by side in ONE set of instructions.  No barriers:
 // a wave's LDS operations are carried out in program order.
+#ifdef STR_ER_HOTSTAT
+// developer counters (tools/dev_hotstat.py): pieces handed to one survivor, children pushed into one parent
+__device__ uint32_t g_hand[1u << 23];
+__device__ uint32_t g_hotstat[16];
+#endif
 constexpr int WTAB = 128;
 struct WaveTab {
     uint32_t key[WTAB];                       // target record (plane-local id), NONE: free
@@ -576,6 +581,9 @@ __global__ __launch_bounds__(256) void k_resolve(BatchDev b)
         // (a record hands over or counts, never both; a target may be handed to by some lanes and counted into by others: one slot)
         const bool     hands = hand_to != NONE;
         const uint32_t tgt = hands ? hand_to : push_to;
+#ifdef STR_ER_HOTSTAT
+        if (hands) atomicAdd(&g_hand[(b.planes[pi].node_base + hand_to) & ((1u << 23) - 1u)], 1u);
+#endif
         uint32_t       kk = push_to != NONE ? 1u : 0u;
         if (tgt != NONE) {
             const uint32_t h = wtab_hash(tgt);
@@ -673,6 +681,18 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
             const uint32_t w = nr[x].par, f = nr[x].nod;          // parent and flags are final since k_resolve
             // (a node nobody pushes into is ready; the others are taken by their last child)
             act = w != NONE && !(f & (NODE_DEAD | NODE_CLOSED)) && aux[x] == 0u;
+#ifdef STR_ER_HOTSTAT
+            {
+                const uint32_t hd = g_hand[(b.planes[pi].node_base + x) & ((1u << 23) - 1u)], ch = aux[x];
+                g_hand[(b.planes[pi].node_base + x) & ((1u << 23) - 1u)] = 0;
+                if (hd) { atomicMax(&g_hotstat[0], hd); atomicAdd(&g_hotstat[1], hd); if (hd >= 16) atomicAdd(&g_hotstat[2], 1u); if (hd >= 128) atomicAdd(&g_hotstat[3], 1u); atomicAdd(&g_hotstat[9], 1u); }
+                if (ch) { atomicMax(&g_hotstat[4], ch); atomicAdd(&g_hotstat[5], ch); if (ch >= 16) atomicAdd(&g_hotstat[6], 1u); if (ch >= 128) atomicAdd(&g_hotstat[7], 1u); if (ch >= 1024) atomicAdd(&g_hotstat[8], 1u); atomicAdd(&g_hotstat[10], 1u); }
+                atomicAdd(&g_hotstat[11], 1u);
+                if (hd >= 16) atomicAdd(&g_hotstat[12], hd);
+                if (ch >= 16) atomicAdd(&g_hotstat[13], ch);
+                if (ch == 1) atomicAdd(&g_hotstat[14], 1u);
+            }
+#endif
             if (act) {
                 q = PAR_ID(w);
                 node_totals(nr + x, c, nd, bx0, by0, bx1, by1);
@@ -730,6 +750,14 @@ __global__ __launch_bounds__(256) void k_reduce(BatchDev b)
     }
 }
 
+#ifdef STR_ER_HOTSTAT
+extern "C" __attribute__((visibility("default"))) int str_er_debug_hotstat(uint32_t *out)
+{
+    uint32_t z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hotstat), sizeof z) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_hotstat), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 void launch_reduce(hipStream_t s, const BatchDev &b)
 {
     if (!b.n_planes) return;

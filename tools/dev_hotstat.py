@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer aid (GPU box; library built with -DSTR_ER_HOTSTAT): how many pieces hand over to one survivor (k_resolve) and how many children push into one parent
-(k_reduce) -- the hot records of the tree passes.  Usage: STR_ER_LIB=.../hotstat.so python tools/dev_hotstat.py F W H levels"""
+(k_reduce) -- the hot records of the tree passes.  Usage: tools/dev_build_var.sh hotstat -DSTR_ER_HOTSTAT; STR_ER_LIB=.../lib/var/hotstat.so python tools/dev_hotstat.py F W H levels"""
 import os, sys, ctypes, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,4 +23,4 @@ for it in range(3):
 v = list(out)
 print(f"{F} x {W}x{H} x {L} levels: records {v[11]}")
 print(f"  hand-overs: {v[1]} pieces to {v[9]} survivors, max {v[0]} to one; survivors with >=16 pieces: {v[2]} (they take {v[12]} pieces), >=128: {v[3]}")
-print(f"  pushes: {v[5]} children into {v[10]} parents, max {v[4]} into one; parents with >=16 children: {v[6]} (they take {v[13]} children), >=128: {v[7]}, >=1024: {v[8]}")
+print(f"  pushes: {v[5]} children into {v[10]} parents, max {v[4]} into one; parents with exactly one: {v[14]}, with >=16 children: {v[6]} (they take {v[13]} children), >=128: {v[7]}, >=1024: {v[8]}")
