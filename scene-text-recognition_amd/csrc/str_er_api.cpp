@@ -735,10 +735,17 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     c->wait_spin_us = (int)b_in.planes.size() <= SPEC_PLANES ? 2000 : 300;      // (for this call only: the guard puts the default back)
     Batch b = b_in;
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
-    // batches (small tile kernel: ~14 records per tile) take 4 x 4 tiles per group, noise-like ones (~250) 2 x 5.
+    // batches (small tile kernel: ~14 records per tile) take 8 x 4 tiles per group with room for 2048 records (a call of a frame or two: 4 x 4 with 1024),
+    // noise-like ones (~250 records per tile) 2 x 5.
+    // (Round 6, tools/dev_groups.sh: ALONE on the GPU the 4 x 4 / 1024-record kernel is the faster one -- 0.41 against 0.48 ms per 48-frame batch, 50 against 81 us
+    // per frame: 64 KB of LDS leave two workgroups a compute unit -- but with six batches in flight the larger groups win: 9.9-10.5 k -> 10.8-11.2 k frames/s on
+    // pyr3x8, +0.5 % on native6, +1 % at 4K.  The other batches' kernels fill what the group kernel leaves idle, and what it saves -- groups of the luma pyramid that
+    // no longer overflow the table and take the global passes whole, a third fewer records and pairs on the groups' outer borders -- are device-scope atomics, which
+    // the batches in flight share.)
     const bool grouped = !import_trees && c->group_mode != 0;
+    const bool big_groups = c->tile_sparse && (int)b_in.planes.size() > SPEC_PLANES;
     {
-        int gx = c->tile_sparse ? 4 : 2, gy = c->tile_sparse ? 4 : 5;       // (tools/dev_groups.sh: 4 x 4 tiles on text-like batches, 2 x 5 on noise)
+        int gx = c->tile_sparse ? (big_groups ? 8 : 4) : 2, gy = c->tile_sparse ? 4 : 5;
         if (c->dbg_group[0] > 0) { gx = c->dbg_group[0]; gy = c->dbg_group[1]; }
         if (grouped) assign_groups(b, gx, gy); else assign_groups(b, 0, 0);
     }
@@ -799,7 +806,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
     if (grouped && b.n_groups) {
-        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 2 : 6));       // (measured, tools/dev_groups.sh)
+        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? (big_groups ? 4 : 2) : 6));       // (measured, tools/dev_groups.sh)
     }
     rec(c, "group");
     if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
