@@ -298,7 +298,8 @@ def main():
                          "frames_per_gpu_per_step counts all of them).  A region of 20 single-batch steps is 0.1 s, which one box-to-box hiccup moves by 10 %%")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region of --steps steps is run this many times; `value` is the median region")
     ap.add_argument("--frames-per-gpu", type=int, default=None,
-                    help="frames per batch (= per step) and GPU; 48-64 amortise the per-batch launch latencies best (32 or 96: about 7 %% slower); default 48 (12 for --size 4k)")
+                    help="frames per batch (= per step) and GPU; default 32 for pyr3x8 (round 6, six batches in flight: 16 / 24 / 32 / 40 / 48 frames -> 12.0 / 12.5 / 12.6 / 10.4 / 11.1-11.3 k frames/s; "
+                         "until round 5 48-64 were best), 48 for native6 (15.8 k against 15.3 k with 32), 12 for --size 4k (8: -1 %%)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
     ap.add_argument("--size", choices=["1080p", "4k"], default="1080p",
                     help="frame size: 1080p = 1920x1080 (the metric's), 4k = 3840x2160 with the 12-level pyramid (BASELINE configs[4]; 12 frames per batch by default)")
@@ -333,7 +334,7 @@ def main():
     if args.workload is None:
         args.workload = "pyr3x12" if args.size == "4k" else "pyr3x8"
     if args.frames_per_gpu is None:
-        args.frames_per_gpu = 12 if args.size == "4k" else 48
+        args.frames_per_gpu = 12 if args.size == "4k" else (32 if args.workload == "pyr3x8" else 48)
 
     # (torch first: it brings its own HIP runtime, which the library must share -- loaded the other way round the process has two)
     import torch
@@ -579,7 +580,7 @@ def main():
         del d_ties
 
     # latency leg: ONE frame per call, one batch in flight (north_star: ">= 500 fps end-to-end on 1920x1080" is a
-    # per-frame statement; the headline `value` needs 48-frame batches x 6 in flight)
+    # per-frame statement; the headline `value` needs 32-frame batches x 6 in flight)
     def latency_leg(w, h, lcfg, frs, d_frs, lstages, with_svm):
         f1 = S.ERFilter(params=S.Params(max_width=w, max_height=h, max_frames=1, n_pyr_levels=lcfg["n_pyr_levels"],
                                         channel_mask=lcfg["channel_mask"], device=dev_index, sibling_order=args.sibling_order))
