@@ -61,7 +61,7 @@ with open(os.path.join(DST, f"{tag}_pmc_per_launch_pyr3x8.csv") if not PMC_JSON_
         w.writerow([d.get(c, "") if not isinstance(d.get(c), float) else f"{d[c]:.6g}" for c in cols])
 # 4. the number bench.py reads for roofline.traffic
 _cfg = {} if PMC_JSON_ONLY else json.load(open(os.path.join(DST, f"bench_{tag}_pyr3x8_text.json")))["config"]
-F = 48 if PMC_JSON_ONLY else _cfg.get("frames_per_batch", _cfg["frames_per_gpu_per_step"])
+F = 32 if PMC_JSON_ONLY else _cfg.get("frames_per_batch", _cfg["frames_per_gpu_per_step"])      # (json-only: bench.py's default batch on pyr3x8, which the counter passes ran)
 # (round 6: the tile trees of a batch are built by two kernels -- k_tile_tree2 on the chroma planes, k_tile_tree on the luma planes, k_tile_tree_fb on the
 # tiles the first hands back: their traffic is added up, like their times in bench.py's roofline)
 TILE_KERNELS = [k for k in ("k_tile_tree2", "k_tile_tree", "k_tile_tree_fb") if k in fetch]
@@ -96,7 +96,7 @@ if not PMC_JSON_ONLY:
         lines.append(f"| `bench_{tag}_{n}.json` | **{d['value']:.0f}** | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} | {r['achieved']:.1f} | {100 * r['frac']:.2f} % | "
                      f"{(d.get('latency_1frame') or {}).get('ms_per_frame', '-')} | {(d.get('pcie_inclusive') or {}).get('value', '-')} | {(d.get('cpu_baseline') or {}).get('value', '-')} |")
     d = json.load(open(os.path.join(DST, f"bench_{tag}_pyr3x8_text.json")))
-    lines += ["", "Per-kernel GPU time per 48-frame batch of pyr3x8, one batch in flight (HIP events, ms): " +
+    lines += ["", f"Per-kernel GPU time per {F}-frame batch of pyr3x8, one batch in flight (HIP events, ms): " +
               ", ".join(f"{k} {v:.2f}" for k, v in d["gpu_ms_per_step_by_kernel_group_serial"].items()) +
               f" (sum {sum(d['gpu_ms_per_step_by_kernel_group_serial'].values()):.2f}; the timed region, six batches overlapping, needs {d['ms_per_step'] / d['config'].get('batches_per_step', 1):.2f} ms per batch).", ""]
     st = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(DST, f"{tag}_kernel_stats_pyr3x8.csv")))}
