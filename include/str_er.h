@@ -212,6 +212,14 @@ int  str_er_tile2_stats(const str_er_ctx *ctx, uint64_t *tiles, uint64_t *handed
 int  str_er_ocr_stage_stats(const str_er_ctx *ctx, uint64_t *scored_early, uint64_t *scored_again);
 const char *str_er_runtime_hint(void);
 int  str_er_apply_runtime_hint(void);
+/* Several contexts of a process keep batches in flight on one GPU (bench.py: six).  The GPU shares itself evenly among their kernels, so equal batches
+ * that started together finish together -- and then all wait together for whatever their host side does next (the flood order walk of an NMS sibling tie,
+ * about 5 ms for a 1080p plane: src/ER.cpp:416-505 depends on the flood's order), with the GPU idle meanwhile: a trace of six 48-frame batches in flight
+ * showed no kernel running for 14 % of the time.  With n > 0, at most n detect calls of the process have their batch's kernels on the GPU at a time: a
+ * call takes a slot before it enqueues and gives it back when its kernels are done, BEFORE the host-side work that follows, so the waiting calls' kernels
+ * run during that work.  Calls of a frame or two (<= 96 planes) do not take part.  n = 0 (the default): no limit.  Process-wide; returns the old value.
+ * A scheduling aid only: results do not depend on it.  (No reference counterpart: text_detect is one frame at a time.) */
+int  str_er_set_batch_slots(int n);
 
 /* ERFilter::set_thresh_step / set_min_area (src/ER.cpp:21-30) */
 int str_er_set_thresh_step(str_er_ctx *ctx, int32_t t);

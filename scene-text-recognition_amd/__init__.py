@@ -14,7 +14,7 @@ from __future__ import annotations
 
 from .binding import (  # noqa: F401
     CLS_POOL, CLS_STRONG, CLS_WEAK, STAGE_ALL, STAGE_CLASSIFY, STAGE_OCR, STAGE_EXTRACT, STAGE_NMS, STAGE_TRACK, STAGE_GROUP, GROUP_INNER_SUP, GROUP_OVERLAP_SUP, STAGE_OCR_LINES, TRACK_DTYPE, TEXT_DTYPE, GBOUND_DTYPE, WANT_NODES,
-    CAND_DTYPE, NODE_DTYPE, PLANE_DTYPE, ERFilter, FrameStream, PlaneResult, Params, Result, StrErError, apply_runtime_hint, lib_path, load_library,
+    CAND_DTYPE, NODE_DTYPE, PLANE_DTYPE, ERFilter, FrameStream, PlaneResult, Params, Result, StrErError, apply_runtime_hint, set_batch_slots, lib_path, load_library,
     flood_order, Comm,
 )
 from . import cascade_io, synth  # noqa: F401

@@ -218,6 +218,11 @@ def load_library():
     return L
 
 
+def set_batch_slots(n: int) -> int:
+    """At most n detect calls of the process have their batch's kernels on the GPU at a time (0: no limit); include/str_er.h."""
+    return int(load_library().str_er_set_batch_slots(int(n)))
+
+
 def apply_runtime_hint() -> int:
     """Opt in to the HIP runtime settings the library recommends (str_er_runtime_hint(): more hardware queues).  Only
     effective before the process's first HIP call (e.g. before torch.cuda is initialised); importing the package does

@@ -6,6 +6,8 @@
 // counters and the packed candidate records.  No computation of the path happens on the
 // host; if the device or a kernel fails the call fails (there is no CPU fallback).
 #include "str_er_ctx.h"
+#include <condition_variable>
+#include <mutex>
 
 thread_local std::string g_create_error;
 
@@ -724,6 +726,29 @@ static int ocr_stage(str_er_ctx *c, const BatchDev &bd, size_t cap, hipStream_t 
     return STR_ER_OK;
 }
 
+// str_er_set_batch_slots (include/str_er.h): at most g_slot_cap large batches have their kernels on the GPU at a time
+static std::mutex              g_slot_mu;
+static std::condition_variable g_slot_cv;
+static int                     g_slot_cap = 0, g_slot_used = 0;
+struct BatchSlot {
+    bool held = false;
+    void take()
+    {
+        std::unique_lock<std::mutex> lk(g_slot_mu);
+        if (g_slot_cap <= 0) return;
+        g_slot_cv.wait(lk, [] { return g_slot_cap <= 0 || g_slot_used < g_slot_cap; });
+        if (g_slot_cap > 0) { ++g_slot_used; held = true; }
+    }
+    void give()
+    {
+        if (!held) return;
+        { std::lock_guard<std::mutex> lk(g_slot_mu); --g_slot_used; }
+        held = false;
+        g_slot_cv.notify_one();
+    }
+    ~BatchSlot() { give(); }
+};
+
 int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result **out,
               std::chrono::steady_clock::time_point t_start, bool pre_recorded, const ImportHook *import_trees, int attempt)
 {
@@ -734,6 +759,8 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     struct SpinGuard { str_er_ctx *c; int old; ~SpinGuard() { c->wait_spin_us = old; } } spin_guard{c, c->wait_spin_us};
     c->wait_spin_us = (int)b_in.planes.size() <= SPEC_PLANES ? 2000 : 300;      // (for this call only: the guard puts the default back)
     Batch b = b_in;
+    BatchSlot slot;                    // (str_er_set_batch_slots: given back when the batch's kernels are done, below, or on any way out)
+    if ((int)b_in.planes.size() > SPEC_PLANES) slot.take();
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
     // batches (small tile kernel: ~14 records per tile) take 8 x 4 tiles per group with room for 2048 records (a call of a frame or two: 4 x 4 with 1024),
     // noise-like ones (~250 records per tile) 2 x 5.
@@ -865,6 +892,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         HIP_TRY(c, hipMemcpyAsync(c->h_zero, c->d_zero, 256 + sizeof(PlaneCtr) * np, hipMemcpyDeviceToHost, s));        // (counters of the batch + plane counters: one block)
     }
     HIP_TRY(c, wait_stream(c, s));
+    slot.give();                       // the batch's kernels are done: what follows on the host (counters, tie walks, results) leaves the GPU to the other calls
     if (c->n_t2_tiles && !import_trees) {     // tiles k_tile_tree2 handed back: if they are many, the chroma planes stay with k_tile_tree for a while
         const uint32_t fbn = c->h_total[1];
         c->t2_tiles_total += c->n_t2_tiles; c->t2_fb_total += fbn;
@@ -1278,6 +1306,14 @@ try {
 } ABI_GUARD(const_cast<str_er_ctx *>(c))
 
 const char *str_er_runtime_hint(void) { return "GPU_MAX_HW_QUEUES=16"; }
+int str_er_set_batch_slots(int n)
+{
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    const int old = g_slot_cap;
+    g_slot_cap = n > 0 ? n : 0;
+    g_slot_cv.notify_all();
+    return old;
+}
 int str_er_ocr_stage_stats(const str_er_ctx *c, uint64_t *scored_early, uint64_t *scored_again)
 {
     if (!c) return STR_ER_EINVAL;

@@ -64,3 +64,55 @@ def test_stream_matches_direct_calls(S, cascade_paths):
     st.submit_copy(batches[0], S.STAGE_ALL)
     assert st.next()[1].cands.tobytes() == ref.text_detect(batches[0]).cands.tobytes()
     st.close(); ref.close()
+
+
+def test_batch_slots_setting_round_trips(S):
+    """str_er_set_batch_slots (include/str_er.h) returns the previous value; 0 / negative = no limit (CPU: no HIP call involved)."""
+    old = S.set_batch_slots(3)
+    try:
+        assert S.set_batch_slots(-5) == 3
+        assert S.set_batch_slots(0) == 0
+    finally:
+        S.set_batch_slots(old)
+
+
+@pytest.mark.gpu
+def test_batch_slots_do_not_change_results_and_do_not_hang(S, cascade_paths):
+    """With one slot the large batches of four contexts take turns on the GPU (a call gives its slot back when its kernels are done, before its host-side work);
+    every call returns what the same call returns without the limit, an error inside a call gives the slot back, and calls of a frame or two never wait for one."""
+    import threading
+    W, H, F = 160, 120, 17                                  # 17 frames x 6 planes = 102 planes: a "large" batch (> 96 planes)
+    prm = S.Params(max_width=W, max_height=H, max_frames=F)
+    ctxs = []
+    for _ in range(4):
+        f = S.ERFilter(params=prm)
+        f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+        ctxs.append(f)
+    batches = [np.stack([S.synth.stext_bgr(S.synth.frame_seed(500 + 31 * b + i), W, H) for i in range(F)]) for b in range(4)]
+    expected = [ctxs[0].text_detect(b) for b in batches]
+    old = S.set_batch_slots(1)
+    try:
+        got = [[None] * 3 for _ in range(4)]
+
+        def work(p):
+            for k in range(3):
+                got[p][k] = ctxs[p].text_detect(batches[(p + k) % 4])
+        th = [threading.Thread(target=work, args=(p,)) for p in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in th), "a call is still waiting for a slot"
+        for p in range(4):
+            for k in range(3):
+                e = expected[(p + k) % 4]
+                assert got[p][k].cands.tobytes() == e.cands.tobytes() and len(e.cands) > 0
+                assert got[p][k].info.tobytes() == e.info.tobytes()
+        with pytest.raises(S.StrErError):                   # (no SVM model loaded: the call fails after it has taken its slot)
+            ctxs[1].text_detect(batches[0], S.STAGE_ALL | S.STAGE_OCR)
+        assert ctxs[2].text_detect(batches[1]).cands.tobytes() == expected[1].cands.tobytes()      # the slot came back
+        assert ctxs[3].text_detect(batches[2][:1]).cands.tobytes() == ctxs[0].text_detect(batches[2][:1]).cands.tobytes()
+    finally:
+        S.set_batch_slots(old)
+        for f in ctxs:
+            f.close()

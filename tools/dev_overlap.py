@@ -21,3 +21,17 @@ print("time by number of kernels running:", {k: f"{100*v/span:.1f}%" for k, v in
 names = collections.Counter()
 for s, e, n in ev: names[n] += e - s
 for n, v in names.most_common(12): print(f"  {n:40s} {v/1e6:8.2f} ms  {100*v/tot:5.1f} %")
+
+# the idle gaps (no kernel running): how long, and what ended before / started after the longest ones
+gaps = []
+end = None
+for st, en, n in sorted(ev):
+    if end is not None and st > end:
+        gaps.append((st - end, last_name, n, end))
+    if end is None or en > end:
+        end, last_name = en, n
+gaps.sort(reverse=True)
+tot_gap = sum(g[0] for g in gaps)
+print(f"idle gaps: {len(gaps)}, total {tot_gap/1e6:.2f} ms; >= 100 us: {sum(1 for g in gaps if g[0] >= 100e3)} ({sum(g[0] for g in gaps if g[0] >= 100e3)/1e6:.2f} ms), 20-100 us: {sum(1 for g in gaps if 20e3 <= g[0] < 100e3)} ({sum(g[0] for g in gaps if 20e3 <= g[0] < 100e3)/1e6:.2f} ms), < 20 us: {sum(1 for g in gaps if g[0] < 20e3)} ({sum(g[0] for g in gaps if g[0] < 20e3)/1e6:.2f} ms)")
+for g in gaps[:12]:
+    print(f"  {g[0]/1e3:8.1f} us after {g[1][:34]:34s} before {g[2][:34]}")
