@@ -22,7 +22,8 @@ struct BatchDev {
     uint32_t         n_seam_blocks;
     uint32_t        *tile_nbase; // plane-local id of every tile's first node record (NONE: the plane ran out of records)
     uint16_t        *tile_nrec;  // ... and how many records the tile has
-    uint8_t         *group_done; // per group of tiles: k_group_merge has joined its inner seams (k_seam skips them)
+    uint8_t         *group_done; // per group of tiles: k_group_merge has joined its inner seams
+    uint32_t        *undone_list, *undone_count;    // the groups k_group_merge left alone (too many records): their inner seams are joined by k_seam_undone
     const uint16_t  *group_plane; // plane of every group
     uint32_t         n_groups;   // batch-wide
     int32_t          group_x, group_y;   // tiles per group (0: no grouping in this batch)

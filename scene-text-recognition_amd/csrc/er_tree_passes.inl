@@ -52,7 +52,11 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     }
     __syncthreads();
     const uint32_t N = s_toff[nt];
-    if (N == NONE || N == 0) return;
+    if (N == NONE) {            // too many records for the table (or a tile without records of its own: an overflowing plane): left alone, and listed for k_seam_undone
+        if (tid == 0) b.undone_list[atomicAdd(b.undone_count, 1u)] = blockIdx.x;
+        return;
+    }
+    if (N == 0) return;
     GM_MARK(1);
     NodeRec *const nr = b.na.rec + pd.node_base;
     auto tile_of = [&](uint32_t i) -> int {         // (records are grouped by tile: the tile whose range holds local index i)
@@ -300,13 +304,14 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
         const uint16_t *seam = b.seam + pd.seam_base;
         const uint32_t *tnb = b.tile_nbase + pd.tile_base;
         uint32_t la, lb, ta, tb;
-        // (a seam inside a group of tiles that k_group_merge has put together is no seam any more)
-        const uint32_t GX = (uint32_t)b.group_x, GY = (uint32_t)b.group_y, groups_x = GX ? ((uint32_t)pd.tiles_x + GX - 1u) / GX : 0u;
+        // (a seam inside a group of tiles is not this kernel's: k_group_merge has joined it in LDS, or listed the group for k_seam_undone -- the host does
+        // not even launch workgroups for the pair ranges that hold inner seams only, launch_seam's table)
+        const uint32_t GX = (uint32_t)b.group_x, GY = (uint32_t)b.group_y;
         bool inner = false;
         if (i < pd.n_hpairs) {
             const uint32_t j = i / pd.w, x = i - j * pd.w;
             ta = j * pd.tiles_x + x / (uint32_t)TILE_W; tb = ta + pd.tiles_x;
-            if (GX && (j + 1u) % GY != 0u) inner = b.group_done[pd.group_base + (j / GY) * groups_x + (x / (uint32_t)TILE_W) / GX] != 0;
+            inner = GX && (j + 1u) % GY != 0u;
             la = lb = 0xFFFFu;
             if (!inner) {
                 la = seam[((size_t)j * 2) * pd.w + x];
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
             const uint32_t k = i2 / pd.h, y = i2 - k * pd.h;
             const size_t   voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
             ta = (y / (uint32_t)TILE_H) * pd.tiles_x + k; tb = ta + 1;
-            if (GX && (k + 1u) % GX != 0u) inner = b.group_done[pd.group_base + ((y / (uint32_t)TILE_H) / GY) * groups_x + k / GX] != 0;
+            inner = GX && (k + 1u) % GX != 0u;
             la = lb = 0xFFFFu;
             if (!inner) {
                 la = seam[voff + ((size_t)k * 2) * pd.h + y];
@@ -369,10 +374,57 @@ __global__ __launch_bounds__(SEAM_BLOCK) void k_seam(BatchDev b, int xcd_affine)
     node_connect(b.na.rec + pd.node_base, s_pa[threadIdx.x], s_pb[threadIdx.x]);
 }
 
+// The inner seams of the groups k_group_merge left alone (more records than its table holds: noise-like content; none on text-like batches), joined on the
+// global records like any other seam.  A fixed grid walks the list: k_group_merge wrote it, so its length is only known on the device.
+__global__ __launch_bounds__(SEAM_BLOCK) void k_seam_undone(BatchDev b)
+{
+    const uint32_t n = *b.undone_count;
+    const int      GX = b.group_x, GY = b.group_y;
+    for (uint32_t u = blockIdx.x; u < n; u += gridDim.x) {
+        const uint32_t  g = b.undone_list[u];
+        const int       pi = b.group_plane[g];
+        const PlaneDesc &pd = b.planes[pi];
+        const int       groups_x = (pd.tiles_x + GX - 1) / GX;
+        const uint32_t  gl = g - pd.group_base;
+        const int       tx0 = (int)(gl % (uint32_t)groups_x) * GX, ty0 = (int)(gl / (uint32_t)groups_x) * GY;
+        const int       gw = min(GX, pd.tiles_x - tx0), gh = min(GY, pd.tiles_y - ty0);
+        const uint16_t *seam = b.seam + pd.seam_base;
+        const uint32_t *tnb = b.tile_nbase + pd.tile_base;
+        const uint32_t  n_hp = (uint32_t)((gh - 1) * gw * TILE_W), n_vp = (uint32_t)((gw - 1) * gh * TILE_H);
+        const size_t    voff = 2u * (size_t)pd.w * (pd.tiles_y - 1);
+        for (uint32_t p0 = 0; p0 < n_hp + n_vp; p0 += (uint32_t)SEAM_BLOCK) {
+            const uint32_t p = p0 + threadIdx.x;
+            uint32_t na = NONE, nbn = NONE;
+            if (p < n_hp) {
+                const int iy = (int)(p / (uint32_t)(gw * TILE_W)), xg = (int)(p % (uint32_t)(gw * TILE_W));      // boundary under tile row iy; column inside the group
+                const int x = tx0 * TILE_W + xg, j = ty0 + iy;
+                if (x < pd.w) {
+                    const uint32_t ea = seam[((size_t)j * 2) * pd.w + x], eb = seam[((size_t)j * 2 + 1) * pd.w + x];
+                    const uint32_t ta = (uint32_t)j * pd.tiles_x + (uint32_t)(x / TILE_W), ba = tnb[ta], bb = tnb[ta + pd.tiles_x];
+                    if (ea != 0xFFFFu && eb != 0xFFFFu && ba != NONE && bb != NONE) { na = ba + ea; nbn = bb + eb; }
+                }
+            } else if (p < n_hp + n_vp) {
+                const uint32_t q = p - n_hp;
+                const int ix = (int)(q / (uint32_t)(gh * TILE_H)), yg = (int)(q % (uint32_t)(gh * TILE_H));
+                const int y = ty0 * TILE_H + yg, k = tx0 + ix;
+                if (y < pd.h) {
+                    const uint32_t ea = seam[voff + ((size_t)k * 2) * pd.h + y], eb = seam[voff + ((size_t)k * 2 + 1) * pd.h + y];
+                    const uint32_t ta = (uint32_t)(y / TILE_H) * pd.tiles_x + (uint32_t)k, ba = tnb[ta], bb = tnb[ta + 1];
+                    if (ea != 0xFFFFu && eb != 0xFFFFu && ba != NONE && bb != NONE) { na = ba + ea; nbn = bb + eb; }
+                }
+            }
+            const uint32_t pa = __shfl_up(na, 1), pb = __shfl_up(nbn, 1);
+            const bool     dup = (threadIdx.x & 63) != 0 && pa == na && pb == nbn;
+            if (na != NONE && nbn != NONE && !dup) node_connect(b.na.rec + pd.node_base, na, nbn);
+        }
+    }
+}
+
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine)
 {
-    if (!b.n_seam_blocks) return;
-    hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(SEAM_BLOCK), 0, s, b, xcd_affine ? 1 : 0);
+    if (b.n_seam_blocks) hipLaunchKernelGGL(k_seam, dim3((b.n_seam_blocks + 7u) / 8u * 8u), dim3(SEAM_BLOCK), 0, s, b, xcd_affine ? 1 : 0);
+    if (b.n_groups && b.group_x > 0 && b.group_y > 0 && b.undone_list)
+        hipLaunchKernelGGL(k_seam_undone, dim3(b.n_groups < 2048u ? b.n_groups : 2048u), dim3(SEAM_BLOCK), 0, s, b);
 }
 
 // ---- a plane put together from strips that other GPUs extracted ---------------------------------------------

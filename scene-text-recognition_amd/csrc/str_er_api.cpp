@@ -99,7 +99,7 @@ BatchDev make_batchdev(str_er_ctx *c, const Batch &b)
     d.n_tiles = b.n_tiles; d.n_pairs = b.n_pairs; d.n_node_blocks = c->n_node_blocks; d.nb_plane = c->d_nb_plane;
     d.tile_plane = c->d_tile_plane; d.seam_block_plane = c->d_sb_plane; d.seam_block_first = c->d_sb_first;
     d.n_seam_blocks = (uint32_t)c->h_sb_plane.size();
-    d.tile_nrec = c->d_tile_nrec; d.group_done = c->d_group_done; d.group_plane = c->d_group_plane; d.n_groups = b.n_groups; d.group_x = b.group_x; d.group_y = b.group_y;
+    d.tile_nrec = c->d_tile_nrec; d.group_done = c->d_group_done; d.group_plane = c->d_group_plane; d.undone_list = c->d_undone; d.undone_count = c->d_total ? c->d_total + 2 : nullptr; d.n_groups = b.n_groups; d.group_x = b.group_x; d.group_y = b.group_y;
     d.na = c->na; d.ka = c->ka; d.tile_nbase = c->d_tile_nbase; d.seam = c->d_seam; d.pool = c->d_pool; d.pool_tmp = c->d_pool_tmp;
     d.cands = c->d_cands; d.total_cands = c->d_total; d.cand_plane = c->d_cand_plane; d.watch = c->d_watch; d.wstamp = c->d_wstamp; d.wparent = c->d_wparent;
     return d;
@@ -654,7 +654,16 @@ int upload_layout(str_er_ctx *c, Batch &b)
             for (int i = 0; i < np; ++i) {
                 const PlaneDesc &pd = b.planes[i];
                 c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
-                for (uint32_t f0 = 0; f0 < pd.n_pairs; f0 += (uint32_t)SEAM_BLOCK) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
+                // k_seam's workgroups: 1024 consecutive pixel pairs each.  With groups of tiles only the seams BETWEEN groups are k_seam's (the inner ones:
+                // k_group_merge, or k_seam_undone for a group it left alone) -- three quarters of all pairs get no workgroup at all.  A seam's last workgroup
+                // reaches into the pairs behind it: inner ones (skipped by the kernel) or outer ones seen twice (a connect is idempotent).
+                auto blocks = [&](uint32_t lo, uint32_t hi) {
+                    for (uint32_t f0 = lo; f0 < hi; f0 += (uint32_t)SEAM_BLOCK) { c->h_sb_plane.push_back((uint16_t)i); c->h_sb_first.push_back(f0); }
+                };
+                if (b.group_x > 0 && b.group_y > 0) {
+                    for (int j = b.group_y - 1; j + 1 < pd.tiles_y; j += b.group_y) blocks((uint32_t)j * (uint32_t)pd.w, (uint32_t)(j + 1) * (uint32_t)pd.w);
+                    for (int k = b.group_x - 1; k + 1 < pd.tiles_x; k += b.group_x) blocks(pd.n_hpairs + (uint32_t)k * (uint32_t)pd.h, pd.n_hpairs + (uint32_t)(k + 1) * (uint32_t)pd.h);
+                } else blocks(0, pd.n_pairs);
             }
             if (c->h_sb_plane.size() > c->sb_slots) return fail(c, STR_ER_ECAPACITY, "seam block table capacity exceeded");
             HIP_TRY(c, hipMemcpyAsync(c->d_tile_plane, c->h_tile_plane.data(), 2 * c->h_tile_plane.size(), hipMemcpyHostToDevice, s));
@@ -762,7 +771,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     BatchSlot slot;                    // (str_er_set_batch_slots: given back when the batch's kernels are done, below, or on any way out)
     if ((int)b_in.planes.size() > SPEC_PLANES) slot.take();
     // tiles are joined in two steps: groups of tiles in LDS (k_group_merge), then the groups through the global passes.  Text-like
-    // batches (small tile kernel: ~14 records per tile) take 8 x 4 tiles per group with room for 2048 records (a call of a frame or two: 4 x 4 with 1024),
+    // batches (small tile kernel: ~14 records per tile) take 8 x 4 tiles per group (a call of a frame or two: 4 x 4) with room for 2048 records,
     // noise-like ones (~250 records per tile) 2 x 5.
     // (Round 6, tools/dev_groups.sh: ALONE on the GPU the 4 x 4 / 1024-record kernel is the faster one -- 0.41 against 0.48 ms per 48-frame batch, 50 against 81 us
     // per frame: 64 KB of LDS leave two workgroups a compute unit -- but with six batches in flight the larger groups win: 9.9-10.5 k -> 10.8-11.2 k frames/s on
@@ -833,7 +842,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
     if (grouped && b.n_groups) {
-        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? (big_groups ? 4 : 2) : 6));       // (measured, tools/dev_groups.sh)
+        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 4 : 6));       // (measured, tools/dev_groups.sh: 2048 records, 1024 lanes on text-like batches)
     }
     rec(c, "group");
     if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
@@ -1492,7 +1501,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
     A(dev_alloc(c, c->d_t1_list, c->tile_slots)); A(dev_alloc(c, c->d_t2_pairs, c->tile_slots)); A(dev_alloc(c, c->d_fb_list, c->tile_slots));
     A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * str_er_ctx::NB_PLANE_SHARE));
-    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots));
+    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots)); A(dev_alloc(c, c->d_undone, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     {   // what a batch starts from zero -- the candidate / handed-back-tile counters, the plane counters, the groups' done flags -- is ONE block: one
         // memset per batch, and the counters come back with one copy (a call of one frame is a chain of ~30 operations: each costs 5 - 10 us)

@@ -159,6 +159,7 @@ struct str_er_ctx {
     uint16_t *d_nb_plane = nullptr; std::vector<uint16_t> h_nb_plane; uint32_t n_node_blocks = 0;      // plane of every workgroup of the per-record kernels
     uint16_t *d_tile_nrec = nullptr;                  // records per tile (k_tile_tree -> k_group_merge)
     uint16_t *d_group_plane = nullptr; std::vector<uint16_t> h_group_plane;      // plane of every group of tiles
+    uint32_t *d_undone = nullptr;                     // the groups k_group_merge left alone, listed on the device (their number: d_total[2]) for k_seam_undone
     uint8_t  *d_group_done = nullptr;                 // per group of tiles: joined in LDS (k_group_merge -> k_seam)
     int       dbg_group[3] = {0, 0, -1};              // developer knobs STR_ER_GROUP_X / _Y / _KERNEL
     int       group_mode = -1;                        // STR_ER_GROUPS: -1 automatic (4 x 4 tiles with the small tile kernel, 2 x 5 with the big one), 0 off
