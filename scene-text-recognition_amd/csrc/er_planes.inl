@@ -235,6 +235,18 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
         sx[k] = x; sx1[k] = (x + 1 < g.sw) ? x + 1 : x;
         a0[k] = __float2int_rn((1.f - fx) * 2048.f); a1[k] = __float2int_rn(fx * 2048.f);
     }
+    // the rows' coefficients are the same for every lane: lane r works out those of row r (the f64 / f32 part of cv::resize's tables) once -- all 64 lanes,
+    // before the lanes beyond the plane's last column leave -- and the row loop reads them into scalar registers: as every lane computing every row's they
+    // were a sixth of the kernel's vector instructions
+    int row_sy, row_b0, row_b1;
+    {
+        const int dy = dy0 + (int)(threadIdx.x & (RESIZE_ROWS - 1));
+        float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
+        row_sy = (int)floorf(fy);
+        fy -= (float)row_sy;
+        row_b0 = __float2int_rn((1.f - fy) * 2048.f); row_b1 = __float2int_rn(fy * 2048.f);
+    }
+    static_assert((RESIZE_ROWS & (RESIZE_ROWS - 1)) == 0 && RESIZE_ROWS <= 64, "a lane per row of the tile");
     // source window of the tile (uniform over the wave)
     const int x_lo = resize_sx(g, tx0) & ~3;
     const int x_last = resize_sx(g, min(tx0 + 255, g.dw - 1));
@@ -265,9 +277,11 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
         }
         __syncthreads();
     }
-    if (!active) return;
     const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_src);
     const bool full = dx0 + 4 <= g.dw && (dstride & 3) == 0;
+    // (the lanes beyond the plane's last column stay for the form below -- their stores are masked, their taps clamped into the window: the row loop reads
+    // the coefficients of row r from lane r, and a lane that had left could not be relied on to hold them)
+    if (!(staged && g.scale_x <= 1.5) && !active) return;
     if (staged && g.scale_x <= 1.5) {
         // The taps of the lane's 4 columns lie within 7 source bytes (reduction <= 1.5): per SOURCE row the lane reads the three dwords
         // that hold them, shifts them to its first tap (two v_alignbyte) and picks the 4 left and the 4 right taps with two byte
@@ -292,10 +306,7 @@ __global__ __launch_bounds__(64) void k_resize(const uint8_t *__restrict__ src, 
         for (int r = 0; r < RESIZE_ROWS; ++r) {
             const int dy = dy0 + r;
             if (dy >= g.dh) break;
-            float fy = (float)((dy + 0.5) * g.scale_y - 0.5);
-            int   sy = (int)floorf(fy);
-            fy -= (float)sy;
-            const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+            const int sy = __builtin_amdgcn_readlane(row_sy, r), b0 = __builtin_amdgcn_readlane(row_b0, r), b1 = __builtin_amdgcn_readlane(row_b1, r);
             const int ya = min(max(sy, 0), g.sh - 1), yb = min(max(sy + 1, 0), g.sh - 1);
             // (ya, yb are the same for every lane: uniform branches)
             if (ya == cb) {
