@@ -653,3 +653,32 @@ def test_strips_of_a_plane_merge_into_the_unsplit_result(S, cascade_paths, oracl
         owner.strip_merge(frames[2], other)
     for f in workers + [owner]:
         f.close()
+
+
+@pytest.mark.gpu
+def test_groups_left_alone_are_joined_by_the_undone_pass(S, cascade_paths, monkeypatch):
+    """k_seam only sees the seams BETWEEN groups of tiles; the seams inside a group are k_group_merge's -- or, for a group with more records than its table
+    holds, k_seam_undone's (the group puts itself on a device-side list).  With the smallest table (512 records) and large groups most groups of a text-like
+    pyramid frame and every group of a noise frame overflow; with 1 x 1 groups nothing is inside a group; without grouping every seam is k_seam's.  All give
+    the records of the default shape, node for node -- on a batch large enough to take the 8 x 4 default (> 96 planes) and on a call of one frame."""
+    W, H = 448, 320
+    rng = np.random.default_rng(77)
+    one = S.synth.stext_bgr(S.synth.frame_seed(70), W, H)[None]
+    many = np.stack([S.synth.stext_bgr(S.synth.frame_seed(71 + i), W, H) for i in range(5)] + [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)])
+    out = {}
+    for shape in (None, ("8", "8", "0"), ("4", "4", "0"), ("1", "1", "2"), ("16", "2", "0"), ("0", "0", "2")):
+        for k, v in zip(("STR_ER_GROUP_X", "STR_ER_GROUP_Y", "STR_ER_GROUP_KERNEL"), shape or (None, None, None)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        f = S.ERFilter(params=S.Params(max_width=W, max_height=H, max_frames=6, n_pyr_levels=3, channel_mask=0x3F))       # 6 frames x 18 planes = 108 planes
+        f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+        out[shape] = [f.text_detect(x, want_nodes=True) for x in (many, one, many)]
+        f.close()
+    for shape, res in out.items():
+        for a, b in zip(out[None], res):
+            assert a.cands.tobytes() == b.cands.tobytes() and a.info.tobytes() == b.info.tobytes(), shape
+            for pa, pb in zip(a.planes, b.planes):
+                assert pa.nodes.tobytes() == pb.nodes.tobytes(), shape
+    assert len(out[None][0].cands) > 0
