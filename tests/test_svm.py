@@ -342,6 +342,38 @@ def test_gpu_config3_full_pipeline(S, cascade_paths, oracle, oracle_cascades, mo
 
 
 @pytest.mark.gpu
+def test_gpu_config3_full_pipeline_120(S, cascade_paths, oracle, model120_path):
+    """The same at the reference's model size (120 samples a class, 4299 support vectors: k_svm_kernel_i8, k_svm_decide, k_svm_couple from the class sums),
+    with the scorer enqueued behind classify: two calls, so that the second one is sized from the first and its early scores are the ones returned."""
+    from oracle.oracle import OracleSVM
+    f = S.ERFilter(params=S.Params(max_width=640, max_height=480, max_frames=1))
+    f.load_cascade(0, cascade_paths[0]); f.load_cascade(1, cascade_paths[1])
+    f.load_svm_model(model120_path, 1800)
+    m = OracleSVM(oracle, model120_path)
+    frames = S.synth.frames_bgr("text", 23, 2, 640, 480)
+    n_checked = 0
+    for fr in frames:
+        res = f.text_detect(fr, S.STAGE_ALL | S.STAGE_OCR)
+        assert res.ocr_label is not None and len(res.ocr_label) == len(res.cands)
+        planes = oracle.compute_channels(fr)
+        for i, c in enumerate(res.cands):
+            if c["cls"] == 0:
+                assert res.ocr_label[i] == -1 and res.ocr_prob[i] == 0
+                continue
+            img = planes[int(c["ch"])]
+            q = oracle.chain_features(img[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]])
+            l, p, _ = m.predict_probability(q / 255.0)
+            assert abs(res.ocr_prob[i] - p.max()) < TOL
+            top2 = np.sort(p)[-2:]
+            if top2[1] - top2[0] > 10 * TOL:
+                assert res.ocr_label[i] == l
+            n_checked += 1
+    assert n_checked > 20
+    assert f.ocr_stage_stats()["scored_early"] >= 1
+    f.close()
+
+
+@pytest.mark.gpu
 def test_gpu_ocr_stage_sized_on_the_device(S, cascade_paths, model_path, monkeypatch):
     """STAGE_OCR is enqueued behind classify, sized from the context's previous batch and working on the device's own count of strong / weak ERs
     (no read of the counters between classify and the scorer, like src/ER.cpp:728-735).  A sequence of batches -- few ERs, many more than guessed (scored
