@@ -61,7 +61,7 @@ void launch_tile_tree_fb(hipStream_t s, const BatchDev &b, const DetectParams &p
 // adjacent tiles (entry: first tile | 1 << 31 if the tile to its right takes part); tiles it does not take end up in fb_list
 void launch_tile_tree2(hipStream_t s, const BatchDev &b, const DetectParams &p, const uint32_t *pairs, uint32_t n_pairs, uint32_t *fb_list, uint32_t *fb_count);
 // the tiles of every group of BatchDev::group_x x group_y tiles joined in LDS, in place (variant: LDS capacity / lanes, see er_kernels.hip)
-void launch_group_merge(hipStream_t s, const BatchDev &b, int variant);
+void launch_group_merge(hipStream_t s, const BatchDev &b, int variant, const uint32_t *glist = nullptr, uint32_t n = 0);
 void launch_seam(hipStream_t s, const BatchDev &b, bool xcd_affine);
 void launch_resolve(hipStream_t s, const BatchDev &b);
 // strips of a plane extracted elsewhere: make a strip's record ids plane-wide; join pixel pairs (plane-local ids) across a cut

@@ -15,8 +15,9 @@
 constexpr int GROUP_MAX_TILES = 64;
 
 template <int CAP, int GROUP_THREADS>
-__global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
+__global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b, const uint32_t *glist)
 {
+    const uint32_t group = glist ? glist[blockIdx.x] : blockIdx.x;       // (a launch per class of planes takes its groups from a list)
     __shared__ uint32_t s_par[CAP], s_cnt[CAP], s_nod[CAP], s_key[CAP], s_x0[CAP], s_y0[CAP], s_x1[CAP], s_y1[CAP];
     __shared__ uint32_t s_toff[GROUP_MAX_TILES + 1], s_tbase[GROUP_MAX_TILES];
     __shared__ uint32_t s_levels[8];
@@ -27,10 +28,10 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
 #define GM_MARK(i) do { } while (0)
 #endif
     const int       GX = b.group_x, GY = b.group_y;
-    const int       pi = b.group_plane[blockIdx.x];
+    const int       pi = b.group_plane[group];
     const PlaneDesc pd = b.planes[pi];
     const int       groups_x = (pd.tiles_x + GX - 1) / GX;
-    const uint32_t  gl = blockIdx.x - pd.group_base;
+    const uint32_t  gl = group - pd.group_base;
     const int       tx0 = (int)(gl % (uint32_t)groups_x) * GX, ty0 = (int)(gl / (uint32_t)groups_x) * GY;
     const int       gw = min(GX, pd.tiles_x - tx0), gh = min(GY, pd.tiles_y - ty0);
     const int       nt = gw * gh;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
     __syncthreads();
     const uint32_t N = s_toff[nt];
     if (N == NONE) {            // too many records for the table (or a tile without records of its own: an overflowing plane): left alone, and listed for k_seam_undone
-        if (tid == 0) b.undone_list[atomicAdd(b.undone_count, 1u)] = blockIdx.x;
+        if (tid == 0) b.undone_list[atomicAdd(b.undone_count, 1u)] = group;
         return;
     }
     if (N == 0) return;
@@ -196,24 +197,26 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_merge(BatchDev b)
         dst[0] = make_uint4(w, s_key[i], s_cnt[i], s_nod[i]);
         dst[1] = make_uint4(s_x0[i], s_y0[i], s_x1[i], s_y1[i]);
     }
-    if (tid == 0) b.group_done[blockIdx.x] = 1;
+    if (tid == 0) b.group_done[group] = 1;
     GM_MARK(6);
 }
 
-// variant: LDS for 512 / 1024 / 2048 / 3072 records per group, 256 / 512 / 1024 lanes
-void launch_group_merge(hipStream_t s, const BatchDev &b, int variant)
+// variant: LDS for 512 / 1024 / 2048 / 3072 records per group, 256 / 512 / 1024 lanes; glist / n: the groups of this launch (nullptr: all b.n_groups)
+void launch_group_merge(hipStream_t s, const BatchDev &b, int variant, const uint32_t *glist, uint32_t n)
 {
     if (!b.n_groups || b.group_x <= 0 || b.group_y <= 0 || b.group_x * b.group_y > GROUP_MAX_TILES) return;
+    if (!glist) n = b.n_groups;
+    if (!n) return;
     switch (variant) {
-    case 0: hipLaunchKernelGGL((k_group_merge<512, 256>), dim3(b.n_groups), dim3(256), 0, s, b); break;
-    case 1: hipLaunchKernelGGL((k_group_merge<1024, 256>), dim3(b.n_groups), dim3(256), 0, s, b); break;
-    case 2: hipLaunchKernelGGL((k_group_merge<1024, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
-    case 3: hipLaunchKernelGGL((k_group_merge<2048, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
-    case 4: hipLaunchKernelGGL((k_group_merge<2048, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
-    case 5: hipLaunchKernelGGL((k_group_merge<3072, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
+    case 0: hipLaunchKernelGGL((k_group_merge<512, 256>), dim3(n), dim3(256), 0, s, b, glist); break;
+    case 1: hipLaunchKernelGGL((k_group_merge<1024, 256>), dim3(n), dim3(256), 0, s, b, glist); break;
+    case 2: hipLaunchKernelGGL((k_group_merge<1024, 512>), dim3(n), dim3(512), 0, s, b, glist); break;
+    case 3: hipLaunchKernelGGL((k_group_merge<2048, 512>), dim3(n), dim3(512), 0, s, b, glist); break;
+    case 4: hipLaunchKernelGGL((k_group_merge<2048, 1024>), dim3(n), dim3(1024), 0, s, b, glist); break;
+    case 5: hipLaunchKernelGGL((k_group_merge<3072, 1024>), dim3(n), dim3(1024), 0, s, b, glist); break;
     // 2528 records: 32 B each + the tile tables = 64 of the 1280-byte LDS granules, so TWO workgroups fit a CU
-    case 6: hipLaunchKernelGGL((k_group_merge<2528, 1024>), dim3(b.n_groups), dim3(1024), 0, s, b); break;
-    default: hipLaunchKernelGGL((k_group_merge<2528, 512>), dim3(b.n_groups), dim3(512), 0, s, b); break;
+    case 6: hipLaunchKernelGGL((k_group_merge<2528, 1024>), dim3(n), dim3(1024), 0, s, b, glist); break;
+    default: hipLaunchKernelGGL((k_group_merge<2528, 512>), dim3(n), dim3(512), 0, s, b, glist); break;
     }
 }
 

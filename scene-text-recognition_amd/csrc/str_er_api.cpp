@@ -651,6 +651,20 @@ int upload_layout(str_er_ctx *c, Batch &b)
                     c->h_group_plane.insert(c->h_group_plane.end(), (size_t)((pd.tiles_x + b.group_x - 1) / b.group_x) * ((pd.tiles_y + b.group_y - 1) / b.group_y), (uint16_t)i);
                 }
             if (!c->h_group_plane.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_group_plane, c->h_group_plane.data(), 2 * c->h_group_plane.size(), hipMemcpyHostToDevice, s));
+            // ... and the groups by class of plane: the chroma planes' first (run_batch launches k_group_merge once per class)
+            c->h_group_list.clear(); c->n_groups_small = 0;
+            if (b.group_x > 0 && b.group_y > 0) {
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int i = 0; i < np; ++i) {
+                        const PlaneDesc &pd = b.planes[i];
+                        if ((pd.ch % 3 != 0) != (pass == 0)) continue;
+                        const uint32_t ng = (uint32_t)((pd.tiles_x + b.group_x - 1) / b.group_x) * (uint32_t)((pd.tiles_y + b.group_y - 1) / b.group_y);
+                        for (uint32_t g = 0; g < ng; ++g) c->h_group_list.push_back(pd.group_base + g);
+                    }
+                    if (pass == 0) c->n_groups_small = (uint32_t)c->h_group_list.size();
+                }
+                if (!c->h_group_list.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_group_list, c->h_group_list.data(), 4 * c->h_group_list.size(), hipMemcpyHostToDevice, s));
+            }
             for (int i = 0; i < np; ++i) {
                 const PlaneDesc &pd = b.planes[i];
                 c->h_tile_plane.insert(c->h_tile_plane.end(), (size_t)pd.tiles_x * pd.tiles_y, (uint16_t)i);
@@ -826,6 +840,11 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
     BatchDev bd = make_batchdev(c, b);
     if (!pre_recorded) { c->n_ev = 0; c->profile.clear(); rec(c, "begin", nullptr, true); }
 
+    // developer aid (tools/dev_exposed.py): STR_ER_DEBUG_STOP_AFTER=n ends the call (with an error) behind stage n -- 0 channels + pyramid, 1 tile trees, 2 group,
+    // 3 seam, 4 resolve, 5 accumulate --: what a stage costs with several batches in flight is the difference of two such runs
+    static const int dbg_stop = [] { const char *e = std::getenv("STR_ER_DEBUG_STOP_AFTER"); return e ? std::atoi(e) : -1; }();
+#define DBG_STOP(n) do { if (dbg_stop == (n)) { (void)wait_stream(c, s); return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_STOP_AFTER"); } } while (0)
+    DBG_STOP(0);
     if (import_trees) {
         const int rci = (*import_trees)(b, bd);
         if (rci != STR_ER_OK) return rci;
@@ -834,6 +853,7 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         { const int rct = launch_tile_trees(c, b, bd, dp); if (rct != STR_ER_OK) return rct; }
         rec(c, "tile_tree");
     }
+    DBG_STOP(1);
     if (c->dbg_tile_only) {     // developer aid (see STR_ER_STOP_AFTER in er_kernels.hip): time the tile kernel alone
         float ms = 0;
         (void)wait_stream(c, s);
@@ -842,13 +862,25 @@ int run_batch(str_er_ctx *c, const Batch &b_in, uint32_t stages, str_er_result *
         return fail(c, STR_ER_ESTATE, "STR_ER_DEBUG_TILE_ONLY is set");
     }
     if (grouped && b.n_groups) {
-        launch_group_merge(s, bd, c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 4 : 6));       // (measured, tools/dev_groups.sh: 2048 records, 1024 lanes on text-like batches)
+        const int variant = c->dbg_group[2] >= 0 ? c->dbg_group[2] : (c->tile_sparse ? 4 : 6);       // (measured, tools/dev_groups.sh: 2048 records, 1024 lanes on text-like batches)
+        // Large text-like batches: a launch per class of planes.  The groups of the chroma planes hold ~150 records: 512 slots and 256 lanes (16 KB of LDS) -- a
+        // group that does overflow is k_seam_undone's.  With six batches in flight k_group_merge cost the line its WHOLE isolated time (tools/dev_exposed.py with
+        // STR_ER_DEBUG_STOP_AFTER: 0.30 of 0.33 ms per 32-frame batch, where seam / resolve / reduce cost half of theirs): the tile kernels hold all 160 KB of a
+        // compute unit's LDS, and a workgroup that wants 64 KB and 16 wave slots waits until four of theirs have left it.  13.0 -> 13.3 k frames/s.
+        if (big_groups && c->dbg_group[2] < 0 && c->n_groups_small && c->h_group_list.size() == b.n_groups) {
+            launch_group_merge(s, bd, 0, c->d_group_list, c->n_groups_small);
+            launch_group_merge(s, bd, variant, c->d_group_list + c->n_groups_small, b.n_groups - c->n_groups_small);
+        } else launch_group_merge(s, bd, variant);
     }
     rec(c, "group");
+    DBG_STOP(2);
     if (!import_trees) launch_seam(s, bd, !c->tile_sparse);
     rec(c, "seam");
+    DBG_STOP(3);
     launch_resolve(s, bd);                            rec(c, "resolve");
+    DBG_STOP(4);
     launch_reduce(s, bd);                             rec(c, "accumulate");
+    DBG_STOP(5);
     launch_root(s, bd, dp);
     launch_select(s, bd, dp);
     launch_kept(s, bd, dp);                           rec(c, "select", nullptr, true);
@@ -1501,7 +1533,7 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     A(dev_alloc(c, c->d_tile_nbase, c->tile_slots));
     A(dev_alloc(c, c->d_t1_list, c->tile_slots)); A(dev_alloc(c, c->d_t2_pairs, c->tile_slots)); A(dev_alloc(c, c->d_fb_list, c->tile_slots));
     A(dev_alloc(c, c->d_nb_plane, (size_t)c->max_planes * str_er_ctx::NB_PLANE_SHARE));
-    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots)); A(dev_alloc(c, c->d_undone, c->tile_slots));
+    A(dev_alloc(c, c->d_tile_nrec, c->tile_slots)); A(dev_alloc(c, c->d_group_plane, c->tile_slots)); A(dev_alloc(c, c->d_undone, c->tile_slots)); A(dev_alloc(c, c->d_group_list, c->tile_slots));
     A(dev_alloc(c, c->d_ranges, 2 * (size_t)c->max_planes + 2));
     {   // what a batch starts from zero -- the candidate / handed-back-tile counters, the plane counters, the groups' done flags -- is ONE block: one
         // memset per batch, and the counters come back with one copy (a call of one frame is a chain of ~30 operations: each costs 5 - 10 us)

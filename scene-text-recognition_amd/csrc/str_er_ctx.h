@@ -159,6 +159,7 @@ struct str_er_ctx {
     uint16_t *d_nb_plane = nullptr; std::vector<uint16_t> h_nb_plane; uint32_t n_node_blocks = 0;      // plane of every workgroup of the per-record kernels
     uint16_t *d_tile_nrec = nullptr;                  // records per tile (k_tile_tree -> k_group_merge)
     uint16_t *d_group_plane = nullptr; std::vector<uint16_t> h_group_plane;      // plane of every group of tiles
+    uint32_t *d_group_list = nullptr; std::vector<uint32_t> h_group_list; uint32_t n_groups_small = 0;      // the groups by class of plane: first those of the chroma planes (few records a tile: k_group_merge with a small table), then the others
     uint32_t *d_undone = nullptr;                     // the groups k_group_merge left alone, listed on the device (their number: d_total[2]) for k_seam_undone
     uint8_t  *d_group_done = nullptr;                 // per group of tiles: joined in LDS (k_group_merge -> k_seam)
     int       dbg_group[3] = {0, 0, -1};              // developer knobs STR_ER_GROUP_X / _Y / _KERNEL
