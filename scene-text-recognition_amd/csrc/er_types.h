@@ -20,7 +20,12 @@ constexpr int      TILE_PX  = TILE_W * TILE_H;   // 2048 / 4096
 constexpr int      TILE_PPT = 8;                 // consecutive pixels per lane
 constexpr int      TILE_THREADS = TILE_PX / TILE_PPT; // 256 / 512: 4 / 8 wavefronts of 64
 constexpr uint32_t NONE     = 0xFFFFFFFFu;
-constexpr int      SEAM_BLOCK = 1024;          // seam pixel pairs (= lanes) per k_seam workgroup; the host lists (plane, first pair) per workgroup
+// (512 since round 6, 1024 before: with several batches in flight a workgroup gets onto a compute unit in the holes the tile kernels' workgroups -- 256 lanes,
+// 20 KB of LDS, all of a unit's wave slots and LDS between eight of them -- leave behind: 1024 lanes need four holes at once.  256 / 512 / 1024: 13.42 / 13.44 / 13.29 k frames/s)
+#ifndef STR_ER_SEAM_BLOCK
+#define STR_ER_SEAM_BLOCK 512
+#endif
+constexpr int      SEAM_BLOCK = STR_ER_SEAM_BLOCK;          // seam pixel pairs (= lanes) per k_seam workgroup; the host lists (plane, first pair) per workgroup
 
 // One logical plane = one (frame, channel, pyramid level): the unit the reference
 // loops over at src/ER.cpp:50-60.  Inverted channels (255-x, src/ER.cpp:125-127) share
