@@ -323,12 +323,13 @@ def main():
                          "(synthetic stand-in for the missing classifier/OCR.model: scene-text-recognition_amd/data/ocr_synth120.model.gz)")
     ap.add_argument("--no-ocr-legs", action="store_true", help="skip `config3_ocr_leg` / `group_ocr_leg` of the default run")
     ap.add_argument("--no-4k-leg", action="store_true", help="skip `config5_4k_leg` of the default run")
-    ap.add_argument("--batch-slots", type=int, default=4,
+    ap.add_argument("--batch-slots", type=int, default=5,
                     help="str_er_set_batch_slots: at most this many batches have their kernels on the GPU at a time (0: no limit).  Equal batches that share the GPU "
                          "evenly finish together and then wait together for their host side (the flood order walk of an NMS tie) with the GPU idle: with 48-frame "
                          "batches 11.1 k frames/s without a limit, 12.3 k with 3; with the default 32-frame batches it makes no difference on the round's boxes")
-    ap.add_argument("--pipelines", type=int, default=6,
-                    help="independent batches in flight per GPU (each has its own context, stream and workspace).  Three hide the "
+    ap.add_argument("--pipelines", type=int, default=7,
+                    help="independent batches in flight per GPU (each has its own context, two streams and workspace; default 7 with 5 batch slots since round 6 -- 13.9 k frames/s "
+                         "against 13.55-13.6 k for 6 with 4 slots).  Three hide the "
                          "host-side result handling and the low-parallelism tails of a batch; the flood order walk that decides an NMS "
                          "sibling tie (about one plane per 48 S-text frames, about 5 ms on a host core at 1080p, 27 ms at 4K) needs a few more")
     args = ap.parse_args()
@@ -345,7 +346,7 @@ def main():
     import torch.distributed as dist
 
     S = importlib.import_module("scene-text-recognition_amd")
-    # Several contexts in flight use three HIP streams each (main, alt NMS pass, tie pass); with the runtime's default of 4 hardware queues
+    # Several contexts in flight use two HIP streams each (main, alt NMS pass; until round 6 a third for the tie pass); with the runtime's default of 4 hardware queues
     # the long single-workgroup kernels of one context's tie pass sit in front of another context's tile kernel (measured: 4940 -> 5330
     # frames/s with 16).  The library does not edit its host's environment; this application opts in (str_er_apply_runtime_hint) before
     # the process's first HIP call -- the runtime reads the setting when it initialises, which importing torch does not do.

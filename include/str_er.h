@@ -187,7 +187,7 @@ const char *str_er_last_error(const str_er_ctx *ctx);
 const char *str_er_strerror(int code);
 int  str_er_abi_version(void);
 /* Settings of the HIP runtime this library works best with, as "NAME=value" (space separated if several): a context uses
- * three HIP streams and hosts keep several contexts in flight, which the runtime's default of 4 hardware queues serialises
+ * two HIP streams (three until round 6, and with STR_ER_PRIO_STREAM) and hosts keep several contexts in flight, which the runtime's default of 4 hardware queues serialises
  * (about 8 % in bench.py).  The runtime reads them when it initialises, so they must be in the environment before the
  * process's first HIP call.  The library never sets them by itself; str_er_apply_runtime_hint() does, for a host that
  * opts in: returns 1 if it set something, 0 if the host's environment already decides, < 0 on error.                  */

@@ -1498,7 +1498,10 @@ int str_er_create(const str_er_params *p, str_er_ctx **out)
     {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (numerically lower = higher priority)
-        if (hipStreamCreateWithPriority(&c->prio, hipStreamNonBlocking, hi) != hipSuccess) A(fail(nullptr, STR_ER_EHIP, "priority stream creation failed"));
+        // (Round 6: no longer created unless STR_ER_PRIO_STREAM is set -- the tie pass then runs on the main stream.  A third stream per context is a third hardware
+        // queue: with six contexts the line gains 1 % without it, seven are 2 % better than six, and the cliff eight contexts fell off -- 13.4 -> 10.9 k frames/s at 24
+        // streams -- is gone: 8 / 9 / 10 contexts 13.65 / 13.69 / 13.77 k.)
+        if (std::getenv("STR_ER_PRIO_STREAM") && hipStreamCreateWithPriority(&c->prio, hipStreamNonBlocking, hi) != hipSuccess) A(fail(nullptr, STR_ER_EHIP, "priority stream creation failed"));
     }
     if (p->sibling_order == 0) {
         c->tie_slot_bytes = ((plane_px + 255) / 256) * 256 + 2 * 4 * (size_t)NMS_WATCH_CAP + 256;
